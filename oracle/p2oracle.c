@@ -1,0 +1,615 @@
+/*
+ * p2oracle.c -- CPU restatement of the plonky2 LDE + Poseidon-commit + FRI-commit path.
+ * TEST INFRASTRUCTURE ONLY (see p2oracle.h).  Citations are into /root/reference.
+ *
+ * The structure deliberately follows the reference (per-column radix-2 DIT NTT after an
+ * explicit bit reversal, gather transpose, recursive Merkle fill, a fresh extension NTT per
+ * FRI round) -- it is the thing the HIP path is checked against and the "port" CPU baseline,
+ * not an optimised CPU prover.  OpenMP mirrors the reference's rayon fork-join points.
+ */
+#include "p2oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "poseidon_constants.h"
+
+typedef unsigned __int128 u128;
+#define P ORA_P
+#define EPS 0xFFFFFFFFULL
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int ora_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------ field */
+/* goldilocks_field.rs:217-224 to_canonical_u64 */
+uint64_t ora_gl_canon(uint64_t x) { return x >= P ? x - P : x; }
+
+/* goldilocks_field.rs:245-262 (Add): canonical output here; equality in the reference is
+ * canonical-value equality (goldilocks_field.rs:33-37) so any representative is equivalent. */
+uint64_t ora_gl_add(uint64_t a, uint64_t b) {
+    u128 s = (u128)ora_gl_canon(a) + ora_gl_canon(b);
+    if (s >= P) s -= P;
+    return (uint64_t)s;
+}
+
+uint64_t ora_gl_sub(uint64_t a, uint64_t b) {
+    a = ora_gl_canon(a);
+    b = ora_gl_canon(b);
+    return a >= b ? a - b : a + (P - b);
+}
+
+/* goldilocks_field.rs:402-415 reduce128: x_lo - x_hi_hi + x_hi_lo * EPSILON */
+static uint64_t reduce128(u128 x) {
+    uint64_t x_lo = (uint64_t)x, x_hi = (uint64_t)(x >> 64);
+    uint64_t x_hi_hi = x_hi >> 32, x_hi_lo = x_hi & EPS;
+    uint64_t t0 = x_lo - x_hi_hi;
+    if (x_lo < x_hi_hi) t0 -= EPS; /* borrow */
+    uint64_t t1 = x_hi_lo * EPS;
+    uint64_t t2 = t0 + t1;
+    if (t2 < t1) t2 += EPS; /* carry: add_no_canonicalize_trashing_input */
+    return ora_gl_canon(t2);
+}
+
+uint64_t ora_gl_mul(uint64_t a, uint64_t b) { return reduce128((u128)a * b); }
+
+uint64_t ora_gl_pow(uint64_t a, uint64_t e) {
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1) r = ora_gl_mul(r, a);
+        a = ora_gl_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+
+uint64_t ora_gl_inv(uint64_t a) { return ora_gl_pow(a, P - 2); } /* Fermat; goldilocks_field.rs:108-147 */
+
+/* types.rs:268-272: POWER_OF_TWO_GENERATOR^(2^(32 - log_n)); goldilocks_field.rs:87 */
+uint64_t ora_gl_root_of_unity(unsigned log_n) {
+    uint64_t w = 7277203076849721926ULL;
+    for (unsigned i = log_n; i < 32; ++i) w = ora_gl_mul(w, w);
+    return w;
+}
+
+/* extension/quadratic.rs:180-194 with W = 7 (goldilocks_extensions.rs:19) */
+void ora_ext2_mul(const uint64_t a[2], const uint64_t b[2], uint64_t out[2]) {
+    uint64_t c0 = ora_gl_add(ora_gl_mul(a[0], b[0]), ora_gl_mul(7, ora_gl_mul(a[1], b[1])));
+    uint64_t c1 = ora_gl_add(ora_gl_mul(a[0], b[1]), ora_gl_mul(a[1], b[0]));
+    out[0] = c0;
+    out[1] = c1;
+}
+
+/* ------------------------------------------------------------------ util */
+static size_t reverse_bits(size_t x, unsigned bits) { /* plonky2/src/util/mod.rs:33-41 */
+    size_t r = 0;
+    for (unsigned i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+static unsigned log2_strict(size_t n) {
+    unsigned l = 0;
+    while (((size_t)1 << l) < n) ++l;
+    return l;
+}
+
+/* util/src/lib.rs:185-234 semantics (a[i] <-> a[bitrev(i)]); elements of `w` words */
+void ora_reverse_index_bits(uint64_t *a, size_t n, size_t w) {
+    unsigned lg = log2_strict(n);
+    uint64_t *tmp = (uint64_t *)malloc(w * sizeof(uint64_t));
+    for (size_t i = 0; i < n; ++i) {
+        size_t j = reverse_bits(i, lg);
+        if (i < j) {
+            memcpy(tmp, a + i * w, w * 8);
+            memcpy(a + i * w, a + j * w, w * 8);
+            memcpy(a + j * w, tmp, w * 8);
+        }
+    }
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------ fft */
+/* fft.rs:165-202 fft_classic: bit-reverse, zero-tail replication (r), DIT layers with
+ * per-layer twiddles root_table[lg_half_m][j] = w_m^j (fft.rs:14-33). */
+void ora_fft(uint64_t *v, unsigned lg_n, unsigned r) {
+    size_t n = (size_t)1 << lg_n;
+    ora_reverse_index_bits(v, n, 1);
+    if (r > 0) {
+        size_t mask = ~(((size_t)1 << r) - 1);
+        for (size_t i = 0; i < n; ++i) v[i] = v[i & mask];
+    }
+    for (unsigned lg_half_m = r; lg_half_m < lg_n; ++lg_half_m) {
+        size_t half_m = (size_t)1 << lg_half_m, m = half_m << 1;
+        uint64_t w_m = ora_gl_root_of_unity(lg_half_m + 1);
+        uint64_t *tw = (uint64_t *)malloc(half_m * 8);
+        tw[0] = 1;
+        for (size_t j = 1; j < half_m; ++j) tw[j] = ora_gl_mul(tw[j - 1], w_m);
+        for (size_t k = 0; k < n; k += m)
+            for (size_t j = 0; j < half_m; ++j) {
+                uint64_t t = ora_gl_mul(tw[j], v[k + half_m + j]);
+                uint64_t u = v[k + j];
+                v[k + j] = ora_gl_add(u, t);
+                v[k + half_m + j] = ora_gl_sub(u, t);
+            }
+        free(tw);
+    }
+}
+
+/* fft.rs:68-91 ifft_with_options: forward NTT, reverse all but the first, times n^-1 */
+void ora_ifft(uint64_t *v, unsigned lg_n) {
+    size_t n = (size_t)1 << lg_n;
+    uint64_t n_inv = ora_gl_inv((uint64_t)n % P); /* types.rs:227-262 inverse_2exp */
+    ora_fft(v, lg_n, 0);
+    if (n == 1) {
+        v[0] = ora_gl_mul(v[0], n_inv);
+        return;
+    }
+    v[0] = ora_gl_mul(v[0], n_inv);
+    v[n / 2] = ora_gl_mul(v[n / 2], n_inv);
+    for (size_t i = 1; i < n / 2; ++i) {
+        size_t j = n - i;
+        uint64_t ci = ora_gl_mul(v[j], n_inv), cj = ora_gl_mul(v[i], n_inv);
+        v[i] = ci;
+        v[j] = cj;
+    }
+}
+
+/* polynomial/mod.rs:280-293: scale coeff t by shift^t, then fft with zero_factor */
+void ora_coset_fft(uint64_t *c, unsigned lg_n, uint64_t shift, unsigned zero_factor) {
+    size_t n = (size_t)1 << lg_n;
+    uint64_t pw = 1;
+    for (size_t t = 0; t < n; ++t) {
+        c[t] = ora_gl_mul(c[t], pw);
+        pw = ora_gl_mul(pw, shift);
+    }
+    ora_fft(c, lg_n, zero_factor);
+}
+
+/* polynomial/mod.rs:63-73 */
+void ora_coset_ifft(uint64_t *v, unsigned lg_n, uint64_t shift) {
+    size_t n = (size_t)1 << lg_n;
+    ora_ifft(v, lg_n);
+    uint64_t si = ora_gl_inv(shift), pw = 1;
+    for (size_t t = 0; t < n; ++t) {
+        v[t] = ora_gl_mul(v[t], pw);
+        pw = ora_gl_mul(pw, si);
+    }
+}
+
+/* ------------------------------------------------------------------ poseidon */
+static inline uint64_t sbox(uint64_t x) { /* poseidon.rs:690-696 */
+    uint64_t x2 = ora_gl_mul(x, x), x4 = ora_gl_mul(x2, x2), x3 = ora_gl_mul(x, x2);
+    return ora_gl_mul(x3, x4);
+}
+
+static void constant_layer(uint64_t s[12], unsigned round) { /* poseidon.rs:632-641 */
+    for (int i = 0; i < 12; ++i) s[i] = ora_gl_add(s[i], P2_POSEIDON_ALL_ROUND_CONSTANTS[i + 12 * round]);
+}
+
+static void sbox_layer(uint64_t s[12]) { /* poseidon.rs:712-718 */
+    for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
+}
+
+/* poseidon.rs:180-199 mds_row_shf + :271-290 mds_layer (u128 accumulate, one reduction) */
+static void mds_layer(uint64_t s[12]) {
+    uint64_t out[12];
+    for (int r = 0; r < 12; ++r) {
+        u128 acc = 0;
+        for (int i = 0; i < 12; ++i) acc += (u128)s[(i + r) % 12] * P2_POSEIDON_MDS_CIRC[i];
+        acc += (u128)s[r] * P2_POSEIDON_MDS_DIAG[r];
+        out[r] = reduce128(acc);
+    }
+    memcpy(s, out, sizeof out);
+}
+
+static void full_rounds(uint64_t s[12], unsigned *round) { /* poseidon.rs:742-749 */
+    for (int k = 0; k < 4; ++k) {
+        constant_layer(s, *round);
+        sbox_layer(s);
+        mds_layer(s);
+        ++*round;
+    }
+}
+
+/* poseidon.rs:752-764 partial_rounds (fast): first-constant layer (:365-375), init matrix
+ * (:415-441), then 22 x { sbox on s0; + scalar constant; sparse matrix (:516-542) } */
+static void partial_rounds_fast(uint64_t s[12], unsigned *round) {
+    for (int i = 0; i < 12; ++i) s[i] = ora_gl_add(s[i], P2_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT[i]);
+    uint64_t t[12];
+    t[0] = s[0];
+    for (int c = 1; c < 12; ++c) t[c] = 0;
+    for (int r = 1; r < 12; ++r)
+        for (int c = 1; c < 12; ++c)
+            t[c] = ora_gl_add(t[c], ora_gl_mul(s[r], P2_POSEIDON_FAST_PARTIAL_ROUND_INITIAL_MATRIX[(r - 1) * 11 + (c - 1)]));
+    memcpy(s, t, sizeof t);
+    for (int i = 0; i < 22; ++i) {
+        s[0] = sbox(s[0]);
+        s[0] = ora_gl_add(s[0], P2_POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[i]);
+        uint64_t m00 = P2_POSEIDON_MDS_CIRC[0] + P2_POSEIDON_MDS_DIAG[0];
+        uint64_t d = ora_gl_mul(s[0], m00);
+        for (int j = 1; j < 12; ++j) d = ora_gl_add(d, ora_gl_mul(s[j], P2_POSEIDON_FAST_PARTIAL_ROUND_W_HATS[i * 11 + j - 1]));
+        for (int j = 1; j < 12; ++j) t[j] = ora_gl_add(s[j], ora_gl_mul(s[0], P2_POSEIDON_FAST_PARTIAL_ROUND_VS[i * 11 + j - 1]));
+        t[0] = d;
+        memcpy(s, t, sizeof t);
+    }
+    *round += 22;
+}
+
+static void partial_rounds_naive(uint64_t s[12], unsigned *round) { /* poseidon.rs:781-788 */
+    for (int k = 0; k < 22; ++k) {
+        constant_layer(s, *round);
+        s[0] = sbox(s[0]);
+        mds_layer(s);
+        ++*round;
+    }
+}
+
+void ora_poseidon(uint64_t s[12]) { /* poseidon.rs:767-777 */
+    unsigned round = 0;
+    full_rounds(s, &round);
+    partial_rounds_fast(s, &round);
+    full_rounds(s, &round);
+    for (int i = 0; i < 12; ++i) s[i] = ora_gl_canon(s[i]);
+}
+
+void ora_poseidon_naive(uint64_t s[12]) { /* poseidon.rs:791-801 */
+    unsigned round = 0;
+    full_rounds(s, &round);
+    partial_rounds_naive(s, &round);
+    full_rounds(s, &round);
+    for (int i = 0; i < 12; ++i) s[i] = ora_gl_canon(s[i]);
+}
+
+/* hashing.rs:118-145: zero state, overwrite-mode absorb of <=8-element chunks, no padding */
+void ora_hash_no_pad(const uint64_t *in, size_t len, uint64_t out[4]) {
+    uint64_t s[12] = {0};
+    for (size_t off = 0; off < len; off += 8) {
+        size_t c = len - off < 8 ? len - off : 8;
+        for (size_t i = 0; i < c; ++i) s[i] = in[off + i];
+        ora_poseidon(s);
+    }
+    /* len == 0: the reference squeezes the all-zero state without permuting */
+    for (int i = 0; i < 4; ++i) out[i] = ora_gl_canon(s[i]);
+}
+
+/* plonk/config.rs:63-74: <= 4 elements are copied (canonical), not hashed */
+void ora_hash_or_noop(const uint64_t *in, size_t len, uint64_t out[4]) {
+    if (len * 8 <= 32) {
+        for (size_t i = 0; i < 4; ++i) out[i] = i < len ? ora_gl_canon(in[i]) : 0;
+    } else {
+        ora_hash_no_pad(in, len, out);
+    }
+}
+
+/* hashing.rs:97-114 compress */
+void ora_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]) {
+    uint64_t s[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], 0, 0, 0, 0};
+    ora_poseidon(s);
+    for (int i = 0; i < 4; ++i) out[i] = s[i];
+}
+
+/* ------------------------------------------------------------------ merkle */
+/* merkle_tree.rs:86-113 fill_subtree.  digests_buf has 2*(n_leaves-1) digests. */
+static void fill_subtree(uint64_t *digests_buf, size_t n_digests, const uint64_t *leaves,
+                         size_t n_leaves, size_t w, uint64_t out[4], int depth) {
+    if (n_digests == 0) {
+        ora_hash_or_noop(leaves, w, out);
+        return;
+    }
+    size_t half = n_digests / 2;
+    uint64_t *left_buf = digests_buf;                      /* [0, half-1) */
+    uint64_t *left_digest = digests_buf + (half - 1) * 4;  /* split_last_mut */
+    uint64_t *right_digest = digests_buf + half * 4;       /* split_first_mut */
+    uint64_t *right_buf = digests_buf + (half + 1) * 4;
+    uint64_t l[4], r[4];
+    if (depth < 6) {
+#pragma omp task shared(l) if (n_leaves > 64)
+        fill_subtree(left_buf, half - 1, leaves, n_leaves / 2, w, l, depth + 1);
+#pragma omp task shared(r) if (n_leaves > 64)
+        fill_subtree(right_buf, half - 1, leaves + (n_leaves / 2) * w, n_leaves / 2, w, r, depth + 1);
+#pragma omp taskwait
+    } else {
+        fill_subtree(left_buf, half - 1, leaves, n_leaves / 2, w, l, depth + 1);
+        fill_subtree(right_buf, half - 1, leaves + (n_leaves / 2) * w, n_leaves / 2, w, r, depth + 1);
+    }
+    memcpy(left_digest, l, 32);
+    memcpy(right_digest, r, 32);
+    ora_two_to_one(l, r, out);
+}
+
+/* merkle_tree.rs:193-224 MerkleTree::new + :115-149 fill_digests_buf */
+void ora_merkle_tree(const uint64_t *leaves, size_t n, size_t w, unsigned cap_height,
+                     uint64_t *digests_out, uint64_t *cap_out) {
+    size_t n_cap = (size_t)1 << cap_height;
+    size_t n_digests = 2 * (n - n_cap);
+    if (n_digests == 0) { /* all-cap tree, merkle_tree.rs:124-133 */
+        for (size_t i = 0; i < n; ++i) ora_hash_or_noop(leaves + i * w, w, cap_out + 4 * i);
+        return;
+    }
+    size_t sub_digests = n_digests >> cap_height, sub_leaves = n >> cap_height;
+#pragma omp parallel
+#pragma omp single
+    for (size_t s = 0; s < n_cap; ++s) {
+#pragma omp task firstprivate(s)
+        fill_subtree(digests_out + s * sub_digests * 4, sub_digests, leaves + s * sub_leaves * w,
+                     sub_leaves, w, cap_out + 4 * s, 0);
+    }
+}
+
+/* merkle_tree.rs:151-190 merkle_tree_prove */
+void ora_merkle_prove(size_t leaf_index, size_t n, unsigned cap_height, const uint64_t *digests,
+                      uint64_t *siblings_out) {
+    unsigned num_layers = log2_strict(n) - cap_height;
+    size_t digest_len = 2 * (n - ((size_t)1 << cap_height));
+    size_t tree_index = leaf_index >> num_layers;
+    size_t tree_len = digest_len >> cap_height;
+    const uint64_t *tree = digests + tree_len * tree_index * 4;
+    size_t pair_index = leaf_index & (((size_t)1 << num_layers) - 1);
+    for (unsigned i = 0; i < num_layers; ++i) {
+        size_t parity = pair_index & 1;
+        pair_index >>= 1;
+        size_t siblings_index = (pair_index << (i + 1)) + ((size_t)1 << i) - 1;
+        size_t sibling_index = 2 * siblings_index + (1 - parity);
+        memcpy(siblings_out + 4 * i, tree + 4 * sibling_index, 32);
+    }
+}
+
+/* merkle_proofs.rs:55-108 verify_merkle_proof_to_cap */
+int ora_merkle_verify(const uint64_t *leaf, size_t w, size_t leaf_index, const uint64_t *cap,
+                      unsigned cap_height, const uint64_t *siblings, unsigned n_siblings) {
+    (void)cap_height;
+    uint64_t cur[4], nxt[4];
+    size_t index = leaf_index;
+    ora_hash_or_noop(leaf, w, cur);
+    for (unsigned i = 0; i < n_siblings; ++i) {
+        if (index & 1)
+            ora_two_to_one(siblings + 4 * i, cur, nxt);
+        else
+            ora_two_to_one(cur, siblings + 4 * i, nxt);
+        memcpy(cur, nxt, 32);
+        index >>= 1;
+    }
+    for (int i = 0; i < 4; ++i)
+        if (cur[i] != ora_gl_canon(cap[4 * index + i])) return 0;
+    return 1;
+}
+
+/* ------------------------------------------------------------------ PolynomialBatch */
+void ora_commit_timed(const uint64_t *cols, size_t W, unsigned lg_n, unsigned rate_bits,
+                      unsigned cap_height, int is_values, uint64_t *coeffs_out,
+                      uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out,
+                      double seconds[4]) {
+    size_t n = (size_t)1 << lg_n, N = n << rate_bits;
+    double t0 = now_s();
+    /* oracle.rs:65-69 "IFFT": par over columns */
+    uint64_t *coeffs = coeffs_out ? coeffs_out : (uint64_t *)malloc(W * n * 8);
+    memcpy(coeffs, cols, W * n * 8);
+    if (is_values) {
+#pragma omp parallel for schedule(dynamic)
+        for (size_t c = 0; c < W; ++c) ora_ifft(coeffs + c * n, lg_n);
+    }
+    double t1 = now_s();
+    /* oracle.rs:114-139 lde_values "FFT + blinding": lde = zero pad (polynomial/mod.rs:199-201),
+     * coset_fft_with_options(coset_shift, Some(rate_bits)) */
+    uint64_t *lde = (uint64_t *)malloc(W * N * 8);
+#pragma omp parallel for schedule(dynamic)
+    for (size_t c = 0; c < W; ++c) {
+        uint64_t *col = lde + c * N;
+        memcpy(col, coeffs + c * n, n * 8);
+        memset(col + n, 0, (N - n) * 8);
+        ora_coset_fft(col, lg_n + rate_bits, ORA_COSET_SHIFT, rate_bits);
+    }
+    double t2 = now_s();
+    /* oracle.rs:97-98 transpose (plonky2/src/util/mod.rs:25-31, gather per output row) then
+     * reverse_index_bits_in_place on the rows */
+    unsigned lg_N = lg_n + rate_bits;
+#pragma omp parallel for schedule(static)
+    for (size_t L = 0; L < N; ++L) {
+        size_t i = reverse_bits(L, lg_N);
+        uint64_t *row = leaves_out + L * W;
+        for (size_t c = 0; c < W; ++c) row[c] = lde[c * N + i];
+    }
+    double t3 = now_s();
+    ora_merkle_tree(leaves_out, N, W, cap_height, digests_out, cap_out);
+    double t4 = now_s();
+    free(lde);
+    if (!coeffs_out) free(coeffs);
+    if (seconds) {
+        seconds[0] += t1 - t0;
+        seconds[1] += t2 - t1;
+        seconds[2] += t3 - t2;
+        seconds[3] += t4 - t3;
+    }
+}
+
+void ora_commit(const uint64_t *cols, size_t W, unsigned lg_n, unsigned rate_bits,
+                unsigned cap_height, int is_values, uint64_t *coeffs_out, uint64_t *leaves_out,
+                uint64_t *digests_out, uint64_t *cap_out) {
+    ora_commit_timed(cols, W, lg_n, rate_bits, cap_height, is_values, coeffs_out, leaves_out,
+                     digests_out, cap_out, NULL);
+}
+
+/* ------------------------------------------------------------------ challenger */
+void ora_challenger_init(ora_challenger *c) { memset(c, 0, sizeof *c); }
+
+static void duplexing(ora_challenger *c) { /* challenger.rs:129-144 */
+    for (uint32_t i = 0; i < c->n_in; ++i) c->state[i] = c->in[i];
+    c->n_in = 0;
+    ora_poseidon(c->state);
+    memcpy(c->out, c->state, 8 * 8);
+    c->n_out = 8;
+}
+
+void ora_challenger_observe(ora_challenger *c, const uint64_t *e, size_t n) { /* challenger.rs:39-48 */
+    for (size_t i = 0; i < n; ++i) {
+        c->n_out = 0;
+        c->in[c->n_in++] = ora_gl_canon(e[i]);
+        if (c->n_in == 8) duplexing(c);
+    }
+}
+
+uint64_t ora_challenger_get(ora_challenger *c) { /* challenger.rs:82-92: pops from the back */
+    if (c->n_in != 0 || c->n_out == 0) duplexing(c);
+    return c->out[--c->n_out];
+}
+
+/* ------------------------------------------------------------------ FRI */
+/* extension NTT with base-field twiddles == two interleaved base NTTs (extension/mod.rs:75-78) */
+static void ext_coset_fft(uint64_t *v /*[n][2]*/, unsigned lg_n, uint64_t shift) {
+    size_t n = (size_t)1 << lg_n;
+    uint64_t *a = (uint64_t *)malloc(n * 8), *b = (uint64_t *)malloc(n * 8);
+    for (size_t i = 0; i < n; ++i) {
+        a[i] = v[2 * i];
+        b[i] = v[2 * i + 1];
+    }
+#pragma omp parallel sections
+    {
+#pragma omp section
+        ora_coset_fft(a, lg_n, shift, 0);
+#pragma omp section
+        ora_coset_fft(b, lg_n, shift, 0);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        v[2 * i] = a[i];
+        v[2 * i + 1] = b[i];
+    }
+    free(a);
+    free(b);
+}
+
+/* fri/prover.rs:84-150 fri_committed_trees */
+void ora_fri_commit(const uint64_t *coeffs_in, unsigned lg_N, unsigned rate_bits,
+                    unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
+                    ora_challenger *ch, uint64_t *leaves_out, uint64_t *digests_out,
+                    uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
+    size_t m = (size_t)1 << lg_N;
+    unsigned lg_m = lg_N;
+    uint64_t *coeffs = (uint64_t *)malloc(m * 16), *values = (uint64_t *)malloc(m * 16);
+    memcpy(coeffs, coeffs_in, m * 16);
+    /* oracle.rs:215-220: lde_final_values = lde_final_poly.coset_fft(coset_shift) */
+    memcpy(values, coeffs_in, m * 16);
+    ext_coset_fft(values, lg_m, ORA_COSET_SHIFT);
+    uint64_t shift = ORA_COSET_SHIFT;
+    size_t n_cap = (size_t)1 << cap_height;
+    for (unsigned rd = 0; rd < n_rounds; ++rd) {
+        unsigned ab = arity_bits[rd];
+        size_t arity = (size_t)1 << ab;
+        ora_reverse_index_bits(values, m, 2);        /* prover.rs:98 */
+        size_t n_leaves = m / arity, w = 2 * arity;  /* prover.rs:99-103 chunk + flatten */
+        size_t n_dig = 2 * (n_leaves - n_cap);
+        uint64_t *dig = digests_out ? digests_out : (uint64_t *)malloc((n_dig ? n_dig : 1) * 32);
+        uint64_t capbuf[4 * 256];
+        uint64_t *cap = caps_out ? caps_out : capbuf;
+        ora_merkle_tree(values, n_leaves, w, cap_height, dig, cap); /* prover.rs:104 */
+        if (leaves_out) {
+            for (size_t i = 0; i < m * 2; ++i) leaves_out[i] = ora_gl_canon(values[i]);
+            leaves_out += m * 2;
+        }
+        ora_challenger_observe(ch, cap, n_cap * 4); /* prover.rs:106 observe_cap */
+        if (digests_out) digests_out += n_dig * 4; else free(dig);
+        if (caps_out) caps_out += n_cap * 4;
+        uint64_t beta[2];
+        beta[0] = ora_challenger_get(ch); /* prover.rs:109 get_extension_challenge */
+        beta[1] = ora_challenger_get(ch);
+        if (betas_out) {
+            betas_out[2 * rd] = beta[0];
+            betas_out[2 * rd + 1] = beta[1];
+        }
+        /* prover.rs:111-117 + plonk_common.rs:120-132 reduce_with_powers (Horner from the back) */
+        size_t m2 = m / arity;
+#pragma omp parallel for schedule(static)
+        for (size_t j = 0; j < m2; ++j) {
+            uint64_t sum[2] = {0, 0}, t[2];
+            for (size_t i = arity; i-- > 0;) {
+                ora_ext2_mul(sum, beta, t);
+                sum[0] = ora_gl_add(t[0], coeffs[2 * (arity * j + i)]);
+                sum[1] = ora_gl_add(t[1], coeffs[2 * (arity * j + i) + 1]);
+            }
+            values[2 * j] = sum[0]; /* values is dead here; reuse as the new coeff buffer */
+            values[2 * j + 1] = sum[1];
+        }
+        memcpy(coeffs, values, m2 * 16);
+        m = m2;
+        lg_m -= ab;
+        shift = ora_gl_pow(shift, arity);            /* prover.rs:118 */
+        ext_coset_fft(values, lg_m, shift);          /* prover.rs:119 (fresh NTT, no zero-tail) */
+    }
+    size_t n_final = m >> rate_bits;                 /* prover.rs:135-137 */
+    for (size_t i = 0; i < 2 * n_final; ++i) coeffs[i] = ora_gl_canon(coeffs[i]);
+    ora_challenger_observe(ch, coeffs, 2 * n_final); /* prover.rs:139 */
+    if (final_out) memcpy(final_out, coeffs, n_final * 16);
+    free(coeffs);
+    free(values);
+}
+
+/* fri/prover.rs:153-202, deterministic (smallest witness) */
+uint64_t ora_fri_pow(ora_challenger *ch, unsigned pow_bits) {
+    uint64_t inter[12];
+    memcpy(inter, ch->state, sizeof inter);
+    for (uint32_t i = 0; i < ch->n_in; ++i) inter[i] = ch->in[i];
+    uint32_t pos = ch->n_in;
+    uint64_t found = 0;
+    for (uint64_t cand = 0;; ++cand) {
+        uint64_t s[12];
+        memcpy(s, inter, sizeof s);
+        s[pos] = cand;
+        ora_poseidon(s);
+        uint64_t resp = s[7]; /* squeeze().iter().last(): last of the RATE elements */
+        unsigned lz = resp ? (unsigned)__builtin_clzll(resp) : 64;
+        if (lz >= pow_bits) {
+            found = cand;
+            break;
+        }
+    }
+    ora_challenger_observe(ch, &found, 1);
+    (void)ora_challenger_get(ch);
+    return found;
+}
+
+/* ------------------------------------------------------------------ prove_openings prelude */
+void ora_reduce_polys_base(const uint64_t *const *polys, size_t n_polys, size_t n,
+                           const uint64_t alpha[2], uint64_t *out) {
+    memset(out, 0, n * 16);
+    uint64_t pw[2] = {1, 0};
+    for (size_t j = 0; j < n_polys; ++j) {
+        for (size_t i = 0; i < n; ++i) { /* mul_extension: ext scalar times base coefficient */
+            out[2 * i] = ora_gl_add(out[2 * i], ora_gl_mul(pw[0], polys[j][i]));
+            out[2 * i + 1] = ora_gl_add(out[2 * i + 1], ora_gl_mul(pw[1], polys[j][i]));
+        }
+        uint64_t t[2];
+        ora_ext2_mul(pw, alpha, t);
+        pw[0] = t[0];
+        pw[1] = t[1];
+    }
+}
+
+void ora_divide_by_linear(const uint64_t *poly, size_t n, const uint64_t z[2], uint64_t *out) {
+    uint64_t acc[2] = {0, 0}, t[2];
+    /* bs[k] for k = n-1 .. 0; quotient coefficient j is bs at index j+1 */
+    for (size_t k = n; k-- > 0;) {
+        ora_ext2_mul(acc, z, t);
+        acc[0] = ora_gl_add(t[0], poly[2 * k]);
+        acc[1] = ora_gl_add(t[1], poly[2 * k + 1]);
+        if (k >= 1) {
+            out[2 * (k - 1)] = acc[0];
+            out[2 * (k - 1) + 1] = acc[1];
+        }
+    }
+    out[2 * (n - 1)] = 0;
+    out[2 * (n - 1) + 1] = 0;
+}
