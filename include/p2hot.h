@@ -1,0 +1,167 @@
+/*
+ * p2hot.h -- C ABI of libp2hot: the MI355X (gfx950) implementation of plonky2's
+ * PolynomialBatch LDE + Poseidon-Merkle commit pipeline and FRI commit phase.
+ *
+ * This is the drop-in boundary a patched `plonky2` crate binds with `extern "C"` (see
+ * INTEGRATION.md).  The reference has no plugin trait for this path; each entry point cites the
+ * reference function whose body it replaces (paths relative to the plonky2 repository).
+ *
+ * Conventions
+ *  - Field elements are uint64_t (GoldilocksField is #[repr(transparent)] u64,
+ *    field/src/goldilocks_field.rs:23-25).  Inputs may be any representative < 2^64; every value
+ *    written to an output buffer is canonical (< P = 2^64 - 2^32 + 1).
+ *  - Extension elements (F^2) are two consecutive words [a0, a1] (field/src/extension/quadratic.rs:13).
+ *  - Digests are 4 words (hash/hash_types.rs:25-27).
+ *  - Functions return 0 (P2HOT_OK) or a P2HOT_E* code; p2hot_last_error() has the text.  No C++
+ *    exception, abort or library-owned host memory crosses this boundary.
+ *  - `*_dev` functions take DEVICE pointers and only enqueue work on the context's HIP stream;
+ *    the others take HOST pointers, stage through device memory owned by the context and return
+ *    after the results are in the caller's buffers.
+ *  - A context is bound to one GPU and is not thread-safe; use one context per GPU (one process
+ *    per GPU in the multi-GPU mode, see plonky2_amd/distributed.py).
+ */
+#ifndef P2HOT_H
+#define P2HOT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2HOT_OK 0
+#define P2HOT_EINVAL 1       /* bad shape / argument (the reference would panic!, e.g. fft.rs:171, merkle_tree.rs:195) */
+#define P2HOT_ENOMEM 2       /* device allocation failed */
+#define P2HOT_EHIP 3         /* HIP runtime error */
+#define P2HOT_EUNSUPPORTED 4 /* valid in the reference but not on this path (e.g. blinding = true: salts come from OsRng, oracle.rs:136) */
+
+#define P2HOT_P 0xFFFFFFFF00000001ULL
+#define P2HOT_COSET_SHIFT 14293326489335486720ULL /* F::coset_shift(), field/src/goldilocks_field.rs:80 */
+
+typedef struct p2hot_ctx p2hot_ctx;
+
+/* ---------------------------------------------------------------- context */
+/* hip_stream: the hipStream_t all work of this context is enqueued on; NULL = the legacy default
+ * stream (which is also PyTorch's default stream).  The caller keeps the stream alive. */
+int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out);
+void p2hot_ctx_destroy(p2hot_ctx *ctx);
+int p2hot_ctx_set_stream(p2hot_ctx *ctx, void *hip_stream);
+int p2hot_ctx_sync(p2hot_ctx *ctx);
+const char *p2hot_last_error(const p2hot_ctx *ctx);
+const char *p2hot_version(void);
+/* 1 when the library was built by the test-only kernel emulator (tests/emu), 0 for the HIP build */
+int p2hot_is_emulated(void);
+
+/* sizes: number of digests (4 words each) in MerkleTree::digests for n_leaves = 2^log_leaves
+ * (hash/merkle_tree.rs:203: 2 * (n_leaves - 2^cap_height)) */
+size_t p2hot_num_digests(unsigned log_leaves, unsigned cap_height);
+
+/* ---------------------------------------------------------------- primitives (device pointers) */
+/* fft_with_options(input, None, None) for `batch` polynomials, in place, natural order in and out:
+ * out[i] = sum_t in[t] * w_n^(i*t)  (field/src/fft.rs:53-65).  poly_stride >= n elements. */
+int p2hot_fft_dev(p2hot_ctx *ctx, uint64_t *d_data, size_t batch, size_t poly_stride, unsigned log_n);
+/* ifft_with_options (field/src/fft.rs:68-91): values on H_n -> coefficients, in place. */
+int p2hot_ifft_dev(p2hot_ctx *ctx, uint64_t *d_data, size_t batch, size_t poly_stride, unsigned log_n);
+/* PolynomialBatch::lde_values (fri/oracle.rs:114-139) = lde(rate_bits) + coset_fft(shift) for W
+ * polynomials, fused with the transpose + reverse_index_bits of oracle.rs:97-98:
+ *   d_lde[c * lde_stride + (L - row_begin)] = p_c(shift * w_N^bitrev(L)),  L in [row_begin, row_begin + row_count)
+ * where N = n << rate_bits.  Rows are produced in whole coset blocks of n rows: row_begin and
+ * row_count must be multiples of n (row block b holds coset j = bitrev_rb(b)). */
+int p2hot_coset_lde_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, size_t W, size_t coeff_stride, unsigned log_n,
+                        unsigned rate_bits, uint64_t shift, size_t row_begin, size_t row_count, uint64_t *d_lde,
+                        size_t lde_stride);
+/* transpose (plonky2/src/util/mod.rs:25-31): column-major [W][rows] -> row-major [rows][W], canonical */
+int p2hot_transpose_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W, size_t rows,
+                        uint64_t *d_rowmajor);
+/* reverse_index_bits (util/src/lib.rs:53-62) on `batch` arrays of 2^log_n words, out of place */
+int p2hot_reverse_index_bits_dev(p2hot_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t batch,
+                                 size_t poly_stride, unsigned log_n);
+/* Poseidon::poseidon on `count` states of 12 words, in place (hash/poseidon.rs:767-777) */
+int p2hot_poseidon_permute_dev(p2hot_ctx *ctx, uint64_t *d_states, size_t count);
+/* MerkleTree::new (hash/merkle_tree.rs:193-224) for the leaf range [leaf_begin, leaf_begin + leaf_count)
+ * of a tree with 2^log_leaves leaves; the range must be a whole number of cap subtrees.
+ * layout: 0 = leaves column-major (element (L, c) at d_leaves[c * leaf_stride + L - leaf_begin]),
+ *         1 = leaves row-major    (d_leaves[(L - leaf_begin) * W + c]).
+ * d_digests / d_cap point at the FULL tree's arrays (reference layout, merkle_tree.rs:50-57);
+ * only the entries of the given range are written. */
+int p2hot_merkle_dev(p2hot_ctx *ctx, const uint64_t *d_leaves, int layout, size_t leaf_stride, size_t W,
+                     unsigned log_leaves, unsigned cap_height, size_t leaf_begin, size_t leaf_count,
+                     uint64_t *d_digests, uint64_t *d_cap);
+/* rows of a column-major matrix: d_out[q][c] = d_colmajor[c * col_stride + d_idx[q]]
+ * (PolynomialBatch::get_lde_values / MerkleTree::get, fri/oracle.rs:142-147, merkle_tree.rs:227) */
+int p2hot_gather_rows_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W,
+                          const uint64_t *d_idx, size_t m, uint64_t *d_out);
+
+/* ---------------------------------------------------------------- PolynomialBatch (device pointers) */
+/* PolynomialBatch::from_values (is_values != 0, fri/oracle.rs:57-79) / from_coeffs (:82-112) with
+ * blinding = false, restricted to the leaf rows [row_begin, row_begin + row_count) (whole coset
+ * blocks and whole cap subtrees; pass 0, N for the full commitment).
+ *   d_cols    [W][n] column-major input (values on H_n, or coefficients), stride col_stride
+ *   d_coeffs  [W][n] out: the coefficient form (`polynomials`); may alias d_cols when
+ *             is_values == 0; NULL only when is_values == 0
+ *   d_lde     [W][row_count] out: column-major LDE, rows in committed (bit-reversed) order,
+ *             stride lde_stride -- the device-resident form of MerkleTree::leaves
+ *   d_leaves  [row_count][W] out, row-major copy (the reference's `leaves`), or NULL
+ *   d_digests, d_cap: FULL-tree arrays (see p2hot_merkle_dev) */
+int p2hot_commit_dev(p2hot_ctx *ctx, const uint64_t *d_cols, size_t col_stride, size_t W, unsigned log_n,
+                     unsigned rate_bits, unsigned cap_height, int is_values, size_t row_begin, size_t row_count,
+                     uint64_t *d_coeffs, size_t coeff_stride, uint64_t *d_lde, size_t lde_stride,
+                     uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap);
+
+/* ---------------------------------------------------------------- Challenger (device-resident) */
+/* plonky2/src/iop/challenger.rs:16-153.  The sponge lives on the GPU so FRI rounds need no host
+ * round trip; the host (or the Rust shim) moves its state in and out with load/store. */
+typedef struct {
+    uint64_t sponge_state[12];
+    uint64_t input_buffer[8];
+    uint64_t output_buffer[8];
+    uint32_t input_len, output_len;
+} p2hot_challenger_state;
+typedef struct p2hot_challenger p2hot_challenger;
+int p2hot_challenger_create(p2hot_ctx *ctx, p2hot_challenger **out); /* Challenger::new */
+void p2hot_challenger_destroy(p2hot_challenger *ch);
+int p2hot_challenger_load(p2hot_challenger *ch, const p2hot_challenger_state *host_state);
+int p2hot_challenger_store(p2hot_challenger *ch, p2hot_challenger_state *host_state);
+/* observe_elements (challenger.rs:50-54) then get_n_challenges (:93-95); host pointers; either count may be 0 */
+int p2hot_challenger_step(p2hot_challenger *ch, const uint64_t *observe, size_t n_observe, uint64_t *challenges,
+                          size_t n_challenges);
+
+/* ---------------------------------------------------------------- FRI commit phase */
+/* fri_committed_trees (fri/prover.rs:84-150) including the `lde_final_values` coset FFT of
+ * prove_openings (fri/oracle.rs:215-220).  Host pointers.
+ *   coeffs        [n][2]: the n = 2^log_n nonzero extension coefficients of final_poly (the
+ *                 reference passes them zero-padded to N = n << rate_bits; the padding is implicit here)
+ *   arity_bits    reduction_arity_bits (fri/reduction_strategies.rs:31-59), n_rounds entries
+ *   challenger    advanced exactly like the reference: per round observe_cap then
+ *                 get_extension_challenge; finally observe the final coefficients
+ *   outputs (any may be NULL), concatenated over rounds r with m_r = N >> sum(arity_bits[0..r)):
+ *     leaves_out   m_r * 2 words per round: tree r's leaves (m_r/arity rows of 2*arity words)
+ *     digests_out  4 * p2hot_num_digests(log m_r - arity_bits[r], cap_height) words per round
+ *     caps_out     4 << cap_height words per round
+ *     betas_out    2 words per round
+ *     final_out    [(m_last >> rate_bits)][2], m_last = N >> sum(arity_bits) */
+int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned log_n, unsigned rate_bits,
+                     unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
+                     p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
+                     uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out);
+/* fri_proof_of_work (fri/prover.rs:153-202), deterministic: returns the SMALLEST valid witness
+ * (the reference's rayon find_any returns an arbitrary valid one), observes it and draws the
+ * response like the reference does. */
+int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bits, uint64_t *witness_out);
+
+/* ---------------------------------------------------------------- PolynomialBatch (host pointers) */
+typedef struct p2hot_batch p2hot_batch; /* device-resident PolynomialBatch: coefficients + LDE + tree */
+/* from_values / from_coeffs.  cols: W host pointers to n words each (Vec<PolynomialValues<F>>).
+ * coeffs_out [W][n], leaves_out [N][W], digests_out, cap_out: caller-allocated or NULL.
+ * handle_out (optional): keeps the device-resident batch for p2hot_batch_rows; free with p2hot_batch_free. */
+int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
+                 unsigned cap_height, int is_values, uint64_t *coeffs_out, uint64_t *leaves_out,
+                 uint64_t *digests_out, uint64_t *cap_out, p2hot_batch **handle_out);
+/* MerkleTree::get for m leaf indices (merkle_tree.rs:227): out [m][W] */
+int p2hot_batch_rows(p2hot_batch *batch, const uint64_t *row_idx, size_t m, uint64_t *out);
+void p2hot_batch_free(p2hot_batch *batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

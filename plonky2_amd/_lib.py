@@ -1,0 +1,92 @@
+"""ctypes binding of libp2hot (include/p2hot.h).
+
+The product library is ``plonky2_amd/libp2hot.so`` -- built by ``__graft_entry__.build()`` with
+``hipcc --offload-arch=gfx950`` -- and there is NO CPU fallback: if it is missing, or no GPU is
+visible, importing the engine raises.  ``load(path)`` exists so the test-suite can bind the
+test-only kernel-emulator build (tests/emu) through the very same signatures.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_SO = os.path.join(_HERE, "libp2hot.so")
+
+OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
+_ERR_NAMES = {EINVAL: "EINVAL", ENOMEM: "ENOMEM", EHIP: "EHIP", EUNSUPPORTED: "EUNSUPPORTED"}
+
+vp = C.c_void_p
+sz = C.c_size_t
+u = C.c_uint
+u64 = C.c_uint64
+i = C.c_int
+
+
+class ChallengerState(C.Structure):
+    _fields_ = [("sponge_state", u64 * 12), ("input_buffer", u64 * 8), ("output_buffer", u64 * 8),
+                ("input_len", C.c_uint32), ("output_len", C.c_uint32)]
+
+
+# name -> (restype, argtypes); every symbol include/p2hot.h declares
+SIGNATURES = {
+    "p2hot_ctx_create": (i, [i, vp, C.POINTER(vp)]),
+    "p2hot_ctx_destroy": (None, [vp]),
+    "p2hot_ctx_set_stream": (i, [vp, vp]),
+    "p2hot_ctx_sync": (i, [vp]),
+    "p2hot_last_error": (C.c_char_p, [vp]),
+    "p2hot_version": (C.c_char_p, []),
+    "p2hot_is_emulated": (i, []),
+    "p2hot_num_digests": (sz, [u, u]),
+    "p2hot_fft_dev": (i, [vp, vp, sz, sz, u]),
+    "p2hot_ifft_dev": (i, [vp, vp, sz, sz, u]),
+    "p2hot_coset_lde_dev": (i, [vp, vp, sz, sz, u, u, u64, sz, sz, vp, sz]),
+    "p2hot_transpose_dev": (i, [vp, vp, sz, sz, sz, vp]),
+    "p2hot_reverse_index_bits_dev": (i, [vp, vp, vp, sz, sz, u]),
+    "p2hot_poseidon_permute_dev": (i, [vp, vp, sz]),
+    "p2hot_merkle_dev": (i, [vp, vp, i, sz, sz, u, u, sz, sz, vp, vp]),
+    "p2hot_gather_rows_dev": (i, [vp, vp, sz, sz, vp, sz, vp]),
+    "p2hot_commit_dev": (i, [vp, vp, sz, sz, u, u, u, i, sz, sz, vp, sz, vp, sz, vp, vp, vp]),
+    "p2hot_challenger_create": (i, [vp, C.POINTER(vp)]),
+    "p2hot_challenger_destroy": (None, [vp]),
+    "p2hot_challenger_load": (i, [vp, C.POINTER(ChallengerState)]),
+    "p2hot_challenger_store": (i, [vp, C.POINTER(ChallengerState)]),
+    "p2hot_challenger_step": (i, [vp, vp, sz, vp, sz]),
+    "p2hot_fri_commit": (i, [vp, vp, u, u, u, C.POINTER(u), u, vp, vp, vp, vp, vp, vp]),
+    "p2hot_fri_pow": (i, [vp, vp, u, C.POINTER(u64)]),
+    "p2hot_commit": (i, [vp, C.POINTER(vp), sz, u, u, u, i, vp, vp, vp, vp, C.POINTER(vp)]),
+    "p2hot_batch_rows": (i, [vp, vp, sz, vp]),
+    "p2hot_batch_free": (None, [vp]),
+}
+
+
+class P2HotError(RuntimeError):
+    def __init__(self, code, text):
+        self.code = code
+        super().__init__("libp2hot %s: %s" % (_ERR_NAMES.get(code, code), text))
+
+
+def load(path):
+    """Bind a libp2hot build; raises if any declared symbol is missing."""
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_product = None
+
+
+def product():
+    """The HIP build.  Fails loudly when it has not been built -- there is no fallback."""
+    global _product
+    if _product is None:
+        if not os.path.exists(PRODUCT_SO):
+            raise RuntimeError(
+                "plonky2_amd/libp2hot.so is missing: build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "plonky2_amd has no CPU fallback.")
+        _product = load(PRODUCT_SO)
+        if _product.p2hot_is_emulated():
+            raise RuntimeError("plonky2_amd/libp2hot.so is an emulator build; refusing to use it as the product")
+    return _product

@@ -1,0 +1,101 @@
+// merkle.hpp -- Poseidon leaf sponge and Merkle levels, one permutation per lane.
+//
+// Replaces MerkleTree::new / fill_digests_buf / fill_subtree (plonky2/src/hash/merkle_tree.rs:193-224,
+// :115-149, :86-113) with level-synchronous grid launches that write straight into the reference's
+// digest layout (merkle_tree.rs:50-57): inside a cap subtree with 2^h leaves, node j of level i
+// (level 0 = leaf digests) lives at digest index 2*(((j>>1) << (i+1)) + 2^i - 1) + (j&1); the
+// level-h node is the cap entry.  The same closed form is what merkle_tree_prove (:151-190) walks.
+//
+// Leaves are read through a "reader" so the LDE matrix is consumed where it lies: column-major
+// (lane L reads element (c, L): a wave reads 512 contiguous bytes per column), row-major
+// (MerkleTree::new on caller-provided rows), or the FRI layout (two planes of extension components,
+// leaf c = values[arity*c .. arity*(c+1)) flattened, fri/prover.rs:99-103).
+#pragma once
+#include "poseidon.hpp"
+
+namespace merkle {
+using gl::u32;
+using gl::u64;
+
+struct ColMajorReader {  // element (L, e) = m[e * stride + L]
+    const u64 *m;
+    size_t stride;
+    __device__ __forceinline__ u64 operator()(size_t L, unsigned e) const { return m[(size_t)e * stride + L]; }
+};
+struct RowMajorReader {  // element (L, e) = m[L * W + e]
+    const u64 *m;
+    size_t W;
+    __device__ __forceinline__ u64 operator()(size_t L, unsigned e) const { return m[L * W + e]; }
+};
+struct FriPlanarReader {  // element (L, e) = plane[e & 1][(L << arity_bits) + (e >> 1)]
+    const u64 *p0, *p1;
+    unsigned arity_bits;
+    __device__ __forceinline__ u64 operator()(size_t L, unsigned e) const {
+        const u64 *p = (e & 1) ? p1 : p0;
+        return p[(L << arity_bits) + (e >> 1)];
+    }
+};
+
+// where node j (global index over the forest of subtrees with 2^h leaves each) of `level` goes
+__device__ __forceinline__ u64 *node_slot(u64 *digests, u64 *cap, unsigned h, unsigned level, size_t j) {
+    if (level == h) return cap + 4 * j;
+    size_t s = j >> (h - level);
+    size_t jl = j & (((size_t)1 << (h - level)) - 1);
+    size_t sub_digests = 2 * (((size_t)1 << h) - 1);
+    size_t idx = 2 * (((jl >> 1) << (level + 1)) + ((size_t)1 << level) - 1) + (jl & 1);
+    return digests + 4 * (s * sub_digests + idx);
+}
+
+// hash_or_noop of every leaf (plonk/config.rs:63-74; sponge hashing.rs:118-145: zero state,
+// overwrite-mode absorb of <= 8 elements per permutation, no padding), digest -> level-0 slot.
+template <class Reader>
+__global__ void __launch_bounds__(256) hash_leaves_kernel(Reader rd, unsigned W, size_t n_leaves, unsigned h,
+                                                         u64 *digests, u64 *cap) {
+    size_t L = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= n_leaves) return;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = 0;
+    if (W <= 4) {
+        for (unsigned i = 0; i < W; ++i) s[i] = rd(L, i);
+    } else {
+        for (unsigned off = 0; off < W; off += 8) {
+            unsigned cnt = W - off < 8 ? W - off : 8;
+#pragma unroll
+            for (unsigned i = 0; i < 8; ++i)
+                if (i < cnt) s[i] = rd(L, off + i);
+            poseidon::permute(s);
+        }
+    }
+    u64 *dst = node_slot(digests, cap, h, 0, L);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = gl::canon(s[i]);
+}
+
+// one tree level: node j = two_to_one(children 2j, 2j+1 of level-1) (merkle_tree.rs:108-112)
+__global__ void __launch_bounds__(256) merkle_level_kernel(u64 *digests, u64 *cap, unsigned h, unsigned level,
+                                                          size_t n_nodes) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_nodes) return;
+    const u64 *ch = node_slot(digests, cap, h, level - 1, 2 * j);  // siblings are adjacent
+    u64 out[4];
+    poseidon::two_to_one(ch, ch + 4, out);
+    u64 *dst = node_slot(digests, cap, h, level, j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = out[i];
+}
+
+// batch of raw permutations, states [count][12] (parity primitive for the reference KATs,
+// poseidon_goldilocks.rs:455-490)
+__global__ void permute_batch_kernel(u64 *states, size_t count) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = states[12 * t + i];
+    poseidon::permute(s);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) states[12 * t + i] = gl::canon(s[i]);
+}
+
+}  // namespace merkle

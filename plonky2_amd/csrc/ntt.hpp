@@ -1,0 +1,170 @@
+// ntt.hpp -- batched radix-2 NTT passes over Goldilocks for gfx950, LDS-staged.
+//
+// Replaces field/src/fft.rs (fft_classic :165-202, ifft_with_options :68-91, root tables :14-33),
+// PolynomialCoeffs::lde + coset_fft_with_options (field/src/polynomial/mod.rs:199-201, :280-293),
+// PolynomialBatch::lde_values (plonky2/src/fri/oracle.rs:114-139) and the two bit-reversal /
+// transpose steps of from_coeffs (oracle.rs:97-98; util/src/lib.rs:185-234; plonky2/src/util/mod.rs:25-31).
+//
+// Design (not the reference's per-column in-cache DIT):
+//  * A size-n transform is a chain of "passes".  A pass takes the current blocks of size n' and
+//    performs LOGR decimation-in-frequency layers on the R = 2^LOGR points {blk*n' + i*stride + base}
+//    (stride = n'/R) inside LDS, then multiplies by the inter-pass twiddle w_{n'}^(base * k1)
+//    (four-step factorisation).  A workgroup stages an R x C tile (C consecutive `base` values, so
+//    every global access is a run of C*8 >= 128 bytes); the last pass (stride 1) is a contiguous tile.
+//    Natural-order input gives bit-reversed output with no separate permutation.
+//  * The rate-1/B coset LDE is B independent size-n transforms of coeff[t] * (g * w_N^j)^t (one per
+//    coset j of H_n in H_N).  In the committed, bit-reversed leaf order coset j is exactly the
+//    contiguous row block bitrev_rb(j), already in the order the DIF passes emit: the reference's
+//    zero-padding, the first rb butterfly layers, the transpose and reverse_index_bits all vanish
+//    into addressing.  Cosets are also the multi-GPU sharding unit.
+//  * Twiddles: one two-level table of w_{2^32}^e (2 x 65536 entries, L2 resident) serves every
+//    size: w_{2^k}^e = HI[E >> 16] * LO[E & 0xffff] with E = e << (32 - k); in-tile twiddles have
+//    E & 0xffff == 0 and cost one load.
+#pragma once
+#include "gl.hpp"
+
+namespace ntt {
+using gl::u32;
+using gl::u64;
+
+constexpr unsigned TILE_LOG = 12;  // elements per workgroup tile (32 KiB of LDS)
+constexpr unsigned THREADS = 256;
+
+struct RootTable {  // device pointers, 65536 entries each
+    const u64 *lo;  // w^e,        e < 2^16
+    const u64 *hi;  // w^(e<<16),  e < 2^16
+};
+
+__device__ __forceinline__ u64 root_pow(const RootTable &t, u32 E) {
+    u64 h = t.hi[E >> 16];
+    u32 l = E & 0xFFFFu;
+    return l ? gl::mul(h, t.lo[l]) : h;
+}
+
+// out[k] = base^(k * step + first), used for the root tables and the coset scale tables
+__global__ void pow_table_kernel(u64 *out, size_t count, u64 base, u64 step, u64 first) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    out[k] = gl::canon(gl::pow(base, k * step + first));
+}
+
+enum { SCALE_NONE = 0, SCALE_CONST = 1, SCALE_TABLE = 2 };
+
+struct PassArgs {
+    const u64 *in;
+    u64 *out;
+    size_t in_poly_stride, out_poly_stride;  // elements between polynomials
+    size_t in_z_stride, out_z_stride;        // elements between grid.z slices (coset blocks)
+    unsigned log_n;                          // polynomial size
+    unsigned log_nblk;                       // block size n' at this pass
+    unsigned log_r;                          // layers done by this pass
+    unsigned log_c;                          // tile columns (strided pass); 0 for the contiguous pass
+    RootTable roots;
+    int scale_mode;
+    u64 scale_const;
+    const u64 *srow, *scol;  // SCALE_TABLE: [z][R] and [z][stride]; first pass only (n' == n)
+    int canon_out;           // store canonical representatives (last pass of an LDE)
+};
+
+// One pass on an R x C tile.  grid = (tiles per polynomial, polynomials, z).
+__global__ void __launch_bounds__(THREADS) ntt_pass_kernel(PassArgs a) {
+    P2HOT_DYN_SHARED(u64, tile);
+    const unsigned tid = threadIdx.x;
+    const unsigned R = 1u << a.log_r, logC = a.log_c, C = 1u << logC;
+    const unsigned log_stride = a.log_nblk - a.log_r;
+    const size_t stride = (size_t)1 << log_stride;
+    const unsigned tiles_per_blk_log = log_stride - logC;
+    const size_t tau = blockIdx.x;
+    const size_t blk = tau >> tiles_per_blk_log;
+    const size_t base0 = (tau & (((size_t)1 << tiles_per_blk_log) - 1)) << logC;
+    const size_t z = blockIdx.z;
+    const u64 *in = a.in + (size_t)blockIdx.y * a.in_poly_stride + z * a.in_z_stride + (blk << a.log_nblk) + base0;
+    u64 *out = a.out + (size_t)blockIdx.y * a.out_poly_stride + z * a.out_z_stride + (blk << a.log_nblk) + base0;
+    const unsigned elems = R << logC;
+
+    // load (+ optional scaling): element e -> row i = e >> logC, column c = e & (C-1)
+    for (unsigned e = tid; e < elems; e += THREADS) {
+        unsigned i = e >> logC, c = e & (C - 1);
+        u64 v = in[((size_t)i << log_stride) + c];
+        if (a.scale_mode == SCALE_CONST) {
+            v = gl::mul(v, a.scale_const);
+        } else if (a.scale_mode == SCALE_TABLE) {
+            u64 s = a.srow[z * R + i];
+            if (log_stride) s = gl::mul(s, a.scol[z * stride + base0 + c]);
+            v = gl::mul(v, s);
+        }
+        tile[e] = v;
+    }
+    __syncthreads();
+
+    // LOGR decimation-in-frequency layers along i; twiddle w_R^(j << s) = HI[j << (16 - log_r + s)]
+    for (unsigned s = 0; s < a.log_r; ++s) {
+        const unsigned log_half = a.log_r - s - 1, half = 1u << log_half;
+        for (unsigned e = tid; e < (elems >> 1); e += THREADS) {
+            unsigned p = e >> logC, c = e & (C - 1);
+            unsigned j = p & (half - 1);
+            unsigned i0 = ((p >> log_half) << (log_half + 1)) + j;
+            unsigned x0 = (i0 << logC) + c, x1 = x0 + (half << logC);
+            u64 u = tile[x0], v = tile[x1];
+            u64 w = a.roots.hi[j << (16 - a.log_r + s)];
+            tile[x0] = gl::add(u, v);
+            tile[x1] = gl::mul(gl::sub(u, v), w);
+        }
+        __syncthreads();
+    }
+
+    // inter-pass twiddle w_{n'}^(base * k1), k1 = bitrev_logr(i), then store
+    for (unsigned e = tid; e < elems; e += THREADS) {
+        unsigned i = e >> logC, c = e & (C - 1);
+        u64 v = tile[e];
+        if (log_stride) {
+            u32 k1 = a.log_r ? (__brev(i) >> (32 - a.log_r)) : 0;
+            u64 ex = (u64)(base0 + c) * k1;  // < n'
+            v = gl::mul(v, root_pow(a.roots, (u32)(ex << (32 - a.log_nblk))));
+        }
+        out[((size_t)i << log_stride) + c] = a.canon_out ? gl::canon(v) : v;
+    }
+}
+
+// out[bitrev_log_n(i)] = canon(in[i])   (util/src/lib.rs:53-62 semantics)
+__global__ void bitrev_permute_kernel(const u64 *in, u64 *out, size_t in_poly_stride, size_t out_poly_stride,
+                                      unsigned log_n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> log_n) return;
+    size_t j = log_n ? (size_t)(__brevll((unsigned long long)i) >> (64 - log_n)) : 0;
+    out[(size_t)blockIdx.y * out_poly_stride + j] = gl::canon(in[(size_t)blockIdx.y * in_poly_stride + i]);
+}
+
+__global__ void canon_kernel(u64 *data, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) data[i] = gl::canon(data[i]);
+}
+
+// column-major [W][rows] (stride between columns) -> row-major [rows][W]
+// (plonky2/src/util/mod.rs:25-31 transpose).  64-row x 32-column LDS tile.
+__global__ void __launch_bounds__(256) transpose_kernel(const u64 *in, size_t stride, unsigned W, size_t rows, u64 *out) {
+    __shared__ u64 t[32][65];
+    const size_t r0 = (size_t)blockIdx.x * 64;
+    const unsigned c0 = blockIdx.y * 32;
+    const unsigned tid = threadIdx.x;
+    for (unsigned e = tid; e < 32 * 64; e += 256) {
+        unsigned c = e >> 6, r = e & 63;
+        if (c0 + c < W && r0 + r < rows) t[c][r] = in[(size_t)(c0 + c) * stride + r0 + r];
+    }
+    __syncthreads();
+    for (unsigned e = tid; e < 32 * 64; e += 256) {
+        unsigned r = e >> 5, c = e & 31;
+        if (c0 + c < W && r0 + r < rows) out[(r0 + r) * W + c0 + c] = gl::canon(t[c][r]);
+    }
+}
+
+// out[m][W] = in[c][idx[m]]  (lazy leaf fetch for query openings, oracle.rs:142-147 / merkle_tree.rs:227)
+__global__ void gather_rows_kernel(const u64 *in, size_t stride, unsigned W, const u64 *idx, size_t m, u64 *out) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * W) return;
+    size_t q = e / W;
+    unsigned c = (unsigned)(e % W);
+    out[e] = gl::canon(in[(size_t)c * stride + idx[q]]);
+}
+
+}  // namespace ntt

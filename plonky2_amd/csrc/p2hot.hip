@@ -1,0 +1,732 @@
+// p2hot.hip -- context, pass planning and the C ABI of libp2hot (see include/p2hot.h).
+// One translation unit: the kernels live in ntt.hpp / merkle.hpp / fri.hpp.
+#include "../../include/p2hot.h"
+
+#include <cstdio>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "fri.hpp"
+#include "merkle.hpp"
+#include "ntt.hpp"
+
+using gl::u32;
+using gl::u64;
+
+// ------------------------------------------------------------------ context
+struct p2hot_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    u64 *tables = nullptr;  // fwd_lo, fwd_hi, inv_lo, inv_hi (65536 each)
+    ntt::RootTable fwd{}, inv{};
+    struct Scratch {
+        void *p = nullptr;
+        size_t cap = 0;
+    } scratch[2];
+    // coset scale tables keyed by (log_n, rate_bits, shift, first block, block count, first-pass log_r)
+    std::map<std::tuple<unsigned, unsigned, u64, size_t, size_t, unsigned>, u64 *> scale_cache;
+};
+
+#define P2_FAIL(ctx, code, ...)                           \
+    do {                                                  \
+        char buf_[512];                                   \
+        snprintf(buf_, sizeof buf_, __VA_ARGS__);         \
+        (ctx)->err = buf_;                                \
+        return (code);                                    \
+    } while (0)
+
+#define P2_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            P2_FAIL(ctx, (e_ == hipErrorOutOfMemory ? P2HOT_ENOMEM : P2HOT_EHIP), "%s: %s", #call, \
+                    hipGetErrorString(e_));                                                       \
+    } while (0)
+
+#define P2_TRY(expr)                   \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != P2HOT_OK) return rc_; \
+    } while (0)
+
+#define P2_LAUNCH_CHECK(ctx) P2_HIP(ctx, hipGetLastError())
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+static int scratch_get(p2hot_ctx *ctx, int slot, size_t bytes, void **out) {
+    auto &s = ctx->scratch[slot];
+    if (s.cap < bytes) {
+        if (s.p) {
+            P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            P2_HIP(ctx, hipFree(s.p));
+            s.p = nullptr;
+            s.cap = 0;
+        }
+        P2_HIP(ctx, hipMalloc(&s.p, bytes));
+        s.cap = bytes;
+    }
+    *out = s.p;
+    return P2HOT_OK;
+}
+
+extern "C" const char *p2hot_version(void) { return "p2hot 0.1 (gfx950)"; }
+extern "C" int p2hot_is_emulated(void) {
+#ifdef P2HOT_EMU
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+extern "C" size_t p2hot_num_digests(unsigned log_leaves, unsigned cap_height) {
+    if (cap_height > log_leaves) return 0;
+    return 2 * (((size_t)1 << log_leaves) - ((size_t)1 << cap_height));
+}
+
+extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
+    if (!out) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = new p2hot_ctx();
+    ctx->device = device;
+    *out = ctx;  // returned even on failure so the caller can read last_error, then destroy
+    P2_HIP(ctx, hipSetDevice(device));
+    ctx->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream
+    P2_HIP(ctx, hipMalloc((void **)&ctx->tables, 4 * 65536 * sizeof(u64)));
+    u64 *t = ctx->tables;
+    const u64 w = gl::ROOT_2_32, wi = gl::inv(gl::ROOT_2_32);
+    P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(256), dim3(256), 0, ctx->stream, t, (size_t)65536, w, (u64)1, (u64)0);
+    P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(256), dim3(256), 0, ctx->stream, t + 65536, (size_t)65536, w,
+                 (u64)65536, (u64)0);
+    P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(256), dim3(256), 0, ctx->stream, t + 2 * 65536, (size_t)65536, wi,
+                 (u64)1, (u64)0);
+    P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(256), dim3(256), 0, ctx->stream, t + 3 * 65536, (size_t)65536, wi,
+                 (u64)65536, (u64)0);
+    P2_LAUNCH_CHECK(ctx);
+    ctx->fwd = ntt::RootTable{t, t + 65536};
+    ctx->inv = ntt::RootTable{t + 2 * 65536, t + 3 * 65536};
+    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return P2HOT_OK;
+}
+
+extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->scale_cache) (void)hipFree(kv.second);
+    for (auto &s : ctx->scratch)
+        if (s.p) (void)hipFree(s.p);
+    if (ctx->tables) (void)hipFree(ctx->tables);
+    delete ctx;
+}
+
+extern "C" int p2hot_ctx_set_stream(p2hot_ctx *ctx, void *hip_stream) {
+    if (!ctx) return P2HOT_EINVAL;
+    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = (hipStream_t)hip_stream;
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_ctx_sync(p2hot_ctx *ctx) {
+    if (!ctx) return P2HOT_EINVAL;
+    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return P2HOT_OK;
+}
+
+extern "C" const char *p2hot_last_error(const p2hot_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// ------------------------------------------------------------------ NTT pass planning
+struct Pass {
+    unsigned log_r, log_c;
+};
+
+static std::vector<Pass> plan_passes(unsigned log_n) {
+    std::vector<Pass> p;
+    if (log_n <= ntt::TILE_LOG) {
+        p.push_back({log_n, 0});
+        return p;
+    }
+    unsigned rem = log_n - ntt::TILE_LOG;
+    unsigned k = (rem + 7) / 8;
+    for (unsigned i = 0; i < k; ++i) {
+        unsigned part = rem / (k - i);
+        if (rem % (k - i)) ++part;
+        p.push_back({part, ntt::TILE_LOG - part});
+        rem -= part;
+    }
+    p.push_back({ntt::TILE_LOG, 0});
+    return p;
+}
+
+// Runs the DIF chain: natural-order input -> bit-reversed output (per polynomial, per z slice).
+// The first pass reads `in` (no z offset: every z slice reads the same polynomials) and writes
+// `out`; later passes run in place on `out`.
+static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, size_t out_stride, size_t out_z_stride,
+                   size_t batch, size_t zcount, unsigned log_n, const ntt::RootTable &roots, int scale_mode,
+                   u64 scale_const, const u64 *srow, const u64 *scol, bool canon_last) {
+    if (batch == 0 || zcount == 0) return P2HOT_OK;
+    if (batch > 65535 || zcount > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "batch %zu / z %zu exceed the grid limit", batch, zcount);
+    std::vector<Pass> passes = plan_passes(log_n);
+    unsigned log_nblk = log_n;
+    for (size_t i = 0; i < passes.size(); ++i) {
+        ntt::PassArgs a{};
+        const bool first = i == 0;
+        a.in = first ? in : out;
+        a.out = out;
+        a.in_poly_stride = first ? in_stride : out_stride;
+        a.in_z_stride = first ? 0 : out_z_stride;
+        a.out_poly_stride = out_stride;
+        a.out_z_stride = out_z_stride;
+        a.log_n = log_n;
+        a.log_nblk = log_nblk;
+        a.log_r = passes[i].log_r;
+        a.log_c = passes[i].log_c;
+        a.roots = roots;
+        a.scale_mode = first ? scale_mode : ntt::SCALE_NONE;
+        a.scale_const = scale_const;
+        a.srow = srow;
+        a.scol = scol;
+        a.canon_out = (canon_last && i + 1 == passes.size()) ? 1 : 0;
+        const unsigned tiles_log = log_n - a.log_r - a.log_c;
+        dim3 grid(1u << tiles_log, (unsigned)batch, (unsigned)zcount);
+        size_t shmem = ((size_t)8) << (a.log_r + a.log_c);
+        P2HOT_LAUNCH(ntt::ntt_pass_kernel, grid, dim3(ntt::THREADS), shmem, ctx->stream, a);
+        P2_LAUNCH_CHECK(ctx);
+        log_nblk -= a.log_r;
+    }
+    return P2HOT_OK;
+}
+
+static unsigned first_pass_log_r(unsigned log_n) { return plan_passes(log_n)[0].log_r; }
+
+static size_t bitrev_sz(size_t x, unsigned bits) {
+    size_t r = 0;
+    for (unsigned i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// ------------------------------------------------------------------ primitives
+static int check_log(p2hot_ctx *ctx, unsigned log_n, const char *what) {
+    if (log_n > 32) P2_FAIL(ctx, P2HOT_EINVAL, "%s: 2^%u exceeds the two-adicity of the field (fft.rs:171-177)", what, log_n);
+    return P2HOT_OK;
+}
+
+static int ntt_natural(p2hot_ctx *ctx, u64 *d_data, size_t batch, size_t stride, unsigned log_n, bool inverse) {
+    if (!ctx) return P2HOT_EINVAL;
+    P2_TRY(check_log(ctx, log_n, "ntt"));
+    const size_t n = (size_t)1 << log_n;
+    if (batch == 0) return P2HOT_OK;
+    if (!d_data || stride < n) P2_FAIL(ctx, P2HOT_EINVAL, "ntt: null data or stride < n");
+    u64 *tmp;
+    P2_TRY(scratch_get(ctx, 0, batch * n * 8, (void **)&tmp));
+    u64 n_inv = gl::inv(n % gl::P);
+    P2_TRY(run_dif(ctx, d_data, stride, tmp, n, 0, batch, 1, log_n, inverse ? ctx->inv : ctx->fwd,
+                   inverse ? ntt::SCALE_CONST : ntt::SCALE_NONE, n_inv, nullptr, nullptr, false));
+    P2HOT_LAUNCH(ntt::bitrev_permute_kernel, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, tmp,
+                 d_data, n, stride, log_n);
+    P2_LAUNCH_CHECK(ctx);
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_fft_dev(p2hot_ctx *ctx, uint64_t *d_data, size_t batch, size_t poly_stride, unsigned log_n) {
+    return ntt_natural(ctx, d_data, batch, poly_stride, log_n, false);
+}
+
+extern "C" int p2hot_ifft_dev(p2hot_ctx *ctx, uint64_t *d_data, size_t batch, size_t poly_stride, unsigned log_n) {
+    return ntt_natural(ctx, d_data, batch, poly_stride, log_n, true);
+}
+
+// scale tables for row blocks [b0, b0 + zc): block b is coset j = bitrev_rb(b), s_b = shift * w_N^j;
+// srow[z][i] = s_b^(i * stride), scol[z][base] = s_b^base
+static int coset_scale_tables(p2hot_ctx *ctx, unsigned log_n, unsigned rate_bits, u64 shift, size_t b0, size_t zc,
+                              const u64 **srow, const u64 **scol) {
+    const unsigned log_r = first_pass_log_r(log_n);
+    auto key = std::make_tuple(log_n, rate_bits, shift, b0, zc, log_r);
+    const size_t R = (size_t)1 << log_r, stride = (size_t)1 << (log_n - log_r);
+    auto it = ctx->scale_cache.find(key);
+    u64 *t;
+    if (it != ctx->scale_cache.end()) {
+        t = it->second;
+    } else {
+        P2_HIP(ctx, hipMalloc((void **)&t, zc * (R + stride) * 8));
+        const u64 wN = gl::root_of_unity(log_n + rate_bits);
+        for (size_t z = 0; z < zc; ++z) {
+            u64 s = gl::mul(shift, gl::pow(wN, bitrev_sz(b0 + z, rate_bits)));
+            P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(cdiv(R, 256)), dim3(256), 0, ctx->stream, t + z * R, R, s,
+                         (u64)stride, (u64)0);
+            P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(cdiv(stride, 256)), dim3(256), 0, ctx->stream,
+                         t + zc * R + z * stride, stride, s, (u64)1, (u64)0);
+        }
+        P2_LAUNCH_CHECK(ctx);
+        ctx->scale_cache[key] = t;
+    }
+    *srow = t;
+    *scol = t + zc * R;
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_coset_lde_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, size_t W, size_t coeff_stride,
+                                   unsigned log_n, unsigned rate_bits, uint64_t shift, size_t row_begin,
+                                   size_t row_count, uint64_t *d_lde, size_t lde_stride) {
+    if (!ctx) return P2HOT_EINVAL;
+    P2_TRY(check_log(ctx, log_n + rate_bits, "coset_lde"));
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    if (W == 0 || row_count == 0) return P2HOT_OK;
+    if (!d_coeffs || !d_lde || coeff_stride < n || lde_stride < row_count)
+        P2_FAIL(ctx, P2HOT_EINVAL, "coset_lde: null pointer or stride too small");
+    if (row_begin % n || row_count % n || row_begin + row_count > N)
+        P2_FAIL(ctx, P2HOT_EINVAL, "coset_lde: rows [%zu,+%zu) are not whole coset blocks of %zu", row_begin, row_count, n);
+    const size_t b0 = row_begin >> log_n, zc = row_count >> log_n;
+    const u64 *srow, *scol;
+    P2_TRY(coset_scale_tables(ctx, log_n, rate_bits, shift, b0, zc, &srow, &scol));
+    return run_dif(ctx, d_coeffs, coeff_stride, d_lde, lde_stride, n, W, zc, log_n, ctx->fwd, ntt::SCALE_TABLE, 0, srow,
+                   scol, true);
+}
+
+extern "C" int p2hot_transpose_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W,
+                                   size_t rows, uint64_t *d_rowmajor) {
+    if (!ctx) return P2HOT_EINVAL;
+    if (W == 0 || rows == 0) return P2HOT_OK;
+    if (!d_colmajor || !d_rowmajor || col_stride < rows) P2_FAIL(ctx, P2HOT_EINVAL, "transpose: bad arguments");
+    if (cdiv(W, 32) > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "transpose: W too large");
+    P2HOT_LAUNCH(ntt::transpose_kernel, dim3(cdiv(rows, 64), cdiv(W, 32)), dim3(256), 0, ctx->stream, d_colmajor,
+                 col_stride, (unsigned)W, rows, d_rowmajor);
+    P2_LAUNCH_CHECK(ctx);
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_reverse_index_bits_dev(p2hot_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t batch,
+                                            size_t poly_stride, unsigned log_n) {
+    if (!ctx) return P2HOT_EINVAL;
+    if (batch == 0) return P2HOT_OK;
+    const size_t n = (size_t)1 << log_n;
+    if (!d_in || !d_out || d_in == d_out || poly_stride < n || batch > 65535)
+        P2_FAIL(ctx, P2HOT_EINVAL, "reverse_index_bits: bad arguments (out of place only)");
+    P2HOT_LAUNCH(ntt::bitrev_permute_kernel, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_in,
+                 d_out, poly_stride, poly_stride, log_n);
+    P2_LAUNCH_CHECK(ctx);
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_poseidon_permute_dev(p2hot_ctx *ctx, uint64_t *d_states, size_t count) {
+    if (!ctx) return P2HOT_EINVAL;
+    if (count == 0) return P2HOT_OK;
+    if (!d_states) P2_FAIL(ctx, P2HOT_EINVAL, "poseidon_permute: null states");
+    P2HOT_LAUNCH(merkle::permute_batch_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, d_states, count);
+    P2_LAUNCH_CHECK(ctx);
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_gather_rows_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W,
+                                     const uint64_t *d_idx, size_t m, uint64_t *d_out) {
+    if (!ctx) return P2HOT_EINVAL;
+    if (W == 0 || m == 0) return P2HOT_OK;
+    if (!d_colmajor || !d_idx || !d_out) P2_FAIL(ctx, P2HOT_EINVAL, "gather_rows: null pointer");
+    P2HOT_LAUNCH(ntt::gather_rows_kernel, dim3(cdiv(m * W, 256)), dim3(256), 0, ctx->stream, d_colmajor, col_stride,
+                 (unsigned)W, d_idx, m, d_out);
+    P2_LAUNCH_CHECK(ctx);
+    return P2HOT_OK;
+}
+
+// ------------------------------------------------------------------ Merkle
+template <class Reader>
+static int merkle_forest(p2hot_ctx *ctx, Reader rd, size_t W, unsigned log_leaves, unsigned cap_height,
+                         size_t leaf_begin, size_t leaf_count, u64 *d_digests, u64 *d_cap) {
+    if (cap_height > log_leaves)
+        P2_FAIL(ctx, P2HOT_EINVAL, "cap_height %u > log2(leaves) %u (merkle_tree.rs:195-200)", cap_height, log_leaves);
+    const unsigned h = log_leaves - cap_height;
+    const size_t sub_leaves = (size_t)1 << h, n_leaves = (size_t)1 << log_leaves;
+    if (leaf_count == 0) return P2HOT_OK;
+    if (leaf_begin % sub_leaves || leaf_count % sub_leaves || leaf_begin + leaf_count > n_leaves)
+        P2_FAIL(ctx, P2HOT_EINVAL, "merkle: leaves [%zu,+%zu) are not whole cap subtrees of %zu", leaf_begin, leaf_count,
+                sub_leaves);
+    if (!d_cap || (h > 0 && !d_digests)) P2_FAIL(ctx, P2HOT_EINVAL, "merkle: null output");
+    const size_t s0 = leaf_begin >> h;
+    u64 *dig = d_digests ? d_digests + 4 * s0 * (2 * (sub_leaves - 1)) : nullptr;
+    u64 *cap = d_cap + 4 * s0;
+    P2HOT_LAUNCH((merkle::hash_leaves_kernel<Reader>), dim3(cdiv(leaf_count, 256)), dim3(256), 0, ctx->stream, rd,
+                 (unsigned)W, leaf_count, h, dig, cap);
+    P2_LAUNCH_CHECK(ctx);
+    for (unsigned level = 1; level <= h; ++level) {
+        size_t nodes = leaf_count >> level;
+        P2HOT_LAUNCH(merkle::merkle_level_kernel, dim3(cdiv(nodes, 256)), dim3(256), 0, ctx->stream, dig, cap, h, level,
+                     nodes);
+        P2_LAUNCH_CHECK(ctx);
+    }
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_merkle_dev(p2hot_ctx *ctx, const uint64_t *d_leaves, int layout, size_t leaf_stride, size_t W,
+                                unsigned log_leaves, unsigned cap_height, size_t leaf_begin, size_t leaf_count,
+                                uint64_t *d_digests, uint64_t *d_cap) {
+    if (!ctx) return P2HOT_EINVAL;
+    if (W > 0 && !d_leaves) P2_FAIL(ctx, P2HOT_EINVAL, "merkle: null leaves");
+    if (W > 0xFFFFFFFFull) P2_FAIL(ctx, P2HOT_EINVAL, "merkle: leaf too wide");
+    if (layout == 0) {
+        if (W > 0 && leaf_stride < leaf_count) P2_FAIL(ctx, P2HOT_EINVAL, "merkle: leaf_stride < leaf_count");
+        return merkle_forest(ctx, merkle::ColMajorReader{d_leaves, leaf_stride}, W, log_leaves, cap_height, leaf_begin,
+                             leaf_count, d_digests, d_cap);
+    } else if (layout == 1) {
+        return merkle_forest(ctx, merkle::RowMajorReader{d_leaves, W}, W, log_leaves, cap_height, leaf_begin, leaf_count,
+                             d_digests, d_cap);
+    }
+    P2_FAIL(ctx, P2HOT_EINVAL, "merkle: unknown layout %d", layout);
+}
+
+// ------------------------------------------------------------------ PolynomialBatch
+extern "C" int p2hot_commit_dev(p2hot_ctx *ctx, const uint64_t *d_cols, size_t col_stride, size_t W, unsigned log_n,
+                                unsigned rate_bits, unsigned cap_height, int is_values, size_t row_begin,
+                                size_t row_count, uint64_t *d_coeffs, size_t coeff_stride, uint64_t *d_lde,
+                                size_t lde_stride, uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap) {
+    if (!ctx) return P2HOT_EINVAL;
+    P2_TRY(check_log(ctx, log_n + rate_bits, "commit"));
+    const size_t n = (size_t)1 << log_n;
+    const unsigned log_N = log_n + rate_bits;
+    if (W > 0 && (!d_cols || col_stride < n)) P2_FAIL(ctx, P2HOT_EINVAL, "commit: null columns or stride < n");
+    if (W > 0 && !d_lde) P2_FAIL(ctx, P2HOT_EINVAL, "commit: d_lde is required");
+    const u64 *coeff_src = d_cols;
+    size_t coeff_src_stride = col_stride;
+    if (is_values) {
+        // "IFFT" (oracle.rs:65-69): DIF chain with inverse roots and n^-1, then bit-reverse into d_coeffs
+        if (W > 0) {
+            if (!d_coeffs || coeff_stride < n) P2_FAIL(ctx, P2HOT_EINVAL, "commit: d_coeffs is required for from_values");
+            u64 *tmp;
+            P2_TRY(scratch_get(ctx, 0, W * n * 8, (void **)&tmp));
+            P2_TRY(run_dif(ctx, d_cols, col_stride, tmp, n, 0, W, 1, log_n, ctx->inv, ntt::SCALE_CONST,
+                           gl::inv(n % gl::P), nullptr, nullptr, false));
+            P2HOT_LAUNCH(ntt::bitrev_permute_kernel, dim3(cdiv(n, 256), (unsigned)W), dim3(256), 0, ctx->stream, tmp,
+                         d_coeffs, n, coeff_stride, log_n);
+            P2_LAUNCH_CHECK(ctx);
+        }
+        coeff_src = d_coeffs;
+        coeff_src_stride = coeff_stride;
+    } else if (d_coeffs && d_coeffs != d_cols && W > 0) {
+        if (coeff_stride < n) P2_FAIL(ctx, P2HOT_EINVAL, "commit: coeff_stride < n");
+        for (size_t c = 0; c < W; ++c)
+            P2_HIP(ctx, hipMemcpyAsync(d_coeffs + c * coeff_stride, d_cols + c * col_stride, n * 8,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // "FFT + blinding" + "transpose LDEs" + reverse_index_bits (oracle.rs:91-98)
+    P2_TRY(p2hot_coset_lde_dev(ctx, coeff_src, W, coeff_src_stride, log_n, rate_bits, gl::COSET_SHIFT, row_begin,
+                               row_count, d_lde, lde_stride));
+    // "build Merkle tree" (oracle.rs:99-103)
+    P2_TRY(p2hot_merkle_dev(ctx, d_lde, 0, lde_stride, W, log_N, cap_height, row_begin, row_count, d_digests, d_cap));
+    if (d_leaves) P2_TRY(p2hot_transpose_dev(ctx, d_lde, lde_stride, W, row_count, d_leaves));
+    return P2HOT_OK;
+}
+
+// ------------------------------------------------------------------ Challenger
+struct p2hot_challenger {
+    p2hot_ctx *ctx;
+    fri::Challenger *d;
+    u64 *d_io;  // small staging buffer
+    size_t io_cap;
+};
+
+static int challenger_io(p2hot_challenger *ch, size_t words, u64 **out) {
+    p2hot_ctx *ctx = ch->ctx;
+    if (ch->io_cap < words) {
+        if (ch->d_io) {
+            P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            P2_HIP(ctx, hipFree(ch->d_io));
+            ch->d_io = nullptr;
+            ch->io_cap = 0;
+        }
+        size_t cap = words < 1024 ? 1024 : words;
+        P2_HIP(ctx, hipMalloc((void **)&ch->d_io, cap * 8));
+        ch->io_cap = cap;
+    }
+    *out = ch->d_io;
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_challenger_create(p2hot_ctx *ctx, p2hot_challenger **out) {
+    if (!ctx || !out) return P2HOT_EINVAL;
+    p2hot_challenger *ch = new p2hot_challenger{ctx, nullptr, nullptr, 0};
+    hipError_t e = hipMalloc((void **)&ch->d, sizeof(fri::Challenger));
+    if (e != hipSuccess) {
+        delete ch;
+        P2_FAIL(ctx, P2HOT_ENOMEM, "challenger: hipMalloc failed");
+    }
+    e = hipMemsetAsync(ch->d, 0, sizeof(fri::Challenger), ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(ch->d);
+        delete ch;
+        P2_FAIL(ctx, P2HOT_EHIP, "challenger: memset failed");
+    }
+    *out = ch;
+    return P2HOT_OK;
+}
+
+extern "C" void p2hot_challenger_destroy(p2hot_challenger *ch) {
+    if (!ch) return;
+    (void)hipStreamSynchronize(ch->ctx->stream);
+    if (ch->d_io) (void)hipFree(ch->d_io);
+    (void)hipFree(ch->d);
+    delete ch;
+}
+
+static_assert(sizeof(p2hot_challenger_state) == sizeof(fri::Challenger), "challenger state layout");
+
+extern "C" int p2hot_challenger_load(p2hot_challenger *ch, const p2hot_challenger_state *st) {
+    if (!ch || !st) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = ch->ctx;
+    if (st->input_len >= 8 || st->output_len > 8) P2_FAIL(ctx, P2HOT_EINVAL, "challenger: buffer lengths out of range");
+    P2_HIP(ctx, hipMemcpyAsync(ch->d, st, sizeof *st, hipMemcpyHostToDevice, ctx->stream));
+    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_challenger_store(p2hot_challenger *ch, p2hot_challenger_state *st) {
+    if (!ch || !st) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = ch->ctx;
+    P2_HIP(ctx, hipMemcpyAsync(st, ch->d, sizeof *st, hipMemcpyDeviceToHost, ctx->stream));
+    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return P2HOT_OK;
+}
+
+// device-side step: observe d_obs[0..n_obs), squeeze n_get challenges into d_out
+static int challenger_step_dev(p2hot_challenger *ch, const u64 *d_obs, size_t n_obs, u64 *d_out, size_t n_get) {
+    p2hot_ctx *ctx = ch->ctx;
+    if (n_obs == 0 && n_get == 0) return P2HOT_OK;
+    P2HOT_LAUNCH(fri::challenger_kernel, dim3(1), dim3(64), 0, ctx->stream, ch->d, d_obs, n_obs, d_out, n_get);
+    P2_LAUNCH_CHECK(ctx);
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_challenger_step(p2hot_challenger *ch, const uint64_t *observe, size_t n_observe,
+                                     uint64_t *challenges, size_t n_challenges) {
+    if (!ch) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = ch->ctx;
+    if ((n_observe && !observe) || (n_challenges && !challenges)) P2_FAIL(ctx, P2HOT_EINVAL, "challenger: null buffer");
+    u64 *io;
+    P2_TRY(challenger_io(ch, n_observe + n_challenges, &io));
+    if (n_observe) P2_HIP(ctx, hipMemcpyAsync(io, observe, n_observe * 8, hipMemcpyHostToDevice, ctx->stream));
+    P2_TRY(challenger_step_dev(ch, io, n_observe, io + n_observe, n_challenges));
+    if (n_challenges)
+        P2_HIP(ctx, hipMemcpyAsync(challenges, io + n_observe, n_challenges * 8, hipMemcpyDeviceToHost, ctx->stream));
+    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return P2HOT_OK;
+}
+
+// ------------------------------------------------------------------ FRI commit phase
+namespace {
+struct DevBuf {  // frees on scope exit (after a stream sync by the owner)
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    u64 *u() const { return (u64 *)p; }
+};
+}  // namespace
+
+extern "C" int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned log_n, unsigned rate_bits,
+                                unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
+                                p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
+                                uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
+    if (!ctx || !challenger || challenger->ctx != ctx) return P2HOT_EINVAL;
+    P2_TRY(check_log(ctx, log_n + rate_bits, "fri_commit"));
+    if (!coeffs || (n_rounds && !arity_bits)) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit: null input");
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    // validate the schedule before touching the device
+    {
+        unsigned lm = log_n + rate_bits, ln = log_n;
+        for (unsigned r = 0; r < n_rounds; ++r) {
+            unsigned ab = arity_bits[r];
+            if (ab == 0 || ab > ln) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit: round %u arity 2^%u does not divide the degree bound", r, ab);
+            if (lm - ab < cap_height)
+                P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit: round %u tree has fewer leaves than the cap (merkle_tree.rs:195-200)", r);
+            lm -= ab;
+            ln -= ab;
+        }
+    }
+    DevBuf stage, planes_a, planes_b, values, leaves, digests, cap, beta;
+    P2_HIP(ctx, hipMalloc(&stage.p, n * 16));
+    P2_HIP(ctx, hipMalloc(&planes_a.p, n * 16));
+    P2_HIP(ctx, hipMalloc(&planes_b.p, n * 16));
+    P2_HIP(ctx, hipMalloc(&values.p, N * 16));
+    P2_HIP(ctx, hipMalloc(&leaves.p, N * 16));
+    const size_t cap_words = (size_t)4 << cap_height;
+    P2_HIP(ctx, hipMalloc(&digests.p, (N > 1 ? N : 1) * 8 * 4));  // >= 2*(N/2 - cap) digests of 32 B
+    P2_HIP(ctx, hipMalloc(&cap.p, cap_words * 8));
+    P2_HIP(ctx, hipMalloc(&beta.p, 16));
+    int rc = P2HOT_OK;
+    auto body = [&]() -> int {
+        P2_HIP(ctx, hipMemcpyAsync(stage.p, coeffs, n * 16, hipMemcpyHostToDevice, ctx->stream));
+        u64 *cur = planes_a.u(), *nxt = planes_b.u();
+        size_t cur_n = n;  // plane length (= plane stride)
+        P2HOT_LAUNCH(fri::deinterleave_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, stage.u(), n, cur, cur + n);
+        P2_LAUNCH_CHECK(ctx);
+        u64 shift = gl::COSET_SHIFT;
+        size_t m = N;
+        unsigned log_cur = log_n;
+        for (unsigned r = 0; r < n_rounds; ++r) {
+            const unsigned ab = arity_bits[r];
+            // values = coeffs.lde(rate_bits).coset_fft(shift), rows in bit-reversed order
+            // (oracle.rs:215-220 for round 0, prover.rs:119 afterwards; prover.rs:98 reverse_index_bits)
+            u64 *v0 = values.u(), *v1 = v0 + m;
+            P2_TRY(p2hot_coset_lde_dev(ctx, cur, 2, cur_n, log_cur, rate_bits, shift, 0, m, v0, m));
+            if (leaves_out) {
+                P2HOT_LAUNCH(fri::interleave_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, v0, v1, m, leaves.u());
+                P2_LAUNCH_CHECK(ctx);
+                P2_HIP(ctx, hipMemcpyAsync(leaves_out, leaves.p, m * 16, hipMemcpyDeviceToHost, ctx->stream));
+                leaves_out += 2 * m;
+            }
+            // prover.rs:99-104: chunk(arity) + flatten -> MerkleTree::new
+            const unsigned log_leaves = log_cur + rate_bits - ab;
+            const size_t n_leaves = (size_t)1 << log_leaves;
+            P2_TRY(merkle_forest(ctx, merkle::FriPlanarReader{v0, v1, ab}, (size_t)2 << ab, log_leaves, cap_height, 0,
+                                 n_leaves, digests.u(), cap.u()));
+            const size_t nd = p2hot_num_digests(log_leaves, cap_height);
+            if (digests_out) {
+                if (nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, digests.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
+                digests_out += 4 * nd;
+            }
+            if (caps_out) {
+                P2_HIP(ctx, hipMemcpyAsync(caps_out, cap.p, cap_words * 8, hipMemcpyDeviceToHost, ctx->stream));
+                caps_out += cap_words;
+            }
+            // prover.rs:106-109: observe_cap, beta = get_extension_challenge (stays on the device)
+            P2_TRY(challenger_step_dev(challenger, cap.u(), cap_words, beta.u(), 2));
+            if (betas_out) {
+                P2_HIP(ctx, hipMemcpyAsync(betas_out, beta.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+                betas_out += 2;
+            }
+            // prover.rs:111-118: fold the coefficients, shift <- shift^arity
+            const size_t out_n = cur_n >> ab;
+            P2HOT_LAUNCH(fri::fold_kernel, dim3(cdiv(out_n, 256)), dim3(256), 0, ctx->stream, cur, cur + cur_n, ab,
+                         beta.u(), out_n, nxt, nxt + out_n);
+            P2_LAUNCH_CHECK(ctx);
+            u64 *t = cur;
+            cur = nxt;
+            nxt = t;
+            cur_n = out_n;
+            log_cur -= ab;
+            m >>= ab;
+            shift = gl::pow(shift, (u64)1 << ab);
+        }
+        // prover.rs:135-139: final_poly = the remaining coefficients, observed by the challenger
+        P2HOT_LAUNCH(fri::interleave_kernel, dim3(cdiv(cur_n, 256)), dim3(256), 0, ctx->stream, cur, cur + cur_n, cur_n,
+                     stage.u());
+        P2_LAUNCH_CHECK(ctx);
+        P2_TRY(challenger_step_dev(challenger, stage.u(), 2 * cur_n, nullptr, 0));
+        if (final_out) P2_HIP(ctx, hipMemcpyAsync(final_out, stage.p, cur_n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        return P2HOT_OK;
+    };
+    rc = body();
+    hipError_t e = hipStreamSynchronize(ctx->stream);  // buffers are freed on return
+    if (rc == P2HOT_OK && e != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "fri_commit: %s", hipGetErrorString(e));
+    return rc;
+}
+
+extern "C" int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bits, uint64_t *witness_out) {
+    if (!ctx || !challenger || challenger->ctx != ctx || !witness_out) return P2HOT_EINVAL;
+    if (pow_bits > 64) P2_FAIL(ctx, P2HOT_EINVAL, "fri_pow: pow_bits > 64");
+    u64 *io;
+    P2_TRY(challenger_io(challenger, 8, &io));
+    unsigned long long best = ~0ull;
+    P2_HIP(ctx, hipMemcpyAsync(io, &best, 8, hipMemcpyHostToDevice, ctx->stream));
+    // candidates 0 ..= P-1 in the reference (prover.rs:182); expected hit after ~2^pow_bits tries.
+    // Chunks double from 2^14 so that small grinds do not pay for a large launch.
+    u64 chunk = (u64)1 << 14;
+    for (u64 start = 0; start < gl::P;) {
+        u64 count = gl::P - start < chunk ? gl::P - start : chunk;
+        P2HOT_LAUNCH(fri::pow_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, challenger->d, pow_bits, start,
+                     count, (unsigned long long *)io);
+        P2_LAUNCH_CHECK(ctx);
+        P2_HIP(ctx, hipMemcpyAsync(&best, io, 8, hipMemcpyDeviceToHost, ctx->stream));
+        P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (best != ~0ull) break;
+        start += count;
+        if (chunk < ((u64)1 << 24)) chunk <<= 1;
+    }
+    if (best == ~0ull) P2_FAIL(ctx, P2HOT_EUNSUPPORTED, "fri_pow: no witness found");
+    *witness_out = best;
+    u64 w = best, resp;
+    return p2hot_challenger_step(challenger, &w, 1, &resp, 1);  // prover.rs:197-198
+}
+
+// ------------------------------------------------------------------ PolynomialBatch, host pointers
+struct p2hot_batch {
+    p2hot_ctx *ctx;
+    u64 *d_lde;
+    size_t W, N;
+};
+
+extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
+                            unsigned cap_height, int is_values, uint64_t *coeffs_out, uint64_t *leaves_out,
+                            uint64_t *digests_out, uint64_t *cap_out, p2hot_batch **handle_out) {
+    if (!ctx) return P2HOT_EINVAL;
+    if (handle_out) *handle_out = nullptr;
+    P2_TRY(check_log(ctx, log_n + rate_bits, "commit"));
+    if (W > 0 && !cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit: null column table");
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    const unsigned log_N = log_n + rate_bits;
+    if (cap_height > log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit: cap_height %u > log2(N) %u (merkle_tree.rs:195-200)", cap_height, log_N);
+    const size_t nd = p2hot_num_digests(log_N, cap_height), cap_words = (size_t)4 << cap_height;
+    DevBuf d_cols, d_coeffs, d_lde, d_leaves, d_dig, d_cap;
+    const size_t Wn = (W ? W : 1) * n * 8, WN = (W ? W : 1) * N * 8;
+    P2_HIP(ctx, hipMalloc(&d_cols.p, Wn));
+    if (is_values) P2_HIP(ctx, hipMalloc(&d_coeffs.p, Wn));
+    P2_HIP(ctx, hipMalloc(&d_lde.p, WN));
+    if (leaves_out) P2_HIP(ctx, hipMalloc(&d_leaves.p, WN));
+    P2_HIP(ctx, hipMalloc(&d_dig.p, (nd ? nd : 1) * 32));
+    P2_HIP(ctx, hipMalloc(&d_cap.p, cap_words * 8));
+    auto body = [&]() -> int {
+        for (size_t c = 0; c < W; ++c) {
+            if (!cols[c]) P2_FAIL(ctx, P2HOT_EINVAL, "commit: column %zu is null", c);
+            P2_HIP(ctx, hipMemcpyAsync(d_cols.u() + c * n, cols[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
+        P2_TRY(p2hot_commit_dev(ctx, d_cols.u(), n, W, log_n, rate_bits, cap_height, is_values, 0, N, d_coeffs.u(), n,
+                                d_lde.u(), N, d_leaves.u(), d_dig.u(), d_cap.u()));
+        if (coeffs_out && W) {
+            if (is_values) {
+                P2_HIP(ctx, hipMemcpyAsync(coeffs_out, d_coeffs.p, W * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+            } else {
+                P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(W * n, 256)), dim3(256), 0, ctx->stream, d_cols.u(), W * n);
+                P2_LAUNCH_CHECK(ctx);
+                P2_HIP(ctx, hipMemcpyAsync(coeffs_out, d_cols.p, W * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+            }
+        }
+        if (leaves_out && W) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, W * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (digests_out && nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
+        if (cap_out) P2_HIP(ctx, hipMemcpyAsync(cap_out, d_cap.p, cap_words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        return P2HOT_OK;
+    };
+    int rc = body();
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (rc == P2HOT_OK && e != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "commit: %s", hipGetErrorString(e));
+    if (rc == P2HOT_OK && handle_out) {
+        *handle_out = new p2hot_batch{ctx, d_lde.u(), W, N};
+        d_lde.p = nullptr;  // ownership moves to the handle
+    }
+    return rc;
+}
+
+extern "C" int p2hot_batch_rows(p2hot_batch *b, const uint64_t *row_idx, size_t m, uint64_t *out) {
+    if (!b) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = b->ctx;
+    if (m == 0 || b->W == 0) return P2HOT_OK;
+    if (!row_idx || !out) P2_FAIL(ctx, P2HOT_EINVAL, "batch_rows: null buffer");
+    for (size_t i = 0; i < m; ++i)
+        if (row_idx[i] >= b->N) P2_FAIL(ctx, P2HOT_EINVAL, "batch_rows: index %llu out of range", (unsigned long long)row_idx[i]);
+    DevBuf d_idx, d_out;
+    P2_HIP(ctx, hipMalloc(&d_idx.p, m * 8));
+    P2_HIP(ctx, hipMalloc(&d_out.p, m * b->W * 8));
+    P2_HIP(ctx, hipMemcpyAsync(d_idx.p, row_idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = p2hot_gather_rows_dev(ctx, b->d_lde, b->N, b->W, d_idx.u(), m, d_out.u());
+    if (rc == P2HOT_OK) {
+        hipError_t e = hipMemcpyAsync(out, d_out.p, m * b->W * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = P2HOT_EHIP;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
+extern "C" void p2hot_batch_free(p2hot_batch *b) {
+    if (!b) return;
+    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipFree(b->d_lde);
+    delete b;
+}

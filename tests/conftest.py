@@ -1,11 +1,14 @@
 import os
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+P = 0xFFFFFFFF00000001
 
 
 def pytest_configure(config):
@@ -24,3 +27,40 @@ def kats():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """Engine over the test-only kernel-source emulator (tests/emu): same kernels, g++, no GPU."""
+    from tests.emu_backend import emu_engine
+    return emu_engine()
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """The product engine: libp2hot.so (HIP, gfx950) on cuda:0 through the C ABI."""
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    import __graft_entry__ as ge
+    ge.build_product()
+    from plonky2_amd import Engine
+    return Engine(0)
+
+
+BACKENDS = ["emu", pytest.param("gpu", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def eng(request):
+    """Every parity test runs on the emulator here (CPU tier) and on the MI355X (-m gpu)."""
+    return request.getfixturevalue(request.param)
+
+
+def rand_field(rng, *shape, noncanonical=False):
+    """uniform field elements; with noncanonical=True some entries are representatives in [P, 2^64)"""
+    a = rng.integers(0, P, size=shape, dtype=np.uint64)
+    if noncanonical:
+        m = rng.random(shape) < 0.05
+        small = rng.integers(0, 2**32 - 1, size=shape, dtype=np.uint64)
+        a = np.where(m, small + np.uint64(P), a)
+    return a

@@ -1,0 +1,62 @@
+"""TEST INFRASTRUCTURE ONLY: an Engine over the kernel-source emulator build (tests/emu).
+
+The emulator compiles the very same plonky2_amd/csrc sources with g++ against a single-threaded
+model of the HIP grid/block/__syncthreads semantics, so `pytest -m "not gpu"` can check kernel index
+arithmetic, the host orchestration and the multi-rank sharding logic against the oracle in the
+GPU-less build container.  "Device" buffers are numpy arrays.  Never imported by plonky2_amd.
+"""
+import os
+import subprocess
+
+import numpy as np
+
+from plonky2_amd import _lib
+from plonky2_amd.engine import Engine
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DIR = os.path.join(_HERE, "emu")
+_SO = os.path.join(_DIR, "libp2hot_emu.so")
+
+
+class DevArray(np.ndarray):
+    """marks an ndarray as an emulated *device* buffer, so host arrays are always copied in (as on the GPU)"""
+
+
+class HostMemory:
+    def empty(self, *shape):
+        return np.empty(shape, dtype=np.uint64).view(DevArray)
+
+    def zeros(self, *shape):
+        return np.zeros(shape, dtype=np.uint64).view(DevArray)
+
+    def from_host(self, a):
+        return np.array(a, dtype=np.uint64, order="C", copy=True).view(DevArray)
+
+    def to_host(self, t):
+        return np.array(t, dtype=np.uint64, copy=True).view(np.ndarray)
+
+    def is_buffer(self, x):
+        return isinstance(x, DevArray)
+
+    def ptr(self, t):
+        assert t.flags["C_CONTIGUOUS"]
+        return t.ctypes.data
+
+    def stream(self):
+        return None
+
+
+_lib_cache = None
+
+
+def emu_lib():
+    global _lib_cache
+    if _lib_cache is None:
+        subprocess.check_call(["make", "-C", _DIR, "-s"])
+        _lib_cache = _lib.load(_SO)
+        assert _lib_cache.p2hot_is_emulated() == 1
+    return _lib_cache
+
+
+def emu_engine():
+    return Engine(0, lib=emu_lib(), memory=HostMemory())

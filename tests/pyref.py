@@ -46,7 +46,7 @@ def naive_coset_lde_rows(coeffs, rate_bits):
 def _load_constants():
     t = open(os.path.join(ROOT, "oracle", "poseidon_constants.h")).read()
     out = {}
-    for name, body in re.findall(r"static const uint64_t (\w+)\[\d+\] = \{(.*?)\};", t, re.S):
+    for name, body in re.findall(r"(?:static const|P2_CONST_QUAL) uint64_t (\w+)\[\d+\] = \{(.*?)\};", t, re.S):
         out[name] = [int(x, 16) for x in re.findall(r"0x[0-9a-f]+", body)]
     return out
 

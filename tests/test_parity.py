@@ -1,0 +1,268 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference's KATs.
+
+Every test is parametrised over `eng`: "emu" runs the same kernel sources under the test-only
+emulator (CPU tier, small sizes), "gpu" is the real thing on the MI355X (-m gpu).  Bit-exact: the
+path is integer arithmetic mod P.
+"""
+import numpy as np
+import pytest
+
+from tests.conftest import P, rand_field
+
+
+def is_gpu(eng):
+    return not eng.lib.p2hot_is_emulated()
+
+
+# ---------------------------------------------------------------- Poseidon
+def test_poseidon_reference_kats(eng, kats):
+    """plonky2/src/hash/poseidon_goldilocks.rs:455-490"""
+    from plonky2_amd.hash.poseidon import poseidon
+    inp = np.array([k["input"] for k in kats["poseidon12"]], dtype=np.uint64)
+    exp = np.array([k["output"] for k in kats["poseidon12"]], dtype=np.uint64)
+    assert (poseidon(inp, eng) == exp).all()
+
+
+def test_poseidon_random_vs_oracle(eng, ora):
+    from plonky2_amd.hash.poseidon import poseidon
+    rng = np.random.default_rng(11)
+    count = 4096 if is_gpu(eng) else 200
+    s = rand_field(rng, count, 12, noncanonical=True)
+    s[0] = P - 1
+    s[1] = np.uint64(2**64 - 1)  # non-canonical representatives are accepted like in the reference
+    got = poseidon(s, eng)
+    exp = np.stack([ora.poseidon(x) for x in s])
+    assert (got == exp).all()
+    assert (got < np.uint64(P)).all()
+
+
+def test_hash_no_pad_and_two_to_one(eng, ora):
+    from plonky2_amd.hash.poseidon import hash_no_pad, hash_or_noop_batch, two_to_one
+    rng = np.random.default_rng(12)
+    for w in (1, 3, 4, 5, 8, 9, 16, 17, 135):
+        rows = rand_field(rng, 8, w, noncanonical=True)
+        got = hash_or_noop_batch(rows, eng)
+        exp = np.stack([ora.hash_or_noop(r) for r in rows])
+        assert (got == exp).all(), w
+        assert (hash_no_pad(rows[0], eng) == ora.hash_no_pad(rows[0])).all(), w
+    l, r = rand_field(rng, 4), rand_field(rng, 4)
+    assert (two_to_one(l, r, eng) == ora.two_to_one(l, r)).all()
+
+
+# ---------------------------------------------------------------- bit reversal / transpose
+def test_reverse_index_bits_reference_table(eng, kats):
+    """plonky2/src/util/mod.rs:61-126"""
+    from plonky2_amd.util import reverse_index_bits
+    got = reverse_index_bits(np.arange(256, dtype=np.uint64), eng)
+    assert got.tolist() == kats["reverse_index_bits_256"]
+
+
+def test_transpose(eng):
+    from plonky2_amd.util import transpose
+    rng = np.random.default_rng(13)
+    for (w, rows) in ((1, 1), (5, 64), (33, 100), (135, 130)):
+        m = rand_field(rng, w, rows)
+        assert (transpose(m, eng) == m.T).all()
+
+
+# ---------------------------------------------------------------- NTT
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 7, 10, 12, 13, 15])
+def test_fft_ifft_vs_oracle(eng, ora, log_n):
+    """field/src/fft.rs:215-249 semantics: natural order in and out; ifft(fft(x)) == x"""
+    from plonky2_amd.field.fft import fft, ifft
+    if log_n > 13 and not is_gpu(eng):
+        pytest.skip("large size runs on the GPU tier")
+    rng = np.random.default_rng(100 + log_n)
+    a = rand_field(rng, 3, 1 << log_n, noncanonical=True)
+    f = fft(a, eng)
+    Pm = np.uint64(P)  # equality in the reference is canonical-value equality (goldilocks_field.rs:33-37)
+    assert (f == np.stack([ora.fft(x.copy()) for x in a]) % Pm).all()
+    assert (ifft(a, eng) == np.stack([ora.ifft(x.copy()) for x in a]) % Pm).all()
+    assert (ifft(f, eng) == a % np.uint64(P)).all()
+
+
+def test_fft_three_pass_sizes(eng, ora):
+    """log_n >= 21 takes three passes (two strided + one contiguous)"""
+    from plonky2_amd.field.fft import fft
+    if not is_gpu(eng):
+        pytest.skip("2^21 points: GPU tier")
+    rng = np.random.default_rng(5)
+    a = rand_field(rng, 1, 1 << 21)
+    assert (fft(a, eng)[0] == ora.fft(a[0].copy())).all()
+
+
+def test_coset_lde_vs_oracle_and_naive(eng, ora):
+    """polynomial/mod.rs:477-516: coset FFT == evaluation on {shift * w^i}"""
+    from plonky2_amd.field.polynomial import lde_coset_fft
+    from tests import pyref
+    rng = np.random.default_rng(14)
+    for (log_n, rb) in ((3, 3), (5, 1), (8, 3), (12, 2), (13, 1)):
+        n = 1 << log_n
+        co = rand_field(rng, 2, n)
+        got = lde_coset_fft(co, rb, engine=eng)
+        for c in range(2):
+            pad = np.zeros(n << rb, dtype=np.uint64)
+            pad[:n] = co[c]
+            assert (got[c] == ora.coset_fft(pad, zero_factor=rb)).all(), (log_n, rb)
+        if log_n == 3:
+            rows = pyref.naive_coset_lde_rows([int(x) for x in co[0]], rb)
+            br = lde_coset_fft(co, rb, bit_reversed=True, engine=eng)[0]
+            assert [int(x) for x in br] == rows
+    # a different shift (FRI rounds use shift^arity)
+    co = rand_field(rng, 1, 64)
+    s = pow(ora.COSET_SHIFT, 16, P)
+    pad = np.zeros(128, dtype=np.uint64)
+    pad[:64] = co[0]
+    assert (lde_coset_fft(co, 1, shift=s, engine=eng)[0] == ora.coset_fft(pad, shift=s, zero_factor=1)).all()
+
+
+# ---------------------------------------------------------------- Merkle
+@pytest.mark.parametrize("n,w,cap", [(1, 7, 0), (2, 3, 0), (2, 3, 1), (16, 4, 2), (64, 5, 0), (64, 135, 4), (256, 32, 8),
+                                     (1024, 20, 4)])
+def test_merkle_tree_vs_oracle(eng, ora, n, w, cap):
+    """merkle_tree.rs:253-311: same digests (reference layout), same cap, every path verifies"""
+    from plonky2_amd.hash.merkle_tree import MerkleTree
+    rng = np.random.default_rng(n * 1000 + w)
+    leaves = rand_field(rng, n, w, noncanonical=True)
+    tree = MerkleTree.new(leaves, cap, engine=eng)
+    digests, capv = ora.merkle_tree(leaves, cap)
+    assert (tree.cap.entries == capv).all()
+    assert (np.asarray(tree.digests).reshape(-1, 4) == digests).all()
+    for i in sorted({0, n - 1, n // 2, (n * 3) // 7}):
+        proof = tree.prove(i)
+        assert (proof == ora.merkle_prove(i, n, cap, digests)).all()
+        assert ora.merkle_verify(leaves[i], i, capv, proof)
+
+
+# ---------------------------------------------------------------- PolynomialBatch
+COMMIT_CASES = [  # (W, log_n, rate_bits, cap_height, is_values)
+    (3, 4, 3, 4, True), (9, 5, 3, 2, True), (135, 6, 3, 4, True), (2, 7, 1, 4, False), (16, 10, 3, 4, False),
+    (20, 9, 3, 4, True), (5, 13, 1, 0, True), (1, 3, 3, 6, True), (4, 2, 1, 3, True), (0, 3, 1, 2, True),
+    (1, 0, 0, 0, True), (2, 0, 3, 1, False),
+]
+
+
+@pytest.mark.parametrize("W,log_n,rb,cap,is_values", COMMIT_CASES)
+def test_polynomial_batch_vs_oracle(eng, ora, W, log_n, rb, cap, is_values):
+    """from_values / from_coeffs (fri/oracle.rs:57-112): polynomials, leaves, digests and cap bit-exact"""
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    rng = np.random.default_rng(W * 131 + log_n * 7 + rb)
+    cols = rand_field(rng, W, 1 << log_n, noncanonical=True)
+    ctor = PolynomialBatch.from_values if is_values else PolynomialBatch.from_coeffs
+    b = ctor(cols, rb, False, cap, engine=eng)
+    o = ora.commit(cols, rb, cap, is_values)
+    assert (b.polynomials == o["coeffs"]).all()
+    assert (b.merkle_tree.cap.entries == o["cap"]).all()
+    assert (np.asarray(b.merkle_tree.digests).reshape(-1, 4) == o["digests"]).all()
+    assert (b.merkle_tree.leaves.reshape(o["leaves"].shape) == o["leaves"]).all()
+    if W:
+        N = 1 << (log_n + rb)
+        for idx in {0, N - 1, N // 3}:
+            from plonky2_amd.util import reverse_bits
+            assert (b.get_lde_values(idx, 1) == o["leaves"][reverse_bits(idx, log_n + rb)]).all()
+        # the row-major `leaves` output of p2hot_commit_dev is the same matrix
+        r = eng.commit(eng.dev(cols), log_n, rb, cap, is_values, want_leaves=True)
+        assert (eng.host(r["leaves"]) == o["leaves"]).all()
+
+
+def test_commit_row_ranges_assemble_to_the_full_tree(eng, ora):
+    """the multi-GPU unit: whole coset blocks computed independently give the same tree"""
+    rng = np.random.default_rng(77)
+    W, log_n, rb, cap = 6, 6, 3, 4
+    cols = rand_field(rng, W, 1 << log_n)
+    o = ora.commit(cols, rb, cap, True)
+    N, n = 1 << (log_n + rb), 1 << log_n
+    nd = eng.num_digests(log_n + rb, cap)
+    digests, capbuf = eng.mem.zeros(nd, 4), eng.mem.zeros(1 << cap, 4)
+    d_cols = eng.dev(cols)
+    for part in range(4):
+        r = eng.commit(d_cols, log_n, rb, cap, True, row_begin=part * 2 * n, row_count=2 * n, want_leaves=True,
+                       digests=digests, cap=capbuf)
+        assert (eng.host(r["leaves"]) == o["leaves"][part * 2 * n:(part + 1) * 2 * n]).all()
+    assert (eng.host(digests) == o["digests"]).all()
+    assert (eng.host(capbuf) == o["cap"]).all()
+
+
+def test_host_pointer_commit_abi(eng, ora):
+    """p2hot_commit / p2hot_batch_rows: the entry points the Rust shim binds (W separate host vectors)"""
+    import ctypes as C
+    rng = np.random.default_rng(78)
+    W, log_n, rb, cap = 7, 5, 3, 4
+    n, N = 1 << log_n, 1 << (log_n + rb)
+    cols = [rand_field(rng, n) for _ in range(W)]
+    ptrs = (C.c_void_p * W)(*[c.ctypes.data for c in cols])
+    coeffs = np.zeros((W, n), dtype=np.uint64)
+    leaves = np.zeros((N, W), dtype=np.uint64)
+    nd = eng.num_digests(log_n + rb, cap)
+    digests = np.zeros((nd, 4), dtype=np.uint64)
+    capv = np.zeros((1 << cap, 4), dtype=np.uint64)
+    handle = C.c_void_p()
+    eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, coeffs.ctypes.data, leaves.ctypes.data,
+                                   digests.ctypes.data, capv.ctypes.data, C.byref(handle)))
+    o = ora.commit(np.stack(cols), rb, cap, True)
+    assert (coeffs == o["coeffs"]).all() and (leaves == o["leaves"]).all()
+    assert (digests == o["digests"]).all() and (capv == o["cap"]).all()
+    idx = np.array([0, 5, N - 1], dtype=np.uint64)
+    rows = np.zeros((3, W), dtype=np.uint64)
+    eng.check(eng.lib.p2hot_batch_rows(handle, idx.ctypes.data, 3, rows.ctypes.data))
+    assert (rows == o["leaves"][idx.astype(np.int64)]).all()
+    eng.lib.p2hot_batch_free(handle)
+
+
+# ---------------------------------------------------------------- Challenger / FRI
+def test_challenger_vs_oracle(eng, ora):
+    from plonky2_amd.iop.challenger import Challenger
+    rng = np.random.default_rng(15)
+    c, oc = Challenger(eng), ora.Challenger()
+    for kind, k in [("o", 3), ("g", 2), ("o", 8), ("g", 1), ("o", 5), ("o", 11), ("g", 9), ("g", 3), ("o", 64), ("g", 2)]:
+        if kind == "o":
+            x = rand_field(rng, k, noncanonical=True)
+            c.observe_elements(x)
+            oc.observe_elements(x)
+        else:
+            assert c.get_n_challenges(k) == oc.get_n_challenges(k)
+    # state round trip (what the Rust shim does with the Challenger's fields)
+    st = c.state()
+    c2 = Challenger(eng)
+    c2.load_state(st)
+    assert c2.get_n_challenges(5) == oc.get_n_challenges(5)
+
+
+FRI_CASES = [(8, 3, 4, [4]), (6, 3, 2, [1, 2]), (9, 1, 4, [4]), (12, 3, 4, [4, 4]), (4, 3, 0, []), (10, 1, 4, [3, 2])]
+
+
+@pytest.mark.parametrize("log_n,rb,cap,arity", FRI_CASES)
+def test_fri_commit_phase_vs_oracle(eng, ora, log_n, rb, cap, arity):
+    """fri_committed_trees (fri/prover.rs:84-150) + fri_proof_of_work (:153-202)"""
+    from plonky2_amd.fri.prover import fri_committed_trees, fri_proof_of_work
+    from plonky2_amd.iop.challenger import Challenger
+    rng = np.random.default_rng(log_n * 10 + rb)
+    n = 1 << log_n
+    co = rand_field(rng, n, 2, noncanonical=True)
+    pad = np.zeros((n << rb, 2), dtype=np.uint64)
+    pad[:n] = co
+    c, oc = Challenger(eng), ora.Challenger()
+    pre = rand_field(rng, 5)
+    c.observe_elements(pre)
+    oc.observe_elements(pre)
+    trees, final, betas = fri_committed_trees(co, c, rb, cap, arity, engine=eng)
+    o = ora.fri_commit(pad, rb, cap, arity, oc)
+    assert (final == o["final"]).all()
+    if arity:
+        assert (betas == o["betas"]).all()
+    for i, t in enumerate(trees):
+        assert (t.leaves == o["leaves"][i]).all(), i
+        assert (np.asarray(t.digests).reshape(-1, 4) == o["digests"][i]).all(), i
+        assert (t.cap.entries == o["caps"][i]).all(), i
+    bits = 10 if is_gpu(eng) else 6
+    assert fri_proof_of_work(c, bits, engine=eng) == ora.fri_pow(oc, bits)
+    assert c.get_n_challenges(3) == oc.get_n_challenges(3)
+
+
+def test_fri_bad_schedule_is_rejected(eng):
+    from plonky2_amd import _lib
+    from plonky2_amd.fri.prover import fri_committed_trees
+    from plonky2_amd.iop.challenger import Challenger
+    co = np.zeros((16, 2), dtype=np.uint64)
+    with pytest.raises(_lib.P2HotError):
+        fri_committed_trees(co, Challenger(eng), 1, 4, [4, 4], engine=eng)  # second round folds past the degree

@@ -157,7 +157,7 @@ def flat(a):
 
 def emit(path, rc, circ, diag, first, scal, vs, w_hats, init):
     def arr(name, vals, per=4):
-        s = "static const uint64_t %s[%d] = {\n" % (name, len(vals))
+        s = "P2_CONST_QUAL uint64_t %s[%d] = {\n" % (name, len(vals))
         for i in range(0, len(vals), per):
             s += "    " + ", ".join("0x%016xULL" % v for v in vals[i:i + per]) + ",\n"
         return s + "};\n\n"
@@ -167,7 +167,9 @@ def emit(path, rc, circ, diag, first, scal, vs, w_hats, init):
                 "// (values: plonky2/src/hash/poseidon.rs:59-157, poseidon_goldilocks.rs:24-25;\n"
                 "//  fast-partial-round tables derived by the tool and checked against\n"
                 "//  poseidon_goldilocks.rs:27-215).\n"
-                "#pragma once\n#include <stdint.h>\n\n")
+                "#pragma once\n#include <stdint.h>\n"
+                "// P2_CONST_QUAL: storage qualifier (the HIP build defines it as __constant__)\n"
+                "#ifndef P2_CONST_QUAL\n#define P2_CONST_QUAL static const\n#endif\n\n")
         f.write(arr("P2_POSEIDON_ALL_ROUND_CONSTANTS", rc))
         f.write(arr("P2_POSEIDON_MDS_CIRC", circ, 12))
         f.write(arr("P2_POSEIDON_MDS_DIAG", diag, 12))
