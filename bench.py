@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- LDE + Poseidon-commit throughput of the HIP hot path (BASELINE.json's metric).
+
+A "step" is one PolynomialBatch::from_values (iNTT -> coset LDE -> Poseidon leaf hash -> Merkle
+tree) over one synthetic batch of trace columns, inputs already resident in HBM:
+  --gpus 1 : W = 135 wire columns, 2^20 rows, rate 1/8 (N = 2^23), cap_height 4 -- the wires commit
+             of the 2^20-gate standard_recursion_config circuit the metric is quoted on (config C3).
+  --gpus G : the same per-GPU work, weak scaling: 2^(20 + log2 G) rows, LDE cosets sharded over the
+             ranks (plonky2_amd.distributed), iNTT column-sharded + RCCL all-gather of coefficients,
+             RCCL all-gather of digests/cap.
+value = W * N_total / t / 1e9 (GFE/s, whole job).  One JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--width 135] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+P = 0xFFFFFFFF00000001
+SEED = 0x9E3779B97F4A7C15
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable float4 copy)
+
+
+def splitmix_columns_torch(torch, device, col_begin, col_count, n):
+    """col[c][i] = splitmix64(SEED ^ (c << 32) ^ i) mod P, generated on the device."""
+    i64 = torch.int64
+
+    def k(v):  # python int -> wrapped int64 constant
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(z, s):
+        return (z >> s) & ((1 << (64 - s)) - 1)
+
+    c = torch.arange(col_begin, col_begin + col_count, dtype=i64, device=device).unsqueeze(1)
+    i = torch.arange(n, dtype=i64, device=device).unsqueeze(0)
+    z = (c << 32) ^ i ^ k(SEED)
+    z = z + k(0x9E3779B97F4A7C15)
+    z = (z ^ lsr(z, 30)) * k(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * k(0x94D049BB133111EB)
+    z = z ^ lsr(z, 31)
+    # unsigned z >= P  <=>  signed z in [-(2^32 - 1), -1]; subtract P == add 2^32 - 1 (mod 2^64)
+    z = torch.where((z < 0) & (z >= -(2**32 - 1)), z + (2**32 - 1), z)
+    return z.contiguous()
+
+
+def splitmix_columns_numpy(col_begin, col_count, n):
+    with np.errstate(over="ignore"):
+        c = np.arange(col_begin, col_begin + col_count, dtype=np.uint64)[:, None]
+        i = np.arange(n, dtype=np.uint64)[None, :]
+        z = (c << np.uint64(32)) ^ i ^ np.uint64(SEED)
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        return np.where(z >= np.uint64(P), z - np.uint64(P), z)
+
+
+def algorithmic_bytes(W, log_n, rate_bits, is_values=True):
+    """each logical array touched once per logical stage, 8-byte elements."""
+    n, N = 1 << log_n, 1 << (log_n + rate_bits)
+    b = {
+        "intt": 16 * W * n if is_values else 0,
+        "lde": 8 * W * n + 8 * W * N,
+        "hash_leaves": 8 * W * N + 32 * N,
+        "merkle_levels": 96 * N,
+    }
+    b["total"] = sum(b.values())
+    return b
+
+
+def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=20.0):
+    """The oracle's C restatement ("port", OpenMP on the host cores) timed on a bounded sample of the
+    same workload: same W / rate / cap, fewer rows.  NOT the Rust prover (no cargo in the image)."""
+    from oracle import p2oracle as ora
+    cores = ora.num_threads()
+    k = min(12, log_n)
+    cols = splitmix_columns_numpy(0, W, 1 << k)
+    t0 = time.perf_counter()
+    ora.commit(cols, rate_bits, cap_height, True)
+    dt = time.perf_counter() - t0
+    total = dt
+    # grow the sample while the predicted time stays inside the budget (cost ~ linear in rows)
+    while k < log_n and total + 2.2 * dt <= budget_s:
+        k += 1
+        cols = splitmix_columns_numpy(0, W, 1 << k)
+        tm = {}
+        t0 = time.perf_counter()
+        ora.commit(cols, rate_bits, cap_height, True, timed=tm)
+        dt = time.perf_counter() - t0
+        total += dt
+    fe = W * (1 << (k + rate_bits))
+    out = {"value": fe / dt / 1e9, "unit": "GFE/s", "cores": cores, "kind": "port",
+           "sample": "from_values W=%d, 2^%d rows, rate 1/%d, cap %d (1/%d of the GPU step's rows), %.2f s; "
+                     "restated CPU baseline (oracle/p2oracle.c, OpenMP), not the Rust prover"
+                     % (W, k, 1 << rate_bits, cap_height, 1 << (log_n - k), dt)}
+    try:
+        out["cpu_model"] = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=20, help="rows per GPU = 2^log_n (weak scaling)")
+    ap.add_argument("--width", type=int, default=135)
+    ap.add_argument("--rate-bits", type=int, default=3)
+    ap.add_argument("--cap-height", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build_product()
+    if dist:
+        dist.barrier()
+    from plonky2_amd import Engine
+    from plonky2_amd.distributed import ShardedCommit
+
+    eng = Engine(local_rank)
+    W, rb, cap = args.width, args.rate_bits, args.cap_height
+    log_g = (world - 1).bit_length()
+    if world != 1 << log_g:
+        raise SystemExit("--gpus must be a power of two")
+    log_n = args.log_n + log_g
+    n, N = 1 << log_n, 1 << (log_n + rb)
+
+    job = ShardedCommit(eng, W, log_n, rb, cap, is_values=True, rank=rank, world=world, dist=dist)
+    # synthetic trace: each rank generates the columns it owns for the iNTT stage, on its device
+    c0, c1 = job.column_range
+    cols = splitmix_columns_torch(torch, eng.mem.device, c0, c1 - c0, n)
+
+    def step():
+        job.run(cols)
+
+    for _ in range(args.warmup):
+        step()
+    eng.profile(True)
+    eng.profile_results(reset=True)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_results(reset=True)
+    eng.profile(False)
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.mem.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        fe = W * N
+        # dominant kernel: the Poseidon leaf sponge over this rank's rows
+        rows_local = N // world
+        ab = algorithmic_bytes(W, log_n, rb)
+        hash_bytes = 8 * W * rows_local + 32 * rows_local
+        kern = {k: {"ms_per_launch": v["ms"] / max(v["launches"], 1), "launches": v["launches"]} for k, v in prof.items()}
+        h = kern.get("hash_leaves", {"ms_per_launch": float("nan")})
+        achieved = hash_bytes / (h["ms_per_launch"] * 1e-3) / 1e9
+        perms = rows_local * ((W + 7) // 8)
+        out = {
+            "metric": "LDE+Poseidon-commit GFE/s", "value": fe / (dt / args.steps) / 1e9, "unit": "GFE/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks)",
+            "data": "synthetic (splitmix64 columns generated on device)",
+            "config": {"workload": "PolynomialBatch::from_values, W=%d, 2^%d rows, rate 1/%d (N=2^%d), cap_height %d, "
+                                   "PoseidonGoldilocksConfig (C3 wires commit at --gpus 1; +1 bit of rows per doubling of GPUs)"
+                                   % (W, log_n, 1 << rb, log_n + rb, cap),
+                       "sharding": "none" if world == 1 else "LDE cosets over %d ranks, RCCL all-gather of coefficients and digests" % world},
+            "roofline": {"kernel": "hash_leaves_kernel<ColMajorReader> (Poseidon leaf sponge)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "note": "integer-VALU bound by nature (%.3g permutations per launch, %.1f Gperm/s); "
+                                 "algorithmic bytes per launch = 8*W*rows + 32*rows = %d"
+                                 % (perms, perms / (h["ms_per_launch"] * 1e-3) / 1e9, hash_bytes)},
+            "kernels": kern,
+            "algorithmic_bytes_per_step": ab,
+            "commit_hbm_frac": ab["total"] / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, log_n, rb, cap)
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

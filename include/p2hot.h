@@ -52,6 +52,13 @@ const char *p2hot_version(void);
 /* 1 when the library was built by the test-only kernel emulator (tests/emu), 0 for the HIP build */
 int p2hot_is_emulated(void);
 
+/* Live per-kernel timing: when enabled, the launches of each kernel family are bracketed with HIP
+ * events on the context's stream.  p2hot_profile_json synchronises, drains them and returns
+ * {"kernel": {"ms": total, "launches": count}, ...} (valid until the next call); reset != 0 clears
+ * the totals.  This is the TimingTree analogue (plonky2/src/util/timing.rs) for the GPU stages. */
+int p2hot_profile_enable(p2hot_ctx *ctx, int on);
+const char *p2hot_profile_json(p2hot_ctx *ctx, int reset);
+
 /* sizes: number of digests (4 words each) in MerkleTree::digests for n_leaves = 2^log_leaves
  * (hash/merkle_tree.rs:203: 2 * (n_leaves - 2^cap_height)) */
 size_t p2hot_num_digests(unsigned log_leaves, unsigned cap_height);

@@ -28,6 +28,36 @@ struct p2hot_ctx {
     } scratch[2];
     // coset scale tables keyed by (log_n, rate_bits, shift, first block, block count, first-pass log_r)
     std::map<std::tuple<unsigned, unsigned, u64, size_t, size_t, unsigned>, u64 *> scale_cache;
+    // live per-kernel timing (HIP events on the launch stream), off by default
+    bool profiling = false;
+    struct ProfRec {
+        const char *name;
+        hipEvent_t e0, e1;
+    };
+    std::vector<ProfRec> prof;
+    std::map<std::string, std::pair<double, unsigned long long>> prof_acc;  // name -> (ms, launches)
+    std::string prof_text;
+};
+
+// Brackets the launches of one kernel family with events when profiling is on.
+struct ProfScope {
+    p2hot_ctx *ctx;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const char *name;
+    ProfScope(p2hot_ctx *c, const char *n) : ctx(c), name(n) {
+#ifndef P2HOT_EMU
+        if (ctx->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+            (void)hipEventRecord(e0, ctx->stream);
+#endif
+    }
+    ~ProfScope() {
+#ifndef P2HOT_EMU
+        if (e0 && e1) {
+            (void)hipEventRecord(e1, ctx->stream);
+            ctx->prof.push_back({name, e0, e1});
+        }
+#endif
+    }
 };
 
 #define P2_FAIL(ctx, code, ...)                           \
@@ -136,6 +166,45 @@ extern "C" int p2hot_ctx_sync(p2hot_ctx *ctx) {
 
 extern "C" const char *p2hot_last_error(const p2hot_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+extern "C" int p2hot_profile_enable(p2hot_ctx *ctx, int on) {
+    if (!ctx) return P2HOT_EINVAL;
+    ctx->profiling = on != 0;
+    return P2HOT_OK;
+}
+
+// Drains the recorded events into the accumulators and returns them as one JSON object
+// {"kernel": {"ms": total, "launches": count}, ...}; reset != 0 clears the accumulators afterwards.
+extern "C" const char *p2hot_profile_json(p2hot_ctx *ctx, int reset) {
+    if (!ctx) return "{}";
+#ifndef P2HOT_EMU
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &r : ctx->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            auto &acc = ctx->prof_acc[r.name];
+            acc.first += ms;
+            acc.second += 1;
+        }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    ctx->prof.clear();
+#endif
+    std::string t = "{";
+    bool first = true;
+    for (auto &kv : ctx->prof_acc) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s\"%s\": {\"ms\": %.6f, \"launches\": %llu}", first ? "" : ", ", kv.first.c_str(),
+                 kv.second.first, kv.second.second);
+        t += buf;
+        first = false;
+    }
+    t += "}";
+    ctx->prof_text = t;
+    if (reset) ctx->prof_acc.clear();
+    return ctx->prof_text.c_str();
+}
+
 // ------------------------------------------------------------------ NTT pass planning
 struct Pass {
     unsigned log_r, log_c;
@@ -191,6 +260,7 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
         const unsigned tiles_log = log_n - a.log_r - a.log_c;
         dim3 grid(1u << tiles_log, (unsigned)batch, (unsigned)zcount);
         size_t shmem = ((size_t)8) << (a.log_r + a.log_c);
+        ProfScope ps(ctx, a.log_c ? "ntt_pass_strided" : "ntt_pass_contig");
         P2HOT_LAUNCH(ntt::ntt_pass_kernel, grid, dim3(ntt::THREADS), shmem, ctx->stream, a);
         P2_LAUNCH_CHECK(ctx);
         log_nblk -= a.log_r;
@@ -290,6 +360,7 @@ extern "C" int p2hot_transpose_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, s
     if (W == 0 || rows == 0) return P2HOT_OK;
     if (!d_colmajor || !d_rowmajor || col_stride < rows) P2_FAIL(ctx, P2HOT_EINVAL, "transpose: bad arguments");
     if (cdiv(W, 32) > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "transpose: W too large");
+    ProfScope ps(ctx, "transpose");
     P2HOT_LAUNCH(ntt::transpose_kernel, dim3(cdiv(rows, 64), cdiv(W, 32)), dim3(256), 0, ctx->stream, d_colmajor,
                  col_stride, (unsigned)W, rows, d_rowmajor);
     P2_LAUNCH_CHECK(ctx);
@@ -345,9 +416,13 @@ static int merkle_forest(p2hot_ctx *ctx, Reader rd, size_t W, unsigned log_leave
     const size_t s0 = leaf_begin >> h;
     u64 *dig = d_digests ? d_digests + 4 * s0 * (2 * (sub_leaves - 1)) : nullptr;
     u64 *cap = d_cap + 4 * s0;
-    P2HOT_LAUNCH((merkle::hash_leaves_kernel<Reader>), dim3(cdiv(leaf_count, 256)), dim3(256), 0, ctx->stream, rd,
-                 (unsigned)W, leaf_count, h, dig, cap);
+    {
+        ProfScope ps(ctx, "hash_leaves");
+        P2HOT_LAUNCH((merkle::hash_leaves_kernel<Reader>), dim3(cdiv(leaf_count, 256)), dim3(256), 0, ctx->stream, rd,
+                     (unsigned)W, leaf_count, h, dig, cap);
+    }
     P2_LAUNCH_CHECK(ctx);
+    ProfScope ps(ctx, "merkle_levels");
     for (unsigned level = 1; level <= h; ++level) {
         size_t nodes = leaf_count >> level;
         P2HOT_LAUNCH(merkle::merkle_level_kernel, dim3(cdiv(nodes, 256)), dim3(256), 0, ctx->stream, dig, cap, h, level,
@@ -395,6 +470,7 @@ extern "C" int p2hot_commit_dev(p2hot_ctx *ctx, const uint64_t *d_cols, size_t c
             P2_TRY(scratch_get(ctx, 0, W * n * 8, (void **)&tmp));
             P2_TRY(run_dif(ctx, d_cols, col_stride, tmp, n, 0, W, 1, log_n, ctx->inv, ntt::SCALE_CONST,
                            gl::inv(n % gl::P), nullptr, nullptr, false));
+            ProfScope ps(ctx, "bitrev_permute");
             P2HOT_LAUNCH(ntt::bitrev_permute_kernel, dim3(cdiv(n, 256), (unsigned)W), dim3(256), 0, ctx->stream, tmp,
                          d_coeffs, n, coeff_stride, log_n);
             P2_LAUNCH_CHECK(ctx);

@@ -1,0 +1,116 @@
+"""Coset-sharded PolynomialBatch commit across the GPUs of one node (one process per GPU).
+
+The reference has no multi-device mode; this is the MI355X design of SURVEY.md 8(e):
+
+  * the rate-1/B LDE is B independent coset transforms, and in the committed (bit-reversed) leaf
+    order coset j is the contiguous row block bitrev(j); with B = 8 and cap_height = 4 a block is
+    two whole cap subtrees.  Rank r therefore owns rows [r*N/G, (r+1)*N/G): it runs the LDE, the
+    Poseidon leaf sponge and the Merkle levels of its rows with NO data-path exchange;
+  * every rank needs all W*n coefficients: the iNTT is column-sharded (ceil(W/G) columns per
+    rank) and followed by ONE all-gather of coefficients (W*n*8 bytes in total);
+  * the digests of a rank's subtrees are a contiguous slice of the reference digest array, so ONE
+    all-gather of digests (+ cap entries) reassembles MerkleTree::digests / ::cap on every rank.
+
+Collectives are torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs; "gloo" in the
+CPU tests).  There is no reduction anywhere, only all-gathers.
+"""
+import numpy as np
+
+
+class ShardPlan:
+    """Pure arithmetic of the sharding (testable without devices)."""
+
+    def __init__(self, W, log_n, rate_bits, cap_height, world):
+        if world < 1 or world & (world - 1):
+            raise ValueError("world size must be a power of two")
+        self.W, self.log_n, self.rate_bits, self.cap_height, self.world = W, log_n, rate_bits, cap_height, world
+        self.n = 1 << log_n
+        self.N = self.n << rate_bits
+        self.log_N = log_n + rate_bits
+        if cap_height > self.log_N:
+            raise ValueError("cap_height > log2(N) (merkle_tree.rs:195-200)")
+        self.rows_per_rank = self.N // world
+        sub_leaves = self.N >> cap_height
+        if world > (1 << rate_bits) or self.rows_per_rank % self.n:
+            raise ValueError("world size %d exceeds the %d LDE cosets" % (world, 1 << rate_bits))
+        if world > (1 << cap_height) or self.rows_per_rank % sub_leaves:
+            raise ValueError("world size %d exceeds the %d cap subtrees" % (world, 1 << cap_height))
+        self.cols_per_rank = -(-W // world) if W else 0
+        self.num_digests = 2 * (self.N - (1 << cap_height))
+        self.digests_per_rank = self.num_digests // world
+        self.cap_per_rank = (1 << cap_height) // world
+
+    def rows(self, rank):
+        return rank * self.rows_per_rank, self.rows_per_rank
+
+    def columns(self, rank):
+        c0 = min(self.W, rank * self.cols_per_rank)
+        return c0, min(self.W, c0 + self.cols_per_rank)
+
+    def cosets(self, rank):
+        """natural coset indices j (points g * w_N^(B*q + j)) whose rows this rank owns"""
+        b0 = rank * self.rows_per_rank // self.n
+        nb = self.rows_per_rank // self.n
+        rb = self.rate_bits
+        return [int(format(b, "0%db" % rb)[::-1], 2) if rb else 0 for b in range(b0, b0 + nb)]
+
+
+class ShardedCommit:
+    """from_values / from_coeffs over `world` ranks.  Buffers are allocated once and reused."""
+
+    def __init__(self, engine, W, log_n, rate_bits, cap_height, is_values=True, rank=0, world=1, dist=None,
+                 want_leaves=False):
+        self.eng, self.dist, self.rank, self.world = engine, dist, rank, world
+        self.plan = p = ShardPlan(W, log_n, rate_bits, cap_height, world)
+        self.is_values = is_values
+        mem = engine.mem
+        self.column_range = p.columns(rank)
+        self.row_begin, self.row_count = p.rows(rank)
+        # coefficient buffer, padded to world * cols_per_rank columns so the all-gather is uniform
+        self.coeffs_all = mem.empty(max(1, world * p.cols_per_rank), p.n)
+        self.lde = mem.empty(W, self.row_count)
+        self.leaves = mem.empty(self.row_count, W) if want_leaves else None
+        self.digests = mem.zeros(max(1, p.num_digests), 4)
+        self.cap = mem.zeros(1 << cap_height, 4)
+
+    def run(self, cols_local):
+        """cols_local: device [c1 - c0][n] -- this rank's columns (values on H_n, or coefficients).
+        Returns dict(coeffs [W][n], lde [W][rows of this rank], digests, cap), all device buffers;
+        digests / cap are the FULL tree's arrays on every rank."""
+        eng, p, lib = self.eng, self.plan, self.eng.lib
+        c0, c1 = self.column_range
+        W = p.W
+        if self.world == 1:
+            eng.check(lib.p2hot_commit_dev(
+                eng.ctx, eng.ptr(cols_local), cols_local.shape[1] if W else p.n, W, p.log_n, p.rate_bits, p.cap_height,
+                1 if self.is_values else 0, 0, p.N, eng.ptr(self.coeffs_all), p.n, eng.ptr(self.lde), self.row_count,
+                eng.ptr(self.leaves), eng.ptr(self.digests), eng.ptr(self.cap)))
+        else:
+            # 1. this rank's columns -> coefficient form, in its slot of the padded buffer
+            slot = self.coeffs_all[self.rank * p.cols_per_rank:(self.rank + 1) * p.cols_per_rank]
+            if c1 > c0:
+                slot[:c1 - c0] = cols_local
+                if self.is_values:
+                    eng.ifft(slot[:c1 - c0], p.log_n)
+            # 2. all-gather of coefficients (W*n*8 bytes over xGMI)
+            self._all_gather(self.coeffs_all, slot)
+            # 3. LDE + leaf sponge + Merkle levels of this rank's rows (whole cosets, whole cap subtrees)
+            eng.check(lib.p2hot_commit_dev(
+                eng.ctx, eng.ptr(self.coeffs_all), p.n, W, p.log_n, p.rate_bits, p.cap_height, 0, self.row_begin,
+                self.row_count, None, 0, eng.ptr(self.lde), self.row_count, eng.ptr(self.leaves), eng.ptr(self.digests),
+                eng.ptr(self.cap)))
+            # 4. all-gather of this rank's contiguous digest slice and cap entries
+            if p.digests_per_rank:
+                d = self.digests[self.rank * p.digests_per_rank:(self.rank + 1) * p.digests_per_rank]
+                self._all_gather(self.digests[:p.num_digests], d)
+            k = self.cap[self.rank * p.cap_per_rank:(self.rank + 1) * p.cap_per_rank]
+            self._all_gather(self.cap, k)
+        return {"coeffs": self.coeffs_all[:W], "lde": self.lde, "leaves": self.leaves,
+                "digests": self.digests[:p.num_digests], "cap": self.cap}
+
+    def _all_gather(self, full, mine):
+        mem = self.eng.mem
+        out = mem.as_torch(full).reshape(-1)
+        inp = mem.as_torch(mine).reshape(-1).clone()  # not in place: the slice aliases `full`
+        mem.collective_fence()
+        self.dist.all_gather_into_tensor(out, inp)

@@ -50,6 +50,13 @@ class TorchMemory:
     def stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
+    def as_torch(self, t):
+        """the buffer as a torch tensor for torch.distributed collectives"""
+        return t
+
+    def collective_fence(self):
+        """libp2hot enqueues on the current torch stream, and so do the collectives: nothing to do"""
+
 
 class Engine:
     def __init__(self, device_index=0, lib=None, memory=None):
@@ -93,6 +100,14 @@ class Engine:
 
     def ptr(self, x):
         return C.c_void_p(self.mem.ptr(x)) if x is not None else None
+
+    def profile(self, on=True):
+        self.check(self.lib.p2hot_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_results(self, reset=True):
+        """{kernel: {"ms": total, "launches": count}} measured with HIP events on the launch stream"""
+        import json
+        return json.loads(self.lib.p2hot_profile_json(self.ctx, 1 if reset else 0).decode())
 
     def num_digests(self, log_leaves, cap_height):
         return self.lib.p2hot_num_digests(log_leaves, cap_height)
