@@ -47,6 +47,25 @@ __host__ __device__ __forceinline__ u64 sub(u64 a, u64 b) {
     return d;
 }
 
+// 32-bit add with carry in/out (v_add_co / v_addc_co chains)
+__host__ __device__ __forceinline__ u32 addc32(u32 a, u32 b, u32 cin, u32 *cout) {
+#if defined(__clang__)
+    return __builtin_addc(a, b, cin, cout);
+#else
+    u64 s = (u64)a + b + cin;
+    *cout = (u32)(s >> 32);
+    return (u32)s;
+#endif
+}
+
+// t + (carry ? EPS : 0) on the 32-bit halves; the caller guarantees it cannot wrap again
+__host__ __device__ __forceinline__ u64 fold_carry(u64 t, bool carry) {
+    u32 e = carry ? 0xFFFFFFFFu : 0u, k;
+    u32 lo = addc32((u32)t, e, 0u, &k);
+    u32 hi = (u32)(t >> 32) + k;
+    return ((u64)hi << 32) | lo;
+}
+
 __host__ __device__ __forceinline__ u64 neg(u64 a) { return sub(0, a); }
 
 // reduce lo + 2^64 * hi (goldilocks_field.rs:402-415): lo - hi_hi + hi_lo * EPS

@@ -6,15 +6,17 @@
 // Hasher::hash_or_noop (plonk/config.rs:63-74).
 //
 // MI355X-first choices (not the reference's CPU schedule):
-//  * The permutation is evaluated in its defining 30-round form (ARK, S-box, MDS; S-box on lane 0
-//    only in rounds 4..25, poseidon.rs:781-801) instead of the reference's "fast partial round"
-//    refactoring: on CDNA a 64x64 multiply costs four quarter-rate v_mad_u64_u32 while the small
-//    circulant MDS (entries <= 41) runs on full-rate 24-bit multiply-adds, so the sparse-matrix
-//    form (22 wide multiplies per partial round) does not win here.  Both forms are the same
-//    function (poseidon.rs:944-957 checks that in the reference); the oracle pins both to the KATs.
-//  * MDS: every state word is split into 22/21/21-bit limbs; y_r = sum_i c_i * x_{(i+r)%12}
-//    (+ 8*x_0 for r = 0) is accumulated per limb in 32-bit registers (264 * 2^22 < 2^32) with
-//    v_mad_u32_u24 and recombined/reduced once per output.
+//  * gfx950 issues v_mad_u64_u32 (32x32+64) at the ordinary VOP3 rate while the 24-bit multiplies
+//    are half rate (measured, tools/ubench.hip), so everything is built from 32x32+64 multiply-adds:
+//    a field multiply is 4 of them plus a two-fold reduction; an MDS output is two 12-term
+//    multiply-add chains over the 32-bit halves of the state (small constants as inline operands).
+//  * The permutation is evaluated in its defining 30-round form (ARK, S-box, MDS; S-box on word 0
+//    only in rounds 4..25, poseidon.rs:781-801) rather than the reference's "fast partial round"
+//    refactoring: with cheap small-constant MDS rows the sparse-matrix form (22 wide multiplies
+//    per partial round plus a 121-multiply pre-matrix) costs more instructions here.  Both forms
+//    are the same function (poseidon.rs:944-957); the oracle pins both to the reference KATs.
+//  * The constant layer is fused into the preceding MDS: the round constants, pre-split into
+//    {lo32, hi32} words, seed the two accumulators straight from SGPRs.
 //  * Round loops stay rolled so the kernel body fits the instruction cache.
 #pragma once
 #include "gl.hpp"
@@ -28,6 +30,7 @@ using gl::u32;
 using gl::u64;
 
 #define RC P2_POSEIDON_ALL_ROUND_CONSTANTS  // poseidon.rs:59-157
+#define RC_SPLIT P2_POSEIDON_ALL_ROUND_CONSTANTS_SPLIT  // [r][i] -> {lo32, hi32} as two u64 words
 
 __device__ __forceinline__ u64 sbox7(u64 x) {  // poseidon.rs:690-696
     u64 x2 = gl::sqr(x);
@@ -36,66 +39,80 @@ __device__ __forceinline__ u64 sbox7(u64 x) {  // poseidon.rs:690-696
     return gl::mul(x3, x4);
 }
 
-// circulant first row [17,15,41,16,2,28,13,13,39,18,34,20], diag [8,0,...] (poseidon_goldilocks.rs:24-25)
-__device__ __forceinline__ void mds_layer(u64 s[12]) {
+// Wave-uniform small constant that the optimiser must not see through: keeps c * x as ONE
+// v_mad_u64_u32 (SGPR operand) instead of a shift + 64-bit add on a zero-extended register pair.
+__device__ __forceinline__ u32 opaque_const(u32 c) {
+#ifndef P2HOT_EMU
+    asm volatile("" : "+s"(c));
+#endif
+    return c;
+}
+
+// MDS layer fused with the NEXT round's constant layer:
+//   y_r = rc_r + sum_i C[i] * x_{(i+r)%12} (+ 8 * x_0 for r = 0)
+// circulant first row C = [17,15,41,16,2,28,13,13,39,18,34,20], diag [8,0,...] (poseidon_goldilocks.rs:24-25).
+// On gfx950 v_mad_u64_u32 issues at the plain VOP3 rate (tools/ubench), so each output is two
+// 12-term multiply-add chains over the 32-bit halves (al, ah < 2^42) and one fold:
+//   y = al + ah * 2^32 = lo64 + w2 * 2^64 = lo64 + w2 * EPS (mod P), w2 < 2^10.
+// rc2 points at the round's constants split as {lo32, hi32} pairs (RC_SPLIT) or is null.
+__device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2) {
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    u32 l0[12], l1[12], l2[12];
+    const u32 c16 = opaque_const(16), c2 = opaque_const(2), c8 = opaque_const(8);
+    u32 xl[12], xh[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
-        u32 lo = (u32)s[i], hi = (u32)(s[i] >> 32);
-        l0[i] = lo & 0x3FFFFFu;                          // bits 0..21
-        l1[i] = ((lo >> 22) | (hi << 10)) & 0x1FFFFFu;   // bits 22..42
-        l2[i] = hi >> 11;                                // bits 43..63
+        xl[i] = (u32)s[i];
+        xh[i] = (u32)(s[i] >> 32);
     }
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
-        u32 a0 = 0, a1 = 0, a2 = 0;
+        u64 al = rc2 ? rc2[2 * r] : 0, ah = rc2 ? rc2[2 * r + 1] : 0;
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             const int j = (i + r) % 12;
-            a0 += C[i] * l0[j];
-            a1 += C[i] * l1[j];
-            a2 += C[i] * l2[j];
+            const u32 c = C[i] == 16 ? c16 : (C[i] == 2 ? c2 : C[i]);
+            al += (u64)xl[j] * c;
+            ah += (u64)xh[j] * c;
         }
         if (r == 0) {
-            a0 += 8u * l0[0];
-            a1 += 8u * l1[0];
-            a2 += 8u * l2[0];
+            al += (u64)xl[0] * c8;
+            ah += (u64)xh[0] * c8;
         }
-        // y = a0 + a1*2^22 + a2*2^43  (< 2^74), then fold bits >= 64 with 2^64 = EPS
-        u64 lo64 = (u64)a0 + ((u64)a1 << 22);
-        u64 t = (u64)a2 << 43;
-        lo64 += t;
-        u64 hi = (u64)(a2 >> 21) + (u64)(lo64 < t);
-        u64 e = (hi << 32) - hi;
-        u64 y = lo64 + e;
-        if (y < e) y += gl::EPS;
-        s[r] = y;
+        u32 k1;
+        u32 w1 = gl::addc32((u32)(al >> 32), (u32)ah, 0u, &k1);
+        u32 w2 = (u32)(ah >> 32) + k1;
+        u64 lo64 = ((u64)w1 << 32) | (u32)al;
+        u64 y = (u64)w2 * 0xFFFFFFFFu + lo64;
+        s[r] = gl::fold_carry(y, y < lo64);
     }
 }
 
-// the permutation; output words are NOT canonicalised (callers canonicalise what they emit)
+// the permutation; output words are NOT canonicalised (callers canonicalise what they emit).
+// Round r: ARK(r) was already added by the previous MDS (or up front for r = 0); S-box; MDS + ARK(r+1).
 __device__ inline void permute(u64 s[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = gl::add_canon(s[i], RC[i]);
     int round = 0;
 #pragma unroll 1
     for (int k = 0; k < 4; ++k, ++round) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = sbox7(gl::add_canon(s[i], RC[12 * round + i]));
-        mds_layer(s);
+        for (int i = 0; i < 12; ++i) s[i] = sbox7(s[i]);
+        mds_layer(s, RC_SPLIT + 24 * (round + 1));
     }
 #pragma unroll 1
     for (int k = 0; k < 22; ++k, ++round) {
-#pragma unroll
-        for (int i = 1; i < 12; ++i) s[i] = gl::add_canon(s[i], RC[12 * round + i]);
-        s[0] = sbox7(gl::add_canon(s[0], RC[12 * round]));
-        mds_layer(s);
+        s[0] = sbox7(s[0]);
+        mds_layer(s, RC_SPLIT + 24 * (round + 1));
     }
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k, ++round) {
+    for (int k = 0; k < 3; ++k, ++round) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = sbox7(gl::add_canon(s[i], RC[12 * round + i]));
-        mds_layer(s);
+        for (int i = 0; i < 12; ++i) s[i] = sbox7(s[i]);
+        mds_layer(s, RC_SPLIT + 24 * (round + 1));
     }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = sbox7(s[i]);
+    mds_layer(s, nullptr);
 }
 
 // two_to_one (hashing.rs:97-114): state = [l, r, 0^4], permute, first 4 words
@@ -113,4 +130,5 @@ __device__ __forceinline__ void two_to_one(const u64 l[4], const u64 r[4], u64 o
 }
 
 #undef RC
+#undef RC_SPLIT
 }  // namespace poseidon

@@ -171,6 +171,9 @@ def emit(path, rc, circ, diag, first, scal, vs, w_hats, init):
                 "// P2_CONST_QUAL: storage qualifier (the HIP build defines it as __constant__)\n"
                 "#ifndef P2_CONST_QUAL\n#define P2_CONST_QUAL static const\n#endif\n\n")
         f.write(arr("P2_POSEIDON_ALL_ROUND_CONSTANTS", rc))
+        f.write("// the same constants with every word split into {lo32, hi32} (two u64 words): the device\n"
+                "// MDS rows start their two 32x32+64 multiply-add chains from them\n")
+        f.write(arr("P2_POSEIDON_ALL_ROUND_CONSTANTS_SPLIT", [h for v in rc for h in (v & 0xFFFFFFFF, v >> 32)]))
         f.write(arr("P2_POSEIDON_MDS_CIRC", circ, 12))
         f.write(arr("P2_POSEIDON_MDS_DIAG", diag, 12))
         f.write(arr("P2_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT", first))

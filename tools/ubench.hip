@@ -1,94 +1,149 @@
 // ubench.hip -- VALU integer instruction-rate probe for gfx950 (tooling, not product).
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench tools/ubench.hip ; run on the GPU box.
-// Reports wave-instructions per cycle per SIMD-equivalent for the ops the Goldilocks/Poseidon
-// kernels are built from, so the kernel design can be priced against measured rates.
+// Every probe issues 8 independent copies of one instruction per loop iteration from a single
+// asm statement (so the compiler can neither fold nor pad them); 8 waves/SIMD resident.
+// Output: cycles per wave64 instruction per SIMD (2.0 = full rate on a SIMD-32).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
-#include <vector>
 
-#define ITERS 4096
-#define NACC 8
+#define ITERS 2048
+
+#define R8(INS)                                                                                    \
+    INS(0) "\n\t" INS(1) "\n\t" INS(2) "\n\t" INS(3) "\n\t" INS(4) "\n\t" INS(5) "\n\t" INS(6) "\n\t" INS(7)
+
+// operand map: %0..%7 = 32-bit accumulators b[i] (+v); %8..%15 = 64-bit accumulators a[i] (+v); %16 = c (v), %17 = d (v)
+#define OPS                                                                                         \
+    : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), \
+      "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])  \
+    : "v"(c), "v"(d)                                                                                 \
+    : "vcc"
+
+#define I_ADD(i) "v_add_u32 %" #i ", %" #i ", %16"
+#define I_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %16"
+#define I_MULHI(i) "v_mul_hi_u32 %" #i ", %" #i ", %16"
+#define I_MAD24(i) "v_mad_u32_u24 %" #i ", %" #i ", 41, %16"
+#define I_MUL24(i) "v_mul_u32_u24 %" #i ", %" #i ", 41"
+#define I_ADD3(i) "v_add3_u32 %" #i ", %" #i ", %16, %17"
+#define I_DOT2(i) "v_dot2_u32_u16 %" #i ", %16, %17, %" #i
+#define I_DOT4(i) "v_dot4_u32_u8 %" #i ", %16, %17, %" #i
+#define I_PERM(i) "v_perm_b32 %" #i ", %" #i ", %16, %17"
+#define I_CNDM(i) "v_cndmask_b32 %" #i ", %" #i ", %16, vcc"
+#define I_ADDCO(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %16"
+#define I_ADDC(i) "v_addc_co_u32 %" #i ", vcc, %" #i ", %16, vcc"
+#define I_ALIGN(i) "v_alignbit_b32 %" #i ", %" #i ", %16, 22"
+#define I_BFE(i) "v_bfe_u32 %" #i ", %" #i ", 5, 21"
+#define I_LSHLOR(i) "v_lshl_or_b32 %" #i ", %" #i ", 16, %16"
+#define I_ANDOR(i) "v_and_or_b32 %" #i ", %" #i ", %16, %17"
+// 64-bit accumulators are operands %8..%15
+#define J(i) "%" #i
+#define I_MAD64(i) "v_mad_u64_u32 %" #i ", vcc, %16, %17, %" #i
+#define I_LSHLADD64(i) "v_lshl_add_u64 %" #i ", %" #i ", 3, %" #i
+#define I_CMP64(i) "v_cmp_lt_u64 vcc, %" #i ", %" #i
+
+#define R8B(INS) INS(8) "\n\t" INS(9) "\n\t" INS(10) "\n\t" INS(11) "\n\t" INS(12) "\n\t" INS(13) "\n\t" INS(14) "\n\t" INS(15)
 
 template <int OP>
-__global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed) {
+__global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t *ticks) {
     uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;
-    uint64_t a[NACC];
-    uint32_t b[NACC], c[NACC];
+    uint64_t a[8];
+    uint32_t b[8];
+    uint32_t c = t * 2654435761u + seed, d = (t ^ seed) * 40503u + 1;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
+    for (int i = 0; i < 8; ++i) {
         a[i] = (uint64_t)t * 0x9E3779B97F4A7C15ull + i + seed;
-        b[i] = t * 2654435761u + i * 7 + seed;
-        c[i] = (t ^ seed) + i * 13 + 1;
+        b[i] = t * 2246822519u + i * 7 + seed;
     }
+    uint64_t t0 = __builtin_readcyclecounter();  // s_memtime: shader-clock ticks
+#pragma unroll 1
     for (int it = 0; it < ITERS; ++it) {
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) {
-            if (OP == 0) {  // v_mad_u64_u32
-                a[i] = (uint64_t)b[i] * c[i] + a[i];
-                b[i] = (uint32_t)a[i];
-            } else if (OP == 1) {  // v_mul_lo_u32
-                b[i] = b[i] * c[i];
-            } else if (OP == 2) {  // v_mul_hi_u32
-                b[i] = __umulhi(b[i], c[i]);
-            } else if (OP == 3) {  // v_mad_u32_u24
-                b[i] = (b[i] & 0xFFFFFFu) * (c[i] & 0xFFFFFFu) + b[i];
-            } else if (OP == 4) {  // v_add_u32
-                b[i] = b[i] + c[i];
-            } else if (OP == 5) {  // 64-bit add (add_co + addc)
-                a[i] = a[i] + (((uint64_t)c[i] << 32) | b[i]);
-            } else if (OP == 6) {  // v_mul_u32_u24 with inline constant
-                b[i] = (b[i] & 0x3FFFFFu) * 41u + c[i];
-            } else if (OP == 7) {  // v_lshl_add_u64-ish
-                a[i] = (a[i] << 3) + (uint64_t)c[i];
-            } else if (OP == 8) {  // v_alignbit / shifts+and (limb split)
-                b[i] = ((b[i] >> 22) | (c[i] << 10)) & 0x1FFFFFu;
-                c[i] = c[i] + b[i];
-            }
-        }
+        if (OP == 0) asm volatile(R8(I_ADD) OPS);
+        if (OP == 1) asm volatile(R8(I_MULLO) OPS);
+        if (OP == 2) asm volatile(R8(I_MULHI) OPS);
+        if (OP == 3) asm volatile(R8(I_MAD24) OPS);
+        if (OP == 4) asm volatile(R8(I_MUL24) OPS);
+        if (OP == 5) asm volatile(R8(I_ADD3) OPS);
+        if (OP == 6) asm volatile(R8(I_DOT2) OPS);
+        if (OP == 7) asm volatile(R8(I_DOT4) OPS);
+        if (OP == 8) asm volatile(R8(I_PERM) OPS);
+        if (OP == 9) asm volatile(R8(I_CNDM) OPS);
+        if (OP == 10) asm volatile(R8(I_ADDCO) OPS);
+        if (OP == 11) asm volatile(R8(I_ADDC) OPS);
+        if (OP == 12) asm volatile(R8(I_ALIGN) OPS);
+        if (OP == 13) asm volatile(R8(I_BFE) OPS);
+        if (OP == 14) asm volatile(R8(I_LSHLOR) OPS);
+        if (OP == 15) asm volatile(R8(I_ANDOR) OPS);
+        if (OP == 16) asm volatile(R8B(I_MAD64) OPS);
+        if (OP == 17) asm volatile(R8B(I_LSHLADD64) OPS);
+        if (OP == 18) asm volatile(R8B(I_CMP64) OPS);
     }
+    uint64_t t1 = __builtin_readcyclecounter();
     uint64_t s = 0;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) s += a[i] + b[i] + c[i];
+    for (int i = 0; i < 8; ++i) s += a[i] + b[i];
     out[t] = s;
+    if ((threadIdx.x & 63) == 0) ticks[t >> 6] = t1 - t0;
 }
 
 template <int OP>
-void run(const char *name, double insts_per_iter) {
-    const int blocks = 256 * 8, threads = 256;
-    uint64_t *d;
-    hipMalloc(&d, (size_t)blocks * threads * 8);
+void run(const char *name) {
+    const int blocks = 256 * 8, threads = 256;  // 8 blocks/CU -> 8 waves/SIMD
+    uint64_t *d, *tk;
+    (void)hipMalloc(&d, (size_t)blocks * threads * 8);
+    (void)hipMalloc(&tk, (size_t)blocks * threads / 64 * 8);
     hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    k<OP><<<blocks, threads>>>(d, 1);
-    hipDeviceSynchronize();
-    hipEventRecord(e0);
-    k<OP><<<blocks, threads>>>(d, 2);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms;
-    hipEventElapsedTime(&ms, e0, e1);
-    double waves = (double)blocks * threads / 64;
-    double winst = waves * ITERS * NACC * insts_per_iter;
-    // 1024 SIMDs at 2.4 GHz
-    printf("%-28s %8.3f ms  %7.2f Gwave-inst/s  = %.3f wave-inst/clk/SIMD (@2.4GHz,1024 SIMDs)\n", name, ms, winst / ms / 1e6,
-           winst / (ms * 1e-3) / (1024 * 2.4e9));
-    hipFree(d);
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    k<OP><<<blocks, threads>>>(d, 1, tk);
+    (void)hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        k<OP><<<blocks, threads>>>(d, 2 + rep, tk);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    double waves_per_simd = (double)blocks * threads / 64 / 1024;
+    double inst_per_simd = waves_per_simd * ITERS * 8;
+    double cycles = best * 1e-3 * 2.4e9;
+    static uint64_t host_ticks[256 * 8 * 4];
+    (void)hipMemcpy(host_ticks, tk, (size_t)blocks * threads / 64 * 8, hipMemcpyDeviceToHost);
+    double avg = 0;
+    for (int i = 0; i < blocks * threads / 64; ++i) avg += (double)host_ticks[i];
+    avg /= (blocks * threads / 64);
+    // every wave shares its SIMD with waves_per_simd - 1 others: SIMD cycles per instruction =
+    // per-wave elapsed ticks / (instructions per wave * resident waves per SIMD)
+    printf("%-18s %7.3f ms  %5.2f cyc/inst/SIMD by wall@2.4GHz | %5.2f by s_memtime (ticks/wave %.0f, implied clock %.2f GHz)\n", name,
+           best, cycles / inst_per_simd, avg / (ITERS * 8.0 * waves_per_simd), avg, avg / (best * 1e-3) / 1e9);
+    (void)hipFree(tk);
+    (void)hipFree(d);
 }
 
 int main() {
     hipDeviceProp_t p;
-    hipGetDeviceProperties(&p, 0);
-    printf("device %s  CUs %d  clock %d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
-    run<4>("v_add_u32", 1);
-    run<0>("v_mad_u64_u32 (+mov)", 1);
-    run<1>("v_mul_lo_u32", 1);
-    run<2>("v_mul_hi_u32", 1);
-    run<3>("v_mad_u32_u24 (+2 and)", 1);
-    run<6>("v_mul_u32_u24 imm (+and,add)", 1);
-    run<5>("add u64 (2 insts)", 1);
-    run<7>("shl3+add u64", 1);
-    run<8>("limb split (3-4 insts)", 1);
+    (void)hipGetDeviceProperties(&p, 0);
+    printf("device %s  CUs %d  clock %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
+    run<0>("v_add_u32");
+    run<5>("v_add3_u32");
+    run<10>("v_add_co_u32");
+    run<11>("v_addc_co_u32");
+    run<9>("v_cndmask_b32");
+    run<1>("v_mul_lo_u32");
+    run<2>("v_mul_hi_u32");
+    run<16>("v_mad_u64_u32");
+    run<3>("v_mad_u32_u24");
+    run<4>("v_mul_u32_u24");
+    run<6>("v_dot2_u32_u16");
+    run<7>("v_dot4_u32_u8");
+    run<8>("v_perm_b32");
+    run<12>("v_alignbit_b32");
+    run<13>("v_bfe_u32");
+    run<14>("v_lshl_or_b32");
+    run<15>("v_and_or_b32");
+    run<17>("v_lshl_add_u64");
+    run<18>("v_cmp_lt_u64");
     return 0;
 }
