@@ -79,6 +79,19 @@ def algorithmic_bytes(W, log_n, rate_bits, is_values=True):
     return b
 
 
+def pmc_traffic(W, log_n, rb, cap, world, kernel):
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), if they were
+    collected for exactly this workload; None otherwise.  Counters cannot be read inside this run."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        w = d["workload"]
+        if (w["W"], w["log_n"], w["rate_bits"], w["cap_height"], w["n_gpus"]) != (W, log_n, rb, cap, world):
+            return None
+        return d["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=20.0):
     """The oracle's C restatement ("port", OpenMP on the host cores) timed on a bounded sample of the
     same workload: same W / rate / cap, fewer rows.  NOT the Rust prover (no cargo in the image)."""
@@ -208,7 +221,8 @@ def main():
                        "sharding": "none" if world == 1 else "LDE cosets over %d ranks, RCCL all-gather of coefficients and digests" % world},
             "roofline": {"kernel": "hash_leaves_kernel<ColMajorReader> (Poseidon leaf sponge)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": pmc_traffic(W, log_n, rb, cap, world, "hash_leaves_kernel"),
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                          "note": "integer-VALU bound by nature (%.3g permutations per launch, %.1f Gperm/s); "
                                  "algorithmic bytes per launch = 8*W*rows + 32*rows = %d"
                                  % (perms, perms / (h["ms_per_launch"] * 1e-3) / 1e9, hash_bytes)},

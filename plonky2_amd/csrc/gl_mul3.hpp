@@ -1,0 +1,73 @@
+// gl_mul3.hpp -- three independent Goldilocks multiplications as ONE hand-scheduled gfx950
+// instruction stream (used by the Poseidon S-box, where independent products come in threes).
+//
+// Why asm: on gfx950 any VALU write of an SGPR/VCC (carry, compare) needs two wait states before
+// a VALU reads it, and hipcc's 64-bit code wastes ~9 of 26 instructions per multiply on v_mov /
+// v_cmp / v_cndmask glue (measured on the ISA).  Interleaving three products round-robin puts
+// exactly two independent instructions between every carry producer and its consumer, so the
+// 17-instruction multiply-reduce needs no s_nop:
+//    1-4   four v_mad_u64_u32: P = a0*b0, M = a1*b0 + a0*b1 (carry cm), Q = a1*b1
+//    5-8   128-bit assembly: lo = {P0, P1+M0}, hi = Q + M1 + carries (+ cm << 32)
+//    9-12  t = lo + hi.lo * (2^32-1), fold the carry (2^64 = 2^32-1 mod P)
+//    13-17 u = t - hi.hi, fold the borrow                    (goldilocks_field.rs:402-415)
+// Temporaries are fixed VGPR/SGPR pairs (declared as clobbers) because inline-asm operands cannot
+// name the halves of a 64-bit register pair.  The C fallback (emulator build) is gl::mul.
+#pragma once
+#include "gl.hpp"
+
+namespace gl {
+
+#ifndef P2HOT_EMU
+// stream register sets: P, M, Q pairs + two SGPR carry pairs
+#define P2_SA "v[70:71]", "v70", "v71", "v[72:73]", "v72", "v73", "v[74:75]", "v74", "v75", "s[40:41]", "s[42:43]"
+#define P2_SB "v[76:77]", "v76", "v77", "v[78:79]", "v78", "v79", "v[80:81]", "v80", "v81", "s[44:45]", "s[46:47]"
+#define P2_SC "v[82:83]", "v82", "v83", "v[84:85]", "v84", "v85", "v[86:87]", "v86", "v87", "s[48:49]", "s[50:51]"
+
+// one instruction of the multiply for one stream; X = register set, a0/a1/b0/b1/r0/r1 = operand names
+#define P2_ST1(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", %[" a0 "], %[" b0 "], 0\n\t"
+#define P2_ST2(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " M ", " C1 ", %[" a1 "], %[" b0 "], 0\n\t"
+#define P2_ST3(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " M ", " C2 ", %[" a0 "], %[" b1 "], " M "\n\t"
+#define P2_ST4(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " Q ", " C1 ", %[" a1 "], %[" b1 "], 0\n\t"
+#define P2_ST5(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_add_co_u32 " P1 ", " C1 ", " P1 ", " M0 "\n\t"
+#define P2_ST6(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " Q0 ", " C1 ", " Q0 ", " M1 ", " C1 "\n\t"
+#define P2_ST7(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " Q1 ", " C1 ", " Q1 ", 0, " C1 "\n\t"
+#define P2_ST8(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " Q1 ", " C2 ", " Q1 ", 0, " C2 "\n\t"
+#define P2_ST9(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", " Q0 ", -1, " P "\n\t"
+#define P2_ST10(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
+#define P2_ST11(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_add_co_u32 " P0 ", " C1 ", " P0 ", " M0 "\n\t"
+#define P2_ST12(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " P1 ", " C1 ", " P1 ", 0, " C1 "\n\t"
+#define P2_ST13(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_sub_co_u32 " P0 ", " C1 ", " P0 ", " Q1 "\n\t"
+#define P2_ST14(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_subb_co_u32 " P1 ", " C1 ", " P1 ", 0, " C1 "\n\t"
+#define P2_ST15(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
+#define P2_ST16(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_sub_co_u32 %[" r0 "], " C1 ", " P0 ", " M0 "\n\t"
+#define P2_ST17(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_subb_co_u32 %[" r1 "], " C1 ", " P1 ", 0, " C1 "\n\t"
+
+#define P2_APPLY(ST, ...) ST(__VA_ARGS__)
+#define P2_ROW(ST)                                                   \
+    P2_APPLY(ST, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")    \
+    P2_APPLY(ST, P2_SB, "xb0", "xb1", "yb0", "yb1", "rb0", "rb1")    \
+    P2_APPLY(ST, P2_SC, "xc0", "xc1", "yc0", "yc1", "rc0", "rc1")
+
+// r[k] = a[k] * b[k] (mod P), k = 0..2; any representatives in, any representative out
+__device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
+    u32 ra0, ra1, rb0, rb1, rc0, rc1;
+    asm(P2_ROW(P2_ST1) P2_ROW(P2_ST2) P2_ROW(P2_ST3) P2_ROW(P2_ST4) P2_ROW(P2_ST5) P2_ROW(P2_ST6) P2_ROW(P2_ST7)
+            P2_ROW(P2_ST8) P2_ROW(P2_ST9) P2_ROW(P2_ST10) P2_ROW(P2_ST11) P2_ROW(P2_ST12) P2_ROW(P2_ST13)
+                P2_ROW(P2_ST14) P2_ROW(P2_ST15) P2_ROW(P2_ST16) P2_ROW(P2_ST17)
+        : [ra0] "=&v"(ra0), [ra1] "=&v"(ra1), [rb0] "=&v"(rb0), [rb1] "=&v"(rb1), [rc0] "=&v"(rc0), [rc1] "=&v"(rc1)
+        : [xa0] "v"((u32)a[0]), [xa1] "v"((u32)(a[0] >> 32)), [ya0] "v"((u32)b[0]), [ya1] "v"((u32)(b[0] >> 32)),
+          [xb0] "v"((u32)a[1]), [xb1] "v"((u32)(a[1] >> 32)), [yb0] "v"((u32)b[1]), [yb1] "v"((u32)(b[1] >> 32)),
+          [xc0] "v"((u32)a[2]), [xc1] "v"((u32)(a[2] >> 32)), [yc0] "v"((u32)b[2]), [yc1] "v"((u32)(b[2] >> 32))
+        : "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84",
+          "v85", "v86", "v87", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51");
+    r[0] = ((u64)ra1 << 32) | ra0;
+    r[1] = ((u64)rb1 << 32) | rb0;
+    r[2] = ((u64)rc1 << 32) | rc0;
+}
+#else
+__host__ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
+    for (int k = 0; k < 3; ++k) r[k] = mul(a[k], b[k]);
+}
+#endif
+
+}  // namespace gl

@@ -20,6 +20,7 @@
 //  * Round loops stay rolled so the kernel body fits the instruction cache.
 #pragma once
 #include "gl.hpp"
+#include "gl_mul3.hpp"
 #ifndef P2HOT_EMU
 #define P2_CONST_QUAL __constant__  // device constant memory; indices are wave-uniform -> scalar loads
 #endif
@@ -37,6 +38,23 @@ __device__ __forceinline__ u64 sbox7(u64 x) {  // poseidon.rs:690-696
     u64 x4 = gl::sqr(x2);
     u64 x3 = gl::mul(x, x2);
     return gl::mul(x3, x4);
+}
+
+// x^7 of three independent words at once: x2 = x*x; (x3 = x*x2 and x4 = x2*x2 are independent); x7 = x3*x4
+__device__ __forceinline__ void sbox7_x3(u64 &a, u64 &b, u64 &c) {
+    u64 x[3] = {a, b, c}, x2[3], x3[3], x4[3];
+    gl::mul3(x, x, x2);
+    gl::mul3(x, x2, x3);
+    gl::mul3(x2, x2, x4);
+    gl::mul3(x3, x4, x);
+    a = x[0];
+    b = x[1];
+    c = x[2];
+}
+
+__device__ __forceinline__ void sbox_layer(u64 s[12]) {  // poseidon.rs:712-718
+#pragma unroll
+    for (int i = 0; i < 12; i += 3) sbox7_x3(s[i], s[i + 1], s[i + 2]);
 }
 
 // Wave-uniform small constant that the optimiser must not see through: keeps c * x as ONE
@@ -95,8 +113,7 @@ __device__ inline void permute(u64 s[12]) {
     int round = 0;
 #pragma unroll 1
     for (int k = 0; k < 4; ++k, ++round) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = sbox7(s[i]);
+        sbox_layer(s);
         mds_layer(s, RC_SPLIT + 24 * (round + 1));
     }
 #pragma unroll 1
@@ -106,12 +123,10 @@ __device__ inline void permute(u64 s[12]) {
     }
 #pragma unroll 1
     for (int k = 0; k < 3; ++k, ++round) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = sbox7(s[i]);
+        sbox_layer(s);
         mds_layer(s, RC_SPLIT + 24 * (round + 1));
     }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = sbox7(s[i]);
+    sbox_layer(s);
     mds_layer(s, nullptr);
 }
 
