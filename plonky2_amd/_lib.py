@@ -88,6 +88,9 @@ def product():
                 "plonky2_amd/libp2hot.so is missing: build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                 "plonky2_amd has no CPU fallback.")
+        # PyTorch-ROCm ships its own libamdhip64; it must be the HIP runtime this process uses, so it is
+        # loaded first and libp2hot's libamdhip64 dependency resolves to the already-loaded copy.
+        import torch  # noqa: F401
         _product = load(PRODUCT_SO)
         if _product.p2hot_is_emulated():
             raise RuntimeError("plonky2_amd/libp2hot.so is an emulator build; refusing to use it as the product")

@@ -126,6 +126,164 @@ __global__ void __launch_bounds__(THREADS) ntt_pass_kernel(PassArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register-radix pass (the production path).  Same tile, same pass algebra as ntt_pass_kernel, but
+// the LOGR layers run as rounds of radix 2^p (p <= 4) butterflies held in registers:
+//   * a round at sub-block size Rb takes the 2^p points {hi*Rb + q*(Rb>>p) + lo} of a unit, does a
+//     2^p-point DFT whose twiddles are powers of w_16 = 2^12 (so w_8 = 2^24, w_4 = 2^48: shifts and one
+//     reduction in Goldilocks, no multiplier), then one table twiddle w_Rb^(lo*k) per output
+//     (four-step inside the tile);
+//   * the tile touches LDS once per round (not once per layer) and the first round loads straight
+//     from global memory with the pre-scaling fused;
+//   * LDS indices are padded by one word per 16 so the stride-16 / stride-256 rounds stay conflict-free.
+// The inverse transform uses w^-j = -2^(96 - e): the butterfly subtracts the other way round.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mul_pow2_le32(u64 x, int s) {  // x * 2^s (mod P), 0 < s <= 32
+    u64 lo = x << (s & 63), hi = x >> ((64 - s) & 63);  // hi < 2^32
+    u64 t = (u64)(u32)hi * 0xFFFFFFFFu + lo;
+    return gl::fold_carry(t, t < lo);
+}
+__device__ __forceinline__ u64 mul_pow2(u64 x, int s) {  // x * 2^s (mod P), 0 <= s < 96, s constant after unrolling
+    if (s == 0) return x;
+    if (s <= 32) return mul_pow2_le32(x, s);
+    if (s < 64) return gl::reduce128(x << (s & 63), x >> ((64 - s) & 63));
+    if (s == 64) return gl::reduce128(0, x);
+    return gl::reduce128(0, mul_pow2_le32(x, s - 64));  // 2^64 = 2^32 - 1: the 128-bit value {0, y}
+}
+
+__device__ __forceinline__ unsigned pad_idx(unsigned i) { return i + (i >> 4); }
+constexpr unsigned TILE_WORDS_PADDED = (1u << TILE_LOG) + (1u << (TILE_LOG - 4));
+
+struct RegPassArgs {
+    PassArgs a;
+    const u64 *local;        // local[2^m + e] = w_{2^m}^e (forward or inverse), m <= TILE_LOG
+    unsigned rounds[4];      // radix bits of each round, sum = log_r, zero-terminated
+    int inverse;
+};
+
+// 2^P-point DFT of x[] in place (DIF, bit-reversed output) with power-of-two twiddles
+template <int P, bool INV>
+__device__ __forceinline__ void dft_pow2(u64 (&x)[1 << P]) {
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+        const int d = 1 << (P - 1 - u);     // butterfly distance
+        const int step = 96 >> (P - 1 - u); // exponent step: w_{2d}^j = 2^(96/d * j)
+#pragma unroll
+        for (int q = 0; q < (1 << P); ++q) {
+            if (q & d) continue;
+            const int j = q & (d - 1);
+            u64 a = x[q], b = x[q + d];
+            x[q] = gl::add(a, b);
+            if (j == 0) {
+                x[q + d] = gl::sub(a, b);
+            } else if (!INV) {
+                x[q + d] = mul_pow2(gl::sub(a, b), step * j);
+            } else {
+                x[q + d] = mul_pow2(gl::sub(b, a), 96 - step * j);
+            }
+        }
+    }
+}
+
+template <int P, bool INV>
+__device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, const u64 *gin, bool from_global, unsigned log_rb,
+                                          unsigned log_stride, size_t z, size_t base0) {
+    const PassArgs &a = ra.a;
+    const unsigned logC = a.log_c, C = 1u << logC;
+    const unsigned elems_log = a.log_r + logC;
+    const unsigned s_log = log_rb - P;  // S = Rb >> P
+    const unsigned R = 1u << a.log_r;
+    const size_t stride = (size_t)1 << log_stride;
+    for (unsigned u = threadIdx.x; u < (1u << (elems_log - P)); u += THREADS) {
+        const unsigned c = u & (C - 1), rest = u >> logC;
+        const unsigned lo = rest & ((1u << s_log) - 1), hi = rest >> s_log;
+        const unsigned i0 = (hi << log_rb) + lo;
+        u64 x[1 << P];
+#pragma unroll
+        for (int q = 0; q < (1 << P); ++q) {
+            const unsigned i = i0 + ((unsigned)q << s_log);
+            if (from_global) {
+                u64 v = gin[((size_t)i << log_stride) + c];
+                if (a.scale_mode == SCALE_CONST) {
+                    v = gl::mul(v, a.scale_const);
+                } else if (a.scale_mode == SCALE_TABLE) {
+                    u64 sc = a.srow[z * R + i];
+                    if (log_stride) sc = gl::mul(sc, a.scol[z * stride + base0 + c]);
+                    v = gl::mul(v, sc);
+                }
+                x[q] = v;
+            } else {
+                x[q] = tile[pad_idx((i << logC) + c)];
+            }
+        }
+        dft_pow2<P, INV>(x);
+        if (s_log) {  // four-step twiddle inside the tile: position q holds frequency k = bitrev_P(q)
+            const u64 *tw = ra.local + ((size_t)1 << log_rb);
+#pragma unroll
+            for (int q = 1; q < (1 << P); ++q) {
+                const unsigned k = __brev((unsigned)q) >> (32 - P);
+                x[q] = gl::mul(x[q], tw[lo * k]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < (1 << P); ++q) tile[pad_idx(((i0 + ((unsigned)q << s_log)) << logC) + c)] = x[q];
+    }
+    __syncthreads();
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(THREADS) ntt_regpass_kernel(RegPassArgs ra) {
+    P2HOT_DYN_SHARED(u64, tile);
+    const PassArgs &a = ra.a;
+    const unsigned tid = threadIdx.x;
+    const unsigned logC = a.log_c, C = 1u << logC;
+    const unsigned log_stride = a.log_nblk - a.log_r;
+    const unsigned tiles_per_blk_log = log_stride - logC;
+    const size_t tau = blockIdx.x;
+    const size_t blk = tau >> tiles_per_blk_log;
+    const size_t base0 = (tau & (((size_t)1 << tiles_per_blk_log) - 1)) << logC;
+    const size_t z = blockIdx.z;
+    const u64 *in = a.in + (size_t)blockIdx.y * a.in_poly_stride + z * a.in_z_stride + (blk << a.log_nblk) + base0;
+    u64 *out = a.out + (size_t)blockIdx.y * a.out_poly_stride + z * a.out_z_stride + (blk << a.log_nblk) + base0;
+    const unsigned elems = 1u << (a.log_r + logC);
+
+    if (ra.rounds[0] == 0) {  // log_r == 0: a pure scale / copy pass
+        for (unsigned e = tid; e < elems; e += THREADS) {
+            u64 v = in[e];
+            if (a.scale_mode == SCALE_CONST) v = gl::mul(v, a.scale_const);
+            if (a.scale_mode == SCALE_TABLE) v = gl::mul(v, a.srow[z]);
+            out[e] = a.canon_out ? gl::canon(v) : v;
+        }
+        return;
+    }
+    unsigned log_rb = a.log_r;
+    bool first = true;
+#pragma unroll 1
+    for (int r = 0; r < 4 && ra.rounds[r]; ++r) {
+        switch (ra.rounds[r]) {
+            case 4: reg_round<4, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+            case 3: reg_round<3, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+            case 2: reg_round<2, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+            default: reg_round<1, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+        }
+        log_rb -= ra.rounds[r];
+        first = false;
+    }
+    // inter-pass twiddle w_{n'}^(base * k1), k1 = bitrev_logr(i), then coalesced store
+    // (unrolled so that several table gathers are in flight per lane)
+#pragma unroll 8
+    for (unsigned e = tid; e < elems; e += THREADS) {
+        unsigned i = e >> logC, c = e & (C - 1);
+        u64 v = tile[pad_idx(e)];
+        if (log_stride) {
+            u32 k1 = __brev(i) >> (32 - a.log_r);
+            u64 ex = (u64)(base0 + c) * k1;
+            v = gl::mul(v, root_pow(a.roots, (u32)(ex << (32 - a.log_nblk))));
+        }
+        out[((size_t)i << log_stride) + c] = a.canon_out ? gl::canon(v) : v;
+    }
+}
+
 // out[bitrev_log_n(i)] = canon(in[i])   (util/src/lib.rs:53-62 semantics)
 __global__ void bitrev_permute_kernel(const u64 *in, u64 *out, size_t in_poly_stride, size_t out_poly_stride,
                                       unsigned log_n) {

@@ -22,6 +22,8 @@ struct p2hot_ctx {
     std::string err;
     u64 *tables = nullptr;  // fwd_lo, fwd_hi, inv_lo, inv_hi (65536 each)
     ntt::RootTable fwd{}, inv{};
+    u64 *local_fwd = nullptr, *local_inv = nullptr;  // [2^m + e] = w_{2^m}^(+-e), m <= TILE_LOG
+    bool use_regpass = true;
     struct Scratch {
         void *p = nullptr;
         size_t cap = 0;
@@ -123,7 +125,7 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     *out = ctx;  // returned even on failure so the caller can read last_error, then destroy
     P2_HIP(ctx, hipSetDevice(device));
     ctx->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream
-    P2_HIP(ctx, hipMalloc((void **)&ctx->tables, 4 * 65536 * sizeof(u64)));
+    P2_HIP(ctx, hipMalloc((void **)&ctx->tables, (4 * 65536 + 4 * (1u << ntt::TILE_LOG)) * sizeof(u64)));
     u64 *t = ctx->tables;
     const u64 w = gl::ROOT_2_32, wi = gl::inv(gl::ROOT_2_32);
     P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(256), dim3(256), 0, ctx->stream, t, (size_t)65536, w, (u64)1, (u64)0);
@@ -136,6 +138,17 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     P2_LAUNCH_CHECK(ctx);
     ctx->fwd = ntt::RootTable{t, t + 65536};
     ctx->inv = ntt::RootTable{t + 2 * 65536, t + 3 * 65536};
+    ctx->local_fwd = t + 4 * 65536;
+    ctx->local_inv = ctx->local_fwd + 2 * (1u << ntt::TILE_LOG);
+    for (unsigned m = 0; m <= ntt::TILE_LOG; ++m) {
+        const size_t cnt = (size_t)1 << m;
+        const u64 wm = gl::root_of_unity(m), wmi = gl::inv(wm);
+        P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, ctx->stream, ctx->local_fwd + cnt, cnt, wm,
+                     (u64)1, (u64)0);
+        P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, ctx->stream, ctx->local_inv + cnt, cnt, wmi,
+                     (u64)1, (u64)0);
+    }
+    P2_LAUNCH_CHECK(ctx);
     P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return P2HOT_OK;
 }
@@ -261,7 +274,27 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
         dim3 grid(1u << tiles_log, (unsigned)batch, (unsigned)zcount);
         size_t shmem = ((size_t)8) << (a.log_r + a.log_c);
         ProfScope ps(ctx, a.log_c ? "ntt_pass_strided" : "ntt_pass_contig");
-        P2HOT_LAUNCH(ntt::ntt_pass_kernel, grid, dim3(ntt::THREADS), shmem, ctx->stream, a);
+        if (ctx->use_regpass) {
+            ntt::RegPassArgs ra{};
+            ra.a = a;
+            const bool inverse = roots.lo == ctx->inv.lo;
+            ra.local = inverse ? ctx->local_inv : ctx->local_fwd;
+            ra.inverse = inverse;
+            unsigned rem = a.log_r, k = 0;  // rounds of radix 16, remainder split as evenly as possible
+            unsigned nr = (rem + 3) / 4;
+            for (unsigned q = 0; q < nr; ++q) {
+                unsigned part = (rem + (nr - q) - 1) / (nr - q);
+                ra.rounds[k++] = part;
+                rem -= part;
+            }
+            size_t shm = (size_t)8 * ntt::TILE_WORDS_PADDED;
+            if (inverse)
+                P2HOT_LAUNCH(ntt::ntt_regpass_kernel<true>, grid, dim3(ntt::THREADS), shm, ctx->stream, ra);
+            else
+                P2HOT_LAUNCH(ntt::ntt_regpass_kernel<false>, grid, dim3(ntt::THREADS), shm, ctx->stream, ra);
+        } else {
+            P2HOT_LAUNCH(ntt::ntt_pass_kernel, grid, dim3(ntt::THREADS), shmem, ctx->stream, a);
+        }
         P2_LAUNCH_CHECK(ctx);
         log_nblk -= a.log_r;
     }
