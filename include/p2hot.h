@@ -57,6 +57,11 @@ int p2hot_is_emulated(void);
  * {"kernel": {"ms": total, "launches": count}, ...} (valid until the next call); reset != 0 clears
  * the totals.  This is the TimingTree analogue (plonky2/src/util/timing.rs) for the GPU stages. */
 int p2hot_profile_enable(p2hot_ctx *ctx, int on);
+/* tuning knob for the NTT pass kernels (0 = LDS radix-2 layers, 3 = register radix 8 [default], 4 = radix 16);
+ * results are identical, only the speed differs */
+int p2hot_tune_ntt(p2hot_ctx *ctx, int radix_bits);
+/* overlap the Poseidon leaf sponge of coset block b with the LDE of block b+1 on a second HIP stream (default 0: measured neutral on MI355X) */
+int p2hot_tune_overlap(p2hot_ctx *ctx, int on);
 const char *p2hot_profile_json(p2hot_ctx *ctx, int reset);
 
 /* sizes: number of digests (4 words each) in MerkleTree::digests for n_leaves = 2^log_leaves

@@ -36,6 +36,8 @@ SIGNATURES = {
     "p2hot_version": (C.c_char_p, []),
     "p2hot_is_emulated": (i, []),
     "p2hot_profile_enable": (i, [vp, i]),
+    "p2hot_tune_ntt": (i, [vp, i]),
+    "p2hot_tune_overlap": (i, [vp, i]),
     "p2hot_profile_json": (C.c_char_p, [vp, i]),
     "p2hot_num_digests": (sz, [u, u]),
     "p2hot_fft_dev": (i, [vp, vp, sz, sz, u]),

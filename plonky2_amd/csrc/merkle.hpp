@@ -49,10 +49,11 @@ __device__ __forceinline__ u64 *node_slot(u64 *digests, u64 *cap, unsigned h, un
 // hash_or_noop of every leaf (plonk/config.rs:63-74; sponge hashing.rs:118-145: zero state,
 // overwrite-mode absorb of <= 8 elements per permutation, no padding), digest -> level-0 slot.
 template <class Reader>
-__global__ void __launch_bounds__(256) hash_leaves_kernel(Reader rd, unsigned W, size_t n_leaves, unsigned h,
-                                                         u64 *digests, u64 *cap) {
-    size_t L = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (L >= n_leaves) return;
+__global__ void __launch_bounds__(256) hash_leaves_kernel(Reader rd, unsigned W, size_t leaf_offset, size_t leaf_count,
+                                                         unsigned h, u64 *digests, u64 *cap) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= leaf_count) return;
+    const size_t L = leaf_offset + t;  // leaf index inside the forest (reader and digest slots are forest-relative)
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = 0;

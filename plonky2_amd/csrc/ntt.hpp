@@ -194,7 +194,7 @@ __device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, cons
     const unsigned s_log = log_rb - P;  // S = Rb >> P
     const unsigned R = 1u << a.log_r;
     const size_t stride = (size_t)1 << log_stride;
-    for (unsigned u = threadIdx.x; u < (1u << (elems_log - P)); u += THREADS) {
+    for (unsigned u = threadIdx.x; u < (1u << (elems_log - P)); u += blockDim.x) {
         const unsigned c = u & (C - 1), rest = u >> logC;
         const unsigned lo = rest & ((1u << s_log) - 1), hi = rest >> s_log;
         const unsigned i0 = (hi << log_rb) + lo;
@@ -231,8 +231,8 @@ __device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, cons
     __syncthreads();
 }
 
-template <bool INV>
-__global__ void __launch_bounds__(THREADS) ntt_regpass_kernel(RegPassArgs ra) {
+template <bool INV, int NT, int MINW>
+__global__ void __launch_bounds__(NT, MINW) ntt_regpass_kernel(RegPassArgs ra) {
     P2HOT_DYN_SHARED(u64, tile);
     const PassArgs &a = ra.a;
     const unsigned tid = threadIdx.x;
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(THREADS) ntt_regpass_kernel(RegPassArgs ra) {
     const unsigned elems = 1u << (a.log_r + logC);
 
     if (ra.rounds[0] == 0) {  // log_r == 0: a pure scale / copy pass
-        for (unsigned e = tid; e < elems; e += THREADS) {
+        for (unsigned e = tid; e < elems; e += NT) {
             u64 v = in[e];
             if (a.scale_mode == SCALE_CONST) v = gl::mul(v, a.scale_const);
             if (a.scale_mode == SCALE_TABLE) v = gl::mul(v, a.srow[z]);
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(THREADS) ntt_regpass_kernel(RegPassArgs ra) {
 #pragma unroll 1
     for (int r = 0; r < 4 && ra.rounds[r]; ++r) {
         switch (ra.rounds[r]) {
-            case 4: reg_round<4, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+            case 4: if (NT == 256) reg_round<4, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
             case 3: reg_round<3, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
             case 2: reg_round<2, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
             default: reg_round<1, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(THREADS) ntt_regpass_kernel(RegPassArgs ra) {
     // inter-pass twiddle w_{n'}^(base * k1), k1 = bitrev_logr(i), then coalesced store
     // (unrolled so that several table gathers are in flight per lane)
 #pragma unroll 8
-    for (unsigned e = tid; e < elems; e += THREADS) {
+    for (unsigned e = tid; e < elems; e += NT) {
         unsigned i = e >> logC, c = e & (C - 1);
         u64 v = tile[pad_idx(e)];
         if (log_stride) {

@@ -24,6 +24,12 @@ struct p2hot_ctx {
     ntt::RootTable fwd{}, inv{};
     u64 *local_fwd = nullptr, *local_inv = nullptr;  // [2^m + e] = w_{2^m}^(+-e), m <= TILE_LOG
     bool use_regpass = true;
+    // second stream: the VALU-bound leaf sponge of coset block b runs beside the wait-bound NTT of block b+1
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> fork_events;
+    hipEvent_t join_event = nullptr;
+    bool overlap = false;  // measured on MI355X: no gain (the sponge's waves fill every CU; the two kernels time-slice)
+    unsigned ntt_radix_bits = 3;  // 3: radix-8 rounds / 512 threads, 4: radix-16 / 256 threads
     struct Scratch {
         void *p = nullptr;
         size_t cap = 0;
@@ -46,16 +52,18 @@ struct ProfScope {
     p2hot_ctx *ctx;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const char *name;
-    ProfScope(p2hot_ctx *c, const char *n) : ctx(c), name(n) {
+    hipStream_t stream;
+    ProfScope(p2hot_ctx *c, const char *n, hipStream_t st = nullptr, bool use_st = false)
+        : ctx(c), name(n), stream(use_st ? st : c->stream) {
 #ifndef P2HOT_EMU
         if (ctx->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
-            (void)hipEventRecord(e0, ctx->stream);
+            (void)hipEventRecord(e0, stream);
 #endif
     }
     ~ProfScope() {
 #ifndef P2HOT_EMU
         if (e0 && e1) {
-            (void)hipEventRecord(e1, ctx->stream);
+            (void)hipEventRecord(e1, stream);
             ctx->prof.push_back({name, e0, e1});
         }
 #endif
@@ -125,6 +133,10 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     *out = ctx;  // returned even on failure so the caller can read last_error, then destroy
     P2_HIP(ctx, hipSetDevice(device));
     ctx->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream
+#ifndef P2HOT_EMU
+    P2_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    P2_HIP(ctx, hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming));
+#endif
     P2_HIP(ctx, hipMalloc((void **)&ctx->tables, (4 * 65536 + 4 * (1u << ntt::TILE_LOG)) * sizeof(u64)));
     u64 *t = ctx->tables;
     const u64 w = gl::ROOT_2_32, wi = gl::inv(gl::ROOT_2_32);
@@ -157,6 +169,14 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+#ifndef P2HOT_EMU
+    if (ctx->side) {
+        (void)hipStreamSynchronize(ctx->side);
+        (void)hipStreamDestroy(ctx->side);
+    }
+    for (auto e : ctx->fork_events) (void)hipEventDestroy(e);
+    if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
+#endif
     for (auto &kv : ctx->scale_cache) (void)hipFree(kv.second);
     for (auto &s : ctx->scratch)
         if (s.p) (void)hipFree(s.p);
@@ -178,6 +198,21 @@ extern "C" int p2hot_ctx_sync(p2hot_ctx *ctx) {
 }
 
 extern "C" const char *p2hot_last_error(const p2hot_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// tuning knob: overlap the leaf sponge of coset block b with the LDE of block b+1 on a second stream (default on)
+extern "C" int p2hot_tune_overlap(p2hot_ctx *ctx, int on) {
+    if (!ctx) return P2HOT_EINVAL;
+    ctx->overlap = on != 0;
+    return P2HOT_OK;
+}
+
+// tuning knob (not part of the drop-in surface): 0 = LDS radix-2 layers, 3 = register radix 8, 4 = radix 16
+extern "C" int p2hot_tune_ntt(p2hot_ctx *ctx, int radix_bits) {
+    if (!ctx || (radix_bits != 0 && radix_bits != 3 && radix_bits != 4)) return P2HOT_EINVAL;
+    ctx->use_regpass = radix_bits != 0;
+    if (radix_bits) ctx->ntt_radix_bits = (unsigned)radix_bits;
+    return P2HOT_OK;
+}
 
 extern "C" int p2hot_profile_enable(p2hot_ctx *ctx, int on) {
     if (!ctx) return P2HOT_EINVAL;
@@ -280,18 +315,29 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
             const bool inverse = roots.lo == ctx->inv.lo;
             ra.local = inverse ? ctx->local_inv : ctx->local_fwd;
             ra.inverse = inverse;
-            unsigned rem = a.log_r, k = 0;  // rounds of radix 16, remainder split as evenly as possible
-            unsigned nr = (rem + 3) / 4;
+            // rounds of radix <= 2^maxp, remainder split as evenly as possible.  Radix 8 with 512 threads
+            // (8 points per lane, <= 64 VGPRs, 8 waves/SIMD) hides the global/LDS/barrier waits better
+            // than radix 16 with 256 threads (measured: the pass is wait-bound, not VALU-bound).
+            const unsigned maxp = ctx->ntt_radix_bits;
+            unsigned rem = a.log_r, k = 0;
+            unsigned nr = (rem + maxp - 1) / maxp;
             for (unsigned q = 0; q < nr; ++q) {
                 unsigned part = (rem + (nr - q) - 1) / (nr - q);
                 ra.rounds[k++] = part;
                 rem -= part;
             }
             size_t shm = (size_t)8 * ntt::TILE_WORDS_PADDED;
-            if (inverse)
-                P2HOT_LAUNCH(ntt::ntt_regpass_kernel<true>, grid, dim3(ntt::THREADS), shm, ctx->stream, ra);
-            else
-                P2HOT_LAUNCH(ntt::ntt_regpass_kernel<false>, grid, dim3(ntt::THREADS), shm, ctx->stream, ra);
+            if (maxp == 3) {
+                if (inverse)
+                    P2HOT_LAUNCH((ntt::ntt_regpass_kernel<true, 512, 8>), grid, dim3(512), shm, ctx->stream, ra);
+                else
+                    P2HOT_LAUNCH((ntt::ntt_regpass_kernel<false, 512, 8>), grid, dim3(512), shm, ctx->stream, ra);
+            } else {
+                if (inverse)
+                    P2HOT_LAUNCH((ntt::ntt_regpass_kernel<true, 256, 4>), grid, dim3(256), shm, ctx->stream, ra);
+                else
+                    P2HOT_LAUNCH((ntt::ntt_regpass_kernel<false, 256, 4>), grid, dim3(256), shm, ctx->stream, ra);
+            }
         } else {
             P2HOT_LAUNCH(ntt::ntt_pass_kernel, grid, dim3(ntt::THREADS), shmem, ctx->stream, a);
         }
@@ -434,35 +480,60 @@ extern "C" int p2hot_gather_rows_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor,
 }
 
 // ------------------------------------------------------------------ Merkle
-template <class Reader>
-static int merkle_forest(p2hot_ctx *ctx, Reader rd, size_t W, unsigned log_leaves, unsigned cap_height,
-                         size_t leaf_begin, size_t leaf_count, u64 *d_digests, u64 *d_cap) {
+struct ForestGeom {
+    unsigned h;    // subtree height = log2(leaves) - cap_height
+    u64 *dig;      // digest slice of the first subtree of the range
+    u64 *cap;      // cap entry of the first subtree of the range
+};
+
+static int forest_geom(p2hot_ctx *ctx, unsigned log_leaves, unsigned cap_height, size_t leaf_begin, size_t leaf_count,
+                       u64 *d_digests, u64 *d_cap, ForestGeom *g) {
     if (cap_height > log_leaves)
         P2_FAIL(ctx, P2HOT_EINVAL, "cap_height %u > log2(leaves) %u (merkle_tree.rs:195-200)", cap_height, log_leaves);
     const unsigned h = log_leaves - cap_height;
     const size_t sub_leaves = (size_t)1 << h, n_leaves = (size_t)1 << log_leaves;
-    if (leaf_count == 0) return P2HOT_OK;
     if (leaf_begin % sub_leaves || leaf_count % sub_leaves || leaf_begin + leaf_count > n_leaves)
         P2_FAIL(ctx, P2HOT_EINVAL, "merkle: leaves [%zu,+%zu) are not whole cap subtrees of %zu", leaf_begin, leaf_count,
                 sub_leaves);
-    if (!d_cap || (h > 0 && !d_digests)) P2_FAIL(ctx, P2HOT_EINVAL, "merkle: null output");
+    if (leaf_count && (!d_cap || (h > 0 && !d_digests))) P2_FAIL(ctx, P2HOT_EINVAL, "merkle: null output");
     const size_t s0 = leaf_begin >> h;
-    u64 *dig = d_digests ? d_digests + 4 * s0 * (2 * (sub_leaves - 1)) : nullptr;
-    u64 *cap = d_cap + 4 * s0;
-    {
-        ProfScope ps(ctx, "hash_leaves");
-        P2HOT_LAUNCH((merkle::hash_leaves_kernel<Reader>), dim3(cdiv(leaf_count, 256)), dim3(256), 0, ctx->stream, rd,
-                     (unsigned)W, leaf_count, h, dig, cap);
-    }
+    g->h = h;
+    g->dig = d_digests ? d_digests + 4 * s0 * (2 * (sub_leaves - 1)) : nullptr;
+    g->cap = d_cap ? d_cap + 4 * s0 : nullptr;
+    return P2HOT_OK;
+}
+
+// leaf sponge for the forest leaves [leaf_offset, leaf_offset + count) on `stream`
+template <class Reader>
+static int hash_leaves_range(p2hot_ctx *ctx, hipStream_t stream, Reader rd, size_t W, const ForestGeom &g,
+                             size_t leaf_offset, size_t count) {
+    if (count == 0) return P2HOT_OK;
+    ProfScope ps(ctx, "hash_leaves", stream, true);
+    P2HOT_LAUNCH((merkle::hash_leaves_kernel<Reader>), dim3(cdiv(count, 256)), dim3(256), 0, stream, rd, (unsigned)W,
+                 leaf_offset, count, g.h, g.dig, g.cap);
     P2_LAUNCH_CHECK(ctx);
+    return P2HOT_OK;
+}
+
+static int merkle_levels(p2hot_ctx *ctx, const ForestGeom &g, size_t leaf_count) {
     ProfScope ps(ctx, "merkle_levels");
-    for (unsigned level = 1; level <= h; ++level) {
+    for (unsigned level = 1; level <= g.h; ++level) {
         size_t nodes = leaf_count >> level;
-        P2HOT_LAUNCH(merkle::merkle_level_kernel, dim3(cdiv(nodes, 256)), dim3(256), 0, ctx->stream, dig, cap, h, level,
-                     nodes);
+        P2HOT_LAUNCH(merkle::merkle_level_kernel, dim3(cdiv(nodes, 256)), dim3(256), 0, ctx->stream, g.dig, g.cap, g.h,
+                     level, nodes);
         P2_LAUNCH_CHECK(ctx);
     }
     return P2HOT_OK;
+}
+
+template <class Reader>
+static int merkle_forest(p2hot_ctx *ctx, Reader rd, size_t W, unsigned log_leaves, unsigned cap_height,
+                         size_t leaf_begin, size_t leaf_count, u64 *d_digests, u64 *d_cap) {
+    ForestGeom g;
+    P2_TRY(forest_geom(ctx, log_leaves, cap_height, leaf_begin, leaf_count, d_digests, d_cap, &g));
+    if (leaf_count == 0) return P2HOT_OK;
+    P2_TRY(hash_leaves_range(ctx, ctx->stream, rd, W, g, 0, leaf_count));
+    return merkle_levels(ctx, g, leaf_count);
 }
 
 extern "C" int p2hot_merkle_dev(p2hot_ctx *ctx, const uint64_t *d_leaves, int layout, size_t leaf_stride, size_t W,
@@ -516,11 +587,38 @@ extern "C" int p2hot_commit_dev(p2hot_ctx *ctx, const uint64_t *d_cols, size_t c
             P2_HIP(ctx, hipMemcpyAsync(d_coeffs + c * coeff_stride, d_cols + c * col_stride, n * 8,
                                        hipMemcpyDeviceToDevice, ctx->stream));
     }
-    // "FFT + blinding" + "transpose LDEs" + reverse_index_bits (oracle.rs:91-98)
-    P2_TRY(p2hot_coset_lde_dev(ctx, coeff_src, W, coeff_src_stride, log_n, rate_bits, gl::COSET_SHIFT, row_begin,
-                               row_count, d_lde, lde_stride));
-    // "build Merkle tree" (oracle.rs:99-103)
-    P2_TRY(p2hot_merkle_dev(ctx, d_lde, 0, lde_stride, W, log_N, cap_height, row_begin, row_count, d_digests, d_cap));
+    // "FFT + blinding" + "transpose LDEs" + reverse_index_bits (oracle.rs:91-98), "build Merkle tree" (oracle.rs:99-103)
+    const size_t blocks = row_count >> log_n;
+#ifndef P2HOT_EMU
+    if (ctx->overlap && W > 0 && blocks > 1 && row_count % n == 0) {
+        // Coset blocks are independent: the LDE of block b+1 (wait-bound) runs on the main stream while the
+        // Poseidon leaf sponge of block b (VALU-bound) runs on the side stream; the levels follow the join.
+        if (W > 0xFFFFFFFFull) P2_FAIL(ctx, P2HOT_EINVAL, "commit: too many columns");
+        ForestGeom g;
+        P2_TRY(forest_geom(ctx, log_N, cap_height, row_begin, row_count, d_digests, d_cap, &g));
+        while (ctx->fork_events.size() < blocks) {
+            hipEvent_t e;
+            P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->fork_events.push_back(e);
+        }
+        for (size_t b = 0; b < blocks; ++b) {
+            P2_TRY(p2hot_coset_lde_dev(ctx, coeff_src, W, coeff_src_stride, log_n, rate_bits, gl::COSET_SHIFT,
+                                       row_begin + b * n, n, d_lde + b * n, lde_stride));
+            P2_HIP(ctx, hipEventRecord(ctx->fork_events[b], ctx->stream));
+            P2_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->fork_events[b], 0));
+            P2_TRY(hash_leaves_range(ctx, ctx->side, merkle::ColMajorReader{d_lde, lde_stride}, W, g, b * n, n));
+        }
+        P2_HIP(ctx, hipEventRecord(ctx->join_event, ctx->side));
+        P2_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->join_event, 0));
+        P2_TRY(merkle_levels(ctx, g, row_count));
+    } else
+#endif
+    {
+        (void)blocks;
+        P2_TRY(p2hot_coset_lde_dev(ctx, coeff_src, W, coeff_src_stride, log_n, rate_bits, gl::COSET_SHIFT, row_begin,
+                                   row_count, d_lde, lde_stride));
+        P2_TRY(p2hot_merkle_dev(ctx, d_lde, 0, lde_stride, W, log_N, cap_height, row_begin, row_count, d_digests, d_cap));
+    }
     if (d_leaves) P2_TRY(p2hot_transpose_dev(ctx, d_lde, lde_stride, W, row_count, d_leaves));
     return P2HOT_OK;
 }

@@ -103,3 +103,47 @@ def test_fri_commit_phase_full_size_vs_oracle(gpu, ora, log_n, rb, arity):
         assert (np.asarray(t.digests).reshape(-1, 4) == o["digests"][i]).all(), i
         assert (t.leaves == o["leaves"][i]).all(), i
     assert c.get_n_challenges(2) == oc.get_n_challenges(2)
+
+
+class _LoopbackDist:
+    """single-process stand-in for torch.distributed: rank r's all-gather input is written into slot r of the
+    output and the other slots are filled from what the other simulated ranks deposited earlier"""
+
+    def __init__(self, world):
+        self.world, self.rank, self.store = world, 0, {}
+        self.calls = 0
+
+    def all_gather_into_tensor(self, out, inp):
+        key = self.calls
+        self.calls += 1
+        self.store.setdefault(key, {})[self.rank] = inp.clone()
+        chunk = inp.numel()
+        for r, t in self.store[key].items():
+            out[r * chunk:(r + 1) * chunk] = t
+
+
+def test_sharded_commit_ranks_on_one_gpu(gpu, ora):
+    """the world > 1 branch of plonky2_amd.distributed on the real GPU: both ranks of a 2-rank job are
+    run one after the other with a loopback all-gather; rank 1 then holds the full tree"""
+    from plonky2_amd.distributed import ShardedCommit
+    rng = np.random.default_rng(9)
+    W, log_n, rb, cap = 9, 12, 3, 4
+    cols = rand_field(rng, W, 1 << log_n)
+    o = ora.commit(cols, rb, cap, True)
+    dist = _LoopbackDist(2)
+    jobs = [ShardedCommit(gpu, W, log_n, rb, cap, is_values=True, rank=r, world=2, dist=dist, want_leaves=True) for r in range(2)]
+    out = None
+    for _pass in range(2):  # second sweep: every rank's deposits are present, like a real collective
+        dist.calls = 0
+        for r, job in enumerate(jobs):
+            dist.rank = r
+            base = dist.calls
+            c0, c1 = job.column_range
+            out = job.run(gpu.dev(cols[c0:c1]))
+            if r == 0:
+                dist.calls = base  # rank 1 replays the same sequence of collectives
+    r0, rc = jobs[1].plan.rows(1)
+    assert (gpu.host(out["coeffs"]) == o["coeffs"]).all()
+    assert (gpu.host(out["leaves"]) == o["leaves"][r0:r0 + rc]).all()
+    assert (gpu.host(out["digests"]) == o["digests"]).all()
+    assert (gpu.host(out["cap"]) == o["cap"]).all()

@@ -7,7 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 
-#define ITERS 2048
+#define ITERS 65536
 
 #define R8(INS)                                                                                    \
     INS(0) "\n\t" INS(1) "\n\t" INS(2) "\n\t" INS(3) "\n\t" INS(4) "\n\t" INS(5) "\n\t" INS(6) "\n\t" INS(7)
@@ -24,6 +24,10 @@
 #define I_MULHI(i) "v_mul_hi_u32 %" #i ", %" #i ", %16"
 #define I_MAD24(i) "v_mad_u32_u24 %" #i ", %" #i ", 41, %16"
 #define I_MUL24(i) "v_mul_u32_u24 %" #i ", %" #i ", 41"
+#define I_MOV(i) "v_mov_b32 %" #i ", %16"
+#define I_XOR(i) "v_xor_b32 %" #i ", %" #i ", %16"
+#define I_ADDE64(i) "v_add_co_u32_e64 %" #i ", s[20:21], %" #i ", %16"
+#define I_LSHL64(i) "v_lshlrev_b64 %" #i ", 3, %" #i
 #define I_ADD3(i) "v_add3_u32 %" #i ", %" #i ", %16, %17"
 #define I_DOT2(i) "v_dot2_u32_u16 %" #i ", %16, %17, %" #i
 #define I_DOT4(i) "v_dot4_u32_u8 %" #i ", %16, %17, %" #i
@@ -76,6 +80,10 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t 
         if (OP == 16) asm volatile(R8B(I_MAD64) OPS);
         if (OP == 17) asm volatile(R8B(I_LSHLADD64) OPS);
         if (OP == 18) asm volatile(R8B(I_CMP64) OPS);
+        if (OP == 19) asm volatile(R8(I_MOV) OPS);
+        if (OP == 20) asm volatile(R8(I_XOR) OPS);
+        if (OP == 21) asm volatile(R8(I_ADDE64) OPS, "s20", "s21");
+        if (OP == 22) asm volatile(R8B(I_LSHL64) OPS);
     }
     uint64_t t1 = __builtin_readcyclecounter();
     uint64_t s = 0;
@@ -127,6 +135,10 @@ int main() {
     (void)hipGetDeviceProperties(&p, 0);
     printf("device %s  CUs %d  clock %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
     run<0>("v_add_u32");
+    run<19>("v_mov_b32");
+    run<20>("v_xor_b32");
+    run<21>("v_add_co_u32_e64");
+    run<22>("v_lshlrev_b64");
     run<5>("v_add3_u32");
     run<10>("v_add_co_u32");
     run<11>("v_addc_co_u32");
