@@ -92,6 +92,18 @@ def pmc_traffic(W, log_n, rb, cap, world, kernel):
         return None
 
 
+def pmc_valu(W, log_n, rb, cap, world):
+    """SQ_INSTS_VALU of one hash_leaves launch from the committed PMC pass (same workload only)"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        w = d["workload"]
+        if (w["W"], w["log_n"], w["rate_bits"], w["cap_height"], w["n_gpus"]) != (W, log_n, rb, cap, world):
+            return None
+        return d["kernels"]["hash_leaves_kernel"].get("sq_insts_valu_per_launch")
+    except Exception:
+        return None
+
+
 def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=20.0):
     """The oracle's C restatement ("port", OpenMP on the host cores) timed on a bounded sample of the
     same workload: same W / rate / cap, fewer rows.  NOT the Rust prover (no cargo in the image)."""
@@ -231,6 +243,14 @@ def main():
                          "note": "integer-VALU bound by nature (%.3g permutations per launch, %.1f Gperm/s); "
                                  "algorithmic bytes per launch = 8*W*rows + 32*rows = %d"
                                  % (perms, perms / (h["ms_per_launch"] * 1e-3) / 1e9, hash_bytes)},
+            "valu": (lambda n: None if not n else {
+                "kernel": "hash_leaves", "insts_per_launch": n / launches_per_step, "unit": "Gwave-inst/s",
+                "achieved": n / launches_per_step / (h["ms_per_launch"] * 1e-3) / 1e9,
+                "peak": 1024 * 2.4 / 2, "frac": n / launches_per_step / (h["ms_per_launch"] * 1e-3) / 1e9 / (1024 * 2.4 / 2),
+                "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VOP2; measured on this chip (tools/ubench) a "
+                        "wave64 VOP3 / carry / v_mad_u64_u32 instruction occupies ~4.5 cycles, so a VOP3-dominated "
+                        "integer kernel saturates its SIMDs near frac 0.5; SQ_INSTS_VALU from profiles/pmc_traffic.json"})(
+                pmc_valu(W, log_n, rb, cap, world)),
             "kernels": kern,
             "algorithmic_bytes_per_step": ab,
             "commit_hbm_frac": ab["total"] / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,

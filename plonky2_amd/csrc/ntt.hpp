@@ -159,6 +159,8 @@ struct RegPassArgs {
     const u64 *local;        // local[2^m + e] = w_{2^m}^e (forward or inverse), m <= TILE_LOG
     unsigned rounds[4];      // radix bits of each round, sum = log_r, zero-terminated
     int inverse;
+    unsigned zloop;          // > 0: this workgroup produces z = 0..zloop-1 itself (coset LDE first pass: the
+                             // coefficient tile is fetched from HBM once and re-read from L2 for the other cosets)
 };
 
 // 2^P-point DFT of x[] in place (DIF, bit-reversed output) with power-of-two twiddles
@@ -242,45 +244,49 @@ __global__ void __launch_bounds__(NT, MINW) ntt_regpass_kernel(RegPassArgs ra) {
     const size_t tau = blockIdx.x;
     const size_t blk = tau >> tiles_per_blk_log;
     const size_t base0 = (tau & (((size_t)1 << tiles_per_blk_log) - 1)) << logC;
-    const size_t z = blockIdx.z;
-    const u64 *in = a.in + (size_t)blockIdx.y * a.in_poly_stride + z * a.in_z_stride + (blk << a.log_nblk) + base0;
-    u64 *out = a.out + (size_t)blockIdx.y * a.out_poly_stride + z * a.out_z_stride + (blk << a.log_nblk) + base0;
     const unsigned elems = 1u << (a.log_r + logC);
-
-    if (ra.rounds[0] == 0) {  // log_r == 0: a pure scale / copy pass
-        for (unsigned e = tid; e < elems; e += NT) {
-            u64 v = in[e];
-            if (a.scale_mode == SCALE_CONST) v = gl::mul(v, a.scale_const);
-            if (a.scale_mode == SCALE_TABLE) v = gl::mul(v, a.srow[z]);
-            out[e] = a.canon_out ? gl::canon(v) : v;
-        }
-        return;
-    }
-    unsigned log_rb = a.log_r;
-    bool first = true;
+    const size_t z_begin = ra.zloop ? 0 : blockIdx.z, z_end = ra.zloop ? ra.zloop : blockIdx.z + 1;
 #pragma unroll 1
-    for (int r = 0; r < 4 && ra.rounds[r]; ++r) {
-        switch (ra.rounds[r]) {
-            case 4: if (NT == 256) reg_round<4, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
-            case 3: reg_round<3, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
-            case 2: reg_round<2, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
-            default: reg_round<1, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+    for (size_t z = z_begin; z < z_end; ++z) {
+        const u64 *in = a.in + (size_t)blockIdx.y * a.in_poly_stride + z * a.in_z_stride + (blk << a.log_nblk) + base0;
+        u64 *out = a.out + (size_t)blockIdx.y * a.out_poly_stride + z * a.out_z_stride + (blk << a.log_nblk) + base0;
+
+        if (ra.rounds[0] == 0) {  // log_r == 0: a pure scale / copy pass
+            for (unsigned e = tid; e < elems; e += NT) {
+                u64 v = in[e];
+                if (a.scale_mode == SCALE_CONST) v = gl::mul(v, a.scale_const);
+                if (a.scale_mode == SCALE_TABLE) v = gl::mul(v, a.srow[z]);
+                out[e] = a.canon_out ? gl::canon(v) : v;
+            }
+            continue;
         }
-        log_rb -= ra.rounds[r];
-        first = false;
-    }
-    // inter-pass twiddle w_{n'}^(base * k1), k1 = bitrev_logr(i), then coalesced store
-    // (unrolled so that several table gathers are in flight per lane)
+        unsigned log_rb = a.log_r;
+        bool first = true;
+#pragma unroll 1
+        for (int r = 0; r < 4 && ra.rounds[r]; ++r) {
+            switch (ra.rounds[r]) {
+                case 4: if (NT == 256) reg_round<4, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+                case 3: reg_round<3, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+                case 2: reg_round<2, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+                default: reg_round<1, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+            }
+            log_rb -= ra.rounds[r];
+            first = false;
+        }
+        // inter-pass twiddle w_{n'}^(base * k1), k1 = bitrev_logr(i), then coalesced store
+        // (unrolled so that several table gathers are in flight per lane)
 #pragma unroll 8
-    for (unsigned e = tid; e < elems; e += NT) {
-        unsigned i = e >> logC, c = e & (C - 1);
-        u64 v = tile[pad_idx(e)];
-        if (log_stride) {
-            u32 k1 = __brev(i) >> (32 - a.log_r);
-            u64 ex = (u64)(base0 + c) * k1;
-            v = gl::mul(v, root_pow(a.roots, (u32)(ex << (32 - a.log_nblk))));
+        for (unsigned e = tid; e < elems; e += NT) {
+            unsigned i = e >> logC, c = e & (C - 1);
+            u64 v = tile[pad_idx(e)];
+            if (log_stride) {
+                u32 k1 = __brev(i) >> (32 - a.log_r);
+                u64 ex = (u64)(base0 + c) * k1;
+                v = gl::mul(v, root_pow(a.roots, (u32)(ex << (32 - a.log_nblk))));
+            }
+            out[((size_t)i << log_stride) + c] = a.canon_out ? gl::canon(v) : v;
         }
-        out[((size_t)i << log_stride) + c] = a.canon_out ? gl::canon(v) : v;
+        if (z + 1 < z_end) __syncthreads();  // the tile is reused by the next coset
     }
 }
 

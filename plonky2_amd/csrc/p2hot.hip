@@ -327,6 +327,10 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
                 rem -= part;
             }
             size_t shm = (size_t)8 * ntt::TILE_WORDS_PADDED;
+            if (first && zcount > 1 && a.in_z_stride == 0) {  // every z slice reads the same input tile
+                ra.zloop = (unsigned)zcount;
+                grid.z = 1;
+            }
             if (maxp == 3) {
                 if (inverse)
                     P2HOT_LAUNCH((ntt::ntt_regpass_kernel<true, 512, 8>), grid, dim3(512), shm, ctx->stream, ra);
