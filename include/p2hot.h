@@ -156,6 +156,26 @@ int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned log_n, uns
                      unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
                      p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
                      uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out);
+/* the same with the coefficients already on the device as two planes [2][n] (component 0, then component 1),
+ * e.g. the output of p2hot_fri_final_poly_dev */
+int p2hot_fri_commit_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs_planar, unsigned log_n, unsigned rate_bits,
+                         unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
+                         p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
+                         uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out);
+/* The final_poly construction of PolynomialBatch::prove_openings (fri/oracle.rs:186-213) on device-resident
+ * coefficient polynomials: for every batch i with opening point z_i,
+ *   F_i = ReducingFactor::reduce_polys_base(polys of the batch)      (util/reducing.rs:83-95)
+ *   q_i = F_i.divide_by_linear(z_i), padded with a zero                 (field/src/polynomial/division.rs:79-92)
+ *   final_poly = final_poly * alpha^(#polys of batch i) + q_i          (shift_poly, reducing.rs:103-106)
+ * d_poly_table: DEVICE array of device pointers, each to n = 2^log_n base-field coefficients; batch i uses
+ * entries [batch_offsets[i], batch_offsets[i+1]).  points [n_batches][2], alpha [2]: host.  d_final: planes [2][n]. */
+int p2hot_fri_final_poly_dev(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, const size_t *batch_offsets,
+                             size_t n_batches, const uint64_t *points, const uint64_t alpha[2], unsigned log_n,
+                             uint64_t *d_final);
+/* merkle_tree_prove (hash/merkle_tree.rs:151-190) for m leaf indices from a device-resident digest array
+ * (the query phase, fri/prover.rs:204-258): d_out [m][log_leaves - cap_height][4] */
+int p2hot_merkle_paths_dev(p2hot_ctx *ctx, const uint64_t *d_digests, unsigned log_leaves, unsigned cap_height,
+                           const uint64_t *d_idx, size_t m, uint64_t *d_out);
 /* fri_proof_of_work (fri/prover.rs:153-202), deterministic: returns the SMALLEST valid witness
  * (the reference's rayon find_any returns an arbitrary valid one), observes it and draws the
  * response like the reference does. */

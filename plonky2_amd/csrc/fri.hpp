@@ -138,6 +138,129 @@ __global__ void fold_kernel(const u64 *c0, const u64 *c1, unsigned arity_bits, c
     o1[j] = gl::canon(acc.a1);
 }
 
+// ---- prove_openings prelude: final_poly = sum_i alpha^(k_i) (F_i(X) - F_i(z_i)) / (X - z_i) ----
+// ReducingFactor::reduce_polys_base (util/reducing.rs:83-95): o[t] = sum_j apow[j] * polys[j][t]
+// (extension scalar times base coefficient = two base multiplies).  Lane = coefficient index, so
+// every polynomial is streamed once with fully coalesced reads; apow / the pointer table are wave-uniform.
+__global__ void __launch_bounds__(256) reduce_polys_base_kernel(const u64 *const *polys, size_t n_polys, const u64 *apow,
+                                                               size_t n, u64 *o0, u64 *o1) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u64 a0 = 0, a1 = 0;
+    for (size_t j = 0; j < n_polys; ++j) {
+        u64 p = polys[j][t];
+        a0 = gl::add(a0, gl::mul(apow[2 * j], p));
+        a1 = gl::add(a1, gl::mul(apow[2 * j + 1], p));
+    }
+    o0[t] = a0;
+    o1[t] = a1;
+}
+
+// divide_by_linear (field/src/polynomial/division.rs:79-92) is the Horner suffix scan
+//   b_k = b_{k+1} * z + c_k,  quotient[k-1] = b_k (k >= 1), padded with a zero.
+// Three steps over chunks of 2^chunk_log coefficients: (1) chunk totals, (2) chunk carries by a
+// suffix scan (one workgroup), (3) replay each chunk from its carry and emit
+//   acc[k] = acc[k] * shift + quotient[k]     (ReducingFactor::shift_poly + `final_poly += quotient`, oracle.rs:210-212)
+__global__ void horner_chunk_totals_kernel(const u64 *c0, const u64 *c1, unsigned chunk_log, size_t n_chunks, gl::ext2 z,
+                                           u64 *p0, u64 *p1) {
+    size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_chunks) return;
+    gl::ext2 acc{0, 0};
+    const size_t base = m << chunk_log;
+    for (size_t i = (size_t)1 << chunk_log; i-- > 0;) {
+        acc = gl::ext_mul(acc, z);
+        acc.a0 = gl::add(acc.a0, c0[base + i]);
+        acc.a1 = gl::add(acc.a1, c1[base + i]);
+    }
+    p0[m] = acc.a0;
+    p1[m] = acc.a1;
+}
+
+// carry[m] = sum_{m' > m} P[m'] * zL^(m' - m - 1)  (zL = z^(chunk length)); one 1024-thread block.
+// Each thread owns `per` consecutive chunks; block-level Hillis-Steele suffix scan through LDS.
+__global__ void __launch_bounds__(1024) horner_carries_kernel(const u64 *p0, const u64 *p1, size_t n_chunks, size_t per,
+                                                             gl::ext2 zL, u64 *t0, u64 *t1) {
+    __shared__ u64 s0[1024], s1[1024];
+    const unsigned tid = threadIdx.x;
+    const size_t lo = (size_t)tid * per, hi = lo + per < n_chunks ? lo + per : n_chunks;
+    // local total of my chunks: L = sum_{g} P[lo + g] * zL^g ; and zL^per
+    gl::ext2 loc{0, 0};
+    for (size_t m = hi; m-- > lo;) {
+        loc = gl::ext_mul(loc, zL);
+        loc.a0 = gl::add(loc.a0, p0[m]);
+        loc.a1 = gl::add(loc.a1, p1[m]);
+    }
+    gl::ext2 zP{1, 0};  // zL^per
+    for (size_t g = 0; g < per; ++g) zP = gl::ext_mul(zP, zL);
+    s0[tid] = lo < n_chunks ? loc.a0 : 0;
+    s1[tid] = lo < n_chunks ? loc.a1 : 0;
+    __syncthreads();
+    // inclusive suffix scan: S[t] = sum_{t' >= t} loc[t'] * zP^(t' - t)
+    gl::ext2 f = zP;
+    for (unsigned d = 1; d < 1024; d <<= 1) {
+        gl::ext2 add{0, 0};
+        if (tid + d < 1024) add = gl::ext_mul(gl::ext2{s0[tid + d], s1[tid + d]}, f);
+        __syncthreads();
+        s0[tid] = gl::add(s0[tid], add.a0);
+        s1[tid] = gl::add(s1[tid], add.a1);
+        __syncthreads();
+        f = gl::ext_mul(f, f);
+    }
+    // carry into my last chunk = S[tid + 1]; walk my chunks backwards
+    gl::ext2 carry{0, 0};
+    if (tid + 1 < 1024) carry = gl::ext2{s0[tid + 1], s1[tid + 1]};
+    for (size_t m = hi; m-- > lo;) {
+        t0[m] = carry.a0;
+        t1[m] = carry.a1;
+        carry = gl::ext_mul(carry, zL);
+        carry.a0 = gl::add(carry.a0, p0[m]);
+        carry.a1 = gl::add(carry.a1, p1[m]);
+    }
+}
+
+__global__ void horner_emit_kernel(const u64 *c0, const u64 *c1, unsigned chunk_log, size_t n_chunks, gl::ext2 z,
+                                   const u64 *t0, const u64 *t1, gl::ext2 shift, int accumulate, u64 *a0, u64 *a1) {
+    size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_chunks) return;
+    gl::ext2 acc{t0[m], t1[m]};
+    const size_t base = m << chunk_log, n = n_chunks << chunk_log;
+    for (size_t i = (size_t)1 << chunk_log; i-- > 0;) {
+        const size_t k = base + i;
+        if (k == n - 1) {  // the padding coefficient of the quotient ("pad back to power of two", oracle.rs:209)
+            gl::ext2 prev = accumulate ? gl::ext_mul(gl::ext2{a0[k], a1[k]}, shift) : gl::ext2{0, 0};
+            a0[k] = gl::canon(prev.a0);
+            a1[k] = gl::canon(prev.a1);
+        }
+        acc = gl::ext_mul(acc, z);
+        acc.a0 = gl::add(acc.a0, c0[k]);
+        acc.a1 = gl::add(acc.a1, c1[k]);
+        if (k >= 1) {  // quotient[k-1] = b_k
+            gl::ext2 prev = accumulate ? gl::ext_mul(gl::ext2{a0[k - 1], a1[k - 1]}, shift) : gl::ext2{0, 0};
+            a0[k - 1] = gl::canon(gl::add(prev.a0, acc.a0));
+            a1[k - 1] = gl::canon(gl::add(prev.a1, acc.a1));
+        }
+    }
+}
+
+// merkle_tree_prove (hash/merkle_tree.rs:151-190) for m leaf indices straight from the device-resident
+// digest array: out[q][i] = sibling at layer i.  Lane = (query, layer).
+__global__ void merkle_paths_kernel(const u64 *digests, unsigned log_leaves, unsigned cap_height, const u64 *idx,
+                                    size_t m, u64 *out) {
+    const unsigned layers = log_leaves - cap_height;
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (layers == 0 || e >= m * layers) return;
+    const size_t q = e / layers;
+    const unsigned i = (unsigned)(e % layers);
+    const size_t leaf = idx[q];
+    const size_t tree_len = 2 * (((size_t)1 << layers) - 1);
+    const size_t pair = (leaf & (((size_t)1 << layers) - 1)) >> i;  // pair_index before this layer's shift
+    const size_t parity = pair & 1;
+    const size_t siblings_index = ((pair >> 1) << (i + 1)) + ((size_t)1 << i) - 1;
+    const u64 *src = digests + 4 * (tree_len * (leaf >> layers) + 2 * siblings_index + (1 - parity));
+#pragma unroll
+    for (int w = 0; w < 4; ++w) out[4 * e + w] = src[w];
+}
+
 // [count][2] <-> two planes (flatten order extension/mod.rs:128-135)
 __global__ void deinterleave_kernel(const u64 *in, size_t count, u64 *p0, u64 *p1) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -2,6 +2,7 @@
 // One translation unit: the kernels live in ntt.hpp / merkle.hpp / fri.hpp.
 #include "../../include/p2hot.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <map>
 #include <string>
@@ -732,13 +733,14 @@ struct DevBuf {  // frees on scope exit (after a stream sync by the owner)
 };
 }  // namespace
 
-extern "C" int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned log_n, unsigned rate_bits,
-                                unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
-                                p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
-                                uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
+// coeffs: host [n][2] interleaved, or (d_planar != NULL) device planes [2][n]
+static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_t *d_planar, unsigned log_n,
+                           unsigned rate_bits, unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
+                           p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
+                           uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
     if (!ctx || !challenger || challenger->ctx != ctx) return P2HOT_EINVAL;
     P2_TRY(check_log(ctx, log_n + rate_bits, "fri_commit"));
-    if (!coeffs || (n_rounds && !arity_bits)) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit: null input");
+    if ((!coeffs && !d_planar) || (n_rounds && !arity_bits)) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit: null input");
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
     // validate the schedule before touching the device
     {
@@ -764,11 +766,15 @@ extern "C" int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned
     P2_HIP(ctx, hipMalloc(&beta.p, 16));
     int rc = P2HOT_OK;
     auto body = [&]() -> int {
-        P2_HIP(ctx, hipMemcpyAsync(stage.p, coeffs, n * 16, hipMemcpyHostToDevice, ctx->stream));
         u64 *cur = planes_a.u(), *nxt = planes_b.u();
         size_t cur_n = n;  // plane length (= plane stride)
-        P2HOT_LAUNCH(fri::deinterleave_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, stage.u(), n, cur, cur + n);
-        P2_LAUNCH_CHECK(ctx);
+        if (d_planar) {
+            P2_HIP(ctx, hipMemcpyAsync(cur, d_planar, n * 16, hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            P2_HIP(ctx, hipMemcpyAsync(stage.p, coeffs, n * 16, hipMemcpyHostToDevice, ctx->stream));
+            P2HOT_LAUNCH(fri::deinterleave_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, stage.u(), n, cur, cur + n);
+            P2_LAUNCH_CHECK(ctx);
+        }
         u64 shift = gl::COSET_SHIFT;
         size_t m = N;
         unsigned log_cur = log_n;
@@ -829,6 +835,103 @@ extern "C" int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned
     hipError_t e = hipStreamSynchronize(ctx->stream);  // buffers are freed on return
     if (rc == P2HOT_OK && e != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "fri_commit: %s", hipGetErrorString(e));
     return rc;
+}
+
+extern "C" int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned log_n, unsigned rate_bits,
+                                unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
+                                p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
+                                uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
+    if (ctx && !coeffs) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit: null coefficients");
+    return fri_commit_core(ctx, coeffs, nullptr, log_n, rate_bits, cap_height, arity_bits, n_rounds, challenger, leaves_out,
+                           digests_out, caps_out, betas_out, final_out);
+}
+
+extern "C" int p2hot_fri_commit_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs_planar, unsigned log_n, unsigned rate_bits,
+                                    unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
+                                    p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
+                                    uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
+    if (ctx && !d_coeffs_planar) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit_dev: null coefficients");
+    return fri_commit_core(ctx, nullptr, d_coeffs_planar, log_n, rate_bits, cap_height, arity_bits, n_rounds, challenger,
+                           leaves_out, digests_out, caps_out, betas_out, final_out);
+}
+
+// ------------------------------------------------------------------ prove_openings prelude
+static gl::ext2 ext_pow(gl::ext2 b, u64 e) {
+    gl::ext2 r{1, 0};
+    while (e) {
+        if (e & 1) r = gl::ext_mul(r, b);
+        b = gl::ext_mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+
+extern "C" int p2hot_fri_final_poly_dev(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, const size_t *batch_offsets,
+                                        size_t n_batches, const uint64_t *points, const uint64_t alpha[2], unsigned log_n,
+                                        uint64_t *d_final) {
+    if (!ctx) return P2HOT_EINVAL;
+    P2_TRY(check_log(ctx, log_n, "fri_final_poly"));
+    if (!batch_offsets || !points || !alpha || !d_final || (n_batches && !d_poly_table))
+        P2_FAIL(ctx, P2HOT_EINVAL, "fri_final_poly: null argument");
+    const size_t n = (size_t)1 << log_n;
+    const unsigned chunk_log = log_n < 6 ? log_n : 6;
+    const size_t n_chunks = n >> chunk_log, per = (n_chunks + 1023) / 1024;
+    size_t max_j = 1;
+    for (size_t i = 0; i < n_batches; ++i) {
+        if (batch_offsets[i + 1] < batch_offsets[i]) P2_FAIL(ctx, P2HOT_EINVAL, "fri_final_poly: offsets must ascend");
+        max_j = std::max(max_j, batch_offsets[i + 1] - batch_offsets[i]);
+    }
+    // scratch: composition planes [2][n], chunk totals [2][n_chunks], carries [2][n_chunks], alpha powers [max_j][2]
+    u64 *sc;
+    P2_TRY(scratch_get(ctx, 1, (2 * n + 4 * n_chunks + 2 * max_j) * 8, (void **)&sc));
+    u64 *c0 = sc, *c1 = sc + n, *p0 = sc + 2 * n, *p1 = p0 + n_chunks, *t0 = p1 + n_chunks, *t1 = t0 + n_chunks;
+    u64 *d_apow = t1 + n_chunks;
+    const gl::ext2 a{gl::canon(alpha[0]), gl::canon(alpha[1])};
+    if (n_batches == 0) P2_HIP(ctx, hipMemsetAsync(d_final, 0, n * 16, ctx->stream));
+    std::vector<u64> apow(2 * max_j);
+    for (size_t i = 0; i < n_batches; ++i) {
+        const size_t J = batch_offsets[i + 1] - batch_offsets[i];
+        gl::ext2 pw{1, 0};
+        for (size_t j = 0; j < J; ++j) {  // base.powers() restarts at 1 for every batch (reducing.rs:88-89)
+            apow[2 * j] = gl::canon(pw.a0);
+            apow[2 * j + 1] = gl::canon(pw.a1);
+            pw = gl::ext_mul(pw, a);
+        }
+        if (J) P2_HIP(ctx, hipMemcpyAsync(d_apow, apow.data(), J * 16, hipMemcpyHostToDevice, ctx->stream));
+        P2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // apow is reused by the next batch
+        {
+            ProfScope ps(ctx, "reduce_polys_base");
+            P2HOT_LAUNCH(fri::reduce_polys_base_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream,
+                         d_poly_table + batch_offsets[i], J, (const u64 *)d_apow, n, c0, c1);
+            P2_LAUNCH_CHECK(ctx);
+        }
+        ProfScope ps(ctx, "divide_by_linear");
+        const gl::ext2 z{gl::canon(points[2 * i]), gl::canon(points[2 * i + 1])};
+        const gl::ext2 zL = ext_pow(z, (u64)1 << chunk_log);
+        const gl::ext2 shift = ext_pow(a, J);  // ReducingFactor::shift_poly: final_poly *= alpha^count (reducing.rs:103-106)
+        P2HOT_LAUNCH(fri::horner_chunk_totals_kernel, dim3(cdiv(n_chunks, 256)), dim3(256), 0, ctx->stream, (const u64 *)c0,
+                     (const u64 *)c1, chunk_log, n_chunks, z, p0, p1);
+        P2HOT_LAUNCH(fri::horner_carries_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u64 *)p0, (const u64 *)p1,
+                     n_chunks, per, zL, t0, t1);
+        P2HOT_LAUNCH(fri::horner_emit_kernel, dim3(cdiv(n_chunks, 256)), dim3(256), 0, ctx->stream, (const u64 *)c0,
+                     (const u64 *)c1, chunk_log, n_chunks, z, (const u64 *)t0, (const u64 *)t1, shift, i > 0 ? 1 : 0, d_final,
+                     d_final + n);
+        P2_LAUNCH_CHECK(ctx);
+    }
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_merkle_paths_dev(p2hot_ctx *ctx, const uint64_t *d_digests, unsigned log_leaves,
+                                      unsigned cap_height, const uint64_t *d_idx, size_t m, uint64_t *d_out) {
+    if (!ctx) return P2HOT_EINVAL;
+    if (cap_height > log_leaves) P2_FAIL(ctx, P2HOT_EINVAL, "merkle_paths: cap_height > log2(leaves)");
+    const unsigned layers = log_leaves - cap_height;
+    if (m == 0 || layers == 0) return P2HOT_OK;
+    if (!d_digests || !d_idx || !d_out) P2_FAIL(ctx, P2HOT_EINVAL, "merkle_paths: null pointer");
+    P2HOT_LAUNCH(fri::merkle_paths_kernel, dim3(cdiv(m * layers, 256)), dim3(256), 0, ctx->stream, d_digests, log_leaves,
+                 cap_height, d_idx, m, d_out);
+    P2_LAUNCH_CHECK(ctx);
+    return P2HOT_OK;
 }
 
 extern "C" int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bits, uint64_t *witness_out) {

@@ -63,3 +63,67 @@ class PolynomialBatch:
         i = index * step
         rev = int(format(i, "0%db" % bits)[::-1], 2) if bits else 0
         return self.merkle_tree.get(rev)
+
+
+# ------------------------------------------------------------------ prove_openings (oracle.rs:176-237)
+class FriBatchInfo:
+    """fri/structure.rs FriBatchInfo: an opening point and the (oracle_index, polynomial_index) pairs opened there"""
+
+    def __init__(self, point, polynomials):
+        self.point = [int(point[0]), int(point[1])]
+        self.polynomials = [(int(o), int(p)) for o, p in polynomials]
+
+
+def final_poly_device(batches, oracles, alpha, engine=None):
+    """The final_poly of prove_openings (oracle.rs:186-213) on the GPU: per batch reduce_polys_base, divide_by_linear,
+    shift_poly + accumulate.  Returns device planes [2][n] (component 0 plane, component 1 plane)."""
+    import ctypes as C
+    eng = engine or oracles[0].engine
+    n = 1 << oracles[0].degree_log
+    ptrs, offsets = [], [0]
+    for b in batches:
+        for (oi, pi) in b.polynomials:
+            co = oracles[oi]._coeffs
+            if co.shape[1] != n:
+                raise ValueError("all oracles must have the same degree")
+            ptrs.append(eng.mem.ptr(co) + 8 * pi * co.shape[1])
+        offsets.append(len(ptrs))
+    table = eng.dev(np.asarray(ptrs if ptrs else [0], dtype=np.uint64))
+    points = np.ascontiguousarray(np.asarray([b.point for b in batches] or [[0, 0]], dtype=np.uint64))
+    al = np.asarray(alpha, dtype=np.uint64)
+    out = eng.mem.zeros(2, n)
+    offs = (C.c_size_t * len(offsets))(*offsets)
+    eng.check(eng.lib.p2hot_fri_final_poly_dev(eng.ctx, eng.ptr(table), offs, len(batches), points.ctypes.data,
+                                               al.ctypes.data, oracles[0].degree_log, eng.ptr(out)))
+    return out
+
+
+def prove_openings(batches, oracles, challenger, rate_bits, cap_height, reduction_arity_bits, proof_of_work_bits,
+                   num_query_rounds, engine=None):
+    """PolynomialBatch::prove_openings + fri_proof (oracle.rs:176-237, fri/prover.rs:24-82) with everything
+    but the transcript bookkeeping on the GPU.  Returns a dict shaped like FriProof:
+      commit_phase_merkle_caps, query_round_proofs [{initial_trees_proof: [(leaf, siblings)...], steps: [(evals, siblings)...]}],
+      final_poly [[c0, c1]...], pow_witness."""
+    from .prover import fri_committed_trees_device, fri_proof_of_work
+    eng = engine or oracles[0].engine
+    alpha = challenger.get_extension_challenge()                      # oracle.rs:186
+    planes = final_poly_device(batches, oracles, alpha, eng)
+    log_n = oracles[0].degree_log
+    trees, final, _betas = fri_committed_trees_device(planes, log_n, challenger, rate_bits, cap_height,
+                                                      reduction_arity_bits, eng)   # prover.rs:40-51
+    pow_witness = fri_proof_of_work(challenger, proof_of_work_bits, eng)           # prover.rs:53-58
+    lde_size = 1 << (log_n + rate_bits)
+    queries = []
+    for rand in challenger.get_n_challenges(num_query_rounds):                     # prover.rs:215-220
+        x = rand % lde_size
+        initial = []
+        for o in oracles:                                                          # prover.rs:238-241
+            initial.append((o.merkle_tree.get(x), o.merkle_tree.prove(x)))
+        steps = []
+        for i, tree in enumerate(trees):                                           # prover.rs:242-253
+            ab = reduction_arity_bits[i]
+            steps.append((tree.get(x >> ab).reshape(-1, 2), tree.prove(x >> ab)))
+            x >>= ab
+        queries.append({"initial_trees_proof": initial, "steps": steps})
+    return {"commit_phase_merkle_caps": [t.cap.entries for t in trees], "query_round_proofs": queries,
+            "final_poly": final, "pow_witness": pow_witness}

@@ -26,6 +26,12 @@ def fri_committed_trees(coeffs, challenger, rate_bits, cap_height, reduction_ari
     log_n = n.bit_length() - 1
     if n != 1 << log_n:
         raise ValueError("coefficient count must be a power of two")
+    return _commit(coeffs, None, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, eng)
+
+
+def _commit(coeffs, planes, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, engine):
+    eng = engine or challenger.engine or default_engine()
+    n = 1 << log_n
     arity = [int(a) for a in reduction_arity_bits]
     N = n << rate_bits
     ncap = 1 << cap_height
@@ -41,9 +47,14 @@ def fri_committed_trees(coeffs, challenger, rate_bits, cap_height, reduction_ari
     betas = np.zeros((max(1, len(sizes)), 2), dtype=np.uint64)
     final = np.zeros((max(1, n_final), 2), dtype=np.uint64)
     ab = (C.c_uint * max(1, len(arity)))(*arity)
-    eng.check(eng.lib.p2hot_fri_commit(eng.ctx, coeffs.ctypes.data, log_n, rate_bits, cap_height, ab, len(arity),
-                                       challenger._h, leaves.ctypes.data, digests.ctypes.data, caps.ctypes.data,
-                                       betas.ctypes.data, final.ctypes.data))
+    if planes is None:
+        eng.check(eng.lib.p2hot_fri_commit(eng.ctx, coeffs.ctypes.data, log_n, rate_bits, cap_height, ab, len(arity),
+                                           challenger._h, leaves.ctypes.data, digests.ctypes.data, caps.ctypes.data,
+                                           betas.ctypes.data, final.ctypes.data))
+    else:
+        eng.check(eng.lib.p2hot_fri_commit_dev(eng.ctx, eng.ptr(planes), log_n, rate_bits, cap_height, ab, len(arity),
+                                               challenger._h, leaves.ctypes.data, digests.ctypes.data, caps.ctypes.data,
+                                               betas.ctypes.data, final.ctypes.data))
     trees, lo, do = [], 0, 0
     for i, (mi, nl, nd) in enumerate(sizes):
         trees.append(MerkleTree(leaves=leaves[lo:lo + 2 * mi].reshape(nl, -1), digests=digests[do:do + 4 * nd].reshape(nd, 4),
@@ -51,6 +62,12 @@ def fri_committed_trees(coeffs, challenger, rate_bits, cap_height, reduction_ari
         lo += 2 * mi
         do += 4 * nd
     return trees, final[:n_final], betas[:len(sizes)]
+
+
+def fri_committed_trees_device(planes, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, engine=None):
+    """fri_committed_trees on coefficients that are already on the device as planes [2][n]
+    (e.g. plonky2_amd.fri.oracle.final_poly_device)."""
+    return _commit(None, planes, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, engine)
 
 
 def fri_proof_of_work(challenger, proof_of_work_bits, engine=None):

@@ -1,0 +1,104 @@
+"""the prove_openings prelude (reduce_polys_base, divide_by_linear, shift/accumulate),
+the FRI commit from device-resident coefficients, proof of work and the query phase, against an
+oracle-side composition that follows fri/oracle.rs:176-237 and fri/prover.rs:24-258 step by step."""
+import numpy as np
+import pytest
+
+from tests.conftest import P, rand_field
+
+
+def _ext_mul(a, b):
+    return [(a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P]
+
+
+def _ext_pow(a, e):
+    r = [1, 0]
+    for _ in range(e):
+        r = _ext_mul(r, a)
+    return r
+
+
+def _oracle_final_poly(ora, batches, coeff_sets, alpha):
+    n = coeff_sets[0].shape[1]
+    final = np.zeros((n, 2), dtype=object)
+    for bi, (point, polys) in enumerate(batches):
+        ps = np.stack([coeff_sets[o][p] for (o, p) in polys])
+        comp = ora.reduce_polys_base(ps, alpha)                 # util/reducing.rs:83-95
+        quo = ora.divide_by_linear(comp, point)                 # division.rs:79-92 (+ zero pad)
+        sh = _ext_pow([int(alpha[0]), int(alpha[1])], len(polys))  # shift_poly, reducing.rs:103-106
+        for k in range(n):
+            f = _ext_mul([int(final[k][0]), int(final[k][1])], sh) if bi else [0, 0]
+            final[k][0] = (f[0] + int(quo[k][0])) % P
+            final[k][1] = (f[1] + int(quo[k][1])) % P
+    return np.array(final.tolist(), dtype=np.uint64)
+
+
+@pytest.mark.parametrize("log_n,widths,rb,cap,arity", [(5, [3, 2], 3, 2, [2]), (8, [7, 4, 2], 3, 4, [4]), (0, [2], 1, 0, []),
+                                                        (7, [2, 2], 1, 4, [1, 2])])
+def test_final_poly_and_prove_openings_vs_oracle(eng, ora, log_n, widths, rb, cap, arity):
+    from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, final_poly_device, prove_openings
+    from plonky2_amd.iop.challenger import Challenger
+    rng = np.random.default_rng(log_n * 31 + len(widths))
+    n = 1 << log_n
+    cols = [rand_field(rng, w, n) for w in widths]
+    oracles = [PolynomialBatch.from_coeffs(c, rb, False, cap, engine=eng) for c in cols]
+    # two opening batches like plonky2's zeta / g*zeta (plonk_common.rs FRI_ORACLES): all polys at z0, the first oracle at z1
+    all_polys = [(oi, pi) for oi, w in enumerate(widths) for pi in range(w)]
+    first = [(0, pi) for pi in range(widths[0])]
+    z0, z1 = rand_field(rng, 2), rand_field(rng, 2)
+    batches = [FriBatchInfo(z0, all_polys), FriBatchInfo(z1, first)]
+    ob = [(z0, all_polys), (z1, first)]
+
+    alpha = rand_field(rng, 2)
+    got = eng.host(final_poly_device(batches, oracles, alpha, eng))      # planes [2][n]
+    exp = _oracle_final_poly(ora, ob, cols, alpha)
+    assert (got.T == exp).all()
+
+    # the whole prove_openings transcript
+    c, oc = Challenger(eng), ora.Challenger()
+    pre = rand_field(rng, 6)
+    c.observe_elements(pre)
+    oc.observe_elements(pre)
+    pow_bits, n_queries = 5, 3
+    proof = prove_openings(batches, oracles, c, rb, cap, arity, pow_bits, n_queries, engine=eng)
+    a = oc.get_extension_challenge()
+    fin = _oracle_final_poly(ora, ob, cols, np.array(a, dtype=np.uint64))
+    pad = np.zeros((n << rb, 2), dtype=np.uint64)
+    pad[:n] = fin
+    o = ora.fri_commit(pad, rb, cap, arity, oc)
+    assert (proof["final_poly"] == o["final"]).all()
+    for i in range(len(arity)):
+        assert (proof["commit_phase_merkle_caps"][i] == o["caps"][i]).all()
+    assert proof["pow_witness"] == ora.fri_pow(oc, pow_bits)
+    N = n << rb
+    commits = [ora.commit(cc, rb, cap, False) for cc in cols]
+    for q, rand in zip(proof["query_round_proofs"], oc.get_n_challenges(n_queries)):
+        x = rand % N
+        for (leaf, sib), cm in zip(q["initial_trees_proof"], commits):
+            assert (leaf == cm["leaves"][x]).all()
+            assert (sib == ora.merkle_prove(x, N, cap, cm["digests"])).all()
+            assert ora.merkle_verify(leaf, x, cm["cap"], sib)
+        for i, ab in enumerate(arity):
+            evals, sib = q["steps"][i]
+            nl = o["leaves"][i].shape[0]
+            assert (evals.reshape(-1) == o["leaves"][i][x >> ab]).all()
+            assert (sib == ora.merkle_prove(x >> ab, nl, cap, o["digests"][i])).all()
+            x >>= ab
+    assert c.get_n_challenges(2) == oc.get_n_challenges(2)
+
+
+def test_merkle_paths_device(eng, ora):
+    """p2hot_merkle_paths_dev == merkle_tree_prove (hash/merkle_tree.rs:151-190)"""
+    rng = np.random.default_rng(8)
+    for (log_n, cap) in ((6, 0), (6, 3), (4, 4), (9, 4)):
+        n = 1 << log_n
+        leaves = rand_field(rng, n, 5)
+        digests, capv = eng.merkle(eng.dev(leaves), 1, 5, log_n, cap)
+        idx = rng.integers(0, n, size=7).astype(np.uint64)
+        layers = log_n - cap
+        out = eng.mem.zeros(7, max(layers, 1), 4)
+        eng.check(eng.lib.p2hot_merkle_paths_dev(eng.ctx, eng.ptr(digests), log_n, cap, eng.ptr(eng.dev(idx)), 7, eng.ptr(out)))
+        got = eng.host(out)
+        od, _ = ora.merkle_tree(leaves, cap)
+        for q, i in enumerate(idx):
+            assert (got[q][:layers] == ora.merkle_prove(int(i), n, cap, od)).all()

@@ -25,7 +25,7 @@ def load(d, counter):
 
 
 def short(name):
-    for key in ("hash_leaves_kernel", "merkle_level_kernel", "ntt_pass_kernel", "bitrev_permute_kernel", "transpose_kernel"):
+    for key in ("hash_leaves_kernel", "merkle_level_kernel", "ntt_regpass_kernel", "ntt_pass_kernel", "bitrev_permute_kernel", "transpose_kernel"):
         if key in name:
             return key
     return None
