@@ -127,7 +127,8 @@ def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=20.0):
     fe = W * (1 << (k + rate_bits))
     out = {"value": fe / dt / 1e9, "unit": "GFE/s", "cores": cores, "kind": "port",
            "sample": "from_values W=%d, 2^%d rows, rate 1/%d, cap %d (1/%d of the GPU step's rows), %.2f s; "
-                     "restated CPU baseline (oracle/p2oracle.c, OpenMP), not the Rust prover"
+                     "restated CPU baseline (oracle/p2oracle.c, OpenMP), not the Rust prover -- the oracle's scalar Poseidon "
+                     "(~17 us per permutation per core) is an order of magnitude slower than the reference's"
                      % (W, k, 1 << rate_bits, cap_height, 1 << (log_n - k), dt)}
     try:
         out["cpu_model"] = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]

@@ -83,12 +83,16 @@ def test_fft_ifft_vs_oracle(eng, ora, log_n):
 
 def test_fft_three_pass_sizes(eng, ora):
     """log_n >= 21 takes three passes (two strided + one contiguous)"""
+    from plonky2_amd.field.fft import ifft
     from plonky2_amd.field.fft import fft
     if not is_gpu(eng):
         pytest.skip("2^21 points: GPU tier")
     rng = np.random.default_rng(5)
-    a = rand_field(rng, 1, 1 << 21)
-    assert (fft(a, eng)[0] == ora.fft(a[0].copy())).all()
+    for log_n in (21, 23):  # pass plans (5,4,12) and (6,5,12); 2^23 is the per-rank transform of config C5
+        a = rand_field(rng, 1, 1 << log_n)
+        f = fft(a, eng)
+        assert (f[0] == ora.fft(a[0].copy())).all(), log_n
+        assert (ifft(f, eng) == a).all(), log_n
 
 
 def test_coset_lde_vs_oracle_and_naive(eng, ora):
