@@ -64,9 +64,47 @@ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
     r[1] = ((u64)rb1 << 32) | rb0;
     r[2] = ((u64)rc1 << 32) | rc0;
 }
+
+// ---- fold3: three MDS-row recombinations in one interleaved stream ------------------------------
+// A row's two accumulators al = sum c*x.lo32, ah = sum c*x.hi32 (< 2^42 each) stand for
+//   y = al + ah*2^32 = {al.lo, al.hi + ah.lo} + w2 * 2^64,  w2 = ah.hi + carry < 2^11,
+// and 2^64 = 2^32 - 1 (mod P):  y = lo64 + w2 * 0xFFFFFFFF, folded once more on carry.
+//   1 v_mov T0 = al.lo   2 v_add_co T1 = al.hi + ah.lo   3 v_addc w2 = ah.hi + c
+//   4 v_mad_u64_u32 T = w2 * -1 + T (carry)   5 v_cndmask e = carry ? -1 : 0   6-7 {r0,r1} = T + e
+#define P2_FD1(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mov_b32 " P0 ", %[" a0 "]\n\t"
+#define P2_FD2(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_add_co_u32 " P1 ", " C1 ", %[" a1 "], %[" b0 "]\n\t"
+#define P2_FD3(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " M0 ", " C1 ", %[" b1 "], 0, " C1 "\n\t"
+#define P2_FD4(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", " M0 ", -1, " P "\n\t"
+#define P2_FD5(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
+#define P2_FD6(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_add_co_u32 %[" r0 "], " C1 ", " P0 ", " M0 "\n\t"
+#define P2_FD7(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 %[" r1 "], " C1 ", " P1 ", 0, " C1 "\n\t"
+
+// y[k] = al[k] + ah[k] * 2^32 (mod P), k = 0..2, for al, ah < 2^42
+__device__ __forceinline__ void fold3(const u64 al[3], const u64 ah[3], u64 y[3]) {
+    u32 ra0, ra1, rb0, rb1, rc0, rc1;
+    asm(P2_ROW(P2_FD1) P2_ROW(P2_FD2) P2_ROW(P2_FD3) P2_ROW(P2_FD4) P2_ROW(P2_FD5) P2_ROW(P2_FD6) P2_ROW(P2_FD7)
+        : [ra0] "=&v"(ra0), [ra1] "=&v"(ra1), [rb0] "=&v"(rb0), [rb1] "=&v"(rb1), [rc0] "=&v"(rc0), [rc1] "=&v"(rc1)
+        : [xa0] "v"((u32)al[0]), [xa1] "v"((u32)(al[0] >> 32)), [ya0] "v"((u32)ah[0]), [ya1] "v"((u32)(ah[0] >> 32)),
+          [xb0] "v"((u32)al[1]), [xb1] "v"((u32)(al[1] >> 32)), [yb0] "v"((u32)ah[1]), [yb1] "v"((u32)(ah[1] >> 32)),
+          [xc0] "v"((u32)al[2]), [xc1] "v"((u32)(al[2] >> 32)), [yc0] "v"((u32)ah[2]), [yc1] "v"((u32)(ah[2] >> 32))
+        : "v70", "v71", "v72", "v76", "v77", "v78", "v82", "v83", "v84", "s40", "s41", "s44", "s45", "s48", "s49");
+    y[0] = ((u64)ra1 << 32) | ra0;
+    y[1] = ((u64)rb1 << 32) | rb0;
+    y[2] = ((u64)rc1 << 32) | rc0;
+}
 #else
 __host__ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
     for (int k = 0; k < 3; ++k) r[k] = mul(a[k], b[k]);
+}
+__host__ __device__ __forceinline__ void fold3(const u64 al[3], const u64 ah[3], u64 y[3]) {
+    for (int k = 0; k < 3; ++k) {
+        u32 k1;
+        u32 w1 = addc32((u32)(al[k] >> 32), (u32)ah[k], 0u, &k1);
+        u32 w2 = (u32)(ah[k] >> 32) + k1;
+        u64 lo64 = ((u64)w1 << 32) | (u32)al[k];
+        u64 t = (u64)w2 * 0xFFFFFFFFu + lo64;
+        y[k] = fold_carry(t, t < lo64);
+    }
 }
 #endif
 

@@ -83,25 +83,29 @@ __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2) {
         xh[i] = (u32)(s[i] >> 32);
     }
 #pragma unroll
-    for (int r = 0; r < 12; ++r) {
-        u64 al = rc2 ? rc2[2 * r] : 0, ah = rc2 ? rc2[2 * r + 1] : 0;
+    for (int g = 0; g < 12; g += 3) {  // three rows at a time: six independent chains, then one fold3 stream
+        u64 al[3], ah[3], y[3];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int j = (i + r) % 12;
-            const u32 c = C[i] == 16 ? c16 : (C[i] == 2 ? c2 : C[i]);
-            al += (u64)xl[j] * c;
-            ah += (u64)xh[j] * c;
+        for (int t = 0; t < 3; ++t) {
+            const int r = g + t;
+            al[t] = rc2 ? rc2[2 * r] : 0;
+            ah[t] = rc2 ? rc2[2 * r + 1] : 0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int j = (i + r) % 12;
+                const u32 c = C[i] == 16 ? c16 : (C[i] == 2 ? c2 : C[i]);
+                al[t] += (u64)xl[j] * c;
+                ah[t] += (u64)xh[j] * c;
+            }
+            if (r == 0) {
+                al[t] += (u64)xl[0] * c8;
+                ah[t] += (u64)xh[0] * c8;
+            }
         }
-        if (r == 0) {
-            al += (u64)xl[0] * c8;
-            ah += (u64)xh[0] * c8;
-        }
-        u32 k1;
-        u32 w1 = gl::addc32((u32)(al >> 32), (u32)ah, 0u, &k1);
-        u32 w2 = (u32)(ah >> 32) + k1;
-        u64 lo64 = ((u64)w1 << 32) | (u32)al;
-        u64 y = (u64)w2 * 0xFFFFFFFFu + lo64;
-        s[r] = gl::fold_carry(y, y < lo64);
+        gl::fold3(al, ah, y);
+        s[g] = y[0];
+        s[g + 1] = y[1];
+        s[g + 2] = y[2];
     }
 }
 
