@@ -16,7 +16,9 @@
 //    per partial round plus a 121-multiply pre-matrix) costs more instructions here.  Both forms
 //    are the same function (poseidon.rs:944-957); the oracle pins both to the reference KATs.
 //  * The constant layer is fused into the preceding MDS: the round constants, pre-split into
-//    {lo32, hi32} words, seed the two accumulators straight from SGPRs.
+//    {lo32, hi32} words, seed the two accumulators straight from SGPRs.  In the partial rounds the
+//    constants of the 11 passive words are pushed forward through the (linear) MDS at table-generation
+//    time, so those rounds add a single scalar to word 0 and round 26 absorbs the remainder.
 //  * Round loops stay rolled so the kernel body fits the instruction cache.
 #pragma once
 #include "gl.hpp"
@@ -31,7 +33,7 @@ using gl::u32;
 using gl::u64;
 
 #define RC P2_POSEIDON_ALL_ROUND_CONSTANTS  // poseidon.rs:59-157
-#define RC_SPLIT P2_POSEIDON_ALL_ROUND_CONSTANTS_SPLIT  // [r][i] -> {lo32, hi32} as two u64 words
+#define RC_SPLIT P2_POSEIDON_PUSHED_ROUND_CONSTANTS_SPLIT  // [r][i] -> {lo32, hi32} as two u64 words; partial rounds: word 0 only
 
 __device__ __forceinline__ u64 sbox7(u64 x) {  // poseidon.rs:690-696
     u64 x2 = gl::sqr(x);
@@ -73,6 +75,7 @@ __device__ __forceinline__ u32 opaque_const(u32 c) {
 // 12-term multiply-add chains over the 32-bit halves (al, ah < 2^42) and one fold:
 //   y = al + ah * 2^32 = lo64 + w2 * 2^64 = lo64 + w2 * EPS (mod P), w2 < 2^10.
 // rc2 points at the round's constants split as {lo32, hi32} pairs (RC_SPLIT) or is null.
+template <bool WORD0_ONLY = false>
 __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2) {
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     const u32 c16 = opaque_const(16), c2 = opaque_const(2), c8 = opaque_const(8);
@@ -88,8 +91,9 @@ __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int r = g + t;
-            al[t] = rc2 ? rc2[2 * r] : 0;
-            ah[t] = rc2 ? rc2[2 * r + 1] : 0;
+            const bool has_rc = rc2 && (!WORD0_ONLY || r == 0);
+            al[t] = has_rc ? rc2[2 * r] : 0;
+            ah[t] = has_rc ? rc2[2 * r + 1] : 0;
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 const int j = (i + r) % 12;
@@ -116,15 +120,23 @@ __device__ inline void permute(u64 s[12]) {
     for (int i = 0; i < 12; ++i) s[i] = gl::add_canon(s[i], RC[i]);
     int round = 0;
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k, ++round) {
+    for (int k = 0; k < 3; ++k, ++round) {
         sbox_layer(s);
         mds_layer(s, RC_SPLIT + 24 * (round + 1));
     }
+    // round 3 -> 4 and the partial rounds 4..24 -> 5..25: the next constant layer is a scalar on word 0
+    // (the passive part of the partial-round constants is pushed forward through the MDS, see the generator)
+    sbox_layer(s);
+    mds_layer<true>(s, RC_SPLIT + 24 * (round + 1));
+    ++round;
 #pragma unroll 1
-    for (int k = 0; k < 22; ++k, ++round) {
+    for (int k = 0; k < 21; ++k, ++round) {
         s[0] = sbox7(s[0]);
-        mds_layer(s, RC_SPLIT + 24 * (round + 1));
+        mds_layer<true>(s, RC_SPLIT + 24 * (round + 1));
     }
+    s[0] = sbox7(s[0]);  // round 25 -> 26: full constant vector again (absorbs the pushed remainder)
+    mds_layer(s, RC_SPLIT + 24 * (round + 1));
+    ++round;
 #pragma unroll 1
     for (int k = 0; k < 3; ++k, ++round) {
         sbox_layer(s);

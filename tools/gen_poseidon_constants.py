@@ -155,6 +155,25 @@ def flat(a):
     return out
 
 
+def pushed_constants(rc, circ, diag):
+    """Dense-MDS form of the partial rounds with the constant layer reduced to one scalar: the passive part of
+    round r's constants (positions 1..11 see no S-box) is pushed forward through the MDS into round r+1,
+        c'_4 = c_4;  scalar_r = c'_r[0];  c'_{r+1} = c_{r+1} + M * (c'_r with position 0 cleared),  r = 4..25,
+    so rounds 4..25 add only scalar_r to word 0 and round 26 adds c'_26.  Same function as
+    poseidon.rs:781-801 (checked against the reference KATs by the tests)."""
+    M = [[(circ[(c - r) % W] + (diag[r] if r == c else 0)) % P for c in range(W)] for r in range(W)]
+    half = N_FULL // 2
+    fused = [rc[W * r:W * (r + 1)] for r in range(N_FULL + N_PART)]
+    cur = fused[half][:]
+    for r in range(half, half + N_PART):
+        scalar, passive = cur[0], [0] + cur[1:]
+        fused[r] = [scalar] + [0] * (W - 1)
+        nxt = mat_vec(M, passive)
+        cur = [(a + b) % P for a, b in zip(rc[W * (r + 1):W * (r + 2)], nxt)]
+    fused[half + N_PART] = cur
+    return [v for row in fused for v in row]
+
+
 def emit(path, rc, circ, diag, first, scal, vs, w_hats, init):
     def arr(name, vals, per=4):
         s = "P2_CONST_QUAL uint64_t %s[%d] = {\n" % (name, len(vals))
@@ -174,6 +193,11 @@ def emit(path, rc, circ, diag, first, scal, vs, w_hats, init):
         f.write("// the same constants with every word split into {lo32, hi32} (two u64 words): the device\n"
                 "// MDS rows start their two 32x32+64 multiply-add chains from them\n")
         f.write(arr("P2_POSEIDON_ALL_ROUND_CONSTANTS_SPLIT", [h for v in rc for h in (v & 0xFFFFFFFF, v >> 32)]))
+        f.write("// round constants with the passive part of the partial rounds pushed forward through the MDS\n"
+                "// (tools/gen_poseidon_constants.py pushed_constants): rounds 4..25 keep only word 0, round 26 absorbs the rest;\n"
+                "// split {lo32, hi32} like the table above\n")
+        f.write(arr("P2_POSEIDON_PUSHED_ROUND_CONSTANTS_SPLIT",
+                    [h for v in pushed_constants(rc, circ, diag) for h in (v & 0xFFFFFFFF, v >> 32)]))
         f.write(arr("P2_POSEIDON_MDS_CIRC", circ, 12))
         f.write(arr("P2_POSEIDON_MDS_DIAG", diag, 12))
         f.write(arr("P2_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT", first))
