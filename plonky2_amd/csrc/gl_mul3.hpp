@@ -65,6 +65,35 @@ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
     r[2] = ((u64)rc1 << 32) | rc0;
 }
 
+// ---- mul1: one multiplication as a single stream (dependent S-box chains of the partial rounds) ----
+// Same 17 instructions as a mul3 stream; the two wait states every carry consumer needs after its
+// producer are explicit `s_nop 1` (they cost this wave latency, not the SIMD issue slots).
+#define P2_NOP "s_nop 1\n\t"
+__device__ __forceinline__ u64 mul1(u64 a, u64 b) {
+    u32 ra0, ra1;
+    asm(P2_APPLY(P2_ST1, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+        P2_APPLY(P2_ST2, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+        P2_APPLY(P2_ST3, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+        P2_APPLY(P2_ST4, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+        P2_APPLY(P2_ST5, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
+        P2_APPLY(P2_ST6, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
+        P2_APPLY(P2_ST7, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+        P2_APPLY(P2_ST8, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+        P2_APPLY(P2_ST9, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
+        P2_APPLY(P2_ST10, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+        P2_APPLY(P2_ST11, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
+        P2_APPLY(P2_ST12, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+        P2_APPLY(P2_ST13, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
+        P2_APPLY(P2_ST14, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
+        P2_APPLY(P2_ST15, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+        P2_APPLY(P2_ST16, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
+        P2_APPLY(P2_ST17, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+        : [ra0] "=&v"(ra0), [ra1] "=&v"(ra1)
+        : [xa0] "v"((u32)a), [xa1] "v"((u32)(a >> 32)), [ya0] "v"((u32)b), [ya1] "v"((u32)(b >> 32))
+        : "v70", "v71", "v72", "v73", "v74", "v75", "s40", "s41", "s42", "s43");
+    return ((u64)ra1 << 32) | ra0;
+}
+
 // ---- fold3: three MDS-row recombinations in one interleaved stream ------------------------------
 // A row's two accumulators al = sum c*x.lo32, ah = sum c*x.hi32 (< 2^42 each) stand for
 //   y = al + ah*2^32 = {al.lo, al.hi + ah.lo} + w2 * 2^64,  w2 = ah.hi + carry < 2^11,
@@ -96,6 +125,7 @@ __device__ __forceinline__ void fold3(const u64 al[3], const u64 ah[3], u64 y[3]
 __host__ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
     for (int k = 0; k < 3; ++k) r[k] = mul(a[k], b[k]);
 }
+__host__ __device__ __forceinline__ u64 mul1(u64 a, u64 b) { return mul(a, b); }
 __host__ __device__ __forceinline__ void fold3(const u64 al[3], const u64 ah[3], u64 y[3]) {
     for (int k = 0; k < 3; ++k) {
         u32 k1;

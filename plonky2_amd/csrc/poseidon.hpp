@@ -42,6 +42,14 @@ __device__ __forceinline__ u64 sbox7(u64 x) {  // poseidon.rs:690-696
     return gl::mul(x3, x4);
 }
 
+// x^7 of one word with the hand-scheduled multiply (the partial rounds' single S-box)
+__device__ __forceinline__ u64 sbox7_asm(u64 x) {
+    u64 x2 = gl::mul1(x, x);
+    u64 x4 = gl::mul1(x2, x2);
+    u64 x3 = gl::mul1(x, x2);
+    return gl::mul1(x3, x4);
+}
+
 // x^7 of three independent words at once: x2 = x*x; (x3 = x*x2 and x4 = x2*x2 are independent); x7 = x3*x4
 __device__ __forceinline__ void sbox7_x3(u64 &a, u64 &b, u64 &c) {
     u64 x[3] = {a, b, c}, x2[3], x3[3], x4[3];
@@ -131,10 +139,10 @@ __device__ inline void permute(u64 s[12]) {
     ++round;
 #pragma unroll 1
     for (int k = 0; k < 21; ++k, ++round) {
-        s[0] = sbox7(s[0]);
+        s[0] = sbox7_asm(s[0]);
         mds_layer<true>(s, RC_SPLIT + 24 * (round + 1));
     }
-    s[0] = sbox7(s[0]);  // round 25 -> 26: full constant vector again (absorbs the pushed remainder)
+    s[0] = sbox7_asm(s[0]);  // round 25 -> 26: full constant vector again (absorbs the pushed remainder)
     mds_layer(s, RC_SPLIT + 24 * (round + 1));
     ++round;
 #pragma unroll 1
