@@ -172,6 +172,11 @@ int p2hot_fri_commit_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs_planar, unsign
 int p2hot_fri_final_poly_dev(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, const size_t *batch_offsets,
                              size_t n_batches, const uint64_t *points, const uint64_t alpha[2], unsigned log_n,
                              uint64_t *d_final);
+/* OpeningSet::new (plonky2/src/plonk/proof.rs:314-327): evaluate n_polys device-resident coefficient
+ * polynomials (d_poly_table: DEVICE array of device pointers, 2^log_n words each) at n_points extension points
+ * (host [n_points][2]): d_out[p][j] = polys[j](points[p]) as [2] words, layout [n_points][n_polys][2]. */
+int p2hot_eval_polys_dev(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, size_t n_polys, unsigned log_n,
+                         const uint64_t *points, size_t n_points, uint64_t *d_out);
 /* merkle_tree_prove (hash/merkle_tree.rs:151-190) for m leaf indices from a device-resident digest array
  * (the query phase, fri/prover.rs:204-258): d_out [m][log_leaves - cap_height][4] */
 int p2hot_merkle_paths_dev(p2hot_ctx *ctx, const uint64_t *d_digests, unsigned log_leaves, unsigned cap_height,

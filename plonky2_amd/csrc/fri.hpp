@@ -242,6 +242,46 @@ __global__ void horner_emit_kernel(const u64 *c0, const u64 *c1, unsigned chunk_
     }
 }
 
+// OpeningSet::new (plonky2/src/plonk/proof.rs:314-327): out[j] = polys[j](z) for an extension point z.
+// One workgroup per polynomial: lane t Horner-folds the coefficients t, t+256, ... with z^256 (coalesced
+// reads), then the 256 partials are combined with weights z^t through LDS.
+__global__ void __launch_bounds__(256) eval_polys_kernel(const u64 *const *polys, size_t n, gl::ext2 z, gl::ext2 z256,
+                                                        u64 *out /* [J][2] */) {
+    __shared__ u64 s0[256], s1[256];
+    const unsigned tid = threadIdx.x;
+    const u64 *c = polys[blockIdx.x];
+    gl::ext2 acc{0, 0};
+    if (tid < n) {
+        size_t last = tid + ((n - 1 - tid) / 256) * 256;  // largest index = tid (mod 256) below n
+        for (size_t t = last;; t -= 256) {
+            acc = gl::ext_mul(acc, z256);
+            acc.a0 = gl::add(acc.a0, c[t]);
+            if (t < 256) break;
+        }
+    }
+    // weight by z^tid
+    gl::ext2 w{1, 0}, b = z;
+    for (unsigned e = tid; e; e >>= 1) {
+        if (e & 1) w = gl::ext_mul(w, b);
+        b = gl::ext_mul(b, b);
+    }
+    acc = gl::ext_mul(acc, w);
+    s0[tid] = acc.a0;
+    s1[tid] = acc.a1;
+    __syncthreads();
+    for (unsigned d = 128; d; d >>= 1) {
+        if (tid < d) {
+            s0[tid] = gl::add(s0[tid], s0[tid + d]);
+            s1[tid] = gl::add(s1[tid], s1[tid + d]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[2 * blockIdx.x] = gl::canon(s0[0]);
+        out[2 * blockIdx.x + 1] = gl::canon(s1[0]);
+    }
+}
+
 // merkle_tree_prove (hash/merkle_tree.rs:151-190) for m leaf indices straight from the device-resident
 // digest array: out[q][i] = sibling at layer i.  Lane = (query, layer).
 __global__ void merkle_paths_kernel(const u64 *digests, unsigned log_leaves, unsigned cap_height, const u64 *idx,

@@ -882,7 +882,7 @@ extern "C" int p2hot_fri_final_poly_dev(p2hot_ctx *ctx, const uint64_t *const *d
         max_j = std::max(max_j, batch_offsets[i + 1] - batch_offsets[i]);
     }
     // scratch: composition planes [2][n], chunk totals [2][n_chunks], carries [2][n_chunks], alpha powers [max_j][2]
-    u64 *sc;
+    u64 *sc = nullptr;
     P2_TRY(scratch_get(ctx, 1, (2 * n + 4 * n_chunks + 2 * max_j) * 8, (void **)&sc));
     u64 *c0 = sc, *c1 = sc + n, *p0 = sc + 2 * n, *p1 = p0 + n_chunks, *t0 = p1 + n_chunks, *t1 = t0 + n_chunks;
     u64 *d_apow = t1 + n_chunks;
@@ -916,6 +916,24 @@ extern "C" int p2hot_fri_final_poly_dev(p2hot_ctx *ctx, const uint64_t *const *d
         P2HOT_LAUNCH(fri::horner_emit_kernel, dim3(cdiv(n_chunks, 256)), dim3(256), 0, ctx->stream, (const u64 *)c0,
                      (const u64 *)c1, chunk_log, n_chunks, z, (const u64 *)t0, (const u64 *)t1, shift, i > 0 ? 1 : 0, d_final,
                      d_final + n);
+        P2_LAUNCH_CHECK(ctx);
+    }
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_eval_polys_dev(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, size_t n_polys, unsigned log_n,
+                                    const uint64_t *points, size_t n_points, uint64_t *d_out) {
+    if (!ctx) return P2HOT_EINVAL;
+    P2_TRY(check_log(ctx, log_n, "eval_polys"));
+    if (n_polys == 0 || n_points == 0) return P2HOT_OK;
+    if (!d_poly_table || !points || !d_out) P2_FAIL(ctx, P2HOT_EINVAL, "eval_polys: null argument");
+    if (n_polys > 0x7FFFFFFFull) P2_FAIL(ctx, P2HOT_EINVAL, "eval_polys: too many polynomials");
+    const size_t n = (size_t)1 << log_n;
+    ProfScope ps(ctx, "eval_polys");
+    for (size_t p = 0; p < n_points; ++p) {
+        const gl::ext2 z{gl::canon(points[2 * p]), gl::canon(points[2 * p + 1])};
+        P2HOT_LAUNCH(fri::eval_polys_kernel, dim3((unsigned)n_polys), dim3(256), 0, ctx->stream, d_poly_table, n, z,
+                     ext_pow(z, 256), d_out + 2 * p * n_polys);
         P2_LAUNCH_CHECK(ctx);
     }
     return P2HOT_OK;

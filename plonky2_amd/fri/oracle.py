@@ -74,6 +74,23 @@ class FriBatchInfo:
         self.polynomials = [(int(o), int(p)) for o, p in polynomials]
 
 
+def eval_openings(oracles, points, engine=None):
+    """OpeningSet::new (plonk/proof.rs:314-327): every polynomial of every oracle at each extension point.
+    Returns a list (per oracle) of arrays [n_points][W][2]."""
+    eng = engine or oracles[0].engine
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.uint64).reshape(-1, 2))
+    out = []
+    for o in oracles:
+        co = o._coeffs
+        W, n = co.shape
+        table = eng.dev(np.asarray([eng.mem.ptr(co) + 8 * j * n for j in range(W)] or [0], dtype=np.uint64))
+        res = eng.mem.zeros(len(pts), max(W, 1), 2)
+        eng.check(eng.lib.p2hot_eval_polys_dev(eng.ctx, eng.ptr(table), W, o.degree_log, pts.ctypes.data, len(pts),
+                                               eng.ptr(res)))
+        out.append(eng.host(res)[:, :W])
+    return out
+
+
 def final_poly_device(batches, oracles, alpha, engine=None):
     """The final_poly of prove_openings (oracle.rs:186-213) on the GPU: per batch reduce_polys_base, divide_by_linear,
     shift_poly + accumulate.  Returns device planes [2][n] (component 0 plane, component 1 plane)."""

@@ -95,6 +95,21 @@ def test_fft_three_pass_sizes(eng, ora):
         assert (ifft(f, eng) == a).all(), log_n
 
 
+def test_ntt_kernel_variants_agree(eng, ora):
+    """p2hot_tune_ntt: LDS radix-2 layers (0), register radix 8 (3, default) and radix 16 (4) are the same function"""
+    from plonky2_amd.field.fft import fft, ifft
+    rng = np.random.default_rng(21)
+    a = rand_field(rng, 2, 1 << 13)
+    exp = np.stack([ora.fft(x.copy()) for x in a])
+    try:
+        for mode in (0, 4, 3):
+            eng.check(eng.lib.p2hot_tune_ntt(eng.ctx, mode))
+            assert (fft(a, eng) == exp).all(), mode
+            assert (ifft(exp, eng) == a).all(), mode
+    finally:
+        eng.check(eng.lib.p2hot_tune_ntt(eng.ctx, 3))
+
+
 def test_coset_lde_vs_oracle_and_naive(eng, ora):
     """polynomial/mod.rs:477-516: coset FFT == evaluation on {shift * w^i}"""
     from plonky2_amd.field.polynomial import lde_coset_fft

@@ -102,3 +102,23 @@ def test_merkle_paths_device(eng, ora):
         od, _ = ora.merkle_tree(leaves, cap)
         for q, i in enumerate(idx):
             assert (got[q][:layers] == ora.merkle_prove(int(i), n, cap, od)).all()
+
+
+def test_eval_openings_vs_horner(eng):
+    """OpeningSet::new (plonk/proof.rs:314-327): p(zeta) in F^2 by Horner on the host vs the device reduction"""
+    from plonky2_amd.fri.oracle import PolynomialBatch, eval_openings
+    rng = np.random.default_rng(33)
+    for log_n in (0, 3, 8, 10):
+        n = 1 << log_n
+        co = rand_field(rng, 5, n)
+        b = PolynomialBatch.from_coeffs(co, 1, False, 0, engine=eng)
+        pts = rand_field(rng, 2, 2)
+        got = eval_openings([b], pts, eng)[0]
+        for pi, z in enumerate(pts):
+            zz = [int(z[0]), int(z[1])]
+            for j in range(5):
+                acc = [0, 0]
+                for c in reversed(co[j]):
+                    acc = _ext_mul(acc, zz)
+                    acc[0] = (acc[0] + int(c)) % P
+                assert [int(got[pi][j][0]), int(got[pi][j][1])] == acc, (log_n, pi, j)
