@@ -240,7 +240,8 @@ def main():
                          "traffic": (lambda t: t / launches_per_step if t else None)(pmc_traffic(W, log_n, rb, cap, world, "hash_leaves_kernel")),
                          "launches_per_step": launches_per_step,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                         "overlap": "launched on a second stream beside the next coset block's LDE; durations are wall time while sharing the GPU",
+                         **({"overlap": "launched on a second stream beside the next coset block's LDE; durations are wall "
+                                        "time while sharing the GPU"} if launches_per_step > 1 else {}),
                          "note": "integer-VALU bound by nature (%.3g permutations per launch, %.1f Gperm/s); "
                                  "algorithmic bytes per launch = 8*W*rows + 32*rows = %d"
                                  % (perms, perms / (h["ms_per_launch"] * 1e-3) / 1e9, hash_bytes)},

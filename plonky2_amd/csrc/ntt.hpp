@@ -299,6 +299,28 @@ __global__ void bitrev_permute_kernel(const u64 *in, u64 *out, size_t in_poly_st
     out[(size_t)blockIdx.y * out_poly_stride + j] = gl::canon(in[(size_t)blockIdx.y * in_poly_stride + i]);
 }
 
+// the same permutation, LDS-tiled for large n: i = (hi:5 | mid | lo:5) -> bitrev(i) = (rev lo | rev mid | rev hi).
+// A workgroup moves the 32 x 32 tile of one `mid`: 256-byte runs on both the read and the write side.
+__global__ void __launch_bounds__(256) bitrev_tiled_kernel(const u64 *in, u64 *out, size_t in_poly_stride,
+                                                          size_t out_poly_stride, unsigned log_n) {
+    __shared__ u64 t[32][33];
+    const unsigned mid_bits = log_n - 10;
+    const size_t mid = blockIdx.x;
+    const size_t rmid = mid_bits ? (size_t)(__brevll((unsigned long long)mid) >> (64 - mid_bits)) : 0;
+    const u64 *src = in + (size_t)blockIdx.y * in_poly_stride;
+    u64 *dst = out + (size_t)blockIdx.y * out_poly_stride;
+    for (unsigned e = threadIdx.x; e < 1024; e += 256) {
+        unsigned hi = e >> 5, lo = e & 31;
+        t[hi][lo] = src[((size_t)hi << (log_n - 5)) | (mid << 5) | lo];
+    }
+    __syncthreads();
+    for (unsigned e = threadIdx.x; e < 1024; e += 256) {
+        unsigned a = e >> 5, b = e & 31;  // output row a = rev5(lo), column b = rev5(hi)
+        unsigned lo = __brev(a) >> 27, hi = __brev(b) >> 27;
+        dst[((size_t)a << (log_n - 5)) | (rmid << 5) | b] = gl::canon(t[hi][lo]);
+    }
+}
+
 __global__ void canon_kernel(u64 *data, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) data[i] = gl::canon(data[i]);

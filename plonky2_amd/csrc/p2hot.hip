@@ -361,6 +361,22 @@ static size_t bitrev_sz(size_t x, unsigned bits) {
 }
 
 // ------------------------------------------------------------------ primitives
+// out[bitrev(i)] = canon(in[i]) for `batch` arrays
+static int launch_bitrev(p2hot_ctx *ctx, const u64 *in, u64 *out, size_t batch, size_t in_stride, size_t out_stride,
+                         unsigned log_n) {
+    const size_t n = (size_t)1 << log_n;
+    ProfScope ps(ctx, "bitrev_permute");
+    if (log_n >= 12) {
+        P2HOT_LAUNCH(ntt::bitrev_tiled_kernel, dim3((unsigned)(n >> 10), (unsigned)batch), dim3(256), 0, ctx->stream, in, out,
+                     in_stride, out_stride, log_n);
+    } else {
+        P2HOT_LAUNCH(ntt::bitrev_permute_kernel, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, in, out,
+                     in_stride, out_stride, log_n);
+    }
+    P2_LAUNCH_CHECK(ctx);
+    return P2HOT_OK;
+}
+
 static int check_log(p2hot_ctx *ctx, unsigned log_n, const char *what) {
     if (log_n > 32) P2_FAIL(ctx, P2HOT_EINVAL, "%s: 2^%u exceeds the two-adicity of the field (fft.rs:171-177)", what, log_n);
     return P2HOT_OK;
@@ -377,10 +393,7 @@ static int ntt_natural(p2hot_ctx *ctx, u64 *d_data, size_t batch, size_t stride,
     u64 n_inv = gl::inv(n % gl::P);
     P2_TRY(run_dif(ctx, d_data, stride, tmp, n, 0, batch, 1, log_n, inverse ? ctx->inv : ctx->fwd,
                    inverse ? ntt::SCALE_CONST : ntt::SCALE_NONE, n_inv, nullptr, nullptr, false));
-    P2HOT_LAUNCH(ntt::bitrev_permute_kernel, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, tmp,
-                 d_data, n, stride, log_n);
-    P2_LAUNCH_CHECK(ctx);
-    return P2HOT_OK;
+    return launch_bitrev(ctx, tmp, d_data, batch, n, stride, log_n);
 }
 
 extern "C" int p2hot_fft_dev(p2hot_ctx *ctx, uint64_t *d_data, size_t batch, size_t poly_stride, unsigned log_n) {
@@ -458,10 +471,7 @@ extern "C" int p2hot_reverse_index_bits_dev(p2hot_ctx *ctx, const uint64_t *d_in
     const size_t n = (size_t)1 << log_n;
     if (!d_in || !d_out || d_in == d_out || poly_stride < n || batch > 65535)
         P2_FAIL(ctx, P2HOT_EINVAL, "reverse_index_bits: bad arguments (out of place only)");
-    P2HOT_LAUNCH(ntt::bitrev_permute_kernel, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_in,
-                 d_out, poly_stride, poly_stride, log_n);
-    P2_LAUNCH_CHECK(ctx);
-    return P2HOT_OK;
+    return launch_bitrev(ctx, d_in, d_out, batch, poly_stride, poly_stride, log_n);
 }
 
 extern "C" int p2hot_poseidon_permute_dev(p2hot_ctx *ctx, uint64_t *d_states, size_t count) {
@@ -579,10 +589,7 @@ extern "C" int p2hot_commit_dev(p2hot_ctx *ctx, const uint64_t *d_cols, size_t c
             P2_TRY(scratch_get(ctx, 0, W * n * 8, (void **)&tmp));
             P2_TRY(run_dif(ctx, d_cols, col_stride, tmp, n, 0, W, 1, log_n, ctx->inv, ntt::SCALE_CONST,
                            gl::inv(n % gl::P), nullptr, nullptr, false));
-            ProfScope ps(ctx, "bitrev_permute");
-            P2HOT_LAUNCH(ntt::bitrev_permute_kernel, dim3(cdiv(n, 256), (unsigned)W), dim3(256), 0, ctx->stream, tmp,
-                         d_coeffs, n, coeff_stride, log_n);
-            P2_LAUNCH_CHECK(ctx);
+            P2_TRY(launch_bitrev(ctx, tmp, d_coeffs, W, n, coeff_stride, log_n));
         }
         coeff_src = d_coeffs;
         coeff_src_stride = coeff_stride;
