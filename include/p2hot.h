@@ -99,6 +99,10 @@ int p2hot_poseidon_permute_dev(p2hot_ctx *ctx, uint64_t *d_states, size_t count)
 int p2hot_merkle_dev(p2hot_ctx *ctx, const uint64_t *d_leaves, int layout, size_t leaf_stride, size_t W,
                      unsigned log_leaves, unsigned cap_height, size_t leaf_begin, size_t leaf_count,
                      uint64_t *d_digests, uint64_t *d_cap);
+/* Field-arithmetic self test (goldilocks_field.rs:245-320, :402-415): for count operand pairs writes six arrays of
+ * `count` words to d_out: a*b by the compiler-scheduled multiply, by the hand-scheduled single stream, by the 3-way
+ * interleaved stream, a+b, a-b (all canonical), and a 0/1 flag that the other two mul3 lanes agreed. */
+int p2hot_field_selftest_dev(p2hot_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t count, uint64_t *d_out);
 /* rows of a column-major matrix: d_out[q][c] = d_colmajor[c * col_stride + d_idx[q]]
  * (PolynomialBatch::get_lde_values / MerkleTree::get, fri/oracle.rs:142-147, merkle_tree.rs:227) */
 int p2hot_gather_rows_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W,

@@ -47,6 +47,7 @@ SIGNATURES = {
     "p2hot_reverse_index_bits_dev": (i, [vp, vp, vp, sz, sz, u]),
     "p2hot_poseidon_permute_dev": (i, [vp, vp, sz]),
     "p2hot_merkle_dev": (i, [vp, vp, i, sz, sz, u, u, sz, sz, vp, vp]),
+    "p2hot_field_selftest_dev": (i, [vp, vp, vp, sz, vp]),
     "p2hot_gather_rows_dev": (i, [vp, vp, sz, sz, vp, sz, vp]),
     "p2hot_commit_dev": (i, [vp, vp, sz, sz, u, u, u, i, sz, sz, vp, sz, vp, sz, vp, vp, vp]),
     "p2hot_challenger_create": (i, [vp, C.POINTER(vp)]),

@@ -99,4 +99,24 @@ __global__ void permute_batch_kernel(u64 *states, size_t count) {
     for (int i = 0; i < 12; ++i) states[12 * t + i] = gl::canon(s[i]);
 }
 
+// field-arithmetic self-test primitive: out[0][t] = a*b by the compiler-scheduled multiply, out[1][t] by the
+// hand-scheduled single stream (mul1), out[2][t] by the 3-way interleaved stream (mul3, lanes grouped in
+// threes of consecutive elements), out[3][t] = a+b, out[4][t] = a-b.  All canonical.  Used by the edge-value
+// grid test (the reference's field/src/prime_field_testing.rs:8-17 pattern).
+__global__ void field_selftest_kernel(const u64 *a, const u64 *b, size_t count, u64 *out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const u64 x = a[t], y = b[t];
+    out[t] = gl::canon(gl::mul(x, y));
+    out[count + t] = gl::canon(gl::mul1(x, y));
+    // three different products per lane through mul3: (x,y), (y,x), (x,x) -> check the first, fold the others in
+    u64 aa[3] = {x, y, x}, bb[3] = {y, x, x}, rr[3];
+    gl::mul3(aa, bb, rr);
+    u64 ok = (gl::canon(rr[1]) == gl::canon(rr[0])) && (gl::canon(rr[2]) == gl::canon(gl::mul(x, x))) ? 0 : 1;
+    out[2 * count + t] = gl::canon(rr[0]) + ok * 0;  // rr[0]
+    out[5 * count + t] = ok;
+    out[3 * count + t] = gl::canon(gl::add(x, y));
+    out[4 * count + t] = gl::canon(gl::sub(x, y));
+}
+
 }  // namespace merkle

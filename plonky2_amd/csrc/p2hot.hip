@@ -483,6 +483,16 @@ extern "C" int p2hot_poseidon_permute_dev(p2hot_ctx *ctx, uint64_t *d_states, si
     return P2HOT_OK;
 }
 
+extern "C" int p2hot_field_selftest_dev(p2hot_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t count,
+                                        uint64_t *d_out) {
+    if (!ctx) return P2HOT_EINVAL;
+    if (count == 0) return P2HOT_OK;
+    if (!d_a || !d_b || !d_out) P2_FAIL(ctx, P2HOT_EINVAL, "field_selftest: null pointer");
+    P2HOT_LAUNCH(merkle::field_selftest_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, d_a, d_b, count, d_out);
+    P2_LAUNCH_CHECK(ctx);
+    return P2HOT_OK;
+}
+
 extern "C" int p2hot_gather_rows_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W,
                                      const uint64_t *d_idx, size_t m, uint64_t *d_out) {
     if (!ctx) return P2HOT_EINVAL;

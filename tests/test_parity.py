@@ -14,6 +14,29 @@ def is_gpu(eng):
     return not eng.lib.p2hot_is_emulated()
 
 
+# ---------------------------------------------------------------- field arithmetic
+def test_field_ops_edge_grid(eng):
+    """add / sub / mul (compiler-scheduled, hand-scheduled single stream, 3-way interleaved stream) on the
+    cartesian grid of edge values the reference uses (field/src/prime_field_testing.rs:8-17: 0, 1, small, 2^32 +- 1,
+    P - 1, and non-canonical representatives up to 2^64 - 1) plus random pairs, against Python big integers"""
+    rng = np.random.default_rng(1)
+    E32 = 2**32
+    edge = [0, 1, 2, 3, E32 - 2, E32 - 1, E32, E32 + 1, 2**63 - 1, 2**63, 2**63 + 1, P - E32, P - 2, P - 1, P, P + 1,
+            P + E32 - 2, 2**64 - E32, 2**64 - 2, 2**64 - 1, 0xFFFFFFFF_00000000, 0x00000000_FFFFFFFF,
+            0xFFFFFFFE_FFFFFFFF, 0x80000000_80000000]
+    a = [x for x in edge for _ in edge] + [int(v) for v in rng.integers(0, 2**63, 4000, dtype=np.uint64) * 2 + 1]
+    b = [y for _ in edge for y in edge] + [int(v) for v in rng.integers(0, 2**63, 4000, dtype=np.uint64) * 2 + rng.integers(0, 2, 4000, dtype=np.uint64)]
+    n = len(a)
+    da, db = eng.dev(np.array(a, dtype=np.uint64)), eng.dev(np.array(b, dtype=np.uint64))
+    out = eng.mem.zeros(6, n)
+    eng.check(eng.lib.p2hot_field_selftest_dev(eng.ctx, eng.ptr(da), eng.ptr(db), n, eng.ptr(out)))
+    o = eng.host(out)
+    mul = np.array([x * y % P for x, y in zip(a, b)], dtype=np.uint64)
+    assert (o[0] == mul).all() and (o[1] == mul).all() and (o[2] == mul).all() and (o[5] == 0).all()
+    assert (o[3] == np.array([(x + y) % P for x, y in zip(a, b)], dtype=np.uint64)).all()
+    assert (o[4] == np.array([(x - y) % P for x, y in zip(a, b)], dtype=np.uint64)).all()
+
+
 # ---------------------------------------------------------------- Poseidon
 def test_poseidon_reference_kats(eng, kats):
     """plonky2/src/hash/poseidon_goldilocks.rs:455-490"""
