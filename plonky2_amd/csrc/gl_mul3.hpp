@@ -69,28 +69,39 @@ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
 // Same 17 instructions as a mul3 stream; the two wait states every carry consumer needs after its
 // producer are explicit `s_nop 1` (they cost this wave latency, not the SIMD issue slots).
 #define P2_NOP "s_nop 1\n\t"
+#define P2_MUL1_BODY(SET)                                                                                          \
+    P2_APPLY(P2_ST1, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_APPLY(P2_ST2, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") \
+    P2_APPLY(P2_ST3, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_APPLY(P2_ST4, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") \
+    P2_APPLY(P2_ST5, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                            \
+    P2_APPLY(P2_ST6, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                            \
+    P2_APPLY(P2_ST7, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_APPLY(P2_ST8, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") \
+    P2_APPLY(P2_ST9, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                            \
+    P2_APPLY(P2_ST10, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")                                                  \
+    P2_APPLY(P2_ST11, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                           \
+    P2_APPLY(P2_ST12, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")                                                  \
+    P2_APPLY(P2_ST13, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                           \
+    P2_APPLY(P2_ST14, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                           \
+    P2_APPLY(P2_ST15, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")                                                  \
+    P2_APPLY(P2_ST16, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                           \
+    P2_APPLY(P2_ST17, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+
 __device__ __forceinline__ u64 mul1(u64 a, u64 b) {
     u32 ra0, ra1;
-    asm(P2_APPLY(P2_ST1, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
-        P2_APPLY(P2_ST2, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
-        P2_APPLY(P2_ST3, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
-        P2_APPLY(P2_ST4, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
-        P2_APPLY(P2_ST5, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
-        P2_APPLY(P2_ST6, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
-        P2_APPLY(P2_ST7, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
-        P2_APPLY(P2_ST8, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
-        P2_APPLY(P2_ST9, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
-        P2_APPLY(P2_ST10, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
-        P2_APPLY(P2_ST11, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
-        P2_APPLY(P2_ST12, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
-        P2_APPLY(P2_ST13, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
-        P2_APPLY(P2_ST14, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
-        P2_APPLY(P2_ST15, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
-        P2_APPLY(P2_ST16, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
-        P2_APPLY(P2_ST17, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+    asm(P2_MUL1_BODY(P2_SA)
         : [ra0] "=&v"(ra0), [ra1] "=&v"(ra1)
         : [xa0] "v"((u32)a), [xa1] "v"((u32)(a >> 32)), [ya0] "v"((u32)b), [ya1] "v"((u32)(b >> 32))
         : "v70", "v71", "v72", "v73", "v74", "v75", "s40", "s41", "s42", "s43");
+    return ((u64)ra1 << 32) | ra0;
+}
+
+// the same stream on a low register set, for kernels that must stay within 64 VGPRs (the NTT passes)
+#define P2_SN "v[58:59]", "v58", "v59", "v[60:61]", "v60", "v61", "v[62:63]", "v62", "v63", "s[60:61]", "s[62:63]"
+__device__ __forceinline__ u64 mul1_lowregs(u64 a, u64 b) {
+    u32 ra0, ra1;
+    asm(P2_MUL1_BODY(P2_SN)
+        : [ra0] "=&v"(ra0), [ra1] "=&v"(ra1)
+        : [xa0] "v"((u32)a), [xa1] "v"((u32)(a >> 32)), [ya0] "v"((u32)b), [ya1] "v"((u32)(b >> 32))
+        : "v58", "v59", "v60", "v61", "v62", "v63", "s60", "s61", "s62", "s63");
     return ((u64)ra1 << 32) | ra0;
 }
 
@@ -126,6 +137,7 @@ __host__ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u6
     for (int k = 0; k < 3; ++k) r[k] = mul(a[k], b[k]);
 }
 __host__ __device__ __forceinline__ u64 mul1(u64 a, u64 b) { return mul(a, b); }
+__host__ __device__ __forceinline__ u64 mul1_lowregs(u64 a, u64 b) { return mul(a, b); }
 __host__ __device__ __forceinline__ void fold3(const u64 al[3], const u64 ah[3], u64 y[3]) {
     for (int k = 0; k < 3; ++k) {
         u32 k1;

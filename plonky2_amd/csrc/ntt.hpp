@@ -22,6 +22,7 @@
 //    E & 0xffff == 0 and cost one load.
 #pragma once
 #include "gl.hpp"
+#include "gl_mul3.hpp"
 
 namespace ntt {
 using gl::u32;
@@ -187,7 +188,12 @@ __device__ __forceinline__ void dft_pow2(u64 (&x)[1 << P]) {
     }
 }
 
-template <int P, bool INV>
+template <int NT>
+__device__ __forceinline__ u64 ntt_mul(u64 a, u64 b) {  // hand-scheduled multiply on the register set that fits the variant
+    return NT == 512 ? gl::mul1_lowregs(a, b) : gl::mul1(a, b);
+}
+
+template <int P, bool INV, int NT>
 __device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, const u64 *gin, bool from_global, unsigned log_rb,
                                           unsigned log_stride, size_t z, size_t base0) {
     const PassArgs &a = ra.a;
@@ -207,11 +213,11 @@ __device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, cons
             if (from_global) {
                 u64 v = gin[((size_t)i << log_stride) + c];
                 if (a.scale_mode == SCALE_CONST) {
-                    v = gl::mul(v, a.scale_const);
+                    v = ntt_mul<NT>(v, a.scale_const);
                 } else if (a.scale_mode == SCALE_TABLE) {
                     u64 sc = a.srow[z * R + i];
-                    if (log_stride) sc = gl::mul(sc, a.scol[z * stride + base0 + c]);
-                    v = gl::mul(v, sc);
+                    if (log_stride) sc = ntt_mul<NT>(sc, a.scol[z * stride + base0 + c]);
+                    v = ntt_mul<NT>(v, sc);
                 }
                 x[q] = v;
             } else {
@@ -224,7 +230,7 @@ __device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, cons
 #pragma unroll
             for (int q = 1; q < (1 << P); ++q) {
                 const unsigned k = __brev((unsigned)q) >> (32 - P);
-                x[q] = gl::mul(x[q], tw[lo * k]);
+                x[q] = ntt_mul<NT>(x[q], tw[lo * k]);
             }
         }
 #pragma unroll
@@ -265,10 +271,10 @@ __global__ void __launch_bounds__(NT, MINW) ntt_regpass_kernel(RegPassArgs ra) {
 #pragma unroll 1
         for (int r = 0; r < 4 && ra.rounds[r]; ++r) {
             switch (ra.rounds[r]) {
-                case 4: if (NT == 256) reg_round<4, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
-                case 3: reg_round<3, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
-                case 2: reg_round<2, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
-                default: reg_round<1, INV>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+                case 4: if (NT == 256) reg_round<4, INV, NT>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+                case 3: reg_round<3, INV, NT>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+                case 2: reg_round<2, INV, NT>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+                default: reg_round<1, INV, NT>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
             }
             log_rb -= ra.rounds[r];
             first = false;
@@ -282,7 +288,10 @@ __global__ void __launch_bounds__(NT, MINW) ntt_regpass_kernel(RegPassArgs ra) {
             if (log_stride) {
                 u32 k1 = __brev(i) >> (32 - a.log_r);
                 u64 ex = (u64)(base0 + c) * k1;
-                v = gl::mul(v, root_pow(a.roots, (u32)(ex << (32 - a.log_nblk))));
+                const u32 E = (u32)(ex << (32 - a.log_nblk));
+                u64 w = a.roots.hi[E >> 16];
+                if (E & 0xFFFFu) w = ntt_mul<NT>(w, a.roots.lo[E & 0xFFFFu]);
+                v = ntt_mul<NT>(v, w);
             }
             out[((size_t)i << log_stride) + c] = a.canon_out ? gl::canon(v) : v;
         }

@@ -334,9 +334,9 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
             }
             if (maxp == 3) {
                 if (inverse)
-                    P2HOT_LAUNCH((ntt::ntt_regpass_kernel<true, 512, 8>), grid, dim3(512), shm, ctx->stream, ra);
+                    P2HOT_LAUNCH((ntt::ntt_regpass_kernel<true, 512, 6>), grid, dim3(512), shm, ctx->stream, ra);
                 else
-                    P2HOT_LAUNCH((ntt::ntt_regpass_kernel<false, 512, 8>), grid, dim3(512), shm, ctx->stream, ra);
+                    P2HOT_LAUNCH((ntt::ntt_regpass_kernel<false, 512, 6>), grid, dim3(512), shm, ctx->stream, ra);
             } else {
                 if (inverse)
                     P2HOT_LAUNCH((ntt::ntt_regpass_kernel<true, 256, 4>), grid, dim3(256), shm, ctx->stream, ra);
