@@ -253,6 +253,16 @@ def main():
                         "wave64 VOP3 / carry / v_mad_u64_u32 instruction occupies ~4.5 cycles, so a VOP3-dominated "
                         "integer kernel saturates its SIMDs near frac 0.5; SQ_INSTS_VALU from profiles/pmc_traffic.json"})(
                 pmc_valu(W, log_n, rb, cap, world)),
+            "roofline_ntt": (lambda k: None if not k else {
+                "kernel": "ntt_regpass_kernel, contiguous (last) passes of the iNTT and of the %d-coset LDE" % (1 << rb),
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                # per step the two contiguous passes read and write every iNTT / LDE element once
+                "achieved": (16 * W * (n // world if world > 1 else n) + 16 * W * rows_local)
+                            / (k["ms_per_launch"] * 1e-3 * k["launches"] / args.steps) / 1e9,
+                "frac": (16 * W * (n // world if world > 1 else n) + 16 * W * rows_local)
+                        / (k["ms_per_launch"] * 1e-3 * k["launches"] / args.steps) / 1e9 / HBM_PEAK_GBS,
+                "note": "HBM-bound by design, measured VALU-bound (about 250 VALU instructions per element-pass)"})(
+                kern.get("ntt_pass_contig")),
             "kernels": kern,
             "algorithmic_bytes_per_step": ab,
             "commit_hbm_frac": ab["total"] / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
