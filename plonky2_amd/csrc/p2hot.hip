@@ -34,7 +34,7 @@ struct p2hot_ctx {
     struct Scratch {
         void *p = nullptr;
         size_t cap = 0;
-    } scratch[2];
+    } scratch[3];  // 0: NTT temporary, 1: final_poly, 2: FRI commit phase (grow-only, reused across calls)
     // coset scale tables keyed by (log_n, rate_bits, shift, first block, block count, first-pass log_r)
     std::map<std::tuple<unsigned, unsigned, u64, size_t, size_t, unsigned>, u64 *> scale_cache;
     // live per-kernel timing (HIP events on the launch stream), off by default
@@ -771,16 +771,26 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
             ln -= ab;
         }
     }
-    DevBuf stage, planes_a, planes_b, values, leaves, digests, cap, beta;
-    P2_HIP(ctx, hipMalloc(&stage.p, n * 16));
-    P2_HIP(ctx, hipMalloc(&planes_a.p, n * 16));
-    P2_HIP(ctx, hipMalloc(&planes_b.p, n * 16));
-    P2_HIP(ctx, hipMalloc(&values.p, N * 16));
-    P2_HIP(ctx, hipMalloc(&leaves.p, N * 16));
+    // one grow-only scratch block, carved up (no per-call hipMalloc / hipFree): stage [n][2], two coefficient plane
+    // pairs [2][n], values [2][N], interleaved leaves [N][2], digests (<= N of them), cap, beta
     const size_t cap_words = (size_t)4 << cap_height;
-    P2_HIP(ctx, hipMalloc(&digests.p, (N > 1 ? N : 1) * 8 * 4));  // >= 2*(N/2 - cap) digests of 32 B
-    P2_HIP(ctx, hipMalloc(&cap.p, cap_words * 8));
-    P2_HIP(ctx, hipMalloc(&beta.p, 16));
+    struct Part {
+        u64 *p;
+        u64 *u() const { return p; }
+    } stage, planes_a, planes_b, values, leaves, digests, cap, beta;
+    {
+        const size_t words = 2 * n * 3 + 2 * N * 2 + 4 * (N > 1 ? N : 1) + cap_words + 2;
+        u64 *base = nullptr;
+        P2_TRY(scratch_get(ctx, 2, words * 8, (void **)&base));
+        stage.p = base;
+        planes_a.p = stage.p + 2 * n;
+        planes_b.p = planes_a.p + 2 * n;
+        values.p = planes_b.p + 2 * n;
+        leaves.p = values.p + 2 * N;
+        digests.p = leaves.p + 2 * N;
+        cap.p = digests.p + 4 * (N > 1 ? N : 1);
+        beta.p = cap.p + cap_words;
+    }
     int rc = P2HOT_OK;
     auto body = [&]() -> int {
         u64 *cur = planes_a.u(), *nxt = planes_b.u();
