@@ -28,8 +28,10 @@ class PolynomialBatch:
 
     @property
     def polynomials(self):
-        """coefficient form, host [W][n] (oracle.rs:32)"""
-        return self.engine.host(self._coeffs)
+        """coefficient form, host [W][n] (oracle.rs:32), canonical representatives"""
+        a = self.engine.host(self._coeffs)
+        P = np.uint64(0xFFFFFFFF00000001)
+        return np.where(a >= P, a - P, a)
 
     @classmethod
     def from_values(cls, values, rate_bits, blinding, cap_height, timing=None, fft_root_table=None, engine=None):

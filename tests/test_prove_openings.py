@@ -122,3 +122,32 @@ def test_eval_openings_vs_horner(eng):
                     acc = _ext_mul(acc, zz)
                     acc[0] = (acc[0] + int(c)) % P
                 assert [int(got[pi][j][0]), int(got[pi][j][1])] == acc, (log_n, pi, j)
+
+
+def test_polynomial_batch_wire_format(eng):
+    """write_polynomial_batch / write_merkle_tree byte layout (util/serialization/mod.rs:1417-1431, :1744-1763)"""
+    import struct
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    from plonky2_amd.util.serialization import read_polynomial_batch, write_polynomial_batch
+    rng = np.random.default_rng(44)
+    co = rand_field(rng, 3, 4, noncanonical=True)
+    b = PolynomialBatch.from_coeffs(co, 1, False, 1, engine=eng)
+    blob = write_polynomial_batch(b)
+    # hand-assembled expectation, field by field
+    exp = struct.pack("<Q", 3)
+    for p in b.polynomials:
+        exp += struct.pack("<Q", 4) + struct.pack("<4Q", *[int(x) for x in p])
+    leaves = b.merkle_tree.leaves
+    exp += struct.pack("<Q", 8)
+    for row in leaves:
+        exp += struct.pack("<Q", 3) + struct.pack("<3Q", *[int(x) for x in row])
+    dig = np.asarray(b.merkle_tree.digests).reshape(-1, 4)
+    exp += struct.pack("<Q", len(dig)) + b"".join(struct.pack("<4Q", *[int(x) for x in d]) for d in dig)
+    exp += struct.pack("<Q", 1) + b"".join(struct.pack("<4Q", *[int(x) for x in c]) for c in b.merkle_tree.cap.entries)
+    exp += struct.pack("<QQ", 2, 1) + b"\x00"
+    assert blob == exp
+    r = read_polynomial_batch(blob)
+    assert (r["polynomials"] == b.polynomials).all() and (r["merkle_tree"].leaves == leaves).all()
+    assert (r["merkle_tree"].digests == dig).all() and (r["merkle_tree"].cap.entries == b.merkle_tree.cap.entries).all()
+    assert (r["degree_log"], r["rate_bits"], r["blinding"]) == (2, 1, False)
+    assert (np.frombuffer(blob[8 + 8:8 + 8 + 32], dtype="<u8") < np.uint64(P)).all()  # canonical on the wire
