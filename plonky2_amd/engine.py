@@ -54,6 +54,9 @@ class TorchMemory:
         """the buffer as a torch tensor for torch.distributed collectives"""
         return t
 
+    def collective_fence(self):
+        """libp2hot enqueues on the current torch stream, and so do the collectives: nothing to do"""
+
 
 class Engine:
     def __init__(self, device_index=0, lib=None, memory=None):

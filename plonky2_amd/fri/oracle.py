@@ -22,7 +22,7 @@ class PolynomialBatch:
         self.blinding = blinding
         W = coeffs.shape[0]
         N = 1 << (degree_log + rate_bits)
-        self.merkle_tree = MerkleTree(None, engine.host(digests), engine.host(cap), cap_height, n_leaves=N,
+        self.merkle_tree = MerkleTree(None, digests, engine.host(cap), cap_height, n_leaves=N, engine=engine,
                                       leaf_getter=lambda idx: engine.host(engine.gather_rows(lde, idx)) if W else
                                       np.zeros((len(idx), 0), dtype=np.uint64))
 
@@ -132,12 +132,15 @@ def prove_openings(batches, oracles, challenger, rate_bits, cap_height, reductio
                                                       reduction_arity_bits, eng)   # prover.rs:40-51
     pow_witness = fri_proof_of_work(challenger, proof_of_work_bits, eng)           # prover.rs:53-58
     lde_size = 1 << (log_n + rate_bits)
+    xs = [rand % lde_size for rand in challenger.get_n_challenges(num_query_rounds)]   # prover.rs:215-220
+    # initial trees: one batched row gather and one batched path gather per oracle, on the device (prover.rs:238-241)
+    idx = np.asarray(xs, dtype=np.uint64)
+    init_rows = [o.merkle_tree._getter(idx) if o.merkle_tree._leaves is None else o.merkle_tree.leaves[idx.astype(np.int64)]
+                 for o in oracles]
+    init_paths = [o.merkle_tree.prove_many(idx) for o in oracles]
     queries = []
-    for rand in challenger.get_n_challenges(num_query_rounds):                     # prover.rs:215-220
-        x = rand % lde_size
-        initial = []
-        for o in oracles:                                                          # prover.rs:238-241
-            initial.append((o.merkle_tree.get(x), o.merkle_tree.prove(x)))
+    for q, x in enumerate(xs):
+        initial = [(init_rows[oi][q], init_paths[oi][q]) for oi in range(len(oracles))]
         steps = []
         for i, tree in enumerate(trees):                                           # prover.rs:242-253
             ab = reduction_arity_bits[i]

@@ -23,13 +23,23 @@ class MerkleTree:
     `leaves` may be given lazily (a callable rows(idx_array) -> [m][w]) when the leaf matrix stays on the GPU.
     """
 
-    def __init__(self, leaves, digests, cap, cap_height, n_leaves=None, leaf_getter=None):
+    def __init__(self, leaves, digests, cap, cap_height, n_leaves=None, leaf_getter=None, engine=None):
+        """digests: host array, or a DEVICE buffer (then `engine` must be given): it stays on the GPU, proofs are
+        gathered there (p2hot_merkle_paths_dev) and `.digests` copies it to the host only when somebody asks."""
         self._leaves = leaves
         self._getter = leaf_getter
-        self.digests = digests
+        self._engine = engine
+        self._digests_dev = digests if engine is not None and engine.mem.is_buffer(digests) else None
+        self._digests = None if self._digests_dev is not None else digests
         self.cap = MerkleCap(cap)
         self.cap_height = cap_height
         self.n_leaves = n_leaves if n_leaves is not None else len(leaves)
+
+    @property
+    def digests(self):
+        if self._digests is None:
+            self._digests = self._engine.host(self._digests_dev)
+        return self._digests
 
     @classmethod
     def new(cls, leaves, cap_height, engine=None):  # merkle_tree.rs:193-224
@@ -43,7 +53,7 @@ class MerkleTree:
             raise ValueError("number of leaves must be a power of two")  # log2_strict, :194
         d_leaves = eng.dev(leaves_h)
         digests, cap = eng.merkle(d_leaves, 1, w, log_n, cap_height)
-        return cls(leaves_h, eng.host(digests), eng.host(cap), cap_height)
+        return cls(leaves_h, digests, eng.host(cap), cap_height, engine=eng)
 
     @property
     def leaves(self):
@@ -58,16 +68,29 @@ class MerkleTree:
 
     def prove(self, leaf_index):
         """merkle_tree_prove (:151-190): siblings bottom-up, [log2(n) - cap_height][4]"""
+        return self.prove_many([leaf_index])[0]
+
+    def prove_many(self, leaf_indices):
+        """[m][log2(n) - cap_height][4]; gathered on the GPU when the digests live there"""
         n = self.n_leaves
-        num_layers = (n.bit_length() - 1) - self.cap_height
+        log_n = n.bit_length() - 1
+        num_layers = log_n - self.cap_height
+        idx = np.asarray(leaf_indices, dtype=np.uint64).reshape(-1)
+        if self._digests_dev is not None and self._digests is None:
+            eng = self._engine
+            out = eng.mem.zeros(len(idx), max(num_layers, 1), 4)
+            eng.check(eng.lib.p2hot_merkle_paths_dev(eng.ctx, eng.ptr(self._digests_dev), log_n, self.cap_height,
+                                                     eng.ptr(eng.dev(idx)), len(idx), eng.ptr(out)))
+            return eng.host(out)[:, :num_layers]
         digests = np.asarray(self.digests, dtype=np.uint64).reshape(-1, 4)
         tree_len = digests.shape[0] >> self.cap_height
-        tree = digests[tree_len * (leaf_index >> num_layers):]
-        pair_index = leaf_index & ((1 << num_layers) - 1)
-        out = np.zeros((num_layers, 4), dtype=np.uint64)
-        for i in range(num_layers):
-            parity = pair_index & 1
-            pair_index >>= 1
-            siblings_index = (pair_index << (i + 1)) + (1 << i) - 1
-            out[i] = tree[2 * siblings_index + (1 - parity)]
+        out = np.zeros((len(idx), num_layers, 4), dtype=np.uint64)
+        for q, leaf_index in enumerate(int(x) for x in idx):
+            tree = digests[tree_len * (leaf_index >> num_layers):]
+            pair_index = leaf_index & ((1 << num_layers) - 1)
+            for i in range(num_layers):
+                parity = pair_index & 1
+                pair_index >>= 1
+                siblings_index = (pair_index << (i + 1)) + (1 << i) - 1
+                out[q, i] = tree[2 * siblings_index + (1 - parity)]
         return out

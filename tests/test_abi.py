@@ -78,3 +78,13 @@ def test_shape_errors_match_reference_panics(emu):
         PolynomialBatch.from_values(co, 1, True, 0, engine=emu)
     with pytest.raises(ValueError):
         PolynomialBatch.from_values(np.zeros((1, 6), dtype=np.uint64), 1, False, 0, engine=emu)
+
+
+def test_memory_backends_have_the_same_surface():
+    """the product's TorchMemory and the test emulator's HostMemory must expose the same methods (the multi-GPU
+    path calls them); checked by name so it runs without a GPU"""
+    from plonky2_amd.engine import TorchMemory
+    from tests.emu_backend import HostMemory
+    pub = lambda c: {m for m in dir(c) if not m.startswith("_")}
+    assert pub(HostMemory) <= pub(TorchMemory) | {"DevArray"}, pub(HostMemory) - pub(TorchMemory)
+    assert pub(TorchMemory) <= pub(HostMemory), pub(TorchMemory) - pub(HostMemory)
