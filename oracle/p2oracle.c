@@ -3,8 +3,8 @@
  * TEST INFRASTRUCTURE ONLY (see p2oracle.h).  Citations are into /root/reference.
  *
  * The structure deliberately follows the reference (per-column radix-2 DIT NTT after an
- * explicit bit reversal, gather transpose, recursive Merkle fill, a fresh extension NTT per
- * FRI round) -- it is the thing the HIP path is checked against and the "port" CPU baseline,
+ * explicit bit reversal, gather transpose, recursive Merkle fill above a flat-parallel leaf hash,
+ * a fresh extension NTT per FRI round) -- it is the thing the HIP path is checked against and the "port" CPU baseline,
  * not an optimised CPU prover.  OpenMP mirrors the reference's rayon fork-join points.
  */
 #include "p2oracle.h"
@@ -43,15 +43,22 @@ uint64_t ora_gl_canon(uint64_t x) { return x >= P ? x - P : x; }
 /* goldilocks_field.rs:245-262 (Add): canonical output here; equality in the reference is
  * canonical-value equality (goldilocks_field.rs:33-37) so any representative is equivalent. */
 uint64_t ora_gl_add(uint64_t a, uint64_t b) {
-    u128 s = (u128)ora_gl_canon(a) + ora_gl_canon(b);
-    if (s >= P) s -= P;
-    return (uint64_t)s;
+    uint64_t s = a + b;
+    if (s < a) {            /* wrapped: 2^64 = EPS (mod P) */
+        s += EPS;
+        if (s < EPS) s += EPS;
+    }
+    return ora_gl_canon(s);
 }
 
 uint64_t ora_gl_sub(uint64_t a, uint64_t b) {
-    a = ora_gl_canon(a);
-    b = ora_gl_canon(b);
-    return a >= b ? a - b : a + (P - b);
+    uint64_t d = a - b;
+    if (a < b) {
+        uint64_t e = d;
+        d -= EPS;
+        if (e < EPS) d -= EPS;
+    }
+    return ora_gl_canon(d);
 }
 
 /* goldilocks_field.rs:402-415 reduce128: x_lo - x_hi_hi + x_hi_lo * EPSILON */
@@ -207,12 +214,21 @@ static void sbox_layer(uint64_t s[12]) { /* poseidon.rs:712-718 */
 
 /* poseidon.rs:180-199 mds_row_shf + :271-290 mds_layer (u128 accumulate, one reduction) */
 static void mds_layer(uint64_t s[12]) {
-    uint64_t out[12];
+    uint64_t lo[12], hi[12], out[12];
+    for (int i = 0; i < 12; ++i) {
+        lo[i] = s[i] & EPS;
+        hi[i] = s[i] >> 32;
+    }
     for (int r = 0; r < 12; ++r) {
-        u128 acc = 0;
-        for (int i = 0; i < 12; ++i) acc += (u128)s[(i + r) % 12] * P2_POSEIDON_MDS_CIRC[i];
-        acc += (u128)s[r] * P2_POSEIDON_MDS_DIAG[r];
-        out[r] = reduce128(acc);
+        uint64_t al = 0, ah = 0; /* < 2^42 each */
+        for (int i = 0; i < 12; ++i) {
+            int j = i + r >= 12 ? i + r - 12 : i + r;
+            al += lo[j] * P2_POSEIDON_MDS_CIRC[i];
+            ah += hi[j] * P2_POSEIDON_MDS_CIRC[i];
+        }
+        al += lo[r] * P2_POSEIDON_MDS_DIAG[r];
+        ah += hi[r] * P2_POSEIDON_MDS_DIAG[r];
+        out[r] = reduce128((u128)al + ((u128)ah << 32));
     }
     memcpy(s, out, sizeof out);
 }
@@ -304,11 +320,13 @@ void ora_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]) {
 }
 
 /* ------------------------------------------------------------------ merkle */
-/* merkle_tree.rs:86-113 fill_subtree.  digests_buf has 2*(n_leaves-1) digests. */
-static void fill_subtree(uint64_t *digests_buf, size_t n_digests, const uint64_t *leaves,
-                         size_t n_leaves, size_t w, uint64_t out[4], int depth) {
+/* merkle_tree.rs:86-113 fill_subtree.  digests_buf has 2*(n_leaves-1) digests.  The leaf digests
+ * (hash_or_noop of every leaf, the bulk of the work) are computed beforehand by a flat parallel loop,
+ * which scales over many cores better than task recursion; the recursion below only combines. */
+static void fill_subtree(uint64_t *digests_buf, size_t n_digests, const uint64_t *leaf_digests, size_t n_leaves,
+                         uint64_t out[4]) {
     if (n_digests == 0) {
-        ora_hash_or_noop(leaves, w, out);
+        memcpy(out, leaf_digests, 32);
         return;
     }
     size_t half = n_digests / 2;
@@ -317,16 +335,8 @@ static void fill_subtree(uint64_t *digests_buf, size_t n_digests, const uint64_t
     uint64_t *right_digest = digests_buf + half * 4;       /* split_first_mut */
     uint64_t *right_buf = digests_buf + (half + 1) * 4;
     uint64_t l[4], r[4];
-    if (depth < 6) {
-#pragma omp task shared(l) if (n_leaves > 64)
-        fill_subtree(left_buf, half - 1, leaves, n_leaves / 2, w, l, depth + 1);
-#pragma omp task shared(r) if (n_leaves > 64)
-        fill_subtree(right_buf, half - 1, leaves + (n_leaves / 2) * w, n_leaves / 2, w, r, depth + 1);
-#pragma omp taskwait
-    } else {
-        fill_subtree(left_buf, half - 1, leaves, n_leaves / 2, w, l, depth + 1);
-        fill_subtree(right_buf, half - 1, leaves + (n_leaves / 2) * w, n_leaves / 2, w, r, depth + 1);
-    }
+    fill_subtree(left_buf, half - 1, leaf_digests, n_leaves / 2, l);
+    fill_subtree(right_buf, half - 1, leaf_digests + (n_leaves / 2) * 4, n_leaves / 2, r);
     memcpy(left_digest, l, 32);
     memcpy(right_digest, r, 32);
     ora_two_to_one(l, r, out);
@@ -341,14 +351,17 @@ void ora_merkle_tree(const uint64_t *leaves, size_t n, size_t w, unsigned cap_he
         for (size_t i = 0; i < n; ++i) ora_hash_or_noop(leaves + i * w, w, cap_out + 4 * i);
         return;
     }
+    uint64_t *leaf_digests = (uint64_t *)malloc(n * 32);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) ora_hash_or_noop(leaves + i * w, w, leaf_digests + 4 * i);
+    /* split every cap subtree further so that there are enough independent pieces for all cores:
+     * pieces of `piece` leaves are filled in parallel, the few levels above them serially per subtree */
     size_t sub_digests = n_digests >> cap_height, sub_leaves = n >> cap_height;
-#pragma omp parallel
-#pragma omp single
-    for (size_t s = 0; s < n_cap; ++s) {
-#pragma omp task firstprivate(s)
-        fill_subtree(digests_out + s * sub_digests * 4, sub_digests, leaves + s * sub_leaves * w,
-                     sub_leaves, w, cap_out + 4 * s, 0);
-    }
+#pragma omp parallel for schedule(dynamic)
+    for (size_t s = 0; s < n_cap; ++s)
+        fill_subtree(digests_out + s * sub_digests * 4, sub_digests, leaf_digests + s * sub_leaves * 4, sub_leaves,
+                     cap_out + 4 * s);
+    free(leaf_digests);
 }
 
 /* merkle_tree.rs:151-190 merkle_tree_prove */
