@@ -161,10 +161,12 @@ int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned log_n, uns
                      p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
                      uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out);
 /* the same with the coefficients already on the device as two planes [2][n] (component 0, then component 1),
- * e.g. the output of p2hot_fri_final_poly_dev */
+ * e.g. the output of p2hot_fri_final_poly_dev.  d_leaves_out is a DEVICE buffer (or NULL): the round trees' leaf
+ * matrices stay on the GPU (same concatenated layout) and the query phase gathers the few rows it opens; the other
+ * outputs are host pointers as above. */
 int p2hot_fri_commit_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs_planar, unsigned log_n, unsigned rate_bits,
                          unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
-                         p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
+                         p2hot_challenger *challenger, uint64_t *d_leaves_out, uint64_t *digests_out,
                          uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out);
 /* The final_poly construction of PolynomialBatch::prove_openings (fri/oracle.rs:186-213) on device-resident
  * coefficient polynomials: for every batch i with opening point z_i,

@@ -243,24 +243,13 @@ __global__ void horner_emit_kernel(const u64 *c0, const u64 *c1, unsigned chunk_
 }
 
 // OpeningSet::new (plonky2/src/plonk/proof.rs:314-327): out[j] = polys[j](z) for an extension point z.
-// One workgroup per polynomial: lane t Horner-folds the coefficients t, t+256, ... with z^256 (coalesced
-// reads), then the 256 partials are combined with weights z^t through LDS.
-__global__ void __launch_bounds__(256) eval_polys_kernel(const u64 *const *polys, size_t n, gl::ext2 z, gl::ext2 z256,
-                                                        u64 *out /* [J][2] */) {
-    __shared__ u64 s0[256], s1[256];
+// Stage 1: workgroup (j, s) evaluates segment s (seg = 2^seg_log coefficients) of polynomial j at z:
+//   lane t Horner-folds the coefficients t, t+256, ... of the segment with z^256 (coalesced reads), the 256
+//   partials are combined with weights z^t through LDS -> part[j][s].
+// Stage 2: workgroup j evaluates the extension polynomial sum_s part[j][s] * (z^seg)^s the same way.
+__device__ __forceinline__ gl::ext2 block_weighted_sum(gl::ext2 acc, gl::ext2 z, u64 *s0, u64 *s1) {
     const unsigned tid = threadIdx.x;
-    const u64 *c = polys[blockIdx.x];
-    gl::ext2 acc{0, 0};
-    if (tid < n) {
-        size_t last = tid + ((n - 1 - tid) / 256) * 256;  // largest index = tid (mod 256) below n
-        for (size_t t = last;; t -= 256) {
-            acc = gl::ext_mul(acc, z256);
-            acc.a0 = gl::add(acc.a0, c[t]);
-            if (t < 256) break;
-        }
-    }
-    // weight by z^tid
-    gl::ext2 w{1, 0}, b = z;
+    gl::ext2 w{1, 0}, b = z;  // weight z^tid
     for (unsigned e = tid; e; e >>= 1) {
         if (e & 1) w = gl::ext_mul(w, b);
         b = gl::ext_mul(b, b);
@@ -276,9 +265,51 @@ __global__ void __launch_bounds__(256) eval_polys_kernel(const u64 *const *polys
         }
         __syncthreads();
     }
+    return gl::ext2{s0[0], s1[0]};
+}
+
+__global__ void __launch_bounds__(256) eval_polys_stage1_kernel(const u64 *const *polys, unsigned seg_log, gl::ext2 z,
+                                                               gl::ext2 z256, u64 *part /* [J][S][2] */) {
+    __shared__ u64 s0[256], s1[256];
+    const unsigned tid = threadIdx.x;
+    const size_t seg = (size_t)1 << seg_log;
+    const u64 *c = polys[blockIdx.x] + (size_t)blockIdx.y * seg;
+    gl::ext2 acc{0, 0};
+    if (tid < seg) {
+        size_t last = tid + ((seg - 1 - tid) / 256) * 256;
+        for (size_t t = last;; t -= 256) {
+            acc = gl::ext_mul(acc, z256);
+            acc.a0 = gl::add(acc.a0, c[t]);
+            if (t < 256) break;
+        }
+    }
+    gl::ext2 r = block_weighted_sum(acc, z, s0, s1);
     if (tid == 0) {
-        out[2 * blockIdx.x] = gl::canon(s0[0]);
-        out[2 * blockIdx.x + 1] = gl::canon(s1[0]);
+        u64 *o = part + 2 * ((size_t)blockIdx.x * gridDim.y + blockIdx.y);
+        o[0] = r.a0;
+        o[1] = r.a1;
+    }
+}
+
+__global__ void __launch_bounds__(256) eval_polys_stage2_kernel(const u64 *part, size_t n_seg, gl::ext2 zs, gl::ext2 zs256,
+                                                               u64 *out /* [J][2] */) {
+    __shared__ u64 s0[256], s1[256];
+    const unsigned tid = threadIdx.x;
+    const u64 *c = part + 2 * (size_t)blockIdx.x * n_seg;
+    gl::ext2 acc{0, 0};
+    if (tid < n_seg) {
+        size_t last = tid + ((n_seg - 1 - tid) / 256) * 256;
+        for (size_t t = last;; t -= 256) {
+            acc = gl::ext_mul(acc, zs256);
+            acc.a0 = gl::add(acc.a0, c[2 * t]);
+            acc.a1 = gl::add(acc.a1, c[2 * t + 1]);
+            if (t < 256) break;
+        }
+    }
+    gl::ext2 r = block_weighted_sum(acc, zs, s0, s1);
+    if (tid == 0) {
+        out[2 * blockIdx.x] = gl::canon(r.a0);
+        out[2 * blockIdx.x + 1] = gl::canon(r.a1);
     }
 }
 

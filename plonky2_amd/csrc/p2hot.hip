@@ -753,7 +753,7 @@ struct DevBuf {  // frees on scope exit (after a stream sync by the owner)
 // coeffs: host [n][2] interleaved, or (d_planar != NULL) device planes [2][n]
 static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_t *d_planar, unsigned log_n,
                            unsigned rate_bits, unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
-                           p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
+                           p2hot_challenger *challenger, uint64_t *leaves_out, bool leaves_on_device, uint64_t *digests_out,
                            uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
     if (!ctx || !challenger || challenger->ctx != ctx) return P2HOT_EINVAL;
     P2_TRY(check_log(ctx, log_n + rate_bits, "fri_commit"));
@@ -812,9 +812,11 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
             u64 *v0 = values.u(), *v1 = v0 + m;
             P2_TRY(p2hot_coset_lde_dev(ctx, cur, 2, cur_n, log_cur, rate_bits, shift, 0, m, v0, m));
             if (leaves_out) {
-                P2HOT_LAUNCH(fri::interleave_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, v0, v1, m, leaves.u());
+                u64 *dst = leaves_on_device ? leaves_out : leaves.u();  // device-resident trees: write in place
+                P2HOT_LAUNCH(fri::interleave_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, v0, v1, m, dst);
                 P2_LAUNCH_CHECK(ctx);
-                P2_HIP(ctx, hipMemcpyAsync(leaves_out, leaves.p, m * 16, hipMemcpyDeviceToHost, ctx->stream));
+                if (!leaves_on_device)
+                    P2_HIP(ctx, hipMemcpyAsync(leaves_out, leaves.p, m * 16, hipMemcpyDeviceToHost, ctx->stream));
                 leaves_out += 2 * m;
             }
             // prover.rs:99-104: chunk(arity) + flatten -> MerkleTree::new
@@ -870,16 +872,16 @@ extern "C" int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned
                                 uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
     if (ctx && !coeffs) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit: null coefficients");
     return fri_commit_core(ctx, coeffs, nullptr, log_n, rate_bits, cap_height, arity_bits, n_rounds, challenger, leaves_out,
-                           digests_out, caps_out, betas_out, final_out);
+                           false, digests_out, caps_out, betas_out, final_out);
 }
 
 extern "C" int p2hot_fri_commit_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs_planar, unsigned log_n, unsigned rate_bits,
                                     unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
-                                    p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
+                                    p2hot_challenger *challenger, uint64_t *d_leaves_out, uint64_t *digests_out,
                                     uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
     if (ctx && !d_coeffs_planar) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit_dev: null coefficients");
     return fri_commit_core(ctx, nullptr, d_coeffs_planar, log_n, rate_bits, cap_height, arity_bits, n_rounds, challenger,
-                           leaves_out, digests_out, caps_out, betas_out, final_out);
+                           d_leaves_out, true, digests_out, caps_out, betas_out, final_out);
 }
 
 // ------------------------------------------------------------------ prove_openings prelude
@@ -956,11 +958,19 @@ extern "C" int p2hot_eval_polys_dev(p2hot_ctx *ctx, const uint64_t *const *d_pol
     if (!d_poly_table || !points || !d_out) P2_FAIL(ctx, P2HOT_EINVAL, "eval_polys: null argument");
     if (n_polys > 0x7FFFFFFFull) P2_FAIL(ctx, P2HOT_EINVAL, "eval_polys: too many polynomials");
     const size_t n = (size_t)1 << log_n;
+    const unsigned seg_log = log_n < 12 ? log_n : 12;  // 4096-coefficient segments -> J * n/4096 workgroups
+    const size_t n_seg = n >> seg_log;
+    if (n_seg > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "eval_polys: polynomial too long");
+    u64 *part;
+    P2_TRY(scratch_get(ctx, 1, n_polys * n_seg * 16, (void **)&part));
     ProfScope ps(ctx, "eval_polys");
     for (size_t p = 0; p < n_points; ++p) {
         const gl::ext2 z{gl::canon(points[2 * p]), gl::canon(points[2 * p + 1])};
-        P2HOT_LAUNCH(fri::eval_polys_kernel, dim3((unsigned)n_polys), dim3(256), 0, ctx->stream, d_poly_table, n, z,
-                     ext_pow(z, 256), d_out + 2 * p * n_polys);
+        const gl::ext2 zs = ext_pow(z, (u64)1 << seg_log);
+        P2HOT_LAUNCH(fri::eval_polys_stage1_kernel, dim3((unsigned)n_polys, (unsigned)n_seg), dim3(256), 0, ctx->stream,
+                     d_poly_table, seg_log, z, ext_pow(z, 256), part);
+        P2HOT_LAUNCH(fri::eval_polys_stage2_kernel, dim3((unsigned)n_polys), dim3(256), 0, ctx->stream, (const u64 *)part,
+                     n_seg, zs, ext_pow(zs, 256), d_out + 2 * p * n_polys);
         P2_LAUNCH_CHECK(ctx);
     }
     return P2HOT_OK;

@@ -108,15 +108,15 @@ def test_eval_openings_vs_horner(eng):
     """OpeningSet::new (plonk/proof.rs:314-327): p(zeta) in F^2 by Horner on the host vs the device reduction"""
     from plonky2_amd.fri.oracle import PolynomialBatch, eval_openings
     rng = np.random.default_rng(33)
-    for log_n in (0, 3, 8, 10):
+    for log_n in (0, 3, 8, 10, 13):  # 13: two 4096-coefficient segments per polynomial (stage 2 combines them)
         n = 1 << log_n
-        co = rand_field(rng, 5, n)
+        co = rand_field(rng, 5 if log_n < 13 else 2, n)
         b = PolynomialBatch.from_coeffs(co, 1, False, 0, engine=eng)
         pts = rand_field(rng, 2, 2)
         got = eval_openings([b], pts, eng)[0]
         for pi, z in enumerate(pts):
             zz = [int(z[0]), int(z[1])]
-            for j in range(5):
+            for j in range(co.shape[0]):
                 acc = [0, 0]
                 for c in reversed(co[j]):
                     acc = _ext_mul(acc, zz)
