@@ -308,3 +308,26 @@ def test_fri_bad_schedule_is_rejected(eng):
     co = np.zeros((16, 2), dtype=np.uint64)
     with pytest.raises(_lib.P2HotError):
         fri_committed_trees(co, Challenger(eng), 1, 4, [4, 4], engine=eng)  # second round folds past the degree
+
+
+def test_commit_random_shapes(eng, ora):
+    """seeded sweep over ragged shapes (odd widths, rate_bits 0..4, cap heights up to the all-cap tree, tiny and
+    multi-pass sizes): every output of from_values / from_coeffs equals the oracle's"""
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    rng = np.random.default_rng(2024)
+    cases = 40 if is_gpu(eng) else 14
+    for _ in range(cases):
+        log_n = int(rng.integers(0, 15 if is_gpu(eng) else 11))
+        rb = int(rng.integers(0, 5))
+        W = int(rng.integers(1, 41))
+        cap = int(rng.integers(0, min(log_n + rb, 6) + 1))
+        is_values = bool(rng.integers(0, 2))
+        cols = rand_field(rng, W, 1 << log_n, noncanonical=True)
+        ctor = PolynomialBatch.from_values if is_values else PolynomialBatch.from_coeffs
+        b = ctor(cols, rb, False, cap, engine=eng)
+        o = ora.commit(cols, rb, cap, is_values)
+        tag = (W, log_n, rb, cap, is_values)
+        assert (b.polynomials == o["coeffs"] % np.uint64(P)).all(), tag
+        assert (b.merkle_tree.cap.entries == o["cap"]).all(), tag
+        assert (np.asarray(b.merkle_tree.digests).reshape(-1, 4) == o["digests"]).all(), tag
+        assert (b.merkle_tree.leaves.reshape(o["leaves"].shape) == o["leaves"]).all(), tag
