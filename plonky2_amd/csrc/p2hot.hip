@@ -317,8 +317,8 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
             ra.local = inverse ? ctx->local_inv : ctx->local_fwd;
             ra.inverse = inverse;
             // rounds of radix <= 2^maxp, remainder split as evenly as possible.  Radix 8 with 512 threads
-            // (8 points per lane, <= 64 VGPRs, 8 waves/SIMD) hides the global/LDS/barrier waits better
-            // than radix 16 with 256 threads (measured: the pass is wait-bound, not VALU-bound).
+            // (8 points per lane, <= 64 VGPRs, 8 waves/SIMD) measured faster than radix 16 with 256 threads:
+            // the pass is mostly VALU issue, and the extra waves cover the global / LDS / barrier waits.
             const unsigned maxp = ctx->ntt_radix_bits;
             unsigned rem = a.log_r, k = 0;
             unsigned nr = (rem + maxp - 1) / maxp;
