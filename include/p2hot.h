@@ -74,6 +74,10 @@ size_t p2hot_num_digests(unsigned log_leaves, unsigned cap_height);
 int p2hot_fft_dev(p2hot_ctx *ctx, uint64_t *d_data, size_t batch, size_t poly_stride, unsigned log_n);
 /* ifft_with_options (field/src/fft.rs:68-91): values on H_n -> coefficients, in place. */
 int p2hot_ifft_dev(p2hot_ctx *ctx, uint64_t *d_data, size_t batch, size_t poly_stride, unsigned log_n);
+/* PolynomialValues::coset_ifft (field/src/polynomial/mod.rs:63-73): values on shift * H_n -> coefficients, in place
+ * (the quotient-side transform of plonk/prover.rs:810-814) */
+int p2hot_coset_ifft_dev(p2hot_ctx *ctx, uint64_t *d_data, size_t batch, size_t poly_stride, unsigned log_n,
+                         uint64_t shift);
 /* PolynomialBatch::lde_values (fri/oracle.rs:114-139) = lde(rate_bits) + coset_fft(shift) for W
  * polynomials, fused with the transpose + reverse_index_bits of oracle.rs:97-98:
  *   d_lde[c * lde_stride + (L - row_begin)] = p_c(shift * w_N^bitrev(L)),  L in [row_begin, row_begin + row_count)

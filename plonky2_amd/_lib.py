@@ -42,6 +42,7 @@ SIGNATURES = {
     "p2hot_num_digests": (sz, [u, u]),
     "p2hot_fft_dev": (i, [vp, vp, sz, sz, u]),
     "p2hot_ifft_dev": (i, [vp, vp, sz, sz, u]),
+    "p2hot_coset_ifft_dev": (i, [vp, vp, sz, sz, u, u64]),
     "p2hot_coset_lde_dev": (i, [vp, vp, sz, sz, u, u, u64, sz, sz, vp, sz]),
     "p2hot_transpose_dev": (i, [vp, vp, sz, sz, sz, vp]),
     "p2hot_reverse_index_bits_dev": (i, [vp, vp, vp, sz, sz, u]),

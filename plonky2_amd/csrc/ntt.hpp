@@ -280,8 +280,6 @@ __global__ void __launch_bounds__(NT, MINW) ntt_regpass_kernel(RegPassArgs ra) {
             first = false;
         }
         // inter-pass twiddle w_{n'}^(base * k1), k1 = bitrev_logr(i), then coalesced store
-        // (unrolled so that several table gathers are in flight per lane)
-#pragma unroll 8
         for (unsigned e = tid; e < elems; e += NT) {
             unsigned i = e >> logC, c = e & (C - 1);
             u64 v = tile[pad_idx(e)];
@@ -328,6 +326,17 @@ __global__ void __launch_bounds__(256) bitrev_tiled_kernel(const u64 *in, u64 *o
         unsigned lo = __brev(a) >> 27, hi = __brev(b) >> 27;
         dst[((size_t)a << (log_n - 5)) | (rmid << 5) | b] = gl::canon(t[hi][lo]);
     }
+}
+
+// data[p][i] *= lo[i & mask] * hi[i >> lo_bits]  (two-level power table): the coefficient rescale of
+// PolynomialValues::coset_ifft (field/src/polynomial/mod.rs:63-73), canonical output
+__global__ void scale_by_powers_kernel(u64 *data, size_t poly_stride, unsigned log_n, const u64 *lo, const u64 *hi,
+                                       unsigned lo_bits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> log_n) return;
+    u64 s = gl::mul(lo[i & (((size_t)1 << lo_bits) - 1)], hi[i >> lo_bits]);
+    u64 *p = data + (size_t)blockIdx.y * poly_stride + i;
+    *p = gl::canon(gl::mul(*p, s));
 }
 
 __global__ void canon_kernel(u64 *data, size_t count) {

@@ -404,6 +404,26 @@ extern "C" int p2hot_ifft_dev(p2hot_ctx *ctx, uint64_t *d_data, size_t batch, si
     return ntt_natural(ctx, d_data, batch, poly_stride, log_n, true);
 }
 
+extern "C" int p2hot_coset_ifft_dev(p2hot_ctx *ctx, uint64_t *d_data, size_t batch, size_t poly_stride, unsigned log_n,
+                                    uint64_t shift) {
+    P2_TRY(ntt_natural(ctx, d_data, batch, poly_stride, log_n, true));
+    if (batch == 0) return P2HOT_OK;
+    if (gl::canon(shift) == 0) P2_FAIL(ctx, P2HOT_EINVAL, "coset_ifft: shift must be nonzero");
+    // coefficient i is multiplied by shift^-i: two-level table shift^-(i & mask), shift^-((i >> lo_bits) << lo_bits)
+    const unsigned lo_bits = (log_n + 1) / 2, hi_bits = log_n - lo_bits;
+    const size_t n_lo = (size_t)1 << lo_bits, n_hi = (size_t)1 << hi_bits, n = (size_t)1 << log_n;
+    u64 *t;
+    P2_TRY(scratch_get(ctx, 1, (n_lo + n_hi) * 8, (void **)&t));
+    const u64 si = gl::inv(shift);
+    P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(cdiv(n_lo, 256)), dim3(256), 0, ctx->stream, t, n_lo, si, (u64)1, (u64)0);
+    P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(cdiv(n_hi, 256)), dim3(256), 0, ctx->stream, t + n_lo, n_hi, si, (u64)n_lo,
+                 (u64)0);
+    P2HOT_LAUNCH(ntt::scale_by_powers_kernel, dim3(cdiv(n, 256), (unsigned)batch), dim3(256), 0, ctx->stream, d_data,
+                 poly_stride, log_n, (const u64 *)t, (const u64 *)(t + n_lo), lo_bits);
+    P2_LAUNCH_CHECK(ctx);
+    return P2HOT_OK;
+}
+
 // scale tables for row blocks [b0, b0 + zc): block b is coset j = bitrev_rb(b), s_b = shift * w_N^j;
 // srow[z][i] = s_b^(i * stride), scol[z][base] = s_b^base
 static int coset_scale_tables(p2hot_ctx *ctx, unsigned log_n, unsigned rate_bits, u64 shift, size_t b0, size_t zc,

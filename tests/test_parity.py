@@ -118,6 +118,20 @@ def test_fft_three_pass_sizes(eng, ora):
         assert (ifft(f, eng) == a).all(), log_n
 
 
+def test_coset_ifft_vs_oracle(eng, ora):
+    """polynomial/mod.rs:477-516: coset_ifft inverts coset_fft; bit-exact vs the oracle"""
+    from plonky2_amd.field.polynomial import coset_ifft, lde_coset_fft
+    rng = np.random.default_rng(31)
+    for log_n in (0, 1, 5, 9, 13):
+        v = rand_field(rng, 2, 1 << log_n, noncanonical=True)
+        got = coset_ifft(v, engine=eng)
+        assert (got == np.stack([ora.coset_ifft(x.copy()) for x in v]) % np.uint64(P)).all(), log_n
+        assert (lde_coset_fft(got, 0, engine=eng) == v % np.uint64(P)).all(), log_n
+    s = 123456789
+    v = rand_field(rng, 1, 64)
+    assert (coset_ifft(v, shift=s, engine=eng)[0] == ora.coset_ifft(v[0].copy(), shift=s)).all()
+
+
 def test_ntt_kernel_variants_agree(eng, ora):
     """p2hot_tune_ntt: LDS radix-2 layers (0), register radix 8 (3, default) and radix 16 (4) are the same function"""
     from plonky2_amd.field.fft import fft, ifft
