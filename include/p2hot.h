@@ -164,6 +164,10 @@ int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned log_n, uns
                      unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
                      p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
                      uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out);
+/* The two Option<usize> arguments of fri_committed_trees (fri/prover.rs:89-90, used by starky's multi-degree
+ * recursion: dummy cap observations + challenges up to max_num_query_steps, zero observations up to
+ * final_poly_coeff_len) for the NEXT p2hot_fri_commit / p2hot_fri_commit_dev call on this context; 0 = None. */
+int p2hot_fri_set_padding(p2hot_ctx *ctx, unsigned max_num_query_steps, size_t final_poly_coeff_len);
 /* the same with the coefficients already on the device as two planes [2][n] (component 0, then component 1),
  * e.g. the output of p2hot_fri_final_poly_dev.  d_leaves_out is a DEVICE buffer (or NULL): the round trees' leaf
  * matrices stay on the GPU (same concatenated layout) and the query phase gathers the few rows it opens; the other

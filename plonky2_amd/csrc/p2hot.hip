@@ -29,7 +29,10 @@ struct p2hot_ctx {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> fork_events;
     hipEvent_t join_event = nullptr;
-    bool overlap = false;  // measured on MI355X: no gain (the sponge's waves fill every CU; the two kernels time-slice)
+    bool overlap = false;
+    // starky multi-degree recursion padding of the next FRI commit (prover.rs:125-132, :142-147); 0 = None
+    unsigned fri_max_num_query_steps = 0;
+    size_t fri_final_poly_coeff_len = 0;  // measured on MI355X: no gain (the sponge's waves fill every CU; the two kernels time-slice)
     unsigned ntt_radix_bits = 3;  // 3: radix-8 rounds / 512 threads, 4: radix-16 / 256 threads
     struct Scratch {
         void *p = nullptr;
@@ -872,16 +875,35 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
             m >>= ab;
             shift = gl::pow(shift, (u64)1 << ab);
         }
+        // prover.rs:122-132: keep the transcript in sync with a verifier circuit that has more query steps:
+        // observe an all-zero cap and draw a dummy challenge per missing step
+        if (ctx->fri_max_num_query_steps > n_rounds) {
+            P2_HIP(ctx, hipMemsetAsync(cap.p, 0, cap_words * 8, ctx->stream));
+            for (unsigned k = n_rounds; k < ctx->fri_max_num_query_steps; ++k)
+                P2_TRY(challenger_step_dev(challenger, cap.u(), cap_words, beta.u(), 2));
+        }
         // prover.rs:135-139: final_poly = the remaining coefficients, observed by the challenger
         P2HOT_LAUNCH(fri::interleave_kernel, dim3(cdiv(cur_n, 256)), dim3(256), 0, ctx->stream, cur, cur + cur_n, cur_n,
                      stage.u());
         P2_LAUNCH_CHECK(ctx);
         P2_TRY(challenger_step_dev(challenger, stage.u(), 2 * cur_n, nullptr, 0));
         if (final_out) P2_HIP(ctx, hipMemcpyAsync(final_out, stage.p, cur_n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        // prover.rs:140-147: observe zeros up to the padded final polynomial length
+        if (ctx->fri_final_poly_coeff_len > cur_n) {
+            const size_t extra = 2 * (ctx->fri_final_poly_coeff_len - cur_n);  // extension elements -> words
+            P2_HIP(ctx, hipMemsetAsync(values.p, 0, (extra < 2 * N ? extra : 2 * N) * 8, ctx->stream));
+            for (size_t done = 0; done < extra;) {
+                size_t chunk = extra - done < 2 * N ? extra - done : 2 * N;
+                P2_TRY(challenger_step_dev(challenger, values.u(), chunk, nullptr, 0));
+                done += chunk;
+            }
+        }
         return P2HOT_OK;
     };
     rc = body();
-    hipError_t e = hipStreamSynchronize(ctx->stream);  // buffers are freed on return
+    ctx->fri_max_num_query_steps = 0;
+    ctx->fri_final_poly_coeff_len = 0;
+    hipError_t e = hipStreamSynchronize(ctx->stream);  // host outputs are complete on return
     if (rc == P2HOT_OK && e != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "fri_commit: %s", hipGetErrorString(e));
     return rc;
 }
@@ -902,6 +924,15 @@ extern "C" int p2hot_fri_commit_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs_pla
     if (ctx && !d_coeffs_planar) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit_dev: null coefficients");
     return fri_commit_core(ctx, nullptr, d_coeffs_planar, log_n, rate_bits, cap_height, arity_bits, n_rounds, challenger,
                            d_leaves_out, true, digests_out, caps_out, betas_out, final_out);
+}
+
+// Option<usize> arguments of fri_committed_trees (prover.rs:89-90) for the NEXT p2hot_fri_commit* call on this
+// context (0 = None); they are consumed (reset to None) by that call.
+extern "C" int p2hot_fri_set_padding(p2hot_ctx *ctx, unsigned max_num_query_steps, size_t final_poly_coeff_len) {
+    if (!ctx) return P2HOT_EINVAL;
+    ctx->fri_max_num_query_steps = max_num_query_steps;
+    ctx->fri_final_poly_coeff_len = final_poly_coeff_len;
+    return P2HOT_OK;
 }
 
 // ------------------------------------------------------------------ prove_openings prelude

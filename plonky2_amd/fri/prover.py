@@ -9,7 +9,8 @@ from ..engine import default_engine
 from ..hash.merkle_tree import MerkleTree
 
 
-def fri_committed_trees(coeffs, challenger, rate_bits, cap_height, reduction_arity_bits, engine=None):
+def fri_committed_trees(coeffs, challenger, rate_bits, cap_height, reduction_arity_bits, engine=None,
+                        final_poly_coeff_len=None, max_num_query_steps=None):
     """fri_committed_trees (prover.rs:84-150).
 
     coeffs: [n][2] uint64 -- the nonzero extension coefficients of final_poly (the reference passes
@@ -26,6 +27,8 @@ def fri_committed_trees(coeffs, challenger, rate_bits, cap_height, reduction_ari
     log_n = n.bit_length() - 1
     if n != 1 << log_n:
         raise ValueError("coefficient count must be a power of two")
+    if final_poly_coeff_len or max_num_query_steps:  # prover.rs:89-90 (starky multi-degree recursion)
+        eng.check(eng.lib.p2hot_fri_set_padding(eng.ctx, max_num_query_steps or 0, final_poly_coeff_len or 0))
     return _commit(coeffs, None, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, eng)
 
 

@@ -345,3 +345,37 @@ def test_commit_random_shapes(eng, ora):
         assert (b.merkle_tree.cap.entries == o["cap"]).all(), tag
         assert (np.asarray(b.merkle_tree.digests).reshape(-1, 4) == o["digests"]).all(), tag
         assert (b.merkle_tree.leaves.reshape(o["leaves"].shape) == o["leaves"]).all(), tag
+
+
+def test_fri_transcript_padding_options(eng, ora):
+    """final_poly_coeff_len / max_num_query_steps (fri/prover.rs:122-147): the challenger observes zero caps, draws
+    dummy challenges and observes zero coefficients exactly like the reference's loop"""
+    from plonky2_amd.fri.prover import fri_committed_trees
+    from plonky2_amd.iop.challenger import Challenger
+    rng = np.random.default_rng(77)
+    log_n, rb, cap, arity = 8, 1, 2, [2, 2]
+    n = 1 << log_n
+    co = rand_field(rng, n, 2)
+    pad = np.zeros((n << rb, 2), dtype=np.uint64)
+    pad[:n] = co
+    c = Challenger(eng)
+    trees, final, betas = fri_committed_trees(co, c, rb, cap, arity, engine=eng, final_poly_coeff_len=24, max_num_query_steps=4)
+    # reference transcript, step by step, on the oracle challenger
+    o = ora.fri_commit(pad, rb, cap, arity, ora.Challenger())
+    oc = ora.Challenger()
+    for i in range(len(arity)):
+        oc.observe_cap(o["caps"][i])
+        assert oc.get_extension_challenge() == [int(x) for x in betas[i]]
+    for _ in range(len(arity), 4):
+        oc.observe_elements(np.zeros(4 << cap, dtype=np.uint64))
+        oc.get_extension_challenge()
+    oc.observe_elements(o["final"].reshape(-1))
+    for _ in range(len(o["final"]), 24):
+        oc.observe_elements(np.zeros(2, dtype=np.uint64))
+    assert (final == o["final"]).all()
+    assert c.get_n_challenges(4) == oc.get_n_challenges(4)
+    # the options are consumed: the next commit is unpadded
+    c2, oc2 = Challenger(eng), ora.Challenger()
+    fri_committed_trees(co, c2, rb, cap, arity, engine=eng)
+    ora.fri_commit(pad, rb, cap, arity, oc2)
+    assert c2.get_n_challenges(2) == oc2.get_n_challenges(2)
