@@ -108,7 +108,8 @@ def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=20.0):
     """The oracle's C restatement ("port", OpenMP on the host cores) timed on a bounded sample of the
     same workload: same W / rate / cap, fewer rows.  NOT the Rust prover (no cargo in the image)."""
     from oracle import p2oracle as ora
-    cores = ora.num_threads()
+    cores = ora.usable_cores()  # min(affinity, cgroup CPU quota): oversubscribing a quota-limited job throttles it
+    ora.set_num_threads(cores)
     k = min(12, log_n)
     cols = splitmix_columns_numpy(0, W, 1 << k)
     t0 = time.perf_counter()
@@ -130,6 +131,7 @@ def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=20.0):
                      "restated CPU baseline (oracle/p2oracle.c, OpenMP), not the Rust prover -- the oracle's scalar Poseidon "
                      "(~17 us per permutation per core) is an order of magnitude slower than the reference's"
                      % (W, k, 1 << rate_bits, cap_height, 1 << (log_n - k), dt)}
+    out["host"] = "%d logical CPUs visible, %d usable by this job (cgroup quota / affinity)" % (os.cpu_count(), cores)
     try:
         out["cpu_model"] = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:

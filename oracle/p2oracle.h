@@ -128,6 +128,7 @@ void ora_reduce_polys_base(const uint64_t *const *polys, size_t n_polys, size_t 
 void ora_divide_by_linear(const uint64_t *poly, size_t n, const uint64_t z[2], uint64_t *out);
 
 int ora_num_threads(void);
+void ora_set_num_threads(int n); /* e.g. the cgroup CPU quota of the job */
 
 #ifdef __cplusplus
 }

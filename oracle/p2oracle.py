@@ -58,6 +58,28 @@ def arr(x, shape=None):
     return a.reshape(shape) if shape is not None else a
 
 
+def set_num_threads(n):
+    lib.ora_set_num_threads(C.c_int(int(n)))
+
+
+def usable_cores():
+    """host cores this job may really use: min(affinity mask, cgroup CPU quota)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def num_threads():
     return lib.ora_num_threads()
 
