@@ -19,6 +19,7 @@ def pytest_configure(config):
 def ora():
     """The CPU oracle (test infrastructure)."""
     from oracle import p2oracle
+    p2oracle.set_num_threads(p2oracle.usable_cores())  # do not oversubscribe a cgroup-limited box
     return p2oracle
 
 
