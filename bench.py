@@ -129,7 +129,7 @@ def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=20.0):
     out = {"value": fe / dt / 1e9, "unit": "GFE/s", "cores": cores, "kind": "port",
            "sample": "from_values W=%d, 2^%d rows, rate 1/%d, cap %d (1/%d of the GPU step's rows), %.2f s; "
                      "restated CPU baseline (oracle/p2oracle.c, OpenMP), not the Rust prover -- the oracle's scalar Poseidon "
-                     "(~17 us per permutation per core) is an order of magnitude slower than the reference's"
+                     "(~10 us per permutation per core on this host) is an order of magnitude slower than the reference's"
                      % (W, k, 1 << rate_bits, cap_height, 1 << (log_n - k), dt)}
     out["host"] = "%d logical CPUs visible, %d usable by this job (cgroup quota / affinity)" % (os.cpu_count(), cores)
     try:
