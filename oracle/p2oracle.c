@@ -250,25 +250,51 @@ static void full_rounds(uint64_t s[12], unsigned *round) { /* poseidon.rs:742-74
     }
 }
 
+/* sum of up to 16 products x*y kept as two u128 halves (low / high 64-bit words summed separately), reduced once:
+ * value = lo_sum + 2^64 * hi_sum, both sums < 2^68 */
+typedef struct {
+    u128 lo, hi;
+} acc256;
+static inline void acc_mul(acc256 *a, uint64_t x, uint64_t y) {
+    u128 p = (u128)x * y;
+    a->lo += (uint64_t)p;
+    a->hi += (uint64_t)(p >> 64);
+}
+static inline uint64_t acc_reduce(const acc256 *a) {
+    /* lo + 2^64*hi with lo, hi < 2^68: fold hi's top bits first (2^128 = -2^32 mod P is avoided by
+     * reducing hi to 64 bits, then one reduce128 of the 128-bit value {lo64 + carry, hi64}) */
+    uint64_t h = reduce128(a->hi);               /* hi mod P, < 2^64 */
+    u128 t = (u128)h * EPS;                      /* 2^64 * h = h * EPS (mod P) */
+    uint64_t l = reduce128(a->lo);
+    return ora_gl_add(l, reduce128(t));
+}
+
 /* poseidon.rs:752-764 partial_rounds (fast): first-constant layer (:365-375), init matrix
  * (:415-441), then 22 x { sbox on s0; + scalar constant; sparse matrix (:516-542) } */
 static void partial_rounds_fast(uint64_t s[12], unsigned *round) {
     for (int i = 0; i < 12; ++i) s[i] = ora_gl_add(s[i], P2_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT[i]);
     uint64_t t[12];
     t[0] = s[0];
-    for (int c = 1; c < 12; ++c) t[c] = 0;
-    for (int r = 1; r < 12; ++r)
-        for (int c = 1; c < 12; ++c)
-            t[c] = ora_gl_add(t[c], ora_gl_mul(s[r], P2_POSEIDON_FAST_PARTIAL_ROUND_INITIAL_MATRIX[(r - 1) * 11 + (c - 1)]));
+    for (int c = 1; c < 12; ++c) {
+        acc256 a = {0, 0};
+        for (int r = 1; r < 12; ++r) acc_mul(&a, s[r], P2_POSEIDON_FAST_PARTIAL_ROUND_INITIAL_MATRIX[(r - 1) * 11 + (c - 1)]);
+        t[c] = acc_reduce(&a);
+    }
     memcpy(s, t, sizeof t);
+    const uint64_t m00 = P2_POSEIDON_MDS_CIRC[0] + P2_POSEIDON_MDS_DIAG[0];
     for (int i = 0; i < 22; ++i) {
         s[0] = sbox(s[0]);
         s[0] = ora_gl_add(s[0], P2_POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[i]);
-        uint64_t m00 = P2_POSEIDON_MDS_CIRC[0] + P2_POSEIDON_MDS_DIAG[0];
-        uint64_t d = ora_gl_mul(s[0], m00);
-        for (int j = 1; j < 12; ++j) d = ora_gl_add(d, ora_gl_mul(s[j], P2_POSEIDON_FAST_PARTIAL_ROUND_W_HATS[i * 11 + j - 1]));
-        for (int j = 1; j < 12; ++j) t[j] = ora_gl_add(s[j], ora_gl_mul(s[0], P2_POSEIDON_FAST_PARTIAL_ROUND_VS[i * 11 + j - 1]));
-        t[0] = d;
+        acc256 a = {0, 0};
+        acc_mul(&a, s[0], m00);
+        for (int j = 1; j < 12; ++j) acc_mul(&a, s[j], P2_POSEIDON_FAST_PARTIAL_ROUND_W_HATS[i * 11 + j - 1]);
+        for (int j = 1; j < 12; ++j) {  /* s_j + s_0 * v_j: one 128-bit multiply-add, one reduction */
+            u128 p = (u128)s[0] * P2_POSEIDON_FAST_PARTIAL_ROUND_VS[i * 11 + j - 1];
+            uint64_t plo = (uint64_t)p, phi = (uint64_t)(p >> 64);
+            u128 q = (u128)plo + s[j];
+            t[j] = reduce128(((u128)(phi + (uint64_t)(q >> 64)) << 64) | (uint64_t)q); /* phi < 2^64 - 1: no overflow */
+        }
+        t[0] = acc_reduce(&a);
         memcpy(s, t, sizeof t);
     }
     *round += 22;
