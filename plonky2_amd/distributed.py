@@ -11,10 +11,19 @@ The reference has no multi-device mode; this is the MI355X design of SURVEY.md 8
   * the digests of a rank's subtrees are a contiguous slice of the reference digest array, so ONE
     all-gather of digests (+ cap entries) reassembles MerkleTree::digests / ::cap on every rank.
 
+  * the coefficient all-gather is pipelined in column chunks: chunk k is gathered asynchronously (RCCL runs on its
+    own stream) while chunk k+1 goes through the iNTT and chunk k-1 through the LDE, so most of the W*n*8-byte
+    exchange hides behind the NTT work; the leaf sponge starts when the last chunk's LDE is done.
+
 Collectives are torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs; "gloo" in the
-CPU tests).  There is no reduction anywhere, only all-gathers.
+CPU tests).  There is no reduction anywhere, only all-gathers.  P2HOT_SYNC_COLLECTIVES=1 selects the
+unpipelined variant (one blocking all-gather of all coefficients).
 """
+import os
+
 import numpy as np
+
+COSET_SHIFT = 14293326489335486720
 
 
 class ShardPlan:
@@ -59,8 +68,11 @@ class ShardedCommit:
     """from_values / from_coeffs over `world` ranks.  Buffers are allocated once and reused."""
 
     def __init__(self, engine, W, log_n, rate_bits, cap_height, is_values=True, rank=0, world=1, dist=None,
-                 want_leaves=False):
+                 want_leaves=False, pipeline_chunks=None):
         self.eng, self.dist, self.rank, self.world = engine, dist, rank, world
+        if pipeline_chunks is None:
+            pipeline_chunks = 1 if os.environ.get("P2HOT_SYNC_COLLECTIVES") == "1" else 4
+        self.pipeline_chunks = pipeline_chunks
         self.plan = p = ShardPlan(W, log_n, rate_bits, cap_height, world)
         self.is_values = is_values
         mem = engine.mem
@@ -85,6 +97,8 @@ class ShardedCommit:
                 eng.ctx, eng.ptr(cols_local), cols_local.shape[1] if W else p.n, W, p.log_n, p.rate_bits, p.cap_height,
                 1 if self.is_values else 0, 0, p.N, eng.ptr(self.coeffs_all), p.n, eng.ptr(self.lde), self.row_count,
                 eng.ptr(self.leaves), eng.ptr(self.digests), eng.ptr(self.cap)))
+        elif self.pipeline_chunks > 1 and p.cols_per_rank > 1:
+            self._run_pipelined(cols_local)
         else:
             # 1. this rank's columns -> coefficient form, in its slot of the padded buffer
             slot = self.coeffs_all[self.rank * p.cols_per_rank:(self.rank + 1) * p.cols_per_rank]
@@ -99,6 +113,7 @@ class ShardedCommit:
                 eng.ctx, eng.ptr(self.coeffs_all), p.n, W, p.log_n, p.rate_bits, p.cap_height, 0, self.row_begin,
                 self.row_count, None, 0, eng.ptr(self.lde), self.row_count, eng.ptr(self.leaves), eng.ptr(self.digests),
                 eng.ptr(self.cap)))
+        if self.world > 1:
             # 4. all-gather of this rank's contiguous digest slice and cap entries
             if p.digests_per_rank:
                 d = self.digests[self.rank * p.digests_per_rank:(self.rank + 1) * p.digests_per_rank]
@@ -107,6 +122,45 @@ class ShardedCommit:
             self._all_gather(self.cap, k)
         return {"coeffs": self.coeffs_all[:W], "lde": self.lde, "leaves": self.leaves,
                 "digests": self.digests[:p.num_digests], "cap": self.cap}
+
+    def _run_pipelined(self, cols_local):
+        """steps 1-3 with the coefficient exchange hidden behind the NTTs (see the module docstring)"""
+        eng, p, lib, mem = self.eng, self.plan, self.eng.lib, self.eng.mem
+        c0, c1 = self.column_range
+        cpr, W = p.cols_per_rank, p.W
+        K = min(self.pipeline_chunks, cpr)
+        cpk = -(-cpr // K)
+        mine = c1 - c0
+        mem.collective_fence()
+        works, spans = [], []
+        for k in range(K):
+            lo, hi = k * cpk, min((k + 1) * cpk, cpr)            # rows of every rank's slot in this chunk
+            if hi <= lo:
+                continue
+            my = self.coeffs_all[self.rank * cpr + lo:self.rank * cpr + hi]
+            valid = max(0, min(hi, mine) - lo)                   # my real (non-padding) columns in the chunk
+            if valid:
+                my[:valid] = cols_local[lo:lo + valid]
+                if self.is_values:
+                    eng.ifft(my[:valid], p.log_n)
+            outs = [mem.as_torch(self.coeffs_all[r * cpr + lo:r * cpr + hi]) for r in range(self.world)]
+            works.append(self.dist.all_gather(outs, mem.as_torch(my).clone(), async_op=True))
+            spans.append((lo, hi))
+        for w, (lo, hi) in zip(works, spans):
+            w.wait()                                             # NCCL: the compute stream waits, the host does not
+            for r in range(self.world):
+                cb = r * cpr + lo
+                cnt = max(0, min(r * cpr + hi, W, (r + 1) * cpr) - cb)
+                if cnt:                                          # LDE of these columns for this rank's coset rows
+                    eng.check(lib.p2hot_coset_lde_dev(
+                        eng.ctx, eng.ptr(self.coeffs_all[cb:cb + cnt]), cnt, p.n, p.log_n, p.rate_bits, COSET_SHIFT,
+                        self.row_begin, self.row_count, eng.ptr(self.lde[cb:cb + cnt]), self.row_count))
+        # leaf sponge + Merkle levels of this rank's rows, straight from the column-major LDE
+        eng.check(lib.p2hot_merkle_dev(eng.ctx, eng.ptr(self.lde), 0, self.row_count, W, p.log_N, p.cap_height,
+                                       self.row_begin, self.row_count, eng.ptr(self.digests), eng.ptr(self.cap)))
+        if self.leaves is not None:
+            eng.check(lib.p2hot_transpose_dev(eng.ctx, eng.ptr(self.lde), self.row_count, W, self.row_count,
+                                              eng.ptr(self.leaves)))
 
     def _all_gather(self, full, mine):
         mem = self.eng.mem

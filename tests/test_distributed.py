@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, W, log_n, rb, cap, is_values, q):
+def _worker(rank, world, port, W, log_n, rb, cap, is_values, chunks, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -32,7 +32,8 @@ def _worker(rank, world, port, W, log_n, rb, cap, is_values, q):
         eng = emu_engine()
         rng = np.random.default_rng(1234)  # every rank derives the same full input
         cols = rand_field(rng, W, 1 << log_n)
-        job = ShardedCommit(eng, W, log_n, rb, cap, is_values=is_values, rank=rank, world=world, dist=dist, want_leaves=True)
+        job = ShardedCommit(eng, W, log_n, rb, cap, is_values=is_values, rank=rank, world=world, dist=dist, want_leaves=True,
+                            pipeline_chunks=chunks)
         c0, c1 = job.column_range
         for _ in range(2):  # buffers are reused across steps
             r = job.run(eng.dev(cols[c0:c1]))
@@ -45,13 +46,15 @@ def _worker(rank, world, port, W, log_n, rb, cap, is_values, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,W,log_n,rb,cap,is_values", [(2, 5, 5, 3, 4, True), (4, 7, 4, 3, 4, True), (2, 3, 6, 1, 2, False),
-                                                            (8, 9, 3, 3, 4, True)])
-def test_sharded_commit_gloo(world, W, log_n, rb, cap, is_values):
+@pytest.mark.parametrize("world,W,log_n,rb,cap,is_values,chunks", [
+    (2, 5, 5, 3, 4, True, 1), (4, 7, 4, 3, 4, True, 1), (2, 3, 6, 1, 2, False, 1), (8, 9, 3, 3, 4, True, 1),
+    # pipelined coefficient exchange: async chunked all-gathers overlapped with the iNTT / LDE of the other chunks
+    (2, 11, 5, 3, 4, True, 4), (4, 135, 3, 3, 4, True, 4), (2, 7, 6, 1, 2, False, 3), (8, 20, 3, 3, 4, True, 2), (4, 5, 4, 3, 4, True, 4)])
+def test_sharded_commit_gloo(world, W, log_n, rb, cap, is_values, chunks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, W, log_n, rb, cap, is_values, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, log_n, rb, cap, is_values, chunks, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -121,8 +121,21 @@ class _LoopbackDist:
         for r, t in self.store[key].items():
             out[r * chunk:(r + 1) * chunk] = t
 
+    def all_gather(self, outs, inp, async_op=False):
+        key = self.calls
+        self.calls += 1
+        self.store.setdefault(key, {})[self.rank] = inp.clone()
+        for r, t in self.store[key].items():
+            outs[r].copy_(t)
 
-def test_sharded_commit_ranks_on_one_gpu(gpu, ora):
+        class _Done:
+            def wait(self):
+                return True
+        return _Done()
+
+
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_sharded_commit_ranks_on_one_gpu(gpu, ora, chunks):
     """the world > 1 branch of plonky2_amd.distributed on the real GPU: both ranks of a 2-rank job are
     run one after the other with a loopback all-gather; rank 1 then holds the full tree"""
     from plonky2_amd.distributed import ShardedCommit
@@ -131,7 +144,8 @@ def test_sharded_commit_ranks_on_one_gpu(gpu, ora):
     cols = rand_field(rng, W, 1 << log_n)
     o = ora.commit(cols, rb, cap, True)
     dist = _LoopbackDist(2)
-    jobs = [ShardedCommit(gpu, W, log_n, rb, cap, is_values=True, rank=r, world=2, dist=dist, want_leaves=True) for r in range(2)]
+    jobs = [ShardedCommit(gpu, W, log_n, rb, cap, is_values=True, rank=r, world=2, dist=dist, want_leaves=True,
+                          pipeline_chunks=chunks) for r in range(2)]
     out = None
     for _pass in range(2):  # second sweep: every rank's deposits are present, like a real collective
         dist.calls = 0
