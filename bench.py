@@ -236,7 +236,8 @@ def main():
             "config": {"workload": "PolynomialBatch::from_values, W=%d, 2^%d rows, rate 1/%d (N=2^%d), cap_height %d, "
                                    "PoseidonGoldilocksConfig (C3 wires commit at --gpus 1; +1 bit of rows per doubling of GPUs)"
                                    % (W, log_n, 1 << rb, log_n + rb, cap),
-                       "sharding": "none" if world == 1 else "LDE cosets over %d ranks, RCCL all-gather of coefficients and digests" % world},
+                       "sharding": "none" if world == 1 else "LDE cosets over %d ranks; iNTT column-sharded, coefficients all-gathered in "
+                                   "async column chunks overlapped with the NTTs; RCCL all-gather of digests + cap" % world},
             "roofline": {"kernel": "hash_leaves_kernel<ColMajorReader> (Poseidon leaf sponge)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (lambda t: t / launches_per_step if t else None)(pmc_traffic(W, log_n, rb, cap, world, "hash_leaves_kernel")),
