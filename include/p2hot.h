@@ -62,6 +62,9 @@ int p2hot_profile_enable(p2hot_ctx *ctx, int on);
 int p2hot_tune_ntt(p2hot_ctx *ctx, int radix_bits);
 /* overlap the Poseidon leaf sponge of coset block b with the LDE of block b+1 on a second HIP stream (default 0: measured neutral on MI355X) */
 int p2hot_tune_overlap(p2hot_ctx *ctx, int on);
+/* leaf-hash / tree-level launches with at most max_perms permutations run the quad-cooperative kernels (4 lanes per
+ * permutation, ~3x lower latency, 1.3x the work); default 2^15, 0 = never.  Results are identical. */
+int p2hot_tune_quad(p2hot_ctx *ctx, size_t max_perms);
 const char *p2hot_profile_json(p2hot_ctx *ctx, int reset);
 
 /* sizes: number of digests (4 words each) in MerkleTree::digests for n_leaves = 2^log_leaves

@@ -12,6 +12,7 @@
 // leaf c = values[arity*c .. arity*(c+1)) flattened, fri/prover.rs:99-103).
 #pragma once
 #include "poseidon.hpp"
+#include "poseidon4.hpp"
 
 namespace merkle {
 using gl::u32;
@@ -84,6 +85,66 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(u64 *digests, u64 *ca
     u64 *dst = node_slot(digests, cap, h, level, j);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dst[i] = out[i];
+}
+
+// ---- quad-cooperative variants (4 lanes per leaf / node, poseidon4.hpp): same results, ~3x lower latency;
+// used when a launch has too few permutations to fill the chip.  Every thread stays alive to the end (the quad
+// exchanges need all four lanes); out-of-range quads compute on zeros and store nothing.
+template <class Reader>
+__global__ void __launch_bounds__(256) hash_leaves_quad_kernel(Reader rd, unsigned W, size_t leaf_offset, size_t leaf_count,
+                                                              unsigned h, u64 *digests, u64 *cap) {
+    const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const unsigned q = threadIdx.x & 3;
+    const bool live = t < leaf_count;
+    const size_t L = leaf_offset + (live ? t : 0);
+    u64 w[3] = {0, 0, 0};  // state words 3q, 3q+1, 3q+2
+    if (W <= 4) {          // hash_or_noop: copy (plonk/config.rs:63-74)
+#pragma unroll
+        for (unsigned u = 0; u < 3; ++u)
+            if (live && 3 * q + u < W) w[u] = rd(L, 3 * q + u);
+    } else {
+        for (unsigned off = 0; off < W; off += 8) {
+            const unsigned cnt = W - off < 8 ? W - off : 8;
+#pragma unroll
+            for (unsigned u = 0; u < 3; ++u) {
+                const unsigned e = 3 * q + u;  // word e of the rate portion is overwritten by input off + e
+                if (live && e < cnt) w[u] = rd(L, off + e);
+            }
+            poseidon4::permute_quad(w, q);
+        }
+    }
+    if (live) {  // digest = words 0..3: lane 0 holds 0,1,2 and lane 1 holds 3
+        u64 *dst = node_slot(digests, cap, h, 0, L);
+        if (q == 0) {
+            dst[0] = gl::canon(w[0]);
+            dst[1] = gl::canon(w[1]);
+            dst[2] = gl::canon(w[2]);
+        } else if (q == 1) {
+            dst[3] = gl::canon(w[0]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) merkle_level_quad_kernel(u64 *digests, u64 *cap, unsigned h, unsigned level,
+                                                               size_t n_nodes) {
+    const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const unsigned q = threadIdx.x & 3;
+    const bool live = j < n_nodes;
+    const u64 *ch = node_slot(digests, cap, h, level - 1, 2 * (live ? j : 0));  // 8 contiguous words [left, right]
+    u64 w[3];
+#pragma unroll
+    for (unsigned u = 0; u < 3; ++u) w[u] = (live && 3 * q + u < 8) ? ch[3 * q + u] : 0;  // words 8..11 = 0
+    poseidon4::permute_quad(w, q);
+    if (live) {
+        u64 *dst = node_slot(digests, cap, h, level, j);
+        if (q == 0) {
+            dst[0] = gl::canon(w[0]);
+            dst[1] = gl::canon(w[1]);
+            dst[2] = gl::canon(w[2]);
+        } else if (q == 1) {
+            dst[3] = gl::canon(w[0]);
+        }
+    }
 }
 
 // batch of raw permutations, states [count][12] (parity primitive for the reference KATs,

@@ -30,6 +30,7 @@ struct p2hot_ctx {
     std::vector<hipEvent_t> fork_events;
     hipEvent_t join_event = nullptr;
     bool overlap = false;
+    size_t quad_threshold = (size_t)1 << 15;  // launches with at most this many permutations use the quad kernels
     // starky multi-degree recursion padding of the next FRI commit (prover.rs:125-132, :142-147); 0 = None
     unsigned fri_max_num_query_steps = 0;
     size_t fri_final_poly_coeff_len = 0;  // measured on MI355X: no gain (the sponge's waves fill every CU; the two kernels time-slice)
@@ -202,6 +203,13 @@ extern "C" int p2hot_ctx_sync(p2hot_ctx *ctx) {
 }
 
 extern "C" const char *p2hot_last_error(const p2hot_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// tuning knob: launches with at most `max_perms` leaves / nodes use the quad-cooperative Poseidon kernels (0 = never)
+extern "C" int p2hot_tune_quad(p2hot_ctx *ctx, size_t max_perms) {
+    if (!ctx) return P2HOT_EINVAL;
+    ctx->quad_threshold = max_perms;
+    return P2HOT_OK;
+}
 
 // tuning knob: overlap the leaf sponge of coset block b with the LDE of block b+1 on a second stream (default on)
 extern "C" int p2hot_tune_overlap(p2hot_ctx *ctx, int on) {
@@ -557,8 +565,13 @@ static int hash_leaves_range(p2hot_ctx *ctx, hipStream_t stream, Reader rd, size
                              size_t leaf_offset, size_t count) {
     if (count == 0) return P2HOT_OK;
     ProfScope ps(ctx, "hash_leaves", stream, true);
-    P2HOT_LAUNCH((merkle::hash_leaves_kernel<Reader>), dim3(cdiv(count, 256)), dim3(256), 0, stream, rd, (unsigned)W,
-                 leaf_offset, count, g.h, g.dig, g.cap);
+    if (count <= ctx->quad_threshold) {  // too few permutations to fill the chip: 4 lanes per leaf, ~3x lower latency
+        P2HOT_LAUNCH((merkle::hash_leaves_quad_kernel<Reader>), dim3(cdiv(4 * count, 256)), dim3(256), 0, stream, rd,
+                     (unsigned)W, leaf_offset, count, g.h, g.dig, g.cap);
+    } else {
+        P2HOT_LAUNCH((merkle::hash_leaves_kernel<Reader>), dim3(cdiv(count, 256)), dim3(256), 0, stream, rd, (unsigned)W,
+                     leaf_offset, count, g.h, g.dig, g.cap);
+    }
     P2_LAUNCH_CHECK(ctx);
     return P2HOT_OK;
 }
@@ -567,8 +580,12 @@ static int merkle_levels(p2hot_ctx *ctx, const ForestGeom &g, size_t leaf_count)
     ProfScope ps(ctx, "merkle_levels");
     for (unsigned level = 1; level <= g.h; ++level) {
         size_t nodes = leaf_count >> level;
-        P2HOT_LAUNCH(merkle::merkle_level_kernel, dim3(cdiv(nodes, 256)), dim3(256), 0, ctx->stream, g.dig, g.cap, g.h,
-                     level, nodes);
+        if (nodes <= ctx->quad_threshold)
+            P2HOT_LAUNCH(merkle::merkle_level_quad_kernel, dim3(cdiv(4 * nodes, 256)), dim3(256), 0, ctx->stream, g.dig,
+                         g.cap, g.h, level, nodes);
+        else
+            P2HOT_LAUNCH(merkle::merkle_level_kernel, dim3(cdiv(nodes, 256)), dim3(256), 0, ctx->stream, g.dig, g.cap, g.h,
+                         level, nodes);
         P2_LAUNCH_CHECK(ctx);
     }
     return P2HOT_OK;

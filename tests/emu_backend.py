@@ -67,4 +67,8 @@ def emu_lib():
 
 
 def emu_engine():
-    return Engine(0, lib=emu_lib(), memory=HostMemory())
+    eng = Engine(0, lib=emu_lib(), memory=HostMemory())
+    # both Poseidon mappings get exercised by the CPU tier: launches of up to 20 permutations take the quad-cooperative
+    # kernels (their emulated cross-lane exchanges are slow), larger ones the one-permutation-per-lane kernels
+    eng.check(eng.lib.p2hot_tune_quad(eng.ctx, 20))
+    return eng

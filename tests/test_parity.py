@@ -379,3 +379,23 @@ def test_fri_transcript_padding_options(eng, ora):
     fri_committed_trees(co, c2, rb, cap, arity, engine=eng)
     ora.fri_commit(pad, rb, cap, arity, oc2)
     assert c2.get_n_challenges(2) == oc2.get_n_challenges(2)
+
+
+def test_quad_and_lane_poseidon_kernels_agree(eng, ora):
+    """p2hot_tune_quad: the quad-cooperative kernels (4 lanes per permutation, DPP quad rotations) and the
+    one-permutation-per-lane kernels produce the same trees; both equal the oracle"""
+    from plonky2_amd.hash.merkle_tree import MerkleTree
+    rng = np.random.default_rng(91)
+    gpu = is_gpu(eng)
+    cases = [(64, 135, 2), (32, 9, 0), (16, 3, 1), (128, 20, 4)] if not gpu else [(4096, 135, 4), (1024, 20, 0), (256, 3, 2), (8192, 16, 4)]
+    try:
+        for (n, w, cap) in cases:
+            leaves = rand_field(rng, n, w, noncanonical=True)
+            digests, capv = ora.merkle_tree(leaves, cap)
+            for thr in (0, 1 << 20):
+                eng.check(eng.lib.p2hot_tune_quad(eng.ctx, thr))
+                t = MerkleTree.new(leaves, cap, engine=eng)
+                assert (t.cap.entries == capv).all(), (n, w, cap, thr)
+                assert (np.asarray(t.digests).reshape(-1, 4) == digests).all(), (n, w, cap, thr)
+    finally:
+        eng.check(eng.lib.p2hot_tune_quad(eng.ctx, 20 if not gpu else 1 << 15))

@@ -196,6 +196,7 @@ def emit(path, rc, circ, diag, first, scal, vs, w_hats, init):
         f.write("// round constants with the passive part of the partial rounds pushed forward through the MDS\n"
                 "// (tools/gen_poseidon_constants.py pushed_constants): rounds 4..25 keep only word 0, round 26 absorbs the rest;\n"
                 "// split {lo32, hi32} like the table above\n")
+        f.write(arr("P2_POSEIDON_PUSHED_ROUND_CONSTANTS", pushed_constants(rc, circ, diag)))
         f.write(arr("P2_POSEIDON_PUSHED_ROUND_CONSTANTS_SPLIT",
                     [h for v in pushed_constants(rc, circ, diag) for h in (v & 0xFFFFFFFF, v >> 32)]))
         f.write(arr("P2_POSEIDON_MDS_CIRC", circ, 12))
