@@ -9,10 +9,11 @@
 //
 // MI355X-first: extension polynomials live as two base-field planes so the F^2 NTT is the batch-of-2
 // base NTT (extension/mod.rs:75-78: the roots of unity are base-field), and the challenger state is
-// a 232-byte device object advanced by a single-wave kernel (one state word per lane, MDS through
-// LDS) -- every FRI round is enqueued without a host round trip; beta never leaves the GPU.
+// a 232-byte device object advanced by a single-wave kernel (state over one quad of lanes, MDS through
+// DPP quad rotations) -- every FRI round is enqueued without a host round trip; beta never leaves the GPU.
 #pragma once
 #include "poseidon.hpp"
+#include "poseidon4.hpp"
 
 namespace fri {
 using gl::u32;
@@ -25,92 +26,56 @@ struct Challenger {  // mirrors challenger.rs:16-24
     u32 n_in, n_out;
 };
 
-// One permutation spread over lanes 0..11 of a wave (x = this lane's state word).
-// All 64 threads of the block must call it.
-__device__ inline u64 permute_lanes(u64 x, unsigned lane, u64 *sh /* [12] */) {
-    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-#pragma unroll 1
-    for (int round = 0; round < 30; ++round) {
-        u64 rc = lane < 12 ? P2_POSEIDON_ALL_ROUND_CONSTANTS[12 * round + (lane < 12 ? lane : 0)] : 0;
-        x = gl::add_canon(x, rc);
-        const bool full = round < 4 || round >= 26;
-        if (full || lane == 0) x = poseidon::sbox7(x);
-        if (lane < 12) sh[lane] = x;
-        __syncthreads();
-        u32 a0 = 0, a1 = 0, a2 = 0;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            unsigned j = i + (lane < 12 ? lane : 0);
-            if (j >= 12) j -= 12;
-            u64 v = sh[j];
-            u32 lo = (u32)v, hi = (u32)(v >> 32);
-            a0 += C[i] * (lo & 0x3FFFFFu);
-            a1 += C[i] * (((lo >> 22) | (hi << 10)) & 0x1FFFFFu);
-            a2 += C[i] * (hi >> 11);
-        }
-        if (lane == 0) {
-            u64 v = sh[0];
-            u32 lo = (u32)v, hi = (u32)(v >> 32);
-            a0 += 8u * (lo & 0x3FFFFFu);
-            a1 += 8u * (((lo >> 22) | (hi << 10)) & 0x1FFFFFu);
-            a2 += 8u * (hi >> 11);
-        }
-        u64 lo64 = (u64)a0 + ((u64)a1 << 22);
-        u64 t = (u64)a2 << 43;
-        lo64 += t;
-        u64 hi = (u64)(a2 >> 21) + (u64)(lo64 < t);
-        u64 e = (hi << 32) - hi;
-        u64 y = lo64 + e;
-        if (y < e) y += gl::EPS;
-        __syncthreads();
-        x = y;
-    }
-    return x;
-}
-
 // observe n_obs elements, then squeeze n_get challenges (popped from the back, challenger.rs:82-92).
-// launch with exactly one 64-thread block.
+// Launch with exactly one 64-thread block.  The sponge state lives in the first quad of the wave (3 words per
+// lane, poseidon4.hpp); the other lanes run the same instruction stream on zeros and store nothing.
 __global__ void __launch_bounds__(64) challenger_kernel(Challenger *ch, const u64 *obs, size_t n_obs, u64 *out,
                                                        size_t n_get) {
-    __shared__ u64 sh[12];
     __shared__ u64 inbuf[8];
     __shared__ u64 outbuf[8];
-    const unsigned lane = threadIdx.x;
+    const unsigned lane = threadIdx.x, q = lane & 3;
+    const bool owner = lane < 4;
     u32 n_in = ch->n_in, n_out = ch->n_out;
-    u64 x = lane < 12 ? ch->state[lane] : 0;
+    u64 w[3];
+#pragma unroll
+    for (unsigned u = 0; u < 3; ++u) w[u] = owner ? ch->state[3 * q + u] : 0;
     if (lane < 8) {
         inbuf[lane] = ch->in[lane];
         outbuf[lane] = ch->out[lane];
     }
     __syncthreads();
+    // duplexing (challenger.rs:129-144): overwrite the first n_in words with the buffered inputs, permute,
+    // refill the output buffer with the rate portion
+    auto duplex = [&]() {
+#pragma unroll
+        for (unsigned u = 0; u < 3; ++u)
+            if (owner && 3 * q + u < n_in) w[u] = inbuf[3 * q + u];
+        poseidon4::permute_quad(w, q);
+#pragma unroll
+        for (unsigned u = 0; u < 3; ++u) {
+            w[u] = gl::canon(w[u]);
+            if (owner && 3 * q + u < 8) outbuf[3 * q + u] = w[u];
+        }
+        n_in = 0;
+        n_out = 8;
+        __syncthreads();
+    };
     for (size_t k = 0; k < n_obs; ++k) {
         n_out = 0;
         if (lane == 0) inbuf[n_in] = gl::canon(obs[k]);
         ++n_in;
         __syncthreads();
-        if (n_in == 8) {
-            if (lane < 8) x = inbuf[lane];
-            x = gl::canon(permute_lanes(x, lane, sh));
-            if (lane < 8) outbuf[lane] = x;
-            n_in = 0;
-            n_out = 8;
-            __syncthreads();
-        }
+        if (n_in == 8) duplex();
     }
     for (size_t k = 0; k < n_get; ++k) {
-        if (n_in != 0 || n_out == 0) {
-            if (lane < n_in) x = inbuf[lane];
-            x = gl::canon(permute_lanes(x, lane, sh));
-            if (lane < 8) outbuf[lane] = x;
-            n_in = 0;
-            n_out = 8;
-            __syncthreads();
-        }
+        if (n_in != 0 || n_out == 0) duplex();
         --n_out;
         if (lane == 0) out[k] = outbuf[n_out];
     }
     __syncthreads();
-    if (lane < 12) ch->state[lane] = x;
+#pragma unroll
+    for (unsigned u = 0; u < 3; ++u)
+        if (owner) ch->state[3 * q + u] = w[u];
     if (lane < 8) {
         ch->in[lane] = inbuf[lane];
         ch->out[lane] = outbuf[lane];
