@@ -34,10 +34,22 @@ __device__ __forceinline__ u64 quad_rot(u64 v) {
     return ((u64)quad_rot32<S>((u32)(v >> 32)) << 32) | quad_rot32<S>((u32)v);
 }
 
+// gfx950 needs two wait states between a VALU write of a VGPR and a DPP read of it.  hipcc pads that hazard for its
+// own instructions but knows nothing about the last instructions of an asm block (mul3 / mul1 / fold3), so the words
+// are passed through an explicit two-state nop that is data-dependent on them before the DPP rotations read them.
+__device__ __forceinline__ void dpp_guard(u64 w[3]) {
+#ifndef P2HOT_EMU
+    asm volatile("s_nop 1" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]));
+#else
+    (void)w;
+#endif
+}
+
 // MDS (+ optional constants rc3[t] for this lane's rows) on the quad-distributed state w[3]
 __device__ __forceinline__ void mds_quad(u64 w[3], unsigned q, const u64 rc3[3], bool has_rc) {
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     u64 z[12];  // z[i] = x_{(i + 3q) % 12}
+    dpp_guard(w);
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         z[u] = w[u];
