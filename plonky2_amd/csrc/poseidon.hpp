@@ -25,6 +25,7 @@
 #include "gl_mul3.hpp"
 #ifndef P2HOT_EMU
 #define P2_CONST_QUAL __constant__  // device constant memory; indices are wave-uniform -> scalar loads
+#define P2_LITERAL_QUAL static constexpr  // entries become instruction-stream immediates (s_mov_b32 literals)
 #endif
 #include "poseidon_constants.h"
 
@@ -121,6 +122,75 @@ __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2) {
     }
 }
 
+// single-row recombination (compiler-scheduled twin of gl::fold3): al + ah * 2^32 mod P for al, ah < 2^61
+__device__ __forceinline__ u64 fold1(u64 al, u64 ah) {
+    u32 k1;
+    u32 w1 = gl::addc32((u32)(al >> 32), (u32)ah, 0u, &k1);
+    u32 w2 = (u32)(ah >> 32) + k1;
+    u64 lo64 = ((u64)w1 << 32) | (u32)al;
+    u64 t = (u64)w2 * 0xFFFFFFFFu + lo64;
+    return gl::fold_carry(t, t < lo64);
+}
+
+// Three partial rounds in one dense pass.  A partial round is y <- M (y + d e0) with d = sbox(y[0] + c) - y[0], so
+//   y1[0] = (M y)[0]   + d0 M[0][0]
+//   y2[0] = (M^2 y)[0] + d0 (M^2)[0][0] + d1 M[0][0]
+//   y3    = M^3 y + d0 (M^3 e0) + d1 (M^2 e0) + d2 (M e0)
+// and the integer powers of the MDS matrix stay small (M^3 < 2^21 per entry, < 2^25 per row), so a row of M^3 y is
+// still two 32x32+64 multiply-add chains (accumulators < 2^58): three rounds cost one 12-row pass (+3 terms per
+// row), two single rows and three S-boxes instead of three 12-row passes.  c[0..2] are the rounds' scalar constants
+// (P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 r]); the state carries NO pending constant on entry or exit.
+__device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c0, u64 c1, u64 c2) {
+    u32 xl[12], xh[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        xl[i] = (u32)s[i];
+        xh[i] = (u32)(s[i] >> 32);
+    }
+    const u64 d0 = gl::sub(sbox7_asm(gl::add_canon(s[0], c0)), s[0]);
+    const u32 d0l = (u32)d0, d0h = (u32)(d0 >> 32);
+    u64 al = (u64)d0l * P2_POSEIDON_MCOL0[0], ah = (u64)d0h * P2_POSEIDON_MCOL0[0];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        al += (u64)xl[j] * P2_POSEIDON_M1_ROW0[j];
+        ah += (u64)xh[j] * P2_POSEIDON_M1_ROW0[j];
+    }
+    const u64 y1 = fold1(al, ah);
+    const u64 d1 = gl::sub(sbox7_asm(gl::add_canon(y1, c1)), y1);
+    const u32 d1l = (u32)d1, d1h = (u32)(d1 >> 32);
+    al = (u64)d0l * P2_POSEIDON_MCOL0[12] + (u64)d1l * P2_POSEIDON_MCOL0[0];
+    ah = (u64)d0h * P2_POSEIDON_MCOL0[12] + (u64)d1h * P2_POSEIDON_MCOL0[0];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        al += (u64)xl[j] * P2_POSEIDON_M2_ROW0[j];
+        ah += (u64)xh[j] * P2_POSEIDON_M2_ROW0[j];
+    }
+    const u64 y2 = fold1(al, ah);
+    const u64 d2 = gl::sub(sbox7_asm(gl::add_canon(y2, c2)), y2);
+    const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
+#pragma unroll
+    for (int g = 0; g < 12; g += 3) {
+        u64 bl[3], bh[3], y[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int i = g + t;
+            bl[t] = (u64)d0l * P2_POSEIDON_MCOL0[24 + i] + (u64)d1l * P2_POSEIDON_MCOL0[12 + i] +
+                    (u64)d2l * P2_POSEIDON_MCOL0[i];
+            bh[t] = (u64)d0h * P2_POSEIDON_MCOL0[24 + i] + (u64)d1h * P2_POSEIDON_MCOL0[12 + i] +
+                    (u64)d2h * P2_POSEIDON_MCOL0[i];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                bl[t] += (u64)xl[j] * P2_POSEIDON_M3[12 * i + j];
+                bh[t] += (u64)xh[j] * P2_POSEIDON_M3[12 * i + j];
+            }
+        }
+        gl::fold3(bl, bh, y);
+        s[g] = y[0];
+        s[g + 1] = y[1];
+        s[g + 2] = y[2];
+    }
+}
+
 // the permutation; output words are NOT canonicalised (callers canonicalise what they emit).
 // Round r: ARK(r) was already added by the previous MDS (or up front for r = 0); S-box; MDS + ARK(r+1).
 __device__ inline void permute(u64 s[12]) {
@@ -132,17 +202,18 @@ __device__ inline void permute(u64 s[12]) {
         sbox_layer(s);
         mds_layer(s, RC_SPLIT + 24 * (round + 1));
     }
-    // round 3 -> 4 and the partial rounds 4..24 -> 5..25: the next constant layer is a scalar on word 0
-    // (the passive part of the partial-round constants is pushed forward through the MDS, see the generator)
+    // round 3: no constant is fused into its MDS -- the batched partial rounds add their scalars themselves
     sbox_layer(s);
-    mds_layer<true>(s, RC_SPLIT + 24 * (round + 1));
+    mds_layer(s, nullptr);
     ++round;
+    // partial rounds 4..24 in seven batches of three (their constants are scalars on word 0: the passive part of the
+    // partial-round constants is pushed forward through the MDS at table-generation time, see the generator)
 #pragma unroll 1
-    for (int k = 0; k < 21; ++k, ++round) {
-        s[0] = sbox7_asm(s[0]);
-        mds_layer<true>(s, RC_SPLIT + 24 * (round + 1));
-    }
-    s[0] = sbox7_asm(s[0]);  // round 25 -> 26: full constant vector again (absorbs the pushed remainder)
+    for (int k = 0; k < 7; ++k, round += 3)
+        partial_rounds3(s, P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * round], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 1)],
+                        P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 2)]);
+    // round 25, then the full constant vector of round 26 (which absorbed the pushed remainder)
+    s[0] = sbox7_asm(gl::add_canon(s[0], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * round]));
     mds_layer(s, RC_SPLIT + 24 * (round + 1));
     ++round;
 #pragma unroll 1

@@ -174,6 +174,21 @@ def pushed_constants(rc, circ, diag):
     return [v for row in fused for v in row]
 
 
+def mds_power_tables(circ, diag):
+    """Integer powers of the MDS matrix for the batched partial rounds (three rounds per dense pass):
+        y3 = M^3 y + d0 * M^3 e0 + d1 * M^2 e0 + d2 * M e0,   d_k = sbox(y_k[0] + c_k) - y_k[0],
+        y1[0] = (M y)[0] + d0 * M[0][0],   y2[0] = (M^2 y)[0] + d0 * (M^2)[0][0] + d1 * M[0][0].
+    All entries are exact small integers (M^3 < 2^21, row sums < 2^25), so a row is still two 32x32+64
+    multiply-add chains.  Returns (row0 of M, row0 of M^2, M^3 row-major, columns 0 of M, M^2, M^3)."""
+    M = [[circ[(c - r) % W] + (diag[r] if r == c else 0) for c in range(W)] for r in range(W)]
+    mul = lambda a, b: [[sum(a[i][t] * b[t][j] for t in range(W)) for j in range(W)] for i in range(W)]
+    M2 = mul(M, M)
+    M3 = mul(M2, M)
+    assert max(max(r) for r in M3) < 1 << 21 and max(sum(r) for r in M3) < 1 << 25
+    col = lambda A: [A[i][0] for i in range(W)]
+    return M[0], M2[0], [v for r in M3 for v in r], col(M) + col(M2) + col(M3)
+
+
 def emit(path, rc, circ, diag, first, scal, vs, w_hats, init):
     def arr(name, vals, per=4):
         s = "P2_CONST_QUAL uint64_t %s[%d] = {\n" % (name, len(vals))
@@ -188,7 +203,10 @@ def emit(path, rc, circ, diag, first, scal, vs, w_hats, init):
                 "//  poseidon_goldilocks.rs:27-215).\n"
                 "#pragma once\n#include <stdint.h>\n"
                 "// P2_CONST_QUAL: storage qualifier (the HIP build defines it as __constant__)\n"
-                "#ifndef P2_CONST_QUAL\n#define P2_CONST_QUAL static const\n#endif\n\n")
+                "#ifndef P2_CONST_QUAL\n#define P2_CONST_QUAL static const\n#endif\n"
+                "// P2_LITERAL_QUAL: tables whose entries must be visible to the compiler as literals (the HIP build\n"
+                "// defines it as static constexpr: they become s_mov_b32 immediates, not constant-memory loads)\n"
+                "#ifndef P2_LITERAL_QUAL\n#define P2_LITERAL_QUAL static const\n#endif\n\n")
         f.write(arr("P2_POSEIDON_ALL_ROUND_CONSTANTS", rc))
         f.write("// the same constants with every word split into {lo32, hi32} (two u64 words): the device\n"
                 "// MDS rows start their two 32x32+64 multiply-add chains from them\n")
@@ -199,6 +217,18 @@ def emit(path, rc, circ, diag, first, scal, vs, w_hats, init):
         f.write(arr("P2_POSEIDON_PUSHED_ROUND_CONSTANTS", pushed_constants(rc, circ, diag)))
         f.write(arr("P2_POSEIDON_PUSHED_ROUND_CONSTANTS_SPLIT",
                     [h for v in pushed_constants(rc, circ, diag) for h in (v & 0xFFFFFFFF, v >> 32)]))
+        def arr32(name, vals, per=12):
+            t = "P2_LITERAL_QUAL uint32_t %s[%d] = {\n" % (name, len(vals))
+            for i in range(0, len(vals), per):
+                t += "    " + ", ".join("%du" % v for v in vals[i:i + per]) + ",\n"
+            return t + "};\n\n"
+        m1r0, m2r0, m3, cols = mds_power_tables(circ, diag)
+        f.write("// integer powers of the MDS matrix for the batched partial rounds (tools/gen_poseidon_constants.py\n"
+                "// mds_power_tables): row 0 of M and M^2, M^3 row-major, then column 0 of M, M^2, M^3\n")
+        f.write(arr32("P2_POSEIDON_M1_ROW0", m1r0))
+        f.write(arr32("P2_POSEIDON_M2_ROW0", m2r0))
+        f.write(arr32("P2_POSEIDON_M3", m3))
+        f.write(arr32("P2_POSEIDON_MCOL0", cols))
         f.write(arr("P2_POSEIDON_MDS_CIRC", circ, 12))
         f.write(arr("P2_POSEIDON_MDS_DIAG", diag, 12))
         f.write(arr("P2_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT", first))
