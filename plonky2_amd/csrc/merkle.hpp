@@ -66,7 +66,11 @@ __global__ void __launch_bounds__(256) hash_leaves_kernel(Reader rd, unsigned W,
 #pragma unroll
             for (unsigned i = 0; i < 8; ++i)
                 if (i < cnt) s[i] = rd(L, off + i);
-            poseidon::permute(s);
+            // the next chunk overwrites words 0..next-1 (overwrite-mode sponge) and the digest is words 0..3:
+            // only the word triples that survive are computed by the last MDS layer
+            const unsigned next = off + 8 < W ? (W - off - 8 < 8 ? W - off - 8 : 8) : 0;
+            const unsigned keep = off + 8 < W ? (0xFu << (next / 3)) & 0xFu : 0x3u;
+            poseidon::permute(s, keep);
         }
     }
     u64 *dst = node_slot(digests, cap, h, 0, L);

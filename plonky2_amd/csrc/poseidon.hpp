@@ -84,8 +84,9 @@ __device__ __forceinline__ u32 opaque_const(u32 c) {
 // 12-term multiply-add chains over the 32-bit halves (al, ah < 2^42) and one fold:
 //   y = al + ah * 2^32 = lo64 + w2 * 2^64 = lo64 + w2 * EPS (mod P), w2 < 2^10.
 // rc2 points at the round's constants split as {lo32, hi32} pairs (RC_SPLIT) or is null.
+// `groups` (wave-uniform): bit g set = rows 3g..3g+2 are wanted; the other rows are left stale.
 template <bool WORD0_ONLY = false>
-__device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2) {
+__device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2, unsigned groups = 0xFu) {
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     const u32 c16 = opaque_const(16), c2 = opaque_const(2), c8 = opaque_const(8);
     u32 xl[12], xh[12];
@@ -96,6 +97,7 @@ __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2) {
     }
 #pragma unroll
     for (int g = 0; g < 12; g += 3) {  // three rows at a time: six independent chains, then one fold3 stream
+        if (!(groups >> (g / 3) & 1u)) continue;
         u64 al[3], ah[3], y[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -193,7 +195,8 @@ __device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c0, u64 c1, u64 c
 
 // the permutation; output words are NOT canonicalised (callers canonicalise what they emit).
 // Round r: ARK(r) was already added by the previous MDS (or up front for r = 0); S-box; MDS + ARK(r+1).
-__device__ inline void permute(u64 s[12]) {
+// `out_groups`: which output word triples the caller reads (bit g = words 3g..3g+2); the last MDS skips the rest
+__device__ inline void permute(u64 s[12], unsigned out_groups = 0xFu) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl::add_canon(s[i], RC[i]);
     int round = 0;
@@ -222,7 +225,7 @@ __device__ inline void permute(u64 s[12]) {
         mds_layer(s, RC_SPLIT + 24 * (round + 1));
     }
     sbox_layer(s);
-    mds_layer(s, nullptr);
+    mds_layer(s, nullptr, out_groups);
 }
 
 // two_to_one (hashing.rs:97-114): state = [l, r, 0^4], permute, first 4 words
@@ -234,7 +237,7 @@ __device__ __forceinline__ void two_to_one(const u64 l[4], const u64 r[4], u64 o
         s[4 + i] = r[i];
         s[8 + i] = 0;
     }
-    permute(s);
+    permute(s, 0x3u);  // words 0..3 only
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = gl::canon(s[i]);
 }
