@@ -194,6 +194,21 @@ int p2hot_fri_final_poly_dev(p2hot_ctx *ctx, const uint64_t *const *d_poly_table
  * (host [n_points][2]): d_out[p][j] = polys[j](points[p]) as [2] words, layout [n_points][n_polys][2]. */
 int p2hot_eval_polys_dev(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, size_t n_polys, unsigned log_n,
                          const uint64_t *points, size_t n_points, uint64_t *d_out);
+/* all_wires_permutation_partial_products (plonky2/src/plonk/prover.rs:356-449): the permutation
+ * argument's Z and partial-product polynomials (values on the trace subgroup) for num_challenges (beta, gamma) pairs.
+ *   d_wires   DEVICE [num_routed][n] column-major (MatrixWitness.wire_values[col][row], iop/witness.rs:283-291)
+ *   d_sigmas  DEVICE [num_routed][n] column-major: sigma_j(w_n^i) (the sigma polynomials' values; prover_data.sigmas
+ *             holds their transpose)
+ *   k_is      HOST [num_routed] coset shifts (common_data.k_is), betas / gammas HOST [num_challenges]
+ *   degree    = common_data.quotient_degree_factor (chunk size); num_prods = ceil(num_routed / degree) - 1
+ *   d_out     DEVICE [num_challenges * (num_prods + 1)][n], ordered as the prover batches them for the commit
+ *             (prover.rs:224-229): Z of challenge 0 .. nc-1, then the num_prods partial products of challenge 0, 1, ...
+ * Canonical outputs; feed d_out to p2hot_commit_dev(is_values = 1).  A zero denominator (the reference panics,
+ * "Tried to invert zero") returns P2HOT_EINVAL. */
+int p2hot_partial_products_dev(p2hot_ctx *ctx, const uint64_t *d_wires, size_t wires_stride, const uint64_t *d_sigmas,
+                               size_t sigmas_stride, const uint64_t *k_is, unsigned num_routed, unsigned log_n,
+                               unsigned degree, const uint64_t *betas, const uint64_t *gammas, unsigned num_challenges,
+                               uint64_t *d_out, size_t out_stride);
 /* merkle_tree_prove (hash/merkle_tree.rs:151-190) for m leaf indices from a device-resident digest array
  * (the query phase, fri/prover.rs:204-258): d_out [m][log_leaves - cap_height][4] */
 int p2hot_merkle_paths_dev(p2hot_ctx *ctx, const uint64_t *d_digests, unsigned log_leaves, unsigned cap_height,

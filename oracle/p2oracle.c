@@ -36,6 +36,47 @@ void ora_set_num_threads(int n) {
 #endif
 }
 
+/* ---- permutation argument ----
+ * wires_permutation_partial_products_and_zs (plonky2/src/plonk/prover.rs:392-449) for one (beta, gamma):
+ * per row the numerators / denominators (:410-424), their element-wise quotients through inverses
+ * (batch_multiplicative_inverse == the element inverses, field/src/types.rs:133), quotient_chunk_products
+ * (util/partial_products.rs:13-24), then the SEQUENTIAL row walk with partial_products_and_z_gx (:28-37) and the
+ * Z(x) / Z(gx) swap (prover.rs:437-441).  out is the transposed result (:444-447): [num_prods + 1][n], the last
+ * polynomial being Z.  Returns -1 if a denominator is zero (the reference panics). */
+int ora_partial_products(const uint64_t *wires, const uint64_t *sigmas, const uint64_t *k_is, size_t num_routed,
+                         unsigned log_n, size_t degree, uint64_t beta, uint64_t gamma, uint64_t *out) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t num_chunks = (num_routed + degree - 1) / degree, num_prods = num_chunks - 1;
+    const uint64_t g = ora_gl_root_of_unity(log_n);
+    uint64_t x = 1, z_x = 1; /* subgroup[i] = g^i (two_adic_subgroup, field/src/types.rs:274-283) */
+    uint64_t *q = (uint64_t *)malloc(sizeof(uint64_t) * (num_chunks ? num_chunks : 1));
+    int rc = 0;
+    for (size_t i = 0; i < n; ++i) {
+        for (size_t c = 0; c < num_chunks; ++c) {
+            uint64_t prod = 1;
+            for (size_t j = c * degree; j < (c + 1) * degree && j < num_routed; ++j) {
+                const uint64_t wire = wires[j * n + i];
+                const uint64_t s_id = ora_gl_mul(k_is[j], x);
+                const uint64_t num = ora_gl_add(ora_gl_add(wire, ora_gl_mul(beta, s_id)), gamma);
+                const uint64_t den = ora_gl_add(ora_gl_add(wire, ora_gl_mul(beta, sigmas[j * n + i])), gamma);
+                if (ora_gl_canon(den) == 0) rc = -1;
+                prod = ora_gl_mul(prod, ora_gl_mul(num, ora_gl_inv(den)));
+            }
+            q[c] = prod;
+        }
+        uint64_t acc = z_x;
+        for (size_t c = 0; c < num_chunks; ++c) {
+            acc = ora_gl_mul(acc, q[c]);
+            if (c < num_prods) out[c * n + i] = ora_gl_canon(acc);
+        }
+        out[num_prods * n + i] = ora_gl_canon(z_x); /* the swap: store Z(x), carry Z(gx) */
+        z_x = acc;
+        x = ora_gl_mul(x, g);
+    }
+    free(q);
+    return rc;
+}
+
 int ora_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

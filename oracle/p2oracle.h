@@ -127,6 +127,12 @@ void ora_reduce_polys_base(const uint64_t *const *polys, size_t n_polys, size_t 
  * quotient has n-1 coeffs; out[n][2] gets them plus a trailing zero ("pad back to power of two"). */
 void ora_divide_by_linear(const uint64_t *poly, size_t n, const uint64_t z[2], uint64_t *out);
 
+/* ---- wires_permutation_partial_products_and_zs (plonk/prover.rs:392-449) for one (beta, gamma).
+ * wires / sigmas: [num_routed][n] column-major (sigmas = the sigma polynomials' values on the subgroup);
+ * out: [num_prods + 1][n], partial products then Z (the reference's transposed Vec order, :444-447). */
+int ora_partial_products(const uint64_t *wires, const uint64_t *sigmas, const uint64_t *k_is, size_t num_routed,
+                         unsigned log_n, size_t degree, uint64_t beta, uint64_t gamma, uint64_t *out);
+
 int ora_num_threads(void);
 void ora_set_num_threads(int n); /* e.g. the cgroup CPU quota of the job */
 

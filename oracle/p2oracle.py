@@ -294,3 +294,17 @@ def divide_by_linear(poly, z):
     zz = arr(z)
     lib.ora_divide_by_linear(_p(poly), C.c_size_t(n), _p(zz), _p(out))
     return out
+
+
+def partial_products(wires, sigmas, k_is, degree, beta, gamma):
+    """wires_permutation_partial_products_and_zs (plonk/prover.rs:392-449): [num_prods + 1][n], Z last"""
+    wires, sigmas, k = arr(wires), arr(sigmas), arr(k_is)
+    r, n = wires.shape
+    num_chunks = -(-r // degree)
+    out = np.zeros((num_chunks, n), dtype=np.uint64)
+    rc = lib.ora_partial_products(_p(wires), _p(sigmas), _p(k), C.c_size_t(r), C.c_uint(n.bit_length() - 1),
+                                  C.c_size_t(degree), C.c_uint64(int(beta)), C.c_uint64(int(gamma)), _p(out))
+    if rc:
+        raise ZeroDivisionError("Tried to invert zero")
+    return out
+

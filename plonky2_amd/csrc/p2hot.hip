@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "fri.hpp"
+#include "plonk.hpp"
 #include "merkle.hpp"
 #include "ntt.hpp"
 
@@ -1041,6 +1042,72 @@ extern "C" int p2hot_eval_polys_dev(p2hot_ctx *ctx, const uint64_t *const *d_pol
                      n_seg, zs, ext_pow(zs, 256), d_out + 2 * p * n_polys);
         P2_LAUNCH_CHECK(ctx);
     }
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_partial_products_dev(p2hot_ctx *ctx, const uint64_t *d_wires, size_t wires_stride,
+                                          const uint64_t *d_sigmas, size_t sigmas_stride, const uint64_t *k_is,
+                                          unsigned num_routed, unsigned log_n, unsigned degree, const uint64_t *betas,
+                                          const uint64_t *gammas, unsigned num_challenges, uint64_t *d_out,
+                                          size_t out_stride) {
+    if (!ctx) return P2HOT_EINVAL;
+    P2_TRY(check_log(ctx, log_n, "partial_products"));
+    if (num_challenges == 0) return P2HOT_OK;
+    const size_t n = (size_t)1 << log_n;
+    if (num_routed == 0 || degree < 2) P2_FAIL(ctx, P2HOT_EINVAL, "partial_products: need num_routed > 0 and degree > 1");
+    if (!d_wires || !d_sigmas || !k_is || !betas || !gammas || !d_out)
+        P2_FAIL(ctx, P2HOT_EINVAL, "partial_products: null argument");
+    if (wires_stride < n || sigmas_stride < n || out_stride < n) P2_FAIL(ctx, P2HOT_EINVAL, "partial_products: stride < n");
+    const unsigned num_chunks = (num_routed + degree - 1) / degree, num_prods = num_chunks - 1;
+    const unsigned chunk_log = log_n < 6 ? log_n : 6;  // rows per scan chunk
+    const size_t n_chunks = n >> chunk_log, per = (n_chunks + 1023) / 1024;
+    // scratch: k_is | chunk denominators [num_chunks][n] | row totals [n] | chunk products | carries | flag
+    const size_t words = num_routed + (size_t)num_chunks * n + n + 2 * n_chunks + 1;
+    u64 *base;
+    P2_TRY(scratch_get(ctx, 0, words * 8, (void **)&base));
+    u64 *d_k = base, *dchunk = d_k + num_routed, *total = dchunk + (size_t)num_chunks * n, *prod = total + n,
+        *carry = prod + n_chunks;
+    unsigned *flag = (unsigned *)(carry + n_chunks);
+    std::vector<u64> kc(num_routed);
+    for (unsigned j = 0; j < num_routed; ++j) kc[j] = gl::canon(k_is[j]);
+    P2_HIP(ctx, hipMemcpyAsync(d_k, kc.data(), (size_t)num_routed * 8, hipMemcpyHostToDevice, ctx->stream));
+    P2_HIP(ctx, hipMemsetAsync(flag, 0, 8, ctx->stream));
+    ProfScope ps(ctx, "partial_products");
+    for (unsigned ch = 0; ch < num_challenges; ++ch) {
+        plonk::PPArgs a{};
+        a.wires = d_wires;
+        a.sigmas = d_sigmas;
+        a.wires_stride = wires_stride;
+        a.sigmas_stride = sigmas_stride;
+        a.k_is = d_k;
+        a.num_routed = num_routed;
+        a.degree = degree;
+        a.num_chunks = num_chunks;
+        a.log_n = log_n;
+        a.beta = gl::canon(betas[ch]);
+        a.gamma = gl::canon(gammas[ch]);
+        a.roots = ctx->fwd;
+        a.pp = d_out + ((size_t)num_challenges + (size_t)ch * num_prods) * out_stride;
+        a.pp_stride = out_stride;
+        a.dchunk = dchunk;
+        a.total = total;
+        a.zero_flag = flag;
+        u64 *z = d_out + (size_t)ch * out_stride;
+        P2HOT_LAUNCH(plonk::pp_quotients_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, a);
+        P2HOT_LAUNCH(plonk::pp_chunk_totals_kernel, dim3(cdiv(n_chunks, 256)), dim3(256), 0, ctx->stream, (const u64 *)total,
+                     chunk_log, n_chunks, prod);
+        P2HOT_LAUNCH(plonk::pp_carries_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u64 *)prod, n_chunks, per, carry);
+        P2HOT_LAUNCH(plonk::pp_emit_z_kernel, dim3(cdiv(n_chunks, 256)), dim3(256), 0, ctx->stream, (const u64 *)total,
+                     chunk_log, n_chunks, (const u64 *)carry, z);
+        if (num_prods)
+            P2HOT_LAUNCH(plonk::pp_scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, a.pp, out_stride, num_prods,
+                         (const u64 *)z, n);
+        P2_LAUNCH_CHECK(ctx);
+    }
+    unsigned zero = 0;
+    P2_HIP(ctx, hipMemcpyAsync(&zero, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (zero) P2_FAIL(ctx, P2HOT_EINVAL, "partial_products: tried to invert zero (a denominator wire + beta*sigma + gamma vanished)");
     return P2HOT_OK;
 }
 

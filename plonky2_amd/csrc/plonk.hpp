@@ -1,0 +1,127 @@
+// plonk.hpp -- the permutation argument's partial products and Z polynomials on the device.
+//
+// Replaces wires_permutation_partial_products_and_zs (plonky2/src/plonk/prover.rs:392-449) with its helpers
+// quotient_chunk_products / partial_products_and_z_gx (plonky2/src/util/partial_products.rs:13-39).  Per row i of
+// the trace (x_i = w_n^i, prover_data.subgroup) and routed wire j the reference forms
+//   num_j = wire + beta * k_j * x_i + gamma,   den_j = wire + beta * sigma_j(x_i) + gamma,
+// multiplies num_j / den_j over chunks of `degree` wires, and walks the rows SEQUENTIALLY:
+//   pp_p(x_i) = Z(x_i) * prod_{c <= p} chunk_c(i)   (p < num_prods),   Z(x_{i+1}) = Z(x_i) * prod_c chunk_c(i),  Z(x_0) = 1.
+// Here the row walk is an exclusive prefix PRODUCT scan (chunk totals -> carries in one workgroup -> replay), and
+// the per-row work is lane-parallel with one field inversion per row: with PN_c / PD_c the prefix products of the
+// chunk numerators / denominators, prod_{k <= c} chunk_k = PN_c * PD_c^-1 and PD_{c-1}^-1 = PD_c^-1 * D_c
+// (Montgomery's trick run backwards over the chunks).  Field arithmetic is exact, so the values equal the
+// reference's element-wise batch_multiplicative_inverse route (field/src/types.rs:133) bit for bit once canonical.
+// A zero denominator makes the reference panic ("Tried to invert zero"); here it raises a flag -> P2HOT_EINVAL.
+#pragma once
+#include "gl.hpp"
+#include "ntt.hpp"
+
+namespace plonk {
+using gl::u32;
+using gl::u64;
+
+struct PPArgs {
+    const u64 *wires, *sigmas;  // [num_routed][n] column-major (element (j, i) at j * stride + i)
+    size_t wires_stride, sigmas_stride;
+    const u64 *k_is;            // device, [num_routed] coset shifts (common_data.k_is)
+    unsigned num_routed, degree, num_chunks, log_n;
+    u64 beta, gamma;
+    ntt::RootTable roots;       // forward table: x_i = w_n^i
+    u64 *pp;                    // [num_chunks - 1][n] (stride pp_stride): prefix quotients, later the partial products
+    size_t pp_stride;
+    u64 *dchunk;                // scratch [num_chunks][n]: chunk denominators
+    u64 *total;                 // scratch [n]: T_i = prod over all chunks of row i
+    unsigned *zero_flag;
+};
+
+// lane = row: prefix quotients Q_c(i) = prod_{k <= c} chunk_k(i) for c < num_chunks - 1, and T_i = Q_last(i)
+__global__ void __launch_bounds__(256) pp_quotients_kernel(PPArgs a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)1 << a.log_n;
+    if (i >= n) return;
+    const u64 x = a.log_n ? ntt::root_pow(a.roots, (u32)(i << (32 - a.log_n))) : 1;
+    const u64 bx = gl::mul(a.beta, x);
+    u64 pn = 1, pd = 1;
+    for (unsigned c = 0; c < a.num_chunks; ++c) {
+        u64 d = 1;
+        const unsigned j_end = (c + 1) * a.degree < a.num_routed ? (c + 1) * a.degree : a.num_routed;
+        for (unsigned j = c * a.degree; j < j_end; ++j) {
+            const u64 w = a.wires[(size_t)j * a.wires_stride + i];
+            const u64 num = gl::add(gl::add(w, gl::mul(bx, a.k_is[j])), a.gamma);
+            const u64 den = gl::add(gl::add(w, gl::mul(a.beta, a.sigmas[(size_t)j * a.sigmas_stride + i])), a.gamma);
+            pn = gl::mul(pn, num);
+            d = gl::mul(d, den);
+        }
+        pd = gl::mul(pd, d);
+        a.dchunk[(size_t)c * n + i] = d;
+        if (c + 1 < a.num_chunks) a.pp[(size_t)c * a.pp_stride + i] = pn;
+    }
+    if (gl::canon(pd) == 0) atomicOr(a.zero_flag, 1u);
+    u64 inv = gl::inv(pd);  // PD_last^-1
+    a.total[i] = gl::mul(pn, inv);
+    for (unsigned c = a.num_chunks; c-- > 0;) {
+        if (c + 1 < a.num_chunks) {
+            u64 *q = a.pp + (size_t)c * a.pp_stride + i;
+            *q = gl::mul(*q, inv);
+        }
+        inv = gl::mul(inv, a.dchunk[(size_t)c * n + i]);
+    }
+}
+
+// lane = chunk of 2^chunk_log rows: its product
+__global__ void pp_chunk_totals_kernel(const u64 *total, unsigned chunk_log, size_t n_chunks, u64 *prod) {
+    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_chunks) return;
+    u64 acc = 1;
+    const size_t base = m << chunk_log;
+    for (size_t i = 0; i < ((size_t)1 << chunk_log); ++i) acc = gl::mul(acc, total[base + i]);
+    prod[m] = acc;
+}
+
+// carry[m] = prod_{m' < m} P[m'] (exclusive prefix product); one 1024-thread block, `per` consecutive chunks per thread
+__global__ void __launch_bounds__(1024) pp_carries_kernel(const u64 *prod, size_t n_chunks, size_t per, u64 *carry) {
+    __shared__ u64 s[1024];
+    const unsigned tid = threadIdx.x;
+    const size_t lo = (size_t)tid * per, hi = lo + per < n_chunks ? lo + per : n_chunks;
+    u64 loc = 1;
+    for (size_t m = lo; m < hi; ++m) loc = gl::mul(loc, prod[m]);
+    s[tid] = loc;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) {  // inclusive Hillis-Steele scan
+        u64 f = 1;
+        if (tid >= d) f = s[tid - d];
+        __syncthreads();
+        s[tid] = gl::mul(s[tid], f);
+        __syncthreads();
+    }
+    u64 c = tid ? s[tid - 1] : 1;
+    for (size_t m = lo; m < hi; ++m) {
+        carry[m] = c;
+        c = gl::mul(c, prod[m]);
+    }
+}
+
+// lane = chunk: Z(x_i) for its rows from the chunk's carry (Z(x_0) = 1)
+__global__ void pp_emit_z_kernel(const u64 *total, unsigned chunk_log, size_t n_chunks, const u64 *carry, u64 *z) {
+    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_chunks) return;
+    u64 acc = carry[m];
+    const size_t base = m << chunk_log;
+    for (size_t i = 0; i < ((size_t)1 << chunk_log); ++i) {
+        z[base + i] = gl::canon(acc);
+        acc = gl::mul(acc, total[base + i]);
+    }
+}
+
+// lane = row: pp_p(x_i) = Z(x_i) * Q_p(i)
+__global__ void pp_scale_kernel(u64 *pp, size_t pp_stride, unsigned num_prods, const u64 *z, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 zi = z[i];
+    for (unsigned p = 0; p < num_prods; ++p) {
+        u64 *q = pp + (size_t)p * pp_stride + i;
+        *q = gl::canon(gl::mul(*q, zi));
+    }
+}
+
+}  // namespace plonk

@@ -71,6 +71,12 @@ static inline unsigned long long atomicMin(unsigned long long *p, unsigned long 
     return o;
 }
 
+static inline unsigned atomicOr(unsigned *p, unsigned v) {
+    unsigned o = *p;
+    *p = o | v;
+    return o;
+}
+
 // ---- host API subset (malloc-backed) ----
 typedef int hipError_t;
 typedef void *hipStream_t;

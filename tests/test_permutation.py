@@ -1,0 +1,119 @@
+"""the permutation argument's partial products and Z polynomials
+(plonky2/src/plonk/prover.rs:356-449, util/partial_products.rs) against the oracle's sequential restatement,
+plus the reference's own invariants: check_partial_products vanishes on every row (partial_products.rs:53-78,
+test :151-176) and Z closes (Z(g^n) = Z(1) = 1) when the wires satisfy the copy constraints sigma encodes."""
+import numpy as np
+import pytest
+
+from tests.conftest import P, rand_field
+
+GEN = 7  # MULTIPLICATIVE_GROUP_GENERATOR, field/src/goldilocks_field.rs:78
+
+
+def _k_is(num_shifts):
+    """get_unique_coset_shifts (field/src/cosets.rs:9-24): g^0 .. g^(num_shifts-1)"""
+    out, x = [], 1
+    for _ in range(num_shifts):
+        out.append(x)
+        x = x * GEN % P
+    return np.asarray(out, dtype=np.uint64)
+
+
+def _subgroup(ora, log_n):
+    g, x, out = ora.root_of_unity(log_n), 1, []
+    for _ in range(1 << log_n):
+        out.append(x)
+        x = x * g % P
+    return out
+
+
+def _permutation_instance(ora, rng, num_routed, log_n):
+    """wires constant on the cycles of a random permutation of the (wire, row) positions, and the sigma values
+    k_{j'} * w^{i'} of the position each (j, i) maps to (circuit_builder.rs sigma_vecs / permutation_argument.rs)"""
+    n = 1 << log_n
+    sub, k = _subgroup(ora, log_n), _k_is(num_routed)
+    m = num_routed * n
+    perm = rng.permutation(m)
+    label = np.arange(m)
+    for s in range(m):  # cycle labels = smallest member
+        if label[s] != s:
+            continue
+        t = perm[s]
+        while t != s:
+            label[t] = s
+            t = perm[t]
+    vals = rand_field(rng, m)
+    wires = vals[label].reshape(num_routed, n)
+    sig = np.zeros(m, dtype=np.uint64)
+    for pos in range(m):
+        j2, i2 = divmod(int(perm[pos]), n)
+        sig[pos] = int(k[j2]) * sub[i2] % P
+    return wires, sig.reshape(num_routed, n), k
+
+
+@pytest.mark.parametrize("num_routed,degree,log_n,nc", [(80, 8, 5, 2), (9, 4, 3, 1), (10, 3, 7, 2), (4, 2, 0, 1), (33, 8, 10, 2)])
+def test_partial_products_vs_oracle(eng, ora, num_routed, degree, log_n, nc):
+    from plonky2_amd.plonk.prover import all_wires_permutation_partial_products, num_partial_products
+    rng = np.random.default_rng(num_routed * 101 + log_n)
+    n = 1 << log_n
+    wires = rand_field(rng, num_routed, n, noncanonical=True)
+    sigmas = rand_field(rng, num_routed, n, noncanonical=True)
+    k = _k_is(num_routed)
+    betas, gammas = rand_field(rng, nc), rand_field(rng, nc)
+    got = eng.host(all_wires_permutation_partial_products(wires, sigmas, k, degree, betas, gammas, eng))
+    num_prods = num_partial_products(num_routed, degree)
+    assert got.shape == (nc * (num_prods + 1), n)
+    for ch in range(nc):
+        exp = ora.partial_products(wires, sigmas, k, degree, betas[ch], gammas[ch])   # [num_prods + 1][n], Z last
+        assert (got[ch] == exp[num_prods]).all()                                       # Zs lead the batch (prover.rs:224-229)
+        assert (got[nc + ch * num_prods: nc + (ch + 1) * num_prods] == exp[:num_prods]).all()
+    assert (got < np.uint64(P)).all()
+
+
+def test_partial_products_invariants_and_commit(eng, ora):
+    """check_partial_products == 0 on every row, Z(1) = 1, Z closes on a satisfied permutation, and the batch commits"""
+    from plonky2_amd.plonk.prover import all_wires_permutation_partial_products, partial_products_and_zs_commitment
+    rng = np.random.default_rng(77)
+    num_routed, degree, log_n = 12, 4, 6
+    n = 1 << log_n
+    wires, sigmas, k = _permutation_instance(ora, rng, num_routed, log_n)
+    beta, gamma = rand_field(rng, 1), rand_field(rng, 1)
+    got = eng.host(all_wires_permutation_partial_products(wires, sigmas, k, degree, beta, gamma, eng))
+    z, pps = got[0], got[1:]
+    sub = _subgroup(ora, log_n)
+    b, g = int(beta[0]), int(gamma[0])
+    assert int(z[0]) == 1
+    for i in range(n):
+        accs = [int(z[i])] + [int(p[i]) for p in pps] + [int(z[(i + 1) % n])]   # Z(x), partials, Z(gx); wraps: Z closes
+        for c in range(num_routed // degree):
+            num = den = 1
+            for j in range(c * degree, (c + 1) * degree):
+                w = int(wires[j][i])
+                num = num * ((w + b * (int(k[j]) * sub[i] % P) + g) % P) % P
+                den = den * ((w + b * int(sigmas[j][i]) + g) % P) % P
+            assert (accs[c] * num - accs[c + 1] * den) % P == 0, (i, c)
+    batch = partial_products_and_zs_commitment(wires, sigmas, k, degree, beta, gamma, 3, 2, engine=eng)
+    exp = ora.commit(got, 3, 2, True)
+    assert (batch.merkle_tree.cap.entries == exp["cap"]).all()
+
+
+def test_partial_products_zero_denominator_is_an_error(eng):
+    """the reference panics in batch_multiplicative_inverse ("Tried to invert zero"); the library reports EINVAL"""
+    from plonky2_amd.plonk.prover import all_wires_permutation_partial_products
+    num_routed, n = 4, 8
+    wires = np.zeros((num_routed, n), dtype=np.uint64)
+    sigmas = np.ones((num_routed, n), dtype=np.uint64)
+    # wire + beta * sigma + gamma = 0 + 5 * 1 + (P - 5) = 0
+    with pytest.raises(Exception, match="invert zero"):
+        all_wires_permutation_partial_products(wires, sigmas, _k_is(num_routed), 2, [5], [P - 5], eng)
+
+
+def test_partial_products_shape_errors(eng):
+    from plonky2_amd.plonk.prover import all_wires_permutation_partial_products
+    w = np.ones((4, 8), dtype=np.uint64)
+    with pytest.raises(ValueError):
+        all_wires_permutation_partial_products(w, w[:3], _k_is(4), 2, [1], [2], eng)
+    with pytest.raises(ValueError):
+        all_wires_permutation_partial_products(w, w, _k_is(4), 4, [1], [2], eng)   # degree must be < num_routed
+    with pytest.raises(ValueError):
+        all_wires_permutation_partial_products(w[:, :6], w[:, :6], _k_is(4), 2, [1], [2], eng)

@@ -45,8 +45,20 @@ for rep in range(2):
     total = 0.0
     oracles = []
     c0 = 0
+    wires = None
     for (W, is_values) in shapes:
-        cols = splitmix_columns_torch(torch, eng.mem.device, c0, W, n)
+        if mode == "plonky2" and W == 20:
+            # the real Zs + partial products of the first 80 wire columns (prover.rs:219-229); sigmas: any columns
+            from plonky2_amd.plonk.prover import all_wires_permutation_partial_products
+            sig = splitmix_columns_torch(torch, eng.mem.device, 1000, 80, n)
+            k_is = [pow(7, j, 0xFFFFFFFF00000001) for j in range(80)]
+            cols, dt = timed("partial products + Zs (80 routed wires, 2 challenges)",
+                             lambda: all_wires_permutation_partial_products(wires[:80], sig, k_is, 8, [3, 5], [11, 13], eng))
+            total += dt
+        else:
+            cols = splitmix_columns_torch(torch, eng.mem.device, c0, W, n)
+        if wires is None:
+            wires = cols
         c0 += W
         ctor = PolynomialBatch.from_values if is_values else PolynomialBatch.from_coeffs
         b, dt = timed("%s W=%d" % ("from_values" if is_values else "from_coeffs", W),
