@@ -184,7 +184,11 @@ def main():
     log_n = args.log_n + log_g
     n, N = 1 << log_n, 1 << (log_n + rb)
 
-    job = ShardedCommit(eng, W, log_n, rb, cap, is_values=True, rank=rank, world=world, dist=dist)
+    # digests stay with the rank that owns the rows (its Merkle paths never leave its cap subtrees); only the cap is
+    # all-gathered (SURVEY 8e collective 2).  P2HOT_GATHER_DIGESTS=1 also reassembles the full digest array everywhere.
+    gather_digests = os.environ.get("P2HOT_GATHER_DIGESTS") == "1"
+    job = ShardedCommit(eng, W, log_n, rb, cap, is_values=True, rank=rank, world=world, dist=dist,
+                        gather_digests=gather_digests)
     # synthetic trace: each rank generates the columns it owns for the iNTT stage, on its device
     c0, c1 = job.column_range
     cols = splitmix_columns_torch(torch, eng.mem.device, c0, c1 - c0, n)
@@ -237,7 +241,7 @@ def main():
                                    "PoseidonGoldilocksConfig (C3 wires commit at --gpus 1; +1 bit of rows per doubling of GPUs)"
                                    % (W, log_n, 1 << rb, log_n + rb, cap),
                        "sharding": "none" if world == 1 else "LDE cosets over %d ranks; iNTT column-sharded, coefficients all-gathered in "
-                                   "async column chunks overlapped with the NTTs; RCCL all-gather of digests + cap" % world},
+                                   "async column chunks overlapped with the NTTs; RCCL all-gather of %s" % (world, "digests + cap" if gather_digests else "the cap (digests stay with the row owner)")},
             "roofline": {"kernel": "hash_leaves_kernel<ColMajorReader> (Poseidon leaf sponge)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (lambda t: t / launches_per_step if t else None)(pmc_traffic(W, log_n, rb, cap, world, "hash_leaves_kernel")),

@@ -9,7 +9,10 @@ The reference has no multi-device mode; this is the MI355X design of SURVEY.md 8
   * every rank needs all W*n coefficients: the iNTT is column-sharded (ceil(W/G) columns per
     rank) and followed by ONE all-gather of coefficients (W*n*8 bytes in total);
   * the digests of a rank's subtrees are a contiguous slice of the reference digest array, so ONE
-    all-gather of digests (+ cap entries) reassembles MerkleTree::digests / ::cap on every rank.
+    all-gather of digests (+ cap entries) reassembles MerkleTree::digests / ::cap on every rank.  That digest
+    exchange is optional (`gather_digests=False`): a Merkle path below the cap never leaves the cap subtree of its
+    leaf, i.e. the slice of the rank that owns the row, so with only the 2^cap_height cap entries all-gathered every
+    query can still be answered by the owner (`ShardedCommit.owner` / `.prove_local`), SURVEY 8(e) collective (2).
 
   * the coefficient all-gather is pipelined in column chunks: chunk k is gathered asynchronously (RCCL runs on its
     own stream) while chunk k+1 goes through the iNTT and chunk k-1 through the LDE, so most of the W*n*8-byte
@@ -68,11 +71,12 @@ class ShardedCommit:
     """from_values / from_coeffs over `world` ranks.  Buffers are allocated once and reused."""
 
     def __init__(self, engine, W, log_n, rate_bits, cap_height, is_values=True, rank=0, world=1, dist=None,
-                 want_leaves=False, pipeline_chunks=None):
+                 want_leaves=False, pipeline_chunks=None, gather_digests=True):
         self.eng, self.dist, self.rank, self.world = engine, dist, rank, world
         if pipeline_chunks is None:
             pipeline_chunks = 1 if os.environ.get("P2HOT_SYNC_COLLECTIVES") == "1" else 4
         self.pipeline_chunks = pipeline_chunks
+        self.gather_digests = gather_digests
         self.plan = p = ShardPlan(W, log_n, rate_bits, cap_height, world)
         self.is_values = is_values
         mem = engine.mem
@@ -88,7 +92,8 @@ class ShardedCommit:
     def run(self, cols_local):
         """cols_local: device [c1 - c0][n] -- this rank's columns (values on H_n, or coefficients).
         Returns dict(coeffs [W][n], lde [W][rows of this rank], digests, cap), all device buffers;
-        digests / cap are the FULL tree's arrays on every rank."""
+        digests / cap are the FULL tree's arrays on every rank (with gather_digests=False only this rank's slice
+        [rank * digests_per_rank, (rank + 1) * digests_per_rank) of `digests` is filled; cap is always complete)."""
         eng, p, lib = self.eng, self.plan, self.eng.lib
         c0, c1 = self.column_range
         W = p.W
@@ -115,13 +120,33 @@ class ShardedCommit:
                 eng.ptr(self.cap)))
         if self.world > 1:
             # 4. all-gather of this rank's contiguous digest slice and cap entries
-            if p.digests_per_rank:
+            if p.digests_per_rank and self.gather_digests:
                 d = self.digests[self.rank * p.digests_per_rank:(self.rank + 1) * p.digests_per_rank]
                 self._all_gather(self.digests[:p.num_digests], d)
             k = self.cap[self.rank * p.cap_per_rank:(self.rank + 1) * p.cap_per_rank]
             self._all_gather(self.cap, k)
         return {"coeffs": self.coeffs_all[:W], "lde": self.lde, "leaves": self.leaves,
                 "digests": self.digests[:p.num_digests], "cap": self.cap}
+
+    def owner(self, leaf_index):
+        """rank whose rows (and therefore whose digest slice) contain leaf `leaf_index` of the committed order"""
+        return int(leaf_index) // self.plan.rows_per_rank
+
+    def prove_local(self, leaf_indices):
+        """(rows [m][W], Merkle paths [m][log2(N) - cap_height][4]) for leaves THIS rank owns, from its LDE block
+        and its digest slice (MerkleTree::get + merkle_tree_prove, merkle_tree.rs:227, :151-190)."""
+        eng, p = self.eng, self.plan
+        idx = np.asarray(leaf_indices, dtype=np.uint64).reshape(-1)
+        if any(self.owner(i) != self.rank for i in idx):
+            raise ValueError("prove_local: a requested leaf belongs to another rank")
+        layers = p.log_N - p.cap_height
+        paths = eng.mem.zeros(max(1, len(idx)), max(layers, 1), 4)
+        d_idx = eng.dev(idx if len(idx) else np.zeros(1, dtype=np.uint64))
+        eng.check(eng.lib.p2hot_merkle_paths_dev(eng.ctx, eng.ptr(self.digests), p.log_N, p.cap_height, eng.ptr(d_idx),
+                                                 len(idx), eng.ptr(paths)))
+        rows = eng.gather_rows(self.lde, idx - np.uint64(self.row_begin)) if len(idx) and p.W else \
+            np.zeros((len(idx), p.W), dtype=np.uint64)
+        return eng.host(rows), eng.host(paths)[:len(idx), :layers]
 
     def _run_pipelined(self, cols_local):
         """steps 1-3 with the coefficient exchange hidden behind the NTTs (see the module docstring)"""

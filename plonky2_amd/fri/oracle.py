@@ -118,19 +118,33 @@ def final_poly_device(batches, oracles, alpha, engine=None):
 
 
 def prove_openings(batches, oracles, challenger, rate_bits, cap_height, reduction_arity_bits, proof_of_work_bits,
-                   num_query_rounds, engine=None):
+                   num_query_rounds, engine=None, timing=None):
     """PolynomialBatch::prove_openings + fri_proof (oracle.rs:176-237, fri/prover.rs:24-82) with everything
     but the transcript bookkeeping on the GPU.  Returns a dict shaped like FriProof:
       commit_phase_merkle_caps, query_round_proofs [{initial_trees_proof: [(leaf, siblings)...], steps: [(evals, siblings)...]}],
-      final_poly [[c0, c1]...], pow_witness."""
+      final_poly [[c0, c1]...], pow_witness.
+    `timing` (a dict, the reference's TimingTree argument): filled with synchronised wall milliseconds per stage."""
+    import time
     from .prover import fri_committed_trees_device, fri_proof_of_work
     eng = engine or oracles[0].engine
+    t_last = [time.perf_counter()]
+
+    def lap(label):
+        if timing is not None:
+            eng.sync()
+            now = time.perf_counter()
+            timing[label] = timing.get(label, 0.0) + (now - t_last[0]) * 1e3
+            t_last[0] = now
+
     alpha = challenger.get_extension_challenge()                      # oracle.rs:186
     planes = final_poly_device(batches, oracles, alpha, eng)
+    lap("reduce + divide_by_linear (final_poly)")
     log_n = oracles[0].degree_log
     trees, final, _betas = fri_committed_trees_device(planes, log_n, challenger, rate_bits, cap_height,
                                                       reduction_arity_bits, eng)   # prover.rs:40-51
+    lap("final FFT + fold codewords in the commitment phase")
     pow_witness = fri_proof_of_work(challenger, proof_of_work_bits, eng)           # prover.rs:53-58
+    lap("find proof-of-work witness")
     lde_size = 1 << (log_n + rate_bits)
     xs = [rand % lde_size for rand in challenger.get_n_challenges(num_query_rounds)]   # prover.rs:215-220
     # initial trees: one batched row gather and one batched path gather per oracle, on the device (prover.rs:238-241)
@@ -138,14 +152,18 @@ def prove_openings(batches, oracles, challenger, rate_bits, cap_height, reductio
     init_rows = [o.merkle_tree._getter(idx) if o.merkle_tree._leaves is None else o.merkle_tree.leaves[idx.astype(np.int64)]
                  for o in oracles]
     init_paths = [o.merkle_tree.prove_many(idx) for o in oracles]
+    # FRI trees: one batched row fetch + one batched path walk per round (prover.rs:242-253 for all queries at once)
+    step_rows, step_paths, idx_r = [], [], idx.copy()
+    for i, tree in enumerate(trees):
+        idx_r = idx_r >> np.uint64(reduction_arity_bits[i])
+        rows = tree._getter(idx_r) if tree._leaves is None else tree.leaves[idx_r.astype(np.int64)]
+        step_rows.append(np.asarray(rows).reshape(len(xs), -1, 2))
+        step_paths.append(tree.prove_many(idx_r))
     queries = []
-    for q, x in enumerate(xs):
+    for q in range(len(xs)):
         initial = [(init_rows[oi][q], init_paths[oi][q]) for oi in range(len(oracles))]
-        steps = []
-        for i, tree in enumerate(trees):                                           # prover.rs:242-253
-            ab = reduction_arity_bits[i]
-            steps.append((tree.get(x >> ab).reshape(-1, 2), tree.prove(x >> ab)))
-            x >>= ab
+        steps = [(step_rows[i][q], step_paths[i][q]) for i in range(len(trees))]
         queries.append({"initial_trees_proof": initial, "steps": steps})
+    lap("produce batch opening proof: query rounds")
     return {"commit_phase_merkle_caps": [t.cap.entries for t in trees], "query_round_proofs": queries,
             "final_poly": final, "pow_witness": pow_witness}

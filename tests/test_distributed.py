@@ -64,6 +64,60 @@ def test_sharded_commit_gloo(world, W, log_n, rb, cap, is_values, chunks):
     assert res == [(r, True) for r in range(world)]
 
 
+def _worker_sharded_digests(rank, world, port, W, log_n, rb, cap, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import p2oracle as ora
+        from plonky2_amd.distributed import ShardedCommit
+        from tests.emu_backend import emu_engine
+        eng = emu_engine()
+        rng = np.random.default_rng(99)
+        cols = rand_field(rng, W, 1 << log_n)
+        job = ShardedCommit(eng, W, log_n, rb, cap, is_values=True, rank=rank, world=world, dist=dist, gather_digests=False)
+        c0, c1 = job.column_range
+        r = job.run(eng.dev(cols[c0:c1]))
+        o = ora.commit(cols, rb, cap, True)
+        p = job.plan
+        d0, d1 = rank * p.digests_per_rank, (rank + 1) * p.digests_per_rank
+        ok = bool((eng.host(r["cap"]) == o["cap"]).all() and (eng.host(r["digests"])[d0:d1] == o["digests"][d0:d1]).all())
+        # every rank answers the queries that fall into its rows; paths verify against the all-gathered cap
+        xs = [int(x) for x in np.random.default_rng(5).integers(0, p.N, 12)] + [0, p.N - 1]
+        mine = [x for x in xs if job.owner(x) == rank]
+        rows, paths = job.prove_local(mine)
+        for x, row, path in zip(mine, rows, paths):
+            ok = ok and bool((row == o["leaves"][x]).all()) and bool((path == ora.merkle_prove(x, p.N, cap, o["digests"])).all())
+            ok = ok and ora.merkle_verify(row, x, eng.host(r["cap"]), path)
+        try:
+            other = next(x for x in range(p.N) if job.owner(x) != rank)
+            job.prove_local([other])
+            ok = False
+        except ValueError:
+            pass
+        q.put((rank, ok, len(mine)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,log_n,rb,cap", [(2, 9, 5, 3, 4), (4, 6, 4, 3, 3)])
+def test_sharded_digests_owner_serves_paths_gloo(world, W, log_n, rb, cap):
+    """gather_digests=False (SURVEY 8e collective 2, cap-only): digests stay with the rank that owns the rows"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded_digests, args=(r, world, port, W, log_n, rb, cap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert [(r, ok) for r, ok, _ in res] == [(r, True) for r in range(world)]
+    assert sum(m for _, _, m in res) == 14  # every query was answered by exactly one owner
+
+
 def test_shard_plan():
     from plonky2_amd.distributed import ShardPlan
     p = ShardPlan(135, 23, 3, 4, 8)  # config C5

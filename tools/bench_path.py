@@ -74,7 +74,10 @@ for rep in range(2):
     allp = [(oi, pi) for oi, (W, _) in enumerate(shapes) for pi in range(W)]
     nxt = [(oi, pi) for oi, (W, _) in enumerate(shapes[:-1]) for pi in range(W)]
     batches = [FriBatchInfo(zeta, allp), FriBatchInfo(gz, nxt)]
+    tm = {}
     _, dt = timed("prove_openings (final_poly, FRI commit, PoW, %d queries)" % nq,
-                  lambda: prove_openings(batches, oracles, ch, rb, cap, arity, 16, nq, engine=eng))
+                  lambda: prove_openings(batches, oracles, ch, rb, cap, arity, 16, nq, engine=eng, timing=tm))
+    for k, v in tm.items():
+        print("      %-52s %7.2f ms" % (k, v))
     total += dt
     print("  %-44s %9.2f ms" % ("path total", total))
