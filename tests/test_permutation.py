@@ -7,7 +7,7 @@ import pytest
 
 from tests.conftest import P, rand_field
 
-GEN = 7  # MULTIPLICATIVE_GROUP_GENERATOR, field/src/goldilocks_field.rs:78
+GEN = 14293326489335486720  # MULTIPLICATIVE_GROUP_GENERATOR, field/src/goldilocks_field.rs:80
 
 
 def _k_is(num_shifts):

@@ -151,3 +151,78 @@ def test_polynomial_batch_wire_format(eng):
     assert (r["merkle_tree"].digests == dig).all() and (r["merkle_tree"].cap.entries == b.merkle_tree.cap.entries).all()
     assert (r["degree_log"], r["rate_bits"], r["blinding"]) == (2, 1, False)
     assert (np.frombuffer(blob[8 + 8:8 + 8 + 32], dtype="<u8") < np.uint64(P)).all()  # canonical on the wire
+
+
+@pytest.mark.parametrize("log_n,widths,rb,cap,arity,pow_bits,nq", [
+    (6, [3, 2], 3, 2, [2, 1], 4, 5),      # mixed arities
+    (8, [5, 4, 2], 3, 4, [4], 6, 4),      # plonky2-like: arity 16, cap 4
+    (7, [2, 2], 1, 3, [1, 2, 1], 3, 6),   # starky-like rate 1/2
+    (4, [3], 2, 0, [], 2, 3),             # no reduction rounds: the final polynomial is the whole codeword's polynomial
+])
+def test_fri_proof_passes_the_reference_verifier(eng, ora, log_n, widths, rb, cap, arity, pow_bits, nq):
+    """The acceptance check of SURVEY 3.5: a proof produced on the device (commits, OpeningSet evaluations,
+    prove_openings) verifies under a restatement of plonky2/src/fri/verifier.rs + challenges.rs that re-derives every
+    challenge from the proof with the ORACLE's challenger; tampering with any part makes it fail."""
+    import copy
+    from oracle import fri_verifier as fv
+    from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, eval_openings, prove_openings
+    from plonky2_amd.iop.challenger import Challenger
+    rng = np.random.default_rng(log_n * 977 + len(widths))
+    n = 1 << log_n
+    oracles = [PolynomialBatch.from_coeffs(rand_field(rng, w, n), rb, False, cap, engine=eng) for w in widths]
+    caps = [np.asarray(o.merkle_tree.cap.entries) for o in oracles]
+    c, oc = Challenger(eng), ora.Challenger()
+    for ch in (c, oc):
+        for k in caps:
+            ch.observe_cap(k)
+    zeta = c.get_extension_challenge()
+    assert list(zeta) == list(oc.get_extension_challenge())
+    g = ora.root_of_unity(log_n)
+    gz = [int(zeta[0]) * g % P, int(zeta[1]) * g % P]                      # zeta_next = g * zeta (plonk/prover.rs:338)
+    all_polys = [(oi, pi) for oi, w in enumerate(widths) for pi in range(w)]
+    first = [(0, pi) for pi in range(widths[0])]
+    inst = [(zeta, all_polys), (gz, first)]                                # FriInstanceInfo.batches
+    ev = eval_openings(oracles, [zeta, gz], eng)                           # [oracle][point][poly][2]
+    openings = [[ev[oi][bi][pi] for (oi, pi) in polys] for bi, (_, polys) in enumerate(inst)]   # FriOpenings
+    for ch in (c, oc):                                                     # Challenger::observe_openings
+        for vals in openings:
+            ch.observe_elements(np.asarray(vals, dtype=np.uint64).reshape(-1))
+    proof = prove_openings([FriBatchInfo(p, polys) for p, polys in inst], oracles, c, rb, cap, arity, pow_bits, nq, engine=eng)
+
+    def verify(pf, op=openings, caps_=caps):
+        vc = oc.clone()
+        chal = fv.fri_challenges(vc, pf["commit_phase_merkle_caps"], pf["final_poly"], pf["pow_witness"], log_n, rb, cap, nq)
+        fv.verify_fri_proof(inst, op, chal, caps_, pf, log_n, rb, arity, pow_bits, nq)
+        return vc
+
+    vc = verify(proof)
+    assert vc.get_n_challenges(2) == c.get_n_challenges(2)                 # prover and verifier transcripts agree to the end
+
+    bad = copy.deepcopy(proof)
+    bad["final_poly"] = np.array(bad["final_poly"], dtype=np.uint64)
+    bad["final_poly"][0][0] = (int(bad["final_poly"][0][0]) + 1) % P
+    with pytest.raises(fv.VerificationError):
+        verify(bad)
+    bad_open = [[np.array(v, dtype=np.uint64) for v in vals] for vals in openings]
+    bad_open[0][0][1] = (int(bad_open[0][0][1]) + 1) % P
+    with pytest.raises(fv.VerificationError):
+        verify(proof, op=bad_open)
+    bad = copy.deepcopy(proof)
+    leaf, sib = bad["query_round_proofs"][0]["initial_trees_proof"][0]
+    leaf = np.array(leaf, dtype=np.uint64)
+    leaf[0] = (int(leaf[0]) + 1) % P
+    bad["query_round_proofs"][0]["initial_trees_proof"][0] = (leaf, sib)
+    with pytest.raises(fv.VerificationError):
+        verify(bad)
+    if arity:
+        bad = copy.deepcopy(proof)
+        evals, sib = bad["query_round_proofs"][-1]["steps"][0]
+        evals = np.array(evals, dtype=np.uint64)
+        evals[0][0] = (int(evals[0][0]) + 1) % P
+        bad["query_round_proofs"][-1]["steps"][0] = (evals, sib)
+        with pytest.raises(fv.VerificationError):
+            verify(bad)
+    bad = copy.deepcopy(proof)
+    bad["pow_witness"] = int(bad["pow_witness"]) + 1   # almost surely not a valid witness, and it shifts the query indices
+    with pytest.raises(fv.VerificationError):
+        verify(bad)

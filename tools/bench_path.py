@@ -51,7 +51,7 @@ for rep in range(2):
             # the real Zs + partial products of the first 80 wire columns (prover.rs:219-229); sigmas: any columns
             from plonky2_amd.plonk.prover import all_wires_permutation_partial_products
             sig = splitmix_columns_torch(torch, eng.mem.device, 1000, 80, n)
-            k_is = [pow(7, j, 0xFFFFFFFF00000001) for j in range(80)]
+            k_is = [pow(14293326489335486720, j, 0xFFFFFFFF00000001) for j in range(80)]
             cols, dt = timed("partial products + Zs (80 routed wires, 2 challenges)",
                              lambda: all_wires_permutation_partial_products(wires[:80], sig, k_is, 8, [3, 5], [11, 13], eng))
             total += dt
