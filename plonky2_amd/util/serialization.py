@@ -75,3 +75,69 @@ def read_polynomial_batch(buf):
     off += 16
     blinding = bool(buf[off])
     return {"polynomials": polys, "merkle_tree": tree, "degree_log": degree_log, "rate_bits": rate_bits, "blinding": blinding}
+
+
+# ------------------------------------------------------------------ FriProof (serialization/mod.rs:1470-1611)
+def _merkle_proof_bytes(siblings):
+    s = np.asarray(siblings, dtype="<u8").reshape(-1, 4)
+    if s.shape[0] > 255:
+        raise ValueError("Merkle proof length must fit in u8.")        # write_merkle_proof :1476-1480
+    return bytes([s.shape[0]]) + s.tobytes()
+
+
+def write_fri_proof(proof):
+    """write_fri_proof (:1595-1611) of the dict plonky2_amd.fri.oracle.prove_openings returns: the commit-phase caps
+    (write_merkle_cap: bare hashes), the query rounds (write_fri_query_rounds :1558-1573: per round the initial-tree
+    (leaf, Merkle proof) pairs then the (evals, Merkle proof) steps -- vectors WITHOUT length prefixes, Merkle proofs
+    with a u8 length), the final polynomial's extension coefficients and the PoW witness; every word a canonical
+    little-endian u64 (write_field :1254-1260)."""
+    out = []
+    for cap in proof["commit_phase_merkle_caps"]:
+        out.append(np.asarray(cap, dtype="<u8").tobytes())
+    for qr in proof["query_round_proofs"]:
+        for leaf, siblings in qr["initial_trees_proof"]:
+            out.append(np.asarray(leaf, dtype="<u8").tobytes())
+            out.append(_merkle_proof_bytes(siblings))
+        for evals, siblings in qr["steps"]:
+            out.append(np.asarray(evals, dtype="<u8").tobytes())
+            out.append(_merkle_proof_bytes(siblings))
+    out.append(np.asarray(proof["final_poly"], dtype="<u8").tobytes())
+    out.append(_u64(int(proof["pow_witness"])))
+    return b"".join(out)
+
+
+def read_fri_proof(buf, oracle_widths, degree_bits, rate_bits, cap_height, reduction_arity_bits, num_query_rounds):
+    """read_fri_proof (serialization/mod.rs:626-660): the shape comes from the circuit's common data, as in the reference"""
+    off = 0
+
+    def words(count, shape):
+        nonlocal off
+        v = np.frombuffer(buf, dtype="<u8", count=count, offset=off).astype(np.uint64).reshape(shape)
+        off += 8 * count
+        return v
+
+    def merkle_proof():
+        nonlocal off
+        length = buf[off]
+        off += 1
+        return words(4 * length, (length, 4))
+
+    ncap = 1 << cap_height
+    caps = [words(4 * ncap, (ncap, 4)) for _ in reduction_arity_bits]
+    queries = []
+    for _ in range(num_query_rounds):
+        initial = []
+        for w in oracle_widths:
+            leaf = words(w, (w,))
+            initial.append((leaf, merkle_proof()))
+        steps = []
+        for ab in reduction_arity_bits:
+            evals = words(2 << ab, (1 << ab, 2))
+            steps.append((evals, merkle_proof()))
+        queries.append({"initial_trees_proof": initial, "steps": steps})
+    n_final = (1 << degree_bits) >> sum(reduction_arity_bits)
+    final = words(2 * n_final, (n_final, 2))
+    pow_witness = int(words(1, (1,))[0])
+    if off != len(buf):
+        raise ValueError("trailing bytes after the FRI proof")
+    return {"commit_phase_merkle_caps": caps, "query_round_proofs": queries, "final_poly": final, "pow_witness": pow_witness}

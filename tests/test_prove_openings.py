@@ -198,6 +198,21 @@ def test_fri_proof_passes_the_reference_verifier(eng, ora, log_n, widths, rb, ca
     vc = verify(proof)
     assert vc.get_n_challenges(2) == c.get_n_challenges(2)                 # prover and verifier transcripts agree to the end
 
+    # wire format (serialization/mod.rs:1595-1611): length as the reference lays it out, round trip, re-verification
+    from plonky2_amd.util.serialization import read_fri_proof, write_fri_proof
+    blob = write_fri_proof(proof)
+    ncap, N = 1 << cap, n << rb
+    expect, m = 32 * ncap * len(arity), N
+    per_query = sum(8 * w + 1 + 32 * (log_n + rb - cap) for w in widths)
+    for ab in arity:
+        m >>= ab
+        per_query += 16 * (1 << ab) + 1 + 32 * max(0, m.bit_length() - 1 - cap)
+    expect += nq * per_query + 16 * (n >> sum(arity)) + 8
+    assert len(blob) == expect
+    back = read_fri_proof(blob, widths, log_n, rb, cap, arity, nq)
+    assert write_fri_proof(back) == blob
+    verify(back)
+
     bad = copy.deepcopy(proof)
     bad["final_poly"] = np.array(bad["final_poly"], dtype=np.uint64)
     bad["final_poly"][0][0] = (int(bad["final_poly"][0][0]) + 1) % P
