@@ -134,8 +134,8 @@ class _LoopbackDist:
         return _Done()
 
 
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_sharded_commit_ranks_on_one_gpu(gpu, ora, chunks):
+@pytest.mark.parametrize("chunks,gather", [(1, True), (3, True), (3, False)])
+def test_sharded_commit_ranks_on_one_gpu(gpu, ora, chunks, gather):
     """the world > 1 branch of plonky2_amd.distributed on the real GPU: both ranks of a 2-rank job are
     run one after the other with a loopback all-gather; rank 1 then holds the full tree"""
     from plonky2_amd.distributed import ShardedCommit
@@ -145,7 +145,7 @@ def test_sharded_commit_ranks_on_one_gpu(gpu, ora, chunks):
     o = ora.commit(cols, rb, cap, True)
     dist = _LoopbackDist(2)
     jobs = [ShardedCommit(gpu, W, log_n, rb, cap, is_values=True, rank=r, world=2, dist=dist, want_leaves=True,
-                          pipeline_chunks=chunks) for r in range(2)]
+                          pipeline_chunks=chunks, gather_digests=gather) for r in range(2)]
     out = None
     for _pass in range(2):  # second sweep: every rank's deposits are present, like a real collective
         dist.calls = 0
@@ -159,5 +159,16 @@ def test_sharded_commit_ranks_on_one_gpu(gpu, ora, chunks):
     r0, rc = jobs[1].plan.rows(1)
     assert (gpu.host(out["coeffs"]) == o["coeffs"]).all()
     assert (gpu.host(out["leaves"]) == o["leaves"][r0:r0 + rc]).all()
-    assert (gpu.host(out["digests"]) == o["digests"]).all()
     assert (gpu.host(out["cap"]) == o["cap"]).all()
+    if gather:
+        assert (gpu.host(out["digests"]) == o["digests"]).all()
+    else:  # digests stay with the row owner: rank 1's slice is filled, and it answers the queries that fall into its rows
+        p = jobs[1].plan
+        d0, d1 = p.digests_per_rank, 2 * p.digests_per_rank
+        assert (gpu.host(out["digests"])[d0:d1] == o["digests"][d0:d1]).all()
+        mine = [r0, r0 + 5, r0 + rc - 1]
+        rows, paths = jobs[1].prove_local(mine)
+        for x, row, path in zip(mine, rows, paths):
+            assert (row == o["leaves"][x]).all()
+            assert (path == ora.merkle_prove(x, p.N, cap, o["digests"])).all()
+            assert ora.merkle_verify(row, x, o["cap"], path)
