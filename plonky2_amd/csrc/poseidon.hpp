@@ -134,24 +134,29 @@ __device__ __forceinline__ u64 fold1(u64 al, u64 ah) {
     return gl::fold_carry(t, t < lo64);
 }
 
-// Three partial rounds in one dense pass.  A partial round is y <- M (y + d e0) with d = sbox(y[0] + c) - y[0], so
-//   y1[0] = (M y)[0]   + d0 M[0][0]
-//   y2[0] = (M^2 y)[0] + d0 (M^2)[0][0] + d1 M[0][0]
-//   y3    = M^3 y + d0 (M^3 e0) + d1 (M^2 e0) + d2 (M e0)
-// and the integer powers of the MDS matrix stay small (M^3 < 2^21 per entry, < 2^25 per row), so a row of M^3 y is
-// still two 32x32+64 multiply-add chains (accumulators < 2^58): three rounds cost one 12-row pass (+3 terms per
-// row), two single rows and three S-boxes instead of three 12-row passes.  c[0..2] are the rounds' scalar constants
+// Three partial rounds in one dense pass.  A partial round is y <- M z with z = y except z[0] = sbox(y[0] + c); writing
+// round r's replacement as y_r[0] + d_r (d_r = sbox(y_r[0] + c_r) - y_r[0]):
+//   y1[0] = (M z)[0]
+//   y2[0] = (M^2 z)[0] + d1 M[0][0]
+//   y3    = M^3 z + d1 (M^2 e0) + d2 (M e0)          (z = the state with round 0's S-box applied to word 0)
+// and the integer powers of the MDS matrix stay small (M^3 < 2^21 per entry, < 2^25 per row), so a row of M^3 z is
+// still two 32x32+64 multiply-add chains (accumulators < 2^58): three rounds cost one 12-row pass (+2 terms per
+// row), two single rows and three S-boxes instead of three 12-row passes.  The matrix entries are s_mov_b32 literals
+// in the instruction stream (P2_LITERAL_QUAL).  A fourth power does not pay: the rows of M^4 sum to 1.04 * 2^32 (the
+// chains would overflow); splitting off its near-constant part t * J costs a scalar t * sum(z) added to all 24
+// accumulators, and the measured gain was 1 %.  c0..c2 are the rounds' scalar constants
 // (P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 r]); the state carries NO pending constant on entry or exit.
 __device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c0, u64 c1, u64 c2) {
     u32 xl[12], xh[12];
+    const u64 z0 = sbox7_asm(gl::add_canon(s[0], c0));
+    xl[0] = (u32)z0;
+    xh[0] = (u32)(z0 >> 32);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 1; i < 12; ++i) {
         xl[i] = (u32)s[i];
         xh[i] = (u32)(s[i] >> 32);
     }
-    const u64 d0 = gl::sub(sbox7_asm(gl::add_canon(s[0], c0)), s[0]);
-    const u32 d0l = (u32)d0, d0h = (u32)(d0 >> 32);
-    u64 al = (u64)d0l * P2_POSEIDON_MCOL0[0], ah = (u64)d0h * P2_POSEIDON_MCOL0[0];
+    u64 al = 0, ah = 0;
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         al += (u64)xl[j] * P2_POSEIDON_M1_ROW0[j];
@@ -160,8 +165,8 @@ __device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c0, u64 c1, u64 c
     const u64 y1 = fold1(al, ah);
     const u64 d1 = gl::sub(sbox7_asm(gl::add_canon(y1, c1)), y1);
     const u32 d1l = (u32)d1, d1h = (u32)(d1 >> 32);
-    al = (u64)d0l * P2_POSEIDON_MCOL0[12] + (u64)d1l * P2_POSEIDON_MCOL0[0];
-    ah = (u64)d0h * P2_POSEIDON_MCOL0[12] + (u64)d1h * P2_POSEIDON_MCOL0[0];
+    al = (u64)d1l * P2_POSEIDON_MCOL0[0];
+    ah = (u64)d1h * P2_POSEIDON_MCOL0[0];
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         al += (u64)xl[j] * P2_POSEIDON_M2_ROW0[j];
@@ -176,10 +181,8 @@ __device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c0, u64 c1, u64 c
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int i = g + t;
-            bl[t] = (u64)d0l * P2_POSEIDON_MCOL0[24 + i] + (u64)d1l * P2_POSEIDON_MCOL0[12 + i] +
-                    (u64)d2l * P2_POSEIDON_MCOL0[i];
-            bh[t] = (u64)d0h * P2_POSEIDON_MCOL0[24 + i] + (u64)d1h * P2_POSEIDON_MCOL0[12 + i] +
-                    (u64)d2h * P2_POSEIDON_MCOL0[i];
+            bl[t] = (u64)d1l * P2_POSEIDON_MCOL0[12 + i] + (u64)d2l * P2_POSEIDON_MCOL0[i];
+            bh[t] = (u64)d1h * P2_POSEIDON_MCOL0[12 + i] + (u64)d2h * P2_POSEIDON_MCOL0[i];
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
                 bl[t] += (u64)xl[j] * P2_POSEIDON_M3[12 * i + j];
