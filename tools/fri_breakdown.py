@@ -25,3 +25,17 @@ for variant in ("all","no_leaves","no_outputs","all"):
         caps.ctypes.data if variant!="no_outputs" else None, betas.ctypes.data, final.ctypes.data))
     t1=time.perf_counter()
     print(variant, "%.2f ms"%((t1-t0)*1e3))
+
+# per-kernel HIP-event times of one device-only call
+eng.profile(True)
+eng.profile_results(reset=True)
+ch = Challenger(eng)
+eng.check(eng.lib.p2hot_fri_commit(eng.ctx, co.ctypes.data, log_n, rb, cap, ab, 4, ch._h, None, None, None, betas.ctypes.data,
+                                   final.ctypes.data))
+prof = eng.profile_results(reset=True)
+eng.profile(False)
+tot = 0.0
+for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+    print("  %-28s %8.3f ms  %4d launches" % (k, v["ms"], v["launches"]))
+    tot += v["ms"]
+print("  kernel time total %.3f ms" % tot)
