@@ -5,10 +5,11 @@
 // a VALU reads it, and hipcc's 64-bit code wastes ~9 of 26 instructions per multiply on v_mov /
 // v_cmp / v_cndmask glue (measured on the ISA).  Interleaving three products round-robin puts
 // exactly two independent instructions between every carry producer and its consumer, so the
-// 17-instruction multiply-reduce needs no s_nop:
+// 16-instruction multiply-reduce needs no s_nop:
 //    1-4   four v_mad_u64_u32: P = a0*b0, M = a1*b0 + a0*b1 (carry cm), Q = a1*b1
 //    5-8   128-bit assembly: lo = {P0, P1+M0}, hi = Q + M1 + carries (+ cm << 32)
-//    9-12  t = lo + hi.lo * (2^32-1), fold the carry (2^64 = 2^32-1 mod P)
+//    9-11  t = lo + hi.lo * (2^32-1), fold the carry (2^64 = 2^32-1 mod P; the fold is a 64-bit add of a 32-bit mask,
+//          i.e. one more v_mad_u64_u32 with multiplier 1)
 //    13-17 u = t - hi.hi, fold the borrow                    (goldilocks_field.rs:402-415)
 // Temporaries are fixed VGPR/SGPR pairs (declared as clobbers) because inline-asm operands cannot
 // name the halves of a 64-bit register pair.  The C fallback (emulator build) is gl::mul.
@@ -34,8 +35,7 @@ namespace gl {
 #define P2_ST8(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " Q1 ", " C2 ", " Q1 ", 0, " C2 "\n\t"
 #define P2_ST9(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", " Q0 ", -1, " P "\n\t"
 #define P2_ST10(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
-#define P2_ST11(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_add_co_u32 " P0 ", " C1 ", " P0 ", " M0 "\n\t"
-#define P2_ST12(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " P1 ", " C1 ", " P1 ", 0, " C1 "\n\t"
+#define P2_ST11(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", " M0 ", 1, " P "\n\t"
 #define P2_ST13(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_sub_co_u32 " P0 ", " C1 ", " P0 ", " Q1 "\n\t"
 #define P2_ST14(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_subb_co_u32 " P1 ", " C1 ", " P1 ", 0, " C1 "\n\t"
 #define P2_ST15(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
@@ -52,7 +52,7 @@ namespace gl {
 __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
     u32 ra0, ra1, rb0, rb1, rc0, rc1;
     asm(P2_ROW(P2_ST1) P2_ROW(P2_ST2) P2_ROW(P2_ST3) P2_ROW(P2_ST4) P2_ROW(P2_ST5) P2_ROW(P2_ST6) P2_ROW(P2_ST7)
-            P2_ROW(P2_ST8) P2_ROW(P2_ST9) P2_ROW(P2_ST10) P2_ROW(P2_ST11) P2_ROW(P2_ST12) P2_ROW(P2_ST13)
+            P2_ROW(P2_ST8) P2_ROW(P2_ST9) P2_ROW(P2_ST10) P2_ROW(P2_ST11) P2_ROW(P2_ST13)
                 P2_ROW(P2_ST14) P2_ROW(P2_ST15) P2_ROW(P2_ST16) P2_ROW(P2_ST17)
         : [ra0] "=&v"(ra0), [ra1] "=&v"(ra1), [rb0] "=&v"(rb0), [rb1] "=&v"(rb1), [rc0] "=&v"(rc0), [rc1] "=&v"(rc1)
         : [xa0] "v"((u32)a[0]), [xa1] "v"((u32)(a[0] >> 32)), [ya0] "v"((u32)b[0]), [ya1] "v"((u32)(b[0] >> 32)),
@@ -66,7 +66,7 @@ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
 }
 
 // ---- mul1: one multiplication as a single stream (dependent S-box chains of the partial rounds) ----
-// Same 17 instructions as a mul3 stream; the two wait states every carry consumer needs after its
+// Same 16 instructions as a mul3 stream; the two wait states every carry consumer needs after its
 // producer are explicit `s_nop 1` (they cost this wave latency, not the SIMD issue slots).
 #define P2_NOP "s_nop 1\n\t"
 #define P2_MUL1_BODY(SET)                                                                                          \
@@ -77,8 +77,7 @@ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
     P2_APPLY(P2_ST7, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_APPLY(P2_ST8, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") \
     P2_APPLY(P2_ST9, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                            \
     P2_APPLY(P2_ST10, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")                                                  \
-    P2_APPLY(P2_ST11, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                           \
-    P2_APPLY(P2_ST12, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")                                                  \
+    P2_APPLY(P2_ST11, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")                                                  \
     P2_APPLY(P2_ST13, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                           \
     P2_APPLY(P2_ST14, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                           \
     P2_APPLY(P2_ST15, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")                                                  \
@@ -110,27 +109,39 @@ __device__ __forceinline__ u64 mul1_lowregs(u64 a, u64 b) {
 //   y = al + ah*2^32 = {al.lo, al.hi + ah.lo} + w2 * 2^64,  w2 = ah.hi + carry < 2^11,
 // and 2^64 = 2^32 - 1 (mod P):  y = lo64 + w2 * 0xFFFFFFFF, folded once more on carry.
 //   1 v_mov T0 = al.lo   2 v_add_co T1 = al.hi + ah.lo   3 v_addc w2 = ah.hi + c
-//   4 v_mad_u64_u32 T = w2 * -1 + T (carry)   5 v_cndmask e = carry ? -1 : 0   6-7 {r0,r1} = T + e
+//   4 v_mad_u64_u32 T = w2 * -1 + T (carry)   5 v_cndmask e = carry ? -1 : 0   6 v_mad_u64_u32 r = e * 1 + T
 #define P2_FD1(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mov_b32 " P0 ", %[" a0 "]\n\t"
 #define P2_FD2(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_add_co_u32 " P1 ", " C1 ", %[" a1 "], %[" b0 "]\n\t"
 #define P2_FD3(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " M0 ", " C1 ", %[" b1 "], 0, " C1 "\n\t"
 #define P2_FD4(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", " M0 ", -1, " P "\n\t"
 #define P2_FD5(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
-#define P2_FD6(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_add_co_u32 %[" r0 "], " C1 ", " P0 ", " M0 "\n\t"
-#define P2_FD7(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 %[" r1 "], " C1 ", " P1 ", 0, " C1 "\n\t"
+#define P2_FD6(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 %[" r0 "], " C1 ", " M0 ", 1, " P "\n\t"
 
 // y[k] = al[k] + ah[k] * 2^32 (mod P), k = 0..2, for al, ah < 2^42
 __device__ __forceinline__ void fold3(const u64 al[3], const u64 ah[3], u64 y[3]) {
-    u32 ra0, ra1, rb0, rb1, rc0, rc1;
-    asm(P2_ROW(P2_FD1) P2_ROW(P2_FD2) P2_ROW(P2_FD3) P2_ROW(P2_FD4) P2_ROW(P2_FD5) P2_ROW(P2_FD6) P2_ROW(P2_FD7)
-        : [ra0] "=&v"(ra0), [ra1] "=&v"(ra1), [rb0] "=&v"(rb0), [rb1] "=&v"(rb1), [rc0] "=&v"(rc0), [rc1] "=&v"(rc1)
+    u64 ra, rb, rc;  // 64-bit outputs: the last instruction of a stream writes the register pair
+    asm(P2_ROW(P2_FD1) P2_ROW(P2_FD2) P2_ROW(P2_FD3) P2_ROW(P2_FD4) P2_ROW(P2_FD5) P2_ROW(P2_FD6)
+        : [ra0] "=&v"(ra), [rb0] "=&v"(rb), [rc0] "=&v"(rc)
         : [xa0] "v"((u32)al[0]), [xa1] "v"((u32)(al[0] >> 32)), [ya0] "v"((u32)ah[0]), [ya1] "v"((u32)(ah[0] >> 32)),
           [xb0] "v"((u32)al[1]), [xb1] "v"((u32)(al[1] >> 32)), [yb0] "v"((u32)ah[1]), [yb1] "v"((u32)(ah[1] >> 32)),
           [xc0] "v"((u32)al[2]), [xc1] "v"((u32)(al[2] >> 32)), [yc0] "v"((u32)ah[2]), [yc1] "v"((u32)(ah[2] >> 32))
         : "v70", "v71", "v72", "v76", "v77", "v78", "v82", "v83", "v84", "s40", "s41", "s44", "s45", "s48", "s49");
-    y[0] = ((u64)ra1 << 32) | ra0;
-    y[1] = ((u64)rb1 << 32) | rb0;
-    y[2] = ((u64)rc1 << 32) | rc0;
+    y[0] = ra;
+    y[1] = rb;
+    y[2] = rc;
+}
+// one row recombination as a single stream (the batched partial rounds' single rows), explicit wait states
+__device__ __forceinline__ u64 fold1(u64 al, u64 ah) {
+    u64 ra;
+    asm(P2_APPLY(P2_FD1, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_APPLY(P2_FD2, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+            P2_NOP P2_APPLY(P2_FD3, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+                P2_APPLY(P2_FD4, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
+                    P2_APPLY(P2_FD5, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+                        P2_APPLY(P2_FD6, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+        : [ra0] "=&v"(ra)
+        : [xa0] "v"((u32)al), [xa1] "v"((u32)(al >> 32)), [ya0] "v"((u32)ah), [ya1] "v"((u32)(ah >> 32))
+        : "v70", "v71", "v72", "s40", "s41");
+    return ra;
 }
 #else
 __host__ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
@@ -138,6 +149,14 @@ __host__ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u6
 }
 __host__ __device__ __forceinline__ u64 mul1(u64 a, u64 b) { return mul(a, b); }
 __host__ __device__ __forceinline__ u64 mul1_lowregs(u64 a, u64 b) { return mul(a, b); }
+__host__ __device__ __forceinline__ u64 fold1(u64 al, u64 ah) {
+    u32 k1;
+    u32 w1 = addc32((u32)(al >> 32), (u32)ah, 0u, &k1);
+    u32 w2 = (u32)(ah >> 32) + k1;
+    u64 lo64 = ((u64)w1 << 32) | (u32)al;
+    u64 t = (u64)w2 * 0xFFFFFFFFu + lo64;
+    return fold_carry(t, t < lo64);
+}
 __host__ __device__ __forceinline__ void fold3(const u64 al[3], const u64 ah[3], u64 y[3]) {
     for (int k = 0; k < 3; ++k) {
         u32 k1;

@@ -124,16 +124,6 @@ __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2, unsigned gr
     }
 }
 
-// single-row recombination (compiler-scheduled twin of gl::fold3): al + ah * 2^32 mod P for al, ah < 2^61
-__device__ __forceinline__ u64 fold1(u64 al, u64 ah) {
-    u32 k1;
-    u32 w1 = gl::addc32((u32)(al >> 32), (u32)ah, 0u, &k1);
-    u32 w2 = (u32)(ah >> 32) + k1;
-    u64 lo64 = ((u64)w1 << 32) | (u32)al;
-    u64 t = (u64)w2 * 0xFFFFFFFFu + lo64;
-    return gl::fold_carry(t, t < lo64);
-}
-
 // Three partial rounds in one dense pass.  A partial round is y <- M z with z = y except z[0] = sbox(y[0] + c); writing
 // round r's replacement as y_r[0] + d_r (d_r = sbox(y_r[0] + c_r) - y_r[0]):
 //   y1[0] = (M z)[0]
@@ -162,7 +152,7 @@ __device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c0, u64 c1, u64 c
         al += (u64)xl[j] * P2_POSEIDON_M1_ROW0[j];
         ah += (u64)xh[j] * P2_POSEIDON_M1_ROW0[j];
     }
-    const u64 y1 = fold1(al, ah);
+    const u64 y1 = gl::fold1(al, ah);
     const u64 d1 = gl::sub(sbox7_asm(gl::add_canon(y1, c1)), y1);
     const u32 d1l = (u32)d1, d1h = (u32)(d1 >> 32);
     al = (u64)d1l * P2_POSEIDON_MCOL0[0];
@@ -172,7 +162,7 @@ __device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c0, u64 c1, u64 c
         al += (u64)xl[j] * P2_POSEIDON_M2_ROW0[j];
         ah += (u64)xh[j] * P2_POSEIDON_M2_ROW0[j];
     }
-    const u64 y2 = fold1(al, ah);
+    const u64 y2 = gl::fold1(al, ah);
     const u64 d2 = gl::sub(sbox7_asm(gl::add_canon(y2, c2)), y2);
     const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
 #pragma unroll
