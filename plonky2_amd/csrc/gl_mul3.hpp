@@ -5,12 +5,12 @@
 // a VALU reads it, and hipcc's 64-bit code wastes ~9 of 26 instructions per multiply on v_mov /
 // v_cmp / v_cndmask glue (measured on the ISA).  Interleaving three products round-robin puts
 // exactly two independent instructions between every carry producer and its consumer, so the
-// 16-instruction multiply-reduce needs no s_nop:
+// 15-instruction multiply-reduce needs no s_nop:
 //    1-4   four v_mad_u64_u32: P = a0*b0, M = a1*b0 + a0*b1 (carry cm), Q = a1*b1
-//    5-8   128-bit assembly: lo = {P0, P1+M0}, hi = Q + M1 + carries (+ cm << 32)
-//    9-11  t = lo + hi.lo * (2^32-1), fold the carry (2^64 = 2^32-1 mod P; the fold is a 64-bit add of a 32-bit mask,
-//          i.e. one more v_mad_u64_u32 with multiplier 1)
-//    13-17 u = t - hi.hi, fold the borrow                    (goldilocks_field.rs:402-415)
+//    5-7   128-bit assembly: lo = {P0, P1+M0}, hi = Q + M1 + carry; cm (weight 2^96 = -1 mod P) is NOT merged into hi
+//    8-12  t = lo - hi.hi - cm (cm enters as the borrow-in of the first subtract), fold the borrow
+//    13-15 u = t + hi.lo * (2^32-1), fold the carry: a 64-bit add of a 32-bit mask = one more v_mad_u64_u32 (x 1),
+//          which also writes the 64-bit result pair directly                      (goldilocks_field.rs:402-415)
 // Temporaries are fixed VGPR/SGPR pairs (declared as clobbers) because inline-asm operands cannot
 // name the halves of a 64-bit register pair.  The C fallback (emulator build) is gl::mul.
 #pragma once
@@ -24,7 +24,7 @@ namespace gl {
 #define P2_SB "v[76:77]", "v76", "v77", "v[78:79]", "v78", "v79", "v[80:81]", "v80", "v81", "s[44:45]", "s[46:47]"
 #define P2_SC "v[82:83]", "v82", "v83", "v[84:85]", "v84", "v85", "v[86:87]", "v86", "v87", "s[48:49]", "s[50:51]"
 
-// one instruction of the multiply for one stream; X = register set, a0/a1/b0/b1/r0/r1 = operand names
+// one instruction of the multiply for one stream; X = register set, a0/a1/b0/b1 = operand names, r0 = the 64-bit result
 #define P2_ST1(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", %[" a0 "], %[" b0 "], 0\n\t"
 #define P2_ST2(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " M ", " C1 ", %[" a1 "], %[" b0 "], 0\n\t"
 #define P2_ST3(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " M ", " C2 ", %[" a0 "], %[" b1 "], " M "\n\t"
@@ -32,15 +32,14 @@ namespace gl {
 #define P2_ST5(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_add_co_u32 " P1 ", " C1 ", " P1 ", " M0 "\n\t"
 #define P2_ST6(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " Q0 ", " C1 ", " Q0 ", " M1 ", " C1 "\n\t"
 #define P2_ST7(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " Q1 ", " C1 ", " Q1 ", 0, " C1 "\n\t"
-#define P2_ST8(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " Q1 ", " C2 ", " Q1 ", 0, " C2 "\n\t"
-#define P2_ST9(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", " Q0 ", -1, " P "\n\t"
+#define P2_ST8(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_subb_co_u32 " P0 ", " C1 ", " P0 ", " Q1 ", " C2 "\n\t"
+#define P2_ST9(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_subb_co_u32 " P1 ", " C1 ", " P1 ", 0, " C1 "\n\t"
 #define P2_ST10(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
-#define P2_ST11(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", " M0 ", 1, " P "\n\t"
-#define P2_ST13(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_sub_co_u32 " P0 ", " C1 ", " P0 ", " Q1 "\n\t"
-#define P2_ST14(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_subb_co_u32 " P1 ", " C1 ", " P1 ", 0, " C1 "\n\t"
-#define P2_ST15(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
-#define P2_ST16(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_sub_co_u32 %[" r0 "], " C1 ", " P0 ", " M0 "\n\t"
-#define P2_ST17(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_subb_co_u32 %[" r1 "], " C1 ", " P1 ", 0, " C1 "\n\t"
+#define P2_ST11(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_sub_co_u32 " P0 ", " C1 ", " P0 ", " M0 "\n\t"
+#define P2_ST12(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_subb_co_u32 " P1 ", " C1 ", " P1 ", 0, " C1 "\n\t"
+#define P2_ST13(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", " Q0 ", -1, " P "\n\t"
+#define P2_ST14(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
+#define P2_ST15(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 %[" r0 "], " C1 ", " M0 ", 1, " P "\n\t"
 
 #define P2_APPLY(ST, ...) ST(__VA_ARGS__)
 #define P2_ROW(ST)                                                   \
@@ -50,58 +49,50 @@ namespace gl {
 
 // r[k] = a[k] * b[k] (mod P), k = 0..2; any representatives in, any representative out
 __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
-    u32 ra0, ra1, rb0, rb1, rc0, rc1;
+    u64 ra, rb, rc;
     asm(P2_ROW(P2_ST1) P2_ROW(P2_ST2) P2_ROW(P2_ST3) P2_ROW(P2_ST4) P2_ROW(P2_ST5) P2_ROW(P2_ST6) P2_ROW(P2_ST7)
-            P2_ROW(P2_ST8) P2_ROW(P2_ST9) P2_ROW(P2_ST10) P2_ROW(P2_ST11) P2_ROW(P2_ST13)
-                P2_ROW(P2_ST14) P2_ROW(P2_ST15) P2_ROW(P2_ST16) P2_ROW(P2_ST17)
-        : [ra0] "=&v"(ra0), [ra1] "=&v"(ra1), [rb0] "=&v"(rb0), [rb1] "=&v"(rb1), [rc0] "=&v"(rc0), [rc1] "=&v"(rc1)
+            P2_ROW(P2_ST8) P2_ROW(P2_ST9) P2_ROW(P2_ST10) P2_ROW(P2_ST11) P2_ROW(P2_ST12) P2_ROW(P2_ST13)
+                P2_ROW(P2_ST14) P2_ROW(P2_ST15)
+        : [ra0] "=&v"(ra), [rb0] "=&v"(rb), [rc0] "=&v"(rc)
         : [xa0] "v"((u32)a[0]), [xa1] "v"((u32)(a[0] >> 32)), [ya0] "v"((u32)b[0]), [ya1] "v"((u32)(b[0] >> 32)),
           [xb0] "v"((u32)a[1]), [xb1] "v"((u32)(a[1] >> 32)), [yb0] "v"((u32)b[1]), [yb1] "v"((u32)(b[1] >> 32)),
           [xc0] "v"((u32)a[2]), [xc1] "v"((u32)(a[2] >> 32)), [yc0] "v"((u32)b[2]), [yc1] "v"((u32)(b[2] >> 32))
         : "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84",
           "v85", "v86", "v87", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51");
-    r[0] = ((u64)ra1 << 32) | ra0;
-    r[1] = ((u64)rb1 << 32) | rb0;
-    r[2] = ((u64)rc1 << 32) | rc0;
+    r[0] = ra;
+    r[1] = rb;
+    r[2] = rc;
 }
 
 // ---- mul1: one multiplication as a single stream (dependent S-box chains of the partial rounds) ----
-// Same 16 instructions as a mul3 stream; the two wait states every carry consumer needs after its
+// Same 15 instructions as a mul3 stream; the two wait states every carry consumer needs after its
 // producer are explicit `s_nop 1` (they cost this wave latency, not the SIMD issue slots).
 #define P2_NOP "s_nop 1\n\t"
-#define P2_MUL1_BODY(SET)                                                                                          \
-    P2_APPLY(P2_ST1, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_APPLY(P2_ST2, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") \
-    P2_APPLY(P2_ST3, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_APPLY(P2_ST4, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") \
-    P2_APPLY(P2_ST5, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                            \
-    P2_APPLY(P2_ST6, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                            \
-    P2_APPLY(P2_ST7, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_APPLY(P2_ST8, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") \
-    P2_APPLY(P2_ST9, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                            \
-    P2_APPLY(P2_ST10, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")                                                  \
-    P2_APPLY(P2_ST11, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")                                                  \
-    P2_APPLY(P2_ST13, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                           \
-    P2_APPLY(P2_ST14, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                           \
-    P2_APPLY(P2_ST15, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")                                                  \
-    P2_APPLY(P2_ST16, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP                                           \
-    P2_APPLY(P2_ST17, SET, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+#define P2_A1(ST, ...) P2_APPLY(ST, __VA_ARGS__, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+#define P2_MUL1_BODY(SET)                                                                                     \
+    P2_A1(P2_ST1, SET) P2_A1(P2_ST2, SET) P2_A1(P2_ST3, SET) P2_A1(P2_ST4, SET) P2_A1(P2_ST5, SET) P2_NOP      \
+    P2_A1(P2_ST6, SET) P2_NOP P2_A1(P2_ST7, SET) P2_A1(P2_ST8, SET) P2_NOP P2_A1(P2_ST9, SET) P2_NOP         \
+    P2_A1(P2_ST10, SET) P2_A1(P2_ST11, SET) P2_NOP P2_A1(P2_ST12, SET) P2_A1(P2_ST13, SET) P2_NOP            \
+    P2_A1(P2_ST14, SET) P2_A1(P2_ST15, SET)
 
 __device__ __forceinline__ u64 mul1(u64 a, u64 b) {
-    u32 ra0, ra1;
+    u64 ra;
     asm(P2_MUL1_BODY(P2_SA)
-        : [ra0] "=&v"(ra0), [ra1] "=&v"(ra1)
+        : [ra0] "=&v"(ra)
         : [xa0] "v"((u32)a), [xa1] "v"((u32)(a >> 32)), [ya0] "v"((u32)b), [ya1] "v"((u32)(b >> 32))
         : "v70", "v71", "v72", "v73", "v74", "v75", "s40", "s41", "s42", "s43");
-    return ((u64)ra1 << 32) | ra0;
+    return ra;
 }
 
 // the same stream on a low register set, for kernels that must stay within 64 VGPRs (the NTT passes)
 #define P2_SN "v[58:59]", "v58", "v59", "v[60:61]", "v60", "v61", "v[62:63]", "v62", "v63", "s[60:61]", "s[62:63]"
 __device__ __forceinline__ u64 mul1_lowregs(u64 a, u64 b) {
-    u32 ra0, ra1;
+    u64 ra;
     asm(P2_MUL1_BODY(P2_SN)
-        : [ra0] "=&v"(ra0), [ra1] "=&v"(ra1)
+        : [ra0] "=&v"(ra)
         : [xa0] "v"((u32)a), [xa1] "v"((u32)(a >> 32)), [ya0] "v"((u32)b), [ya1] "v"((u32)(b >> 32))
         : "v58", "v59", "v60", "v61", "v62", "v63", "s60", "s61", "s62", "s63");
-    return ((u64)ra1 << 32) | ra0;
+    return ra;
 }
 
 // ---- fold3: three MDS-row recombinations in one interleaved stream ------------------------------
