@@ -5,12 +5,15 @@
 // a VALU reads it, and hipcc's 64-bit code wastes ~9 of 26 instructions per multiply on v_mov /
 // v_cmp / v_cndmask glue (measured on the ISA).  Interleaving three products round-robin puts
 // exactly two independent instructions between every carry producer and its consumer, so the
-// 15-instruction multiply-reduce needs no s_nop:
+// 14-instruction multiply-reduce needs no s_nop:
 //    1-4   four v_mad_u64_u32: P = a0*b0, M = a1*b0 + a0*b1 (carry cm), Q = a1*b1
 //    5-7   128-bit assembly: lo = {P0, P1+M0}, hi = Q + M1 + carry; cm (weight 2^96 = -1 mod P) is NOT merged into hi
-//    8-12  t = lo - hi.hi - cm (cm enters as the borrow-in of the first subtract), fold the borrow
-//    13-15 u = t + hi.lo * (2^32-1), fold the carry: a 64-bit add of a 32-bit mask = one more v_mad_u64_u32 (x 1),
-//          which also writes the 64-bit result pair directly                      (goldilocks_field.rs:402-415)
+//    8-9   t = lo - hi.hi - cm (mod 2^64; cm enters as the borrow-in of the first subtract), borrow b
+//    10    u = t + hi.lo * (2^32-1) (mod 2^64), carry c
+//    11-14 the value is u + (c - b) * 2^64 = u + e * (2^32 - 1) with e = c - b in {-1, 0, 1} (never out of [0, 2^64):
+//          see the bounds in gl::reduce128): e by a v_cndmask and a v_subb, then u + (e << 32) - e as a 32-bit add on
+//          the high word and one SIGNED multiply-add (v_mad_i64_i32, e * -1), which writes the 64-bit result pair
+//                                                                               (goldilocks_field.rs:402-415)
 // Temporaries are fixed VGPR/SGPR pairs (declared as clobbers) because inline-asm operands cannot
 // name the halves of a 64-bit register pair.  The C fallback (emulator build) is gl::mul.
 #pragma once
@@ -34,12 +37,11 @@ namespace gl {
 #define P2_ST7(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " Q1 ", " C1 ", " Q1 ", 0, " C1 "\n\t"
 #define P2_ST8(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_subb_co_u32 " P0 ", " C1 ", " P0 ", " Q1 ", " C2 "\n\t"
 #define P2_ST9(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_subb_co_u32 " P1 ", " C1 ", " P1 ", 0, " C1 "\n\t"
-#define P2_ST10(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
-#define P2_ST11(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_sub_co_u32 " P0 ", " C1 ", " P0 ", " M0 "\n\t"
-#define P2_ST12(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_subb_co_u32 " P1 ", " C1 ", " P1 ", 0, " C1 "\n\t"
-#define P2_ST13(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", " Q0 ", -1, " P "\n\t"
-#define P2_ST14(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
-#define P2_ST15(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 %[" r0 "], " C1 ", " M0 ", 1, " P "\n\t"
+#define P2_ST10(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C2 ", " Q0 ", -1, " P "\n\t"
+#define P2_ST11(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, 1, " C2 "\n\t"
+#define P2_ST12(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_subb_co_u32 " M0 ", " C1 ", " M0 ", 0, " C1 "\n\t"
+#define P2_ST13(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_add_u32 " P1 ", " P1 ", " M0 "\n\t"
+#define P2_ST14(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_i64_i32 %[" r0 "], " C1 ", " M0 ", -1, " P "\n\t"
 
 #define P2_APPLY(ST, ...) ST(__VA_ARGS__)
 #define P2_ROW(ST)                                                   \
@@ -52,7 +54,7 @@ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
     u64 ra, rb, rc;
     asm(P2_ROW(P2_ST1) P2_ROW(P2_ST2) P2_ROW(P2_ST3) P2_ROW(P2_ST4) P2_ROW(P2_ST5) P2_ROW(P2_ST6) P2_ROW(P2_ST7)
             P2_ROW(P2_ST8) P2_ROW(P2_ST9) P2_ROW(P2_ST10) P2_ROW(P2_ST11) P2_ROW(P2_ST12) P2_ROW(P2_ST13)
-                P2_ROW(P2_ST14) P2_ROW(P2_ST15)
+                P2_ROW(P2_ST14)
         : [ra0] "=&v"(ra), [rb0] "=&v"(rb), [rc0] "=&v"(rc)
         : [xa0] "v"((u32)a[0]), [xa1] "v"((u32)(a[0] >> 32)), [ya0] "v"((u32)b[0]), [ya1] "v"((u32)(b[0] >> 32)),
           [xb0] "v"((u32)a[1]), [xb1] "v"((u32)(a[1] >> 32)), [yb0] "v"((u32)b[1]), [yb1] "v"((u32)(b[1] >> 32)),
@@ -65,15 +67,14 @@ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
 }
 
 // ---- mul1: one multiplication as a single stream (dependent S-box chains of the partial rounds) ----
-// Same 15 instructions as a mul3 stream; the two wait states every carry consumer needs after its
+// Same 14 instructions as a mul3 stream; the two wait states every carry consumer needs after its
 // producer are explicit `s_nop 1` (they cost this wave latency, not the SIMD issue slots).
 #define P2_NOP "s_nop 1\n\t"
 #define P2_A1(ST, ...) P2_APPLY(ST, __VA_ARGS__, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
 #define P2_MUL1_BODY(SET)                                                                                     \
     P2_A1(P2_ST1, SET) P2_A1(P2_ST2, SET) P2_A1(P2_ST3, SET) P2_A1(P2_ST4, SET) P2_A1(P2_ST5, SET) P2_NOP      \
-    P2_A1(P2_ST6, SET) P2_NOP P2_A1(P2_ST7, SET) P2_A1(P2_ST8, SET) P2_NOP P2_A1(P2_ST9, SET) P2_NOP         \
-    P2_A1(P2_ST10, SET) P2_A1(P2_ST11, SET) P2_NOP P2_A1(P2_ST12, SET) P2_A1(P2_ST13, SET) P2_NOP            \
-    P2_A1(P2_ST14, SET) P2_A1(P2_ST15, SET)
+    P2_A1(P2_ST6, SET) P2_NOP P2_A1(P2_ST7, SET) P2_A1(P2_ST8, SET) P2_NOP P2_A1(P2_ST9, SET)                \
+    P2_A1(P2_ST10, SET) P2_NOP P2_A1(P2_ST11, SET) P2_A1(P2_ST12, SET) P2_A1(P2_ST13, SET) P2_A1(P2_ST14, SET)
 
 __device__ __forceinline__ u64 mul1(u64 a, u64 b) {
     u64 ra;
