@@ -97,26 +97,24 @@ __device__ __forceinline__ u64 mul1_lowregs(u64 a, u64 b) {
 }
 
 // ---- fold3: three MDS-row recombinations in one interleaved stream ------------------------------
-// A row's two accumulators al = sum c*x.lo32, ah = sum c*x.hi32 (< 2^42 each) stand for
-//   y = al + ah*2^32 = {al.lo, al.hi + ah.lo} + w2 * 2^64,  w2 = ah.hi + carry < 2^11,
-// and 2^64 = 2^32 - 1 (mod P):  y = lo64 + w2 * 0xFFFFFFFF, folded once more on carry.
-//   1 v_mov T0 = al.lo   2 v_add_co T1 = al.hi + ah.lo   3 v_addc w2 = ah.hi + c
-//   4 v_mad_u64_u32 T = w2 * -1 + T (carry)   5 v_cndmask e = carry ? -1 : 0   6 v_mad_u64_u32 r = e * 1 + T
-#define P2_FD1(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mov_b32 " P0 ", %[" a0 "]\n\t"
-#define P2_FD2(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_add_co_u32 " P1 ", " C1 ", %[" a1 "], %[" b0 "]\n\t"
-#define P2_FD3(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_addc_co_u32 " M0 ", " C1 ", %[" b1 "], 0, " C1 "\n\t"
-#define P2_FD4(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", " M0 ", -1, " P "\n\t"
-#define P2_FD5(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
-#define P2_FD6(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 %[" r0 "], " C1 ", " M0 ", 1, " P "\n\t"
+// A row's two accumulators al = sum c*x.lo32, ah = sum c*x.hi32 (each < 2^63) stand for
+//   y = al + ah*2^32 = al + ah.lo * 2^32 + ah.hi * 2^64 = al + ah.hi * (2^32 - 1) + ah.lo * 2^32   (mod P):
+//   1 v_mad_u64_u32 T = ah.hi * -1 + al      (< 2^64: no carry)
+//   2 v_add_co      T.hi += ah.lo            (carry c: weight 2^64 = 2^32 - 1)
+//   3 v_cndmask     e = c ? -1 : 0           4 v_mad_u64_u32 r = e * 1 + T   (T < 2^63 after a wrap: no second carry)
+// a0 names the 64-bit operand al, b0 / b1 the halves of ah, r0 the 64-bit result.
+#define P2_FD1(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 " P ", " C1 ", %[" b1 "], -1, %[" a0 "]\n\t"
+#define P2_FD2(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_add_co_u32 " P1 ", " C1 ", " P1 ", %[" b0 "]\n\t"
+#define P2_FD3(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
+#define P2_FD4(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 %[" r0 "], " C1 ", " M0 ", 1, " P "\n\t"
 
-// y[k] = al[k] + ah[k] * 2^32 (mod P), k = 0..2, for al, ah < 2^42
+// y[k] = al[k] + ah[k] * 2^32 (mod P), k = 0..2, for al, ah < 2^63
 __device__ __forceinline__ void fold3(const u64 al[3], const u64 ah[3], u64 y[3]) {
     u64 ra, rb, rc;  // 64-bit outputs: the last instruction of a stream writes the register pair
-    asm(P2_ROW(P2_FD1) P2_ROW(P2_FD2) P2_ROW(P2_FD3) P2_ROW(P2_FD4) P2_ROW(P2_FD5) P2_ROW(P2_FD6)
+    asm(P2_ROW(P2_FD1) P2_ROW(P2_FD2) P2_ROW(P2_FD3) P2_ROW(P2_FD4)
         : [ra0] "=&v"(ra), [rb0] "=&v"(rb), [rc0] "=&v"(rc)
-        : [xa0] "v"((u32)al[0]), [xa1] "v"((u32)(al[0] >> 32)), [ya0] "v"((u32)ah[0]), [ya1] "v"((u32)(ah[0] >> 32)),
-          [xb0] "v"((u32)al[1]), [xb1] "v"((u32)(al[1] >> 32)), [yb0] "v"((u32)ah[1]), [yb1] "v"((u32)(ah[1] >> 32)),
-          [xc0] "v"((u32)al[2]), [xc1] "v"((u32)(al[2] >> 32)), [yc0] "v"((u32)ah[2]), [yc1] "v"((u32)(ah[2] >> 32))
+        : [xa0] "v"(al[0]), [ya0] "v"((u32)ah[0]), [ya1] "v"((u32)(ah[0] >> 32)), [xb0] "v"(al[1]), [yb0] "v"((u32)ah[1]),
+          [yb1] "v"((u32)(ah[1] >> 32)), [xc0] "v"(al[2]), [yc0] "v"((u32)ah[2]), [yc1] "v"((u32)(ah[2] >> 32))
         : "v70", "v71", "v72", "v76", "v77", "v78", "v82", "v83", "v84", "s40", "s41", "s44", "s45", "s48", "s49");
     y[0] = ra;
     y[1] = rb;
@@ -125,13 +123,9 @@ __device__ __forceinline__ void fold3(const u64 al[3], const u64 ah[3], u64 y[3]
 // one row recombination as a single stream (the batched partial rounds' single rows), explicit wait states
 __device__ __forceinline__ u64 fold1(u64 al, u64 ah) {
     u64 ra;
-    asm(P2_APPLY(P2_FD1, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_APPLY(P2_FD2, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
-            P2_NOP P2_APPLY(P2_FD3, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
-                P2_APPLY(P2_FD4, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1") P2_NOP
-                    P2_APPLY(P2_FD5, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
-                        P2_APPLY(P2_FD6, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")
+    asm(P2_A1(P2_FD1, P2_SA) P2_A1(P2_FD2, P2_SA) P2_NOP P2_A1(P2_FD3, P2_SA) P2_A1(P2_FD4, P2_SA)
         : [ra0] "=&v"(ra)
-        : [xa0] "v"((u32)al), [xa1] "v"((u32)(al >> 32)), [ya0] "v"((u32)ah), [ya1] "v"((u32)(ah >> 32))
+        : [xa0] "v"(al), [ya0] "v"((u32)ah), [ya1] "v"((u32)(ah >> 32))
         : "v70", "v71", "v72", "s40", "s41");
     return ra;
 }
