@@ -77,18 +77,79 @@ __device__ __forceinline__ u32 opaque_const(u32 c) {
     return c;
 }
 
+// One term of three MDS rows: the six accumulators (lo / hi halves of rows r, r+1, r+2) each take x * C in ONE
+// multiply-add.  Written as asm because hipcc re-associates the 12-term chains into two half chains plus a 64-bit add
+// (24 extra instructions per layer) and adds the round constants with separate 64-bit adds; here a chain is exactly
+// its 12 multiply-adds, the first of which reads the constant from its SGPR pair as the addend.
+template <u32 C>
+__device__ __forceinline__ void mds_term(u64 (&al)[3], u64 (&ah)[3], u32 l0, u32 h0, u32 l1, u32 h1, u32 l2, u32 h2) {
+#ifndef P2HOT_EMU
+    u64 d;
+    asm("v_mad_u64_u32 %0, %6, %7, %13, %0\n\t"
+        "v_mad_u64_u32 %1, %6, %8, %13, %1\n\t"
+        "v_mad_u64_u32 %2, %6, %9, %13, %2\n\t"
+        "v_mad_u64_u32 %3, %6, %10, %13, %3\n\t"
+        "v_mad_u64_u32 %4, %6, %11, %13, %4\n\t"
+        "v_mad_u64_u32 %5, %6, %12, %13, %5"
+        : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "=&s"(d)
+        : "v"(l0), "v"(h0), "v"(l1), "v"(h1), "v"(l2), "v"(h2), "n"(C));
+#else
+    al[0] += (u64)l0 * C;
+    ah[0] += (u64)h0 * C;
+    al[1] += (u64)l1 * C;
+    ah[1] += (u64)h1 * C;
+    al[2] += (u64)l2 * C;
+    ah[2] += (u64)h2 * C;
+#endif
+}
+// the first term (C[0] = 17): starts the six chains from the six wave-uniform 64-bit addends k (SGPR pairs) or from 0
+template <bool HAS_K>
+__device__ __forceinline__ void mds_first(u64 (&al)[3], u64 (&ah)[3], u32 l0, u32 h0, u32 l1, u32 h1, u32 l2, u32 h2,
+                                          const u64 *k) {
+#ifndef P2HOT_EMU
+    u64 d;
+    if (HAS_K) {
+        asm("v_mad_u64_u32 %0, %6, %7, 17, %13\n\t"
+            "v_mad_u64_u32 %1, %6, %8, 17, %14\n\t"
+            "v_mad_u64_u32 %2, %6, %9, 17, %15\n\t"
+            "v_mad_u64_u32 %3, %6, %10, 17, %16\n\t"
+            "v_mad_u64_u32 %4, %6, %11, 17, %17\n\t"
+            "v_mad_u64_u32 %5, %6, %12, 17, %18"
+            : "=&v"(al[0]), "=&v"(ah[0]), "=&v"(al[1]), "=&v"(ah[1]), "=&v"(al[2]), "=&v"(ah[2]), "=&s"(d)
+            : "v"(l0), "v"(h0), "v"(l1), "v"(h1), "v"(l2), "v"(h2), "s"(k[0]), "s"(k[1]), "s"(k[2]), "s"(k[3]), "s"(k[4]),
+              "s"(k[5]));
+    } else {
+        asm("v_mad_u64_u32 %0, %6, %7, 17, 0\n\t"
+            "v_mad_u64_u32 %1, %6, %8, 17, 0\n\t"
+            "v_mad_u64_u32 %2, %6, %9, 17, 0\n\t"
+            "v_mad_u64_u32 %3, %6, %10, 17, 0\n\t"
+            "v_mad_u64_u32 %4, %6, %11, 17, 0\n\t"
+            "v_mad_u64_u32 %5, %6, %12, 17, 0"
+            : "=&v"(al[0]), "=&v"(ah[0]), "=&v"(al[1]), "=&v"(ah[1]), "=&v"(al[2]), "=&v"(ah[2]), "=&s"(d)
+            : "v"(l0), "v"(h0), "v"(l1), "v"(h1), "v"(l2), "v"(h2));
+    }
+#else
+    const u64 z[6] = {0, 0, 0, 0, 0, 0};
+    const u64 *kk = HAS_K ? k : z;
+    al[0] = (u64)l0 * 17u + kk[0];
+    ah[0] = (u64)h0 * 17u + kk[1];
+    al[1] = (u64)l1 * 17u + kk[2];
+    ah[1] = (u64)h1 * 17u + kk[3];
+    al[2] = (u64)l2 * 17u + kk[4];
+    ah[2] = (u64)h2 * 17u + kk[5];
+#endif
+}
+
 // MDS layer fused with the NEXT round's constant layer:
 //   y_r = rc_r + sum_i C[i] * x_{(i+r)%12} (+ 8 * x_0 for r = 0)
 // circulant first row C = [17,15,41,16,2,28,13,13,39,18,34,20], diag [8,0,...] (poseidon_goldilocks.rs:24-25).
 // On gfx950 v_mad_u64_u32 issues at the plain VOP3 rate (tools/ubench), so each output is two
 // 12-term multiply-add chains over the 32-bit halves (al, ah < 2^42) and one fold:
-//   y = al + ah * 2^32 = lo64 + w2 * 2^64 = lo64 + w2 * EPS (mod P), w2 < 2^10.
+//   y = al + ah * 2^32 (mod P), gl::fold3.
 // rc2 points at the round's constants split as {lo32, hi32} pairs (RC_SPLIT) or is null.
 // `groups` (wave-uniform): bit g set = rows 3g..3g+2 are wanted; the other rows are left stale.
 template <bool WORD0_ONLY = false>
 __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2, unsigned groups = 0xFu) {
-    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    const u32 c16 = opaque_const(16), c2 = opaque_const(2), c8 = opaque_const(8);
     u32 xl[12], xh[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -99,23 +160,30 @@ __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2, unsigned gr
     for (int g = 0; g < 12; g += 3) {  // three rows at a time: six independent chains, then one fold3 stream
         if (!(groups >> (g / 3) & 1u)) continue;
         u64 al[3], ah[3], y[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int r = g + t;
-            const bool has_rc = rc2 && (!WORD0_ONLY || r == 0);
-            al[t] = has_rc ? rc2[2 * r] : 0;
-            ah[t] = has_rc ? rc2[2 * r + 1] : 0;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                const int j = (i + r) % 12;
-                const u32 c = C[i] == 16 ? c16 : (C[i] == 2 ? c2 : C[i]);
-                al[t] += (u64)xl[j] * c;
-                ah[t] += (u64)xh[j] * c;
-            }
-            if (r == 0) {
-                al[t] += (u64)xl[0] * c8;
-                ah[t] += (u64)xh[0] * c8;
-            }
+#define P2_X(i) xl[(g + (i)) % 12], xh[(g + (i)) % 12], xl[(g + (i) + 1) % 12], xh[(g + (i) + 1) % 12], xl[(g + (i) + 2) % 12], xh[(g + (i) + 2) % 12]
+        if (rc2 && !WORD0_ONLY) {
+            mds_first<true>(al, ah, P2_X(0), rc2 + 2 * g);
+        } else if (rc2 && g == 0) {  // word 0 only: rows 1, 2 start from zero
+            const u64 k[6] = {rc2[0], rc2[1], 0, 0, 0, 0};
+            mds_first<true>(al, ah, P2_X(0), k);
+        } else {
+            mds_first<false>(al, ah, P2_X(0), nullptr);
+        }
+        mds_term<15>(al, ah, P2_X(1));
+        mds_term<41>(al, ah, P2_X(2));
+        mds_term<16>(al, ah, P2_X(3));
+        mds_term<2>(al, ah, P2_X(4));
+        mds_term<28>(al, ah, P2_X(5));
+        mds_term<13>(al, ah, P2_X(6));
+        mds_term<13>(al, ah, P2_X(7));
+        mds_term<39>(al, ah, P2_X(8));
+        mds_term<18>(al, ah, P2_X(9));
+        mds_term<34>(al, ah, P2_X(10));
+        mds_term<20>(al, ah, P2_X(11));
+#undef P2_X
+        if (g == 0) {  // diag [8, 0, ...]: row 0 only
+            al[0] += (u64)xl[0] * opaque_const(8);
+            ah[0] += (u64)xh[0] * opaque_const(8);
         }
         gl::fold3(al, ah, y);
         s[g] = y[0];
