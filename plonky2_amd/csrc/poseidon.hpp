@@ -148,7 +148,6 @@ __device__ __forceinline__ void mds_first(u64 (&al)[3], u64 (&ah)[3], u32 l0, u3
 //   y = al + ah * 2^32 (mod P), gl::fold3.
 // rc2 points at the round's constants split as {lo32, hi32} pairs (RC_SPLIT) or is null.
 // `groups` (wave-uniform): bit g set = rows 3g..3g+2 are wanted; the other rows are left stale.
-template <bool WORD0_ONLY = false>
 __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2, unsigned groups = 0xFu) {
     u32 xl[12], xh[12];
 #pragma unroll
@@ -161,14 +160,10 @@ __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2, unsigned gr
         if (!(groups >> (g / 3) & 1u)) continue;
         u64 al[3], ah[3], y[3];
 #define P2_X(i) xl[(g + (i)) % 12], xh[(g + (i)) % 12], xl[(g + (i) + 1) % 12], xh[(g + (i) + 1) % 12], xl[(g + (i) + 2) % 12], xh[(g + (i) + 2) % 12]
-        if (rc2 && !WORD0_ONLY) {
+        if (rc2)
             mds_first<true>(al, ah, P2_X(0), rc2 + 2 * g);
-        } else if (rc2 && g == 0) {  // word 0 only: rows 1, 2 start from zero
-            const u64 k[6] = {rc2[0], rc2[1], 0, 0, 0, 0};
-            mds_first<true>(al, ah, P2_X(0), k);
-        } else {
+        else
             mds_first<false>(al, ah, P2_X(0), nullptr);
-        }
         mds_term<15>(al, ah, P2_X(1));
         mds_term<41>(al, ah, P2_X(2));
         mds_term<16>(al, ah, P2_X(3));
