@@ -277,8 +277,11 @@ static std::vector<Pass> plan_passes(unsigned log_n) {
         p.push_back({log_n, 0});
         return p;
     }
+    // strided passes take up to 9 bits each: a tile is then 512 rows x 8 columns, i.e. 64-byte row segments -- half
+    // the 128-byte segments of an 8-bit pass, but 2^21 (the per-GPU transform of a 2-GPU C3 job) needs two passes
+    // instead of three, and the passes are ALU-bound, not HBM-bound
     unsigned rem = log_n - ntt::TILE_LOG;
-    unsigned k = (rem + 7) / 8;
+    unsigned k = (rem + 8) / 9;
     for (unsigned i = 0; i < k; ++i) {
         unsigned part = rem / (k - i);
         if (rem % (k - i)) ++part;
