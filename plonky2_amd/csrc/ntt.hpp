@@ -193,7 +193,8 @@ __device__ __forceinline__ u64 ntt_mul(u64 a, u64 b) {  // hand-scheduled multip
     return NT == 512 ? gl::mul1_lowregs(a, b) : gl::mul1(a, b);
 }
 
-template <int P, bool INV, int NT>
+// SCALE: the pass's scale mode when known at compile time (the per-point mode tests disappear), -1 = read a.scale_mode
+template <int P, bool INV, int NT, int SCALE>
 __device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, const u64 *gin, bool from_global, unsigned log_rb,
                                           unsigned log_stride, size_t z, size_t base0) {
     const PassArgs &a = ra.a;
@@ -212,9 +213,10 @@ __device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, cons
             const unsigned i = i0 + ((unsigned)q << s_log);
             if (from_global) {
                 u64 v = gin[((size_t)i << log_stride) + c];
-                if (a.scale_mode == SCALE_CONST) {
+                const int mode = SCALE >= 0 ? SCALE : a.scale_mode;
+                if (mode == SCALE_CONST) {
                     v = ntt_mul<NT>(v, a.scale_const);
-                } else if (a.scale_mode == SCALE_TABLE) {
+                } else if (mode == SCALE_TABLE) {
                     u64 sc = a.srow[z * R + i];
                     if (log_stride) sc = ntt_mul<NT>(sc, a.scol[z * stride + base0 + c]);
                     v = ntt_mul<NT>(v, sc);
@@ -239,7 +241,7 @@ __device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, cons
     __syncthreads();
 }
 
-template <bool INV, int NT, int MINW>
+template <bool INV, int NT, int MINW, int SCALE = -1>
 __global__ void __launch_bounds__(NT, MINW) ntt_regpass_kernel(RegPassArgs ra) {
     P2HOT_DYN_SHARED(u64, tile);
     const PassArgs &a = ra.a;
@@ -271,10 +273,10 @@ __global__ void __launch_bounds__(NT, MINW) ntt_regpass_kernel(RegPassArgs ra) {
 #pragma unroll 1
         for (int r = 0; r < 4 && ra.rounds[r]; ++r) {
             switch (ra.rounds[r]) {
-                case 4: if (NT == 256) reg_round<4, INV, NT>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
-                case 3: reg_round<3, INV, NT>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
-                case 2: reg_round<2, INV, NT>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
-                default: reg_round<1, INV, NT>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+                case 4: if (NT == 256) reg_round<4, INV, NT, SCALE>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+                case 3: reg_round<3, INV, NT, SCALE>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+                case 2: reg_round<2, INV, NT, SCALE>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+                default: reg_round<1, INV, NT, SCALE>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
             }
             log_rb -= ra.rounds[r];
             first = false;

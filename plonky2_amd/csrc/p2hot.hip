@@ -347,11 +347,16 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
                 ra.zloop = (unsigned)zcount;
                 grid.z = 1;
             }
-            if (maxp == 3) {
-                if (inverse)
-                    P2HOT_LAUNCH((ntt::ntt_regpass_kernel<true, 512, 6>), grid, dim3(512), shm, ctx->stream, ra);
-                else
-                    P2HOT_LAUNCH((ntt::ntt_regpass_kernel<false, 512, 6>), grid, dim3(512), shm, ctx->stream, ra);
+            if (maxp == 3) {  // one kernel per (direction, scale mode): the per-point mode tests are compiled out
+#define P2_NTT512(INVF, MODE) P2HOT_LAUNCH((ntt::ntt_regpass_kernel<INVF, 512, 6, MODE>), grid, dim3(512), shm, ctx->stream, ra)
+                if (a.scale_mode == ntt::SCALE_TABLE) {
+                    if (inverse) P2_NTT512(true, ntt::SCALE_TABLE); else P2_NTT512(false, ntt::SCALE_TABLE);
+                } else if (a.scale_mode == ntt::SCALE_CONST) {
+                    if (inverse) P2_NTT512(true, ntt::SCALE_CONST); else P2_NTT512(false, ntt::SCALE_CONST);
+                } else {
+                    if (inverse) P2_NTT512(true, ntt::SCALE_NONE); else P2_NTT512(false, ntt::SCALE_NONE);
+                }
+#undef P2_NTT512
             } else {
                 if (inverse)
                     P2HOT_LAUNCH((ntt::ntt_regpass_kernel<true, 256, 4>), grid, dim3(256), shm, ctx->stream, ra);
