@@ -194,8 +194,8 @@ __device__ __forceinline__ u64 ntt_mul(u64 a, u64 b) {  // hand-scheduled multip
 }
 
 // SCALE: the pass's scale mode when known at compile time (the per-point mode tests disappear), -1 = read a.scale_mode
-template <int P, bool INV, int NT, int SCALE>
-__device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, const u64 *gin, bool from_global, unsigned log_rb,
+template <int P, bool INV, int NT, int SCALE, bool from_global>
+__device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, const u64 *gin, unsigned log_rb,
                                           unsigned log_stride, size_t z, size_t base0) {
     const PassArgs &a = ra.a;
     const unsigned logC = a.log_c, C = 1u << logC;
@@ -272,12 +272,23 @@ __global__ void __launch_bounds__(NT, MINW) ntt_regpass_kernel(RegPassArgs ra) {
         bool first = true;
 #pragma unroll 1
         for (int r = 0; r < 4 && ra.rounds[r]; ++r) {
-            switch (ra.rounds[r]) {
-                case 4: if (NT == 256) reg_round<4, INV, NT, SCALE>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
-                case 3: reg_round<3, INV, NT, SCALE>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
-                case 2: reg_round<2, INV, NT, SCALE>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
-                default: reg_round<1, INV, NT, SCALE>(ra, tile, in, first, log_rb, log_stride, z, base0); break;
+#define P2_ROUND(PP, FG) reg_round<PP, INV, NT, SCALE, FG>(ra, tile, in, log_rb, log_stride, z, base0)
+            if (first) {  // the first round loads from global memory (with the pass's scaling), the others from the tile
+                switch (ra.rounds[r]) {
+                    case 4: if (NT == 256) P2_ROUND(4, true); break;
+                    case 3: P2_ROUND(3, true); break;
+                    case 2: P2_ROUND(2, true); break;
+                    default: P2_ROUND(1, true); break;
+                }
+            } else {
+                switch (ra.rounds[r]) {
+                    case 4: if (NT == 256) P2_ROUND(4, false); break;
+                    case 3: P2_ROUND(3, false); break;
+                    case 2: P2_ROUND(2, false); break;
+                    default: P2_ROUND(1, false); break;
+                }
             }
+#undef P2_ROUND
             log_rb -= ra.rounds[r];
             first = false;
         }
