@@ -194,11 +194,11 @@ __device__ __forceinline__ u64 ntt_mul(u64 a, u64 b) {  // hand-scheduled multip
 }
 
 // SCALE: the pass's scale mode when known at compile time (the per-point mode tests disappear), -1 = read a.scale_mode
-template <int P, bool INV, int NT, int SCALE, bool from_global>
+template <int P, bool INV, int NT, int SCALE, bool from_global, bool CONTIG>
 __device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, const u64 *gin, unsigned log_rb,
                                           unsigned log_stride, size_t z, size_t base0) {
     const PassArgs &a = ra.a;
-    const unsigned logC = a.log_c, C = 1u << logC;
+    const unsigned logC = CONTIG ? 0u : a.log_c, C = 1u << logC;  // CONTIG: the last pass, one column, unit stride
     const unsigned elems_log = a.log_r + logC;
     const unsigned s_log = log_rb - P;  // S = Rb >> P
     const unsigned R = 1u << a.log_r;
@@ -241,13 +241,14 @@ __device__ __forceinline__ void reg_round(const RegPassArgs &ra, u64 *tile, cons
     __syncthreads();
 }
 
-template <bool INV, int NT, int MINW, int SCALE = -1>
+// CONTIG: the contiguous (last) pass of a transform -- log_c = 0 and unit stride known at compile time
+template <bool INV, int NT, int MINW, int SCALE = -1, bool CONTIG = false>
 __global__ void __launch_bounds__(NT, MINW) ntt_regpass_kernel(RegPassArgs ra) {
     P2HOT_DYN_SHARED(u64, tile);
     const PassArgs &a = ra.a;
     const unsigned tid = threadIdx.x;
-    const unsigned logC = a.log_c, C = 1u << logC;
-    const unsigned log_stride = a.log_nblk - a.log_r;
+    const unsigned logC = CONTIG ? 0u : a.log_c, C = 1u << logC;
+    const unsigned log_stride = CONTIG ? 0u : a.log_nblk - a.log_r;
     const unsigned tiles_per_blk_log = log_stride - logC;
     const size_t tau = blockIdx.x;
     const size_t blk = tau >> tiles_per_blk_log;
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(NT, MINW) ntt_regpass_kernel(RegPassArgs ra) {
         bool first = true;
 #pragma unroll 1
         for (int r = 0; r < 4 && ra.rounds[r]; ++r) {
-#define P2_ROUND(PP, FG) reg_round<PP, INV, NT, SCALE, FG>(ra, tile, in, log_rb, log_stride, z, base0)
+#define P2_ROUND(PP, FG) reg_round<PP, INV, NT, SCALE, FG, CONTIG>(ra, tile, in, log_rb, log_stride, z, base0)
             if (first) {  // the first round loads from global memory (with the pass's scaling), the others from the tile
                 switch (ra.rounds[r]) {
                     case 4: if (NT == 256) P2_ROUND(4, true); break;
