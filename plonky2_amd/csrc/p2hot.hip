@@ -348,7 +348,7 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
                 grid.z = 1;
             }
             if (maxp == 3) {  // one kernel per (direction, scale mode): the per-point mode tests are compiled out
-#define P2_NTT512C(INVF, MODE, CT) P2HOT_LAUNCH((ntt::ntt_regpass_kernel<INVF, 512, 6, MODE, CT>), grid, dim3(512), shm, ctx->stream, ra)
+#define P2_NTT512C(INVF, MODE, CT) P2HOT_LAUNCH((ntt::ntt_regpass_kernel<INVF, 512, (CT) ? 8 : 6, MODE, CT>), grid, dim3(512), shm, ctx->stream, ra)
 #define P2_NTT512(INVF, MODE) do { if (a.log_c == 0 && log_nblk == a.log_r) P2_NTT512C(INVF, MODE, true); else P2_NTT512C(INVF, MODE, false); } while (0)
                 if (a.scale_mode == ntt::SCALE_TABLE) {
                     if (inverse) P2_NTT512(true, ntt::SCALE_TABLE); else P2_NTT512(false, ntt::SCALE_TABLE);
