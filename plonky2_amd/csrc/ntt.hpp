@@ -160,6 +160,8 @@ struct RegPassArgs {
     const u64 *local;        // local[2^m + e] = w_{2^m}^e (forward or inverse), m <= TILE_LOG
     unsigned rounds[4];      // radix bits of each round, sum = log_r, zero-terminated
     int inverse;
+    const u64 *twid;         // inter-pass twiddles of this (strided) pass as a table laid out like one block of the data,
+                             // twid[(i << log_stride) + col] = w_{n'}^(col * bitrev(i)); null = build them from the root tables
     unsigned zloop;          // > 0: this workgroup produces z = 0..zloop-1 itself (coset LDE first pass: the
                              // coefficient tile is fetched from HBM once and re-read from L2 for the other cosets)
 };
@@ -294,21 +296,41 @@ __global__ void __launch_bounds__(NT, MINW) ntt_regpass_kernel(RegPassArgs ra) {
             first = false;
         }
         // inter-pass twiddle w_{n'}^(base * k1), k1 = bitrev_logr(i), then coalesced store
-        for (unsigned e = tid; e < elems; e += NT) {
-            unsigned i = e >> logC, c = e & (C - 1);
-            u64 v = tile[pad_idx(e)];
-            if (log_stride) {
-                u32 k1 = __brev(i) >> (32 - a.log_r);
-                u64 ex = (u64)(base0 + c) * k1;
-                const u32 E = (u32)(ex << (32 - a.log_nblk));
-                u64 w = a.roots.hi[E >> 16];
-                if (E & 0xFFFFu) w = ntt_mul<NT>(w, a.roots.lo[E & 0xFFFFu]);
-                v = ntt_mul<NT>(v, w);
+        if (!CONTIG && log_stride && ra.twid) {  // from the per-pass table: one coalesced load instead of two gathers + a multiply
+            const u64 *tw = ra.twid + base0;
+            for (unsigned e = tid; e < elems; e += NT) {
+                unsigned i = e >> logC, c = e & (C - 1);
+                const size_t off = ((size_t)i << log_stride) + c;
+                u64 v = ntt_mul<NT>(tile[pad_idx(e)], tw[off]);
+                out[off] = a.canon_out ? gl::canon(v) : v;
             }
-            out[((size_t)i << log_stride) + c] = a.canon_out ? gl::canon(v) : v;
+        } else {
+            for (unsigned e = tid; e < elems; e += NT) {
+                unsigned i = e >> logC, c = e & (C - 1);
+                u64 v = tile[pad_idx(e)];
+                if (log_stride) {
+                    u32 k1 = __brev(i) >> (32 - a.log_r);
+                    u64 ex = (u64)(base0 + c) * k1;
+                    const u32 E = (u32)(ex << (32 - a.log_nblk));
+                    u64 w = a.roots.hi[E >> 16];
+                    if (E & 0xFFFFu) w = ntt_mul<NT>(w, a.roots.lo[E & 0xFFFFu]);
+                    v = ntt_mul<NT>(v, w);
+                }
+                out[((size_t)i << log_stride) + c] = a.canon_out ? gl::canon(v) : v;
+            }
         }
         if (z + 1 < z_end) __syncthreads();  // the tile is reused by the next coset
     }
+}
+
+// the inter-pass twiddles of a strided pass over blocks of 2^log_nblk elements with 2^log_r rows per tile column
+__global__ void interpass_twiddle_kernel(u64 *t, unsigned log_nblk, unsigned log_r, RootTable roots) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >> log_nblk) return;
+    const unsigned log_stride = log_nblk - log_r;
+    const u32 i = (u32)(idx >> log_stride), col = (u32)(idx & (((size_t)1 << log_stride) - 1));
+    const u32 k1 = log_r ? __brev(i) >> (32 - log_r) : 0;
+    t[idx] = gl::canon(root_pow(roots, (u32)(((u64)col * k1) << (32 - log_nblk))));
 }
 
 // out[bitrev_log_n(i)] = canon(in[i])   (util/src/lib.rs:53-62 semantics)

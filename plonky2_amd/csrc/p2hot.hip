@@ -42,6 +42,7 @@ struct p2hot_ctx {
     } scratch[3];  // 0: NTT temporary, 1: final_poly, 2: FRI commit phase (grow-only, reused across calls)
     // coset scale tables keyed by (log_n, rate_bits, shift, first block, block count, first-pass log_r)
     std::map<std::tuple<unsigned, unsigned, u64, size_t, size_t, unsigned>, u64 *> scale_cache;
+    std::map<std::tuple<int, unsigned, unsigned>, u64 *> twid_cache;  // (inverse, log_nblk, log_r) -> inter-pass twiddle table
     // live per-kernel timing (HIP events on the launch stream), off by default
     bool profiling = false;
     struct ProfRec {
@@ -184,6 +185,7 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
 #endif
     for (auto &kv : ctx->scale_cache) (void)hipFree(kv.second);
+    for (auto &kv : ctx->twid_cache) (void)hipFree(kv.second);
     for (auto &s : ctx->scratch)
         if (s.p) (void)hipFree(s.p);
     if (ctx->tables) (void)hipFree(ctx->tables);
@@ -329,6 +331,22 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
             ntt::RegPassArgs ra{};
             ra.a = a;
             const bool inverse = roots.lo == ctx->inv.lo;
+            // strided passes multiply by w_{n'}^(col * k1) on the way out: the same 2^log_nblk values for every block, polynomial
+            // and coset, kept as a table (<= 128 MiB) laid out like a block so that the load is as coalesced as the store
+            ra.twid = nullptr;
+            if (log_nblk > a.log_r && log_nblk <= 24) {
+                auto key = std::make_tuple((int)inverse, log_nblk, a.log_r);
+                auto it = ctx->twid_cache.find(key);
+                if (it == ctx->twid_cache.end()) {
+                    u64 *t = nullptr;
+                    P2_HIP(ctx, hipMalloc((void **)&t, (size_t)8 << log_nblk));
+                    P2HOT_LAUNCH(ntt::interpass_twiddle_kernel, dim3(cdiv((size_t)1 << log_nblk, 256)), dim3(256), 0, ctx->stream,
+                                 t, log_nblk, a.log_r, roots);
+                    P2_LAUNCH_CHECK(ctx);
+                    it = ctx->twid_cache.emplace(key, t).first;
+                }
+                ra.twid = it->second;
+            }
             ra.local = inverse ? ctx->local_inv : ctx->local_fwd;
             ra.inverse = inverse;
             // rounds of radix <= 2^maxp, remainder split as evenly as possible.  Radix 8 with 512 threads
