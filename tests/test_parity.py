@@ -59,6 +59,29 @@ def test_poseidon_random_vs_oracle(eng, ora):
     assert (got < np.uint64(P)).all()
 
 
+def test_poseidon_edge_states_vs_oracle(eng, ora):
+    """states built from the boundary words of the representation (0, 1, 2^32 -+ 1, P -+ 1, P, 2^64 - 1) in every
+    position pattern: the carry / borrow folds of the hand-written multiply and row-fold streams see their extremes"""
+    from plonky2_amd.hash.poseidon import poseidon
+    edge = [0, 1, 2**32 - 1, 2**32, 2**32 + 1, P - 1, P, P + 1, 2**63, 2**64 - 2**32, 2**64 - 1]
+    rng = np.random.default_rng(3)
+    states = []
+    for v in edge:
+        states.append([v] * 12)                                   # the same word everywhere
+        states.append([v if i % 2 else edge[(i + 3) % len(edge)] for i in range(12)])
+        states.append([v if i == 0 else 0 for i in range(12)])    # only the word the partial rounds raise
+    for _ in range(64 + 31):                                       # random mixtures of edge words
+        states.append([edge[int(k)] for k in rng.integers(0, len(edge), 12)])
+    s = np.array(states, dtype=np.uint64)
+    got = poseidon(s.copy(), eng)                                  # one permutation per lane (poseidon.hpp)
+    exp = np.stack([ora.poseidon(x) for x in s])
+    assert (got == exp).all()
+    # the quad-cooperative kernel (poseidon4.hpp) through the leaf hash of a small batch: 8-word rows = one permutation
+    from plonky2_amd.hash.poseidon import hash_or_noop_batch
+    rows = s[:64, :8].copy()
+    assert (hash_or_noop_batch(rows, eng) == np.stack([ora.hash_or_noop(r) for r in rows])).all()
+
+
 def test_hash_no_pad_and_two_to_one(eng, ora):
     from plonky2_amd.hash.poseidon import hash_no_pad, hash_or_noop_batch, two_to_one
     rng = np.random.default_rng(12)
