@@ -130,6 +130,24 @@ def test_fft_ifft_vs_oracle(eng, ora, log_n):
     assert (ifft(f, eng) == a % np.uint64(P)).all()
 
 
+@pytest.mark.parametrize("log_n", [3, 6, 12, 14])
+def test_fft_boundary_words_vs_oracle(eng, ora, log_n):
+    """transforms of vectors made of the representation's boundary words (0, 1, 2^32 -+ 1, P -+ 1, P, 2^64 - 1):
+    the butterflies' add / sub double folds and the hand-written power-of-two twiddle multiplies at their extremes"""
+    from plonky2_amd.field.fft import fft, ifft
+    edge = np.array([0, 1, 2**32 - 1, 2**32, 2**32 + 1, P - 1, P, P + 1, 2**63, 2**64 - 2**32, 2**64 - 1], dtype=np.uint64)
+    rng = np.random.default_rng(log_n)
+    n = 1 << log_n
+    rows = [np.full(n, v, dtype=np.uint64) for v in (P - 1, 2**64 - 1, 2**32 - 1)]
+    rows += [edge[rng.integers(0, len(edge), n)] for _ in range(3)]
+    a = np.stack(rows)
+    f = fft(a.copy(), eng)
+    for k in range(len(a)):
+        assert (f[k] == ora.fft(a[k].copy()) % np.uint64(P)).all(), k
+    back = ifft(f.copy(), eng)
+    assert (back == a % np.uint64(P)).all()
+
+
 def test_fft_three_pass_sizes(eng, ora):
     """log_n = 21 is the largest two-pass size (a 9-bit strided pass); log_n >= 22 takes three passes"""
     from plonky2_amd.field.fft import ifft
