@@ -74,7 +74,7 @@ class ShardedCommit:
                  want_leaves=False, pipeline_chunks=None, gather_digests=True):
         self.eng, self.dist, self.rank, self.world = engine, dist, rank, world
         if pipeline_chunks is None:
-            pipeline_chunks = 1 if os.environ.get("P2HOT_SYNC_COLLECTIVES") == "1" else 4
+            pipeline_chunks = 1 if os.environ.get("P2HOT_SYNC_COLLECTIVES") == "1" else 8
         self.pipeline_chunks = pipeline_chunks
         self.gather_digests = gather_digests
         self.plan = p = ShardPlan(W, log_n, rate_bits, cap_height, world)
