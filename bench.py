@@ -268,7 +268,7 @@ def main():
                             / (k["ms_per_launch"] * 1e-3 * k["launches"] / args.steps) / 1e9,
                 "frac": (16 * W * (n // world if world > 1 else n) + 16 * W * rows_local)
                         / (k["ms_per_launch"] * 1e-3 * k["launches"] / args.steps) / 1e9 / HBM_PEAK_GBS,
-                "note": "HBM-bound by design, measured VALU-bound (about 250 VALU instructions per element-pass)"})(
+                "note": "HBM-bound by design, measured VALU-bound (about 210 VALU instructions per element-pass, profiles/*_pmc_sq.txt)"})(
                 kern.get("ntt_pass_contig")),
             "kernels": kern,
             "algorithmic_bytes_per_step": ab,
