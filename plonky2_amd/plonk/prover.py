@@ -53,3 +53,33 @@ def partial_products_and_zs_commitment(wires, sigmas, k_is, quotient_degree_fact
     eng = engine or default_engine()
     zs_pp = all_wires_permutation_partial_products(wires, sigmas, k_is, quotient_degree_factor, betas, gammas, eng)
     return PolynomialBatch.from_values(zs_pp, rate_bits, False, cap_height, engine=eng)
+
+
+def quotient_poly_chunks(quotient_values, degree_bits, quotient_degree_factor, engine=None):
+    """The gate-independent tail of the quotient computation (prover.rs:274-289, :810-815): the quotient polynomials
+    arrive as values on the coset g*H of size n << ceil(log2(quotient_degree_factor)) (one row per challenge, natural
+    order), are interpolated with coset_ifft, trimmed to quotient_degree_factor * n coefficients (the reference panics
+    with "Quotient has failed, the vanishing polynomial is not divisible by Z_H" if the tail is not zero) and split
+    into quotient_degree_factor chunks of n coefficients.  Returns a device buffer
+    [num_challenges * quotient_degree_factor][n] ready for PolynomialBatch.from_coeffs."""
+    from ..engine import COSET_SHIFT
+    eng = engine or default_engine()
+    d = eng.dev(quotient_values)
+    if d.ndim != 2:
+        raise ValueError("expected [num_challenges][n << quotient_degree_bits]")
+    nc, m = d.shape
+    n = 1 << degree_bits
+    qbits = max(0, (quotient_degree_factor - 1).bit_length())
+    if m != n << qbits:
+        raise ValueError("quotient values must live on the coset of size n << ceil(log2(quotient_degree_factor))")
+    work = eng.mem.empty(nc, m)
+    work[:] = d                                                             # coset_ifft works in place
+    eng.check(eng.lib.p2hot_coset_ifft_dev(eng.ctx, eng.ptr(work), nc, m, degree_bits + qbits, COSET_SHIFT))
+    keep = n * quotient_degree_factor
+    if keep < m and eng.host(work[:, keep:]).any():                         # trim_to_len (polynomial/mod.rs:164-178)
+        raise ValueError("Quotient has failed, the vanishing polynomial is not divisible by Z_H")
+    out = eng.mem.empty(nc * quotient_degree_factor, n)
+    for ch in range(nc):                                                    # PolynomialCoeffs::chunks (mod.rs:136-142)
+        out[ch * quotient_degree_factor:(ch + 1) * quotient_degree_factor] = \
+            work[ch, :keep].reshape(quotient_degree_factor, n)
+    return out

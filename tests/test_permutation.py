@@ -117,3 +117,32 @@ def test_partial_products_shape_errors(eng):
         all_wires_permutation_partial_products(w, w, _k_is(4), 4, [1], [2], eng)   # degree must be < num_routed
     with pytest.raises(ValueError):
         all_wires_permutation_partial_products(w[:, :6], w[:, :6], _k_is(4), 2, [1], [2], eng)
+
+
+@pytest.mark.parametrize("degree_bits,factor,nc", [(5, 8, 2), (4, 6, 1), (3, 2, 2)])
+def test_quotient_poly_chunks(eng, ora, degree_bits, factor, nc):
+    """the gate-independent tail of the quotient (prover.rs:274-289, :810-815): coset_ifft, trim, split into chunks,
+    commit -- against the oracle's coset_ifft and from_coeffs; a quotient of too high degree is rejected like the
+    reference's trim_to_len"""
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    from plonky2_amd.plonk.prover import quotient_poly_chunks
+    rng = np.random.default_rng(degree_bits * 10 + factor)
+    n = 1 << degree_bits
+    qbits = (factor - 1).bit_length()
+    m = n << qbits
+    coeffs = np.zeros((nc, m), dtype=np.uint64)
+    coeffs[:, :n * factor] = rand_field(rng, nc, n * factor)                # degree < factor * n
+    values = np.stack([ora.coset_fft(c.copy()) for c in coeffs])            # what compute_quotient_polys evaluates
+    chunks = quotient_poly_chunks(values, degree_bits, factor, eng)
+    got = eng.host(chunks)
+    assert got.shape == (nc * factor, n)
+    for ch in range(nc):
+        back = ora.coset_ifft(values[ch].copy()) % np.uint64(P)
+        assert (got[ch * factor:(ch + 1) * factor].reshape(-1) == back[:n * factor]).all()
+    batch = PolynomialBatch.from_coeffs(chunks, 3, False, 1, engine=eng)
+    assert (batch.merkle_tree.cap.entries == ora.commit(got, 3, 1, False)["cap"]).all()
+    if n * factor < m:
+        coeffs[0, m - 1] = 5                                                # not divisible by Z_H
+        bad = np.stack([ora.coset_fft(c.copy()) for c in coeffs])
+        with pytest.raises(ValueError, match="Quotient has failed"):
+            quotient_poly_chunks(bad, degree_bits, factor, eng)
