@@ -1199,12 +1199,79 @@ extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t 
     const size_t nd = p2hot_num_digests(log_N, cap_height), cap_words = (size_t)4 << cap_height;
     DevBuf d_cols, d_coeffs, d_lde, d_leaves, d_dig, d_cap;
     const size_t Wn = (W ? W : 1) * n * 8, WN = (W ? W : 1) * N * 8;
+#ifndef P2HOT_EMU
+    const size_t kBlockCols = 16;  // columns per upload / transform block of the pipelined path
+    const bool pipeline = W >= 2 * kBlockCols && W * n >= ((size_t)1 << 22);
+#else
+    const bool pipeline = false;
+#endif
     P2_HIP(ctx, hipMalloc(&d_cols.p, Wn));
-    if (is_values) P2_HIP(ctx, hipMalloc(&d_coeffs.p, Wn));
+    if (is_values && !pipeline) P2_HIP(ctx, hipMalloc(&d_coeffs.p, Wn));  // the pipelined path transforms in place
     P2_HIP(ctx, hipMalloc(&d_lde.p, WN));
     if (leaves_out) P2_HIP(ctx, hipMalloc(&d_leaves.p, WN));
     P2_HIP(ctx, hipMalloc(&d_dig.p, (nd ? nd : 1) * 32));
     P2_HIP(ctx, hipMalloc(&d_cap.p, cap_words * 8));
+#ifndef P2HOT_EMU
+    // Large batches: the PCIe copies run on the side stream beside the compute stream.  Column blocks are uploaded,
+    // transformed (iNTT) and extended (LDE) one after the other -- the upload of block b+1 overlaps the transforms of
+    // block b -- and the coefficient blocks go back to the host while the leaf sponge runs.
+    if (pipeline) {
+        std::vector<hipEvent_t> up, done;
+        auto pipelined = [&]() -> int {
+            const size_t nb = (W + kBlockCols - 1) / kBlockCols;
+            for (size_t c = 0; c < W; ++c)
+                if (!cols[c]) P2_FAIL(ctx, P2HOT_EINVAL, "commit: column %zu is null", c);
+            for (size_t b = 0; b < 2 * nb; ++b) {
+                hipEvent_t e;
+                P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                (b < nb ? up : done).push_back(e);
+            }
+            // the side stream must not start before work already queued on the compute stream has finished with d_cols
+            P2_HIP(ctx, hipEventRecord(ctx->join_event, ctx->stream));
+            P2_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->join_event, 0));
+            for (size_t b = 0; b < nb; ++b) {
+                const size_t c0 = b * kBlockCols, cnt = (c0 + kBlockCols <= W ? kBlockCols : W - c0);
+                for (size_t c = c0; c < c0 + cnt; ++c)
+                    P2_HIP(ctx, hipMemcpyAsync(d_cols.u() + c * n, cols[c], n * 8, hipMemcpyHostToDevice, ctx->side));
+                P2_HIP(ctx, hipEventRecord(up[b], ctx->side));
+                P2_HIP(ctx, hipStreamWaitEvent(ctx->stream, up[b], 0));
+                u64 *blk = d_cols.u() + c0 * n;  // the block becomes its coefficients in place
+                if (is_values) {
+                    P2_TRY(p2hot_ifft_dev(ctx, blk, cnt, n, log_n));
+                } else if (coeffs_out) {
+                    P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(cnt * n, 256)), dim3(256), 0, ctx->stream, blk, cnt * n);
+                    P2_LAUNCH_CHECK(ctx);
+                }
+                P2_HIP(ctx, hipEventRecord(done[b], ctx->stream));
+                P2_TRY(p2hot_coset_lde_dev(ctx, blk, cnt, n, log_n, rate_bits, gl::COSET_SHIFT, 0, N, d_lde.u() + c0 * N, N));
+            }
+            P2_TRY(p2hot_merkle_dev(ctx, d_lde.u(), 0, N, W, log_N, cap_height, 0, N, d_dig.u(), d_cap.u()));
+            if (leaves_out) P2_TRY(p2hot_transpose_dev(ctx, d_lde.u(), N, W, N, d_leaves.u()));
+            // queued behind the uploads on the side stream; each waits for its block's transform only
+            if (coeffs_out)
+                for (size_t b = 0; b < nb; ++b) {
+                    const size_t c0 = b * kBlockCols, cnt = (c0 + kBlockCols <= W ? kBlockCols : W - c0);
+                    P2_HIP(ctx, hipStreamWaitEvent(ctx->side, done[b], 0));
+                    P2_HIP(ctx, hipMemcpyAsync(coeffs_out + c0 * n, d_cols.u() + c0 * n, cnt * n * 8, hipMemcpyDeviceToHost, ctx->side));
+                }
+            if (leaves_out) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, W * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+            if (digests_out && nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
+            if (cap_out) P2_HIP(ctx, hipMemcpyAsync(cap_out, d_cap.p, cap_words * 8, hipMemcpyDeviceToHost, ctx->stream));
+            return P2HOT_OK;
+        };
+        int prc = pipelined();
+        hipError_t e1 = hipStreamSynchronize(ctx->side), e2 = hipStreamSynchronize(ctx->stream);
+        for (hipEvent_t ev : up) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : done) (void)hipEventDestroy(ev);
+        if (prc == P2HOT_OK && (e1 != hipSuccess || e2 != hipSuccess))
+            P2_FAIL(ctx, P2HOT_EHIP, "commit: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        if (prc == P2HOT_OK && handle_out) {
+            *handle_out = new p2hot_batch{ctx, d_lde.u(), W, N};
+            d_lde.p = nullptr;  // ownership moves to the handle
+        }
+        return prc;
+    }
+#endif
     auto body = [&]() -> int {
         for (size_t c = 0; c < W; ++c) {
             if (!cols[c]) P2_FAIL(ctx, P2HOT_EINVAL, "commit: column %zu is null", c);

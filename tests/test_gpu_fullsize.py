@@ -172,3 +172,35 @@ def test_sharded_commit_ranks_on_one_gpu(gpu, ora, chunks, gather):
             assert (row == o["leaves"][x]).all()
             assert (path == ora.merkle_prove(x, p.N, cap, o["digests"])).all()
             assert ora.merkle_verify(row, x, o["cap"], path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("is_values,want_leaves", [(True, False), (False, True)])
+def test_host_pointer_commit_pipelined_path(gpu, ora, is_values, want_leaves):
+    """p2hot_commit above its pipelining threshold (column blocks uploaded on the side stream beside the transforms,
+    coefficient blocks downloaded beside the leaf sponge): same bytes as the oracle, and as the small-batch path"""
+    import ctypes as C
+    rng = np.random.default_rng(4242)
+    W, log_n, rb, cap = 37, 17, 3, 4          # W * n = 2^22.2 elements: 3 column blocks, the last one partial
+    n, N = 1 << log_n, 1 << (log_n + rb)
+    cols = [rand_field(rng, n, noncanonical=True) for _ in range(W)]
+    ptrs = (C.c_void_p * W)(*[c.ctypes.data for c in cols])
+    coeffs = np.zeros((W, n), dtype=np.uint64)
+    leaves = np.zeros((N, W), dtype=np.uint64) if want_leaves else None
+    nd = gpu.num_digests(log_n + rb, cap)
+    digests = np.zeros((nd, 4), dtype=np.uint64)
+    capv = np.zeros((1 << cap, 4), dtype=np.uint64)
+    handle = C.c_void_p()
+    gpu.check(gpu.lib.p2hot_commit(gpu.ctx, ptrs, W, log_n, rb, cap, 1 if is_values else 0, coeffs.ctypes.data,
+                                   leaves.ctypes.data if want_leaves else None, digests.ctypes.data, capv.ctypes.data,
+                                   C.byref(handle)))
+    o = ora.commit(np.stack(cols), rb, cap, is_values)
+    assert (coeffs == o["coeffs"] % np.uint64(P)).all()
+    assert (digests == o["digests"]).all() and (capv == o["cap"]).all()
+    if want_leaves:
+        assert (leaves == o["leaves"]).all()
+    idx = np.array([0, 77, N - 1], dtype=np.uint64)
+    rows = np.zeros((3, W), dtype=np.uint64)
+    gpu.check(gpu.lib.p2hot_batch_rows(handle, idx.ctypes.data, 3, rows.ctypes.data))
+    assert (rows == o["leaves"][idx.astype(np.int64)]).all()
+    gpu.lib.p2hot_batch_free(handle)
