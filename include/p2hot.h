@@ -222,12 +222,20 @@ int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bit
 typedef struct p2hot_batch p2hot_batch; /* device-resident PolynomialBatch: coefficients + LDE + tree */
 /* from_values / from_coeffs.  cols: W host pointers to n words each (Vec<PolynomialValues<F>>).
  * coeffs_out [W][n], leaves_out [N][W], digests_out, cap_out: caller-allocated or NULL.
- * handle_out (optional): keeps the device-resident batch for p2hot_batch_rows; free with p2hot_batch_free. */
+ * handle_out (optional): keeps the device-resident batch (LDE matrix + digests) for p2hot_batch_rows /
+ * p2hot_batch_paths; free with p2hot_batch_free. */
 int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
                  unsigned cap_height, int is_values, uint64_t *coeffs_out, uint64_t *leaves_out,
                  uint64_t *digests_out, uint64_t *cap_out, p2hot_batch **handle_out);
 /* MerkleTree::get for m leaf indices (merkle_tree.rs:227): out [m][W] */
 int p2hot_batch_rows(p2hot_batch *batch, const uint64_t *row_idx, size_t m, uint64_t *out);
+/* merkle_tree_prove (merkle_tree.rs:151-190) for m leaf indices from the batch's device-resident digests:
+ * out [m][log2(N) - cap_height][4].  With it the caller may pass digests_out = NULL to p2hot_commit and never copy
+ * the digest array (0.54 GB at the C3 shape) to the host: the query phase needs a few dozen paths per tree. */
+int p2hot_batch_paths(p2hot_batch *batch, const uint64_t *leaf_idx, size_t m, uint64_t *out);
+/* returns the batch's device blocks to its context's block cache; call it BEFORE p2hot_ctx_destroy of that context
+ * (the host-pointer entry points keep their device blocks in a grow-only per-context cache: a fresh allocation of the
+ * 9 GB LDE matrix costs up to a second) */
 void p2hot_batch_free(p2hot_batch *batch);
 
 #ifdef __cplusplus

@@ -67,6 +67,7 @@ SIGNATURES = {
     "p2hot_fri_pow": (i, [vp, vp, u, C.POINTER(u64)]),
     "p2hot_commit": (i, [vp, C.POINTER(vp), sz, u, u, u, i, vp, vp, vp, vp, C.POINTER(vp)]),
     "p2hot_batch_rows": (i, [vp, vp, sz, vp]),
+    "p2hot_batch_paths": (i, [vp, vp, sz, vp]),
     "p2hot_batch_free": (None, [vp]),
 }
 

@@ -42,7 +42,11 @@ struct p2hot_ctx {
     } scratch[3];  // 0: NTT temporary, 1: final_poly, 2: FRI commit phase (grow-only, reused across calls)
     // coset scale tables keyed by (log_n, rate_bits, shift, first block, block count, first-pass log_r)
     std::map<std::tuple<unsigned, unsigned, u64, size_t, size_t, unsigned>, u64 *> scale_cache;
-    std::map<std::tuple<int, unsigned, unsigned>, u64 *> twid_cache;  // (inverse, log_nblk, log_r) -> inter-pass twiddle table
+    std::map<std::tuple<int, unsigned, unsigned>, u64 *> twid_cache;
+    // grow-only cache of device blocks for the host-pointer entry points: a fresh hipMalloc of the 9 GB LDE matrix
+    // costs up to a second (the driver clears VRAM), so blocks go back to this list instead of hipFree
+    std::vector<std::pair<void *, size_t>> pool_free;  // (pointer, capacity)
+    std::map<void *, size_t> pool_live;  // (inverse, log_nblk, log_r) -> inter-pass twiddle table
     // live per-kernel timing (HIP events on the launch stream), off by default
     bool profiling = false;
     struct ProfRec {
@@ -119,6 +123,51 @@ static int scratch_get(p2hot_ctx *ctx, int slot, size_t bytes, void **out) {
     return P2HOT_OK;
 }
 
+// block cache of the host-pointer entry points (see p2hot_ctx::pool_free)
+static int pool_alloc(p2hot_ctx *ctx, size_t bytes, void **out) {
+    if (bytes == 0) bytes = 8;
+    size_t best = ctx->pool_free.size();
+    for (size_t k = 0; k < ctx->pool_free.size(); ++k) {
+        const size_t cap = ctx->pool_free[k].second;
+        if (cap >= bytes && cap <= 2 * bytes + ((size_t)1 << 20) && (best == ctx->pool_free.size() || cap < ctx->pool_free[best].second))
+            best = k;
+    }
+    if (best != ctx->pool_free.size()) {
+        *out = ctx->pool_free[best].first;
+        ctx->pool_live[*out] = ctx->pool_free[best].second;
+        ctx->pool_free.erase(ctx->pool_free.begin() + best);
+        return P2HOT_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {  // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        for (auto &b : ctx->pool_free) (void)hipFree(b.first);
+        ctx->pool_free.clear();
+        P2_HIP(ctx, hipMalloc(&p, bytes));
+    }
+    ctx->pool_live[p] = bytes;
+    *out = p;
+    return P2HOT_OK;
+}
+static void pool_release(p2hot_ctx *ctx, void *p) {
+    if (!p) return;
+    auto it = ctx->pool_live.find(p);
+    if (it == ctx->pool_live.end()) return;
+    ctx->pool_free.emplace_back(p, it->second);
+    ctx->pool_live.erase(it);
+}
+namespace {
+struct PoolBuf {  // returns its block to the context's cache on scope exit (the owner syncs the stream first)
+    p2hot_ctx *ctx;
+    void *p = nullptr;
+    explicit PoolBuf(p2hot_ctx *c) : ctx(c) {}
+    PoolBuf(const PoolBuf &) = delete;
+    ~PoolBuf() { pool_release(ctx, p); }
+    u64 *u() const { return (u64 *)p; }
+};
+}  // namespace
+
 extern "C" const char *p2hot_version(void) { return "p2hot 0.1 (gfx950)"; }
 extern "C" int p2hot_is_emulated(void) {
 #ifdef P2HOT_EMU
@@ -186,6 +235,8 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
 #endif
     for (auto &kv : ctx->scale_cache) (void)hipFree(kv.second);
     for (auto &kv : ctx->twid_cache) (void)hipFree(kv.second);
+    for (auto &b : ctx->pool_free) (void)hipFree(b.first);
+    for (auto &kv : ctx->pool_live) (void)hipFree(kv.first);
     for (auto &s : ctx->scratch)
         if (s.p) (void)hipFree(s.p);
     if (ctx->tables) (void)hipFree(ctx->tables);
@@ -809,16 +860,6 @@ extern "C" int p2hot_challenger_step(p2hot_challenger *ch, const uint64_t *obser
 }
 
 // ------------------------------------------------------------------ FRI commit phase
-namespace {
-struct DevBuf {  // frees on scope exit (after a stream sync by the owner)
-    void *p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
-    u64 *u() const { return (u64 *)p; }
-};
-}  // namespace
-
 // coeffs: host [n][2] interleaved, or (d_planar != NULL) device planes [2][n]
 static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_t *d_planar, unsigned log_n,
                            unsigned rate_bits, unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
@@ -1184,6 +1225,8 @@ struct p2hot_batch {
     p2hot_ctx *ctx;
     u64 *d_lde;
     size_t W, N;
+    u64 *d_dig;  // the tree's digest array (reference layout) stays on the device for p2hot_batch_paths
+    unsigned log_N, cap_height;
 };
 
 extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
@@ -1197,7 +1240,7 @@ extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t 
     const unsigned log_N = log_n + rate_bits;
     if (cap_height > log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit: cap_height %u > log2(N) %u (merkle_tree.rs:195-200)", cap_height, log_N);
     const size_t nd = p2hot_num_digests(log_N, cap_height), cap_words = (size_t)4 << cap_height;
-    DevBuf d_cols, d_coeffs, d_lde, d_leaves, d_dig, d_cap;
+    PoolBuf d_cols(ctx), d_coeffs(ctx), d_lde(ctx), d_leaves(ctx), d_dig(ctx), d_cap(ctx);
     const size_t Wn = (W ? W : 1) * n * 8, WN = (W ? W : 1) * N * 8;
 #ifndef P2HOT_EMU
     const size_t kBlockCols = 16;  // columns per upload / transform block of the pipelined path
@@ -1205,12 +1248,12 @@ extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t 
 #else
     const bool pipeline = false;
 #endif
-    P2_HIP(ctx, hipMalloc(&d_cols.p, Wn));
-    if (is_values && !pipeline) P2_HIP(ctx, hipMalloc(&d_coeffs.p, Wn));  // the pipelined path transforms in place
-    P2_HIP(ctx, hipMalloc(&d_lde.p, WN));
-    if (leaves_out) P2_HIP(ctx, hipMalloc(&d_leaves.p, WN));
-    P2_HIP(ctx, hipMalloc(&d_dig.p, (nd ? nd : 1) * 32));
-    P2_HIP(ctx, hipMalloc(&d_cap.p, cap_words * 8));
+    P2_TRY(pool_alloc(ctx, Wn, &d_cols.p));
+    if (is_values && !pipeline) P2_TRY(pool_alloc(ctx, Wn, &d_coeffs.p));  // the pipelined path transforms in place
+    P2_TRY(pool_alloc(ctx, WN, &d_lde.p));
+    if (leaves_out) P2_TRY(pool_alloc(ctx, WN, &d_leaves.p));
+    P2_TRY(pool_alloc(ctx, (nd ? nd : 1) * 32, &d_dig.p));
+    P2_TRY(pool_alloc(ctx, cap_words * 8, &d_cap.p));
 #ifndef P2HOT_EMU
     // Large batches: the PCIe copies run on the side stream beside the compute stream.  Column blocks are uploaded,
     // transformed (iNTT) and extended (LDE) one after the other -- the upload of block b+1 overlaps the transforms of
@@ -1266,8 +1309,9 @@ extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t 
         if (prc == P2HOT_OK && (e1 != hipSuccess || e2 != hipSuccess))
             P2_FAIL(ctx, P2HOT_EHIP, "commit: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
         if (prc == P2HOT_OK && handle_out) {
-            *handle_out = new p2hot_batch{ctx, d_lde.u(), W, N};
-            d_lde.p = nullptr;  // ownership moves to the handle
+            *handle_out = new p2hot_batch{ctx, d_lde.u(), W, N, d_dig.u(), log_N, cap_height};
+            d_lde.p = nullptr;  // ownership moves to the handle (still a live block of the context's cache)
+            d_dig.p = nullptr;
         }
         return prc;
     }
@@ -1297,8 +1341,9 @@ extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t 
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (rc == P2HOT_OK && e != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "commit: %s", hipGetErrorString(e));
     if (rc == P2HOT_OK && handle_out) {
-        *handle_out = new p2hot_batch{ctx, d_lde.u(), W, N};
+        *handle_out = new p2hot_batch{ctx, d_lde.u(), W, N, d_dig.u(), log_N, cap_height};
         d_lde.p = nullptr;  // ownership moves to the handle
+        d_dig.p = nullptr;
     }
     return rc;
 }
@@ -1310,9 +1355,9 @@ extern "C" int p2hot_batch_rows(p2hot_batch *b, const uint64_t *row_idx, size_t 
     if (!row_idx || !out) P2_FAIL(ctx, P2HOT_EINVAL, "batch_rows: null buffer");
     for (size_t i = 0; i < m; ++i)
         if (row_idx[i] >= b->N) P2_FAIL(ctx, P2HOT_EINVAL, "batch_rows: index %llu out of range", (unsigned long long)row_idx[i]);
-    DevBuf d_idx, d_out;
-    P2_HIP(ctx, hipMalloc(&d_idx.p, m * 8));
-    P2_HIP(ctx, hipMalloc(&d_out.p, m * b->W * 8));
+    PoolBuf d_idx(ctx), d_out(ctx);
+    P2_TRY(pool_alloc(ctx, m * 8, &d_idx.p));
+    P2_TRY(pool_alloc(ctx, m * b->W * 8, &d_out.p));
     P2_HIP(ctx, hipMemcpyAsync(d_idx.p, row_idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
     int rc = p2hot_gather_rows_dev(ctx, b->d_lde, b->N, b->W, d_idx.u(), m, d_out.u());
     if (rc == P2HOT_OK) {
@@ -1323,9 +1368,31 @@ extern "C" int p2hot_batch_rows(p2hot_batch *b, const uint64_t *row_idx, size_t 
     return rc;
 }
 
+extern "C" int p2hot_batch_paths(p2hot_batch *b, const uint64_t *leaf_idx, size_t m, uint64_t *out) {
+    if (!b) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = b->ctx;
+    const unsigned layers = b->log_N - b->cap_height;
+    if (m == 0 || layers == 0) return P2HOT_OK;
+    if (!leaf_idx || !out) P2_FAIL(ctx, P2HOT_EINVAL, "batch_paths: null buffer");
+    for (size_t i = 0; i < m; ++i)
+        if (leaf_idx[i] >= b->N) P2_FAIL(ctx, P2HOT_EINVAL, "batch_paths: index %llu out of range", (unsigned long long)leaf_idx[i]);
+    PoolBuf d_idx(ctx), d_out(ctx);
+    P2_TRY(pool_alloc(ctx, m * 8, &d_idx.p));
+    P2_TRY(pool_alloc(ctx, m * layers * 32, &d_out.p));
+    P2_HIP(ctx, hipMemcpyAsync(d_idx.p, leaf_idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = p2hot_merkle_paths_dev(ctx, b->d_dig, b->log_N, b->cap_height, d_idx.u(), m, d_out.u());
+    if (rc == P2HOT_OK) {
+        hipError_t e = hipMemcpyAsync(out, d_out.p, m * layers * 32, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = P2HOT_EHIP;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
 extern "C" void p2hot_batch_free(p2hot_batch *b) {
     if (!b) return;
     (void)hipStreamSynchronize(b->ctx->stream);
-    (void)hipFree(b->d_lde);
+    pool_release(b->ctx, b->d_lde);
+    pool_release(b->ctx, b->d_dig);
     delete b;
 }

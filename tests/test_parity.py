@@ -306,6 +306,21 @@ def test_host_pointer_commit_abi(eng, ora):
     rows = np.zeros((3, W), dtype=np.uint64)
     eng.check(eng.lib.p2hot_batch_rows(handle, idx.ctypes.data, 3, rows.ctypes.data))
     assert (rows == o["leaves"][idx.astype(np.int64)]).all()
+    # Merkle paths from the handle's device-resident digests (merkle_tree_prove, merkle_tree.rs:151-190)
+    layers = log_n + rb - cap
+    paths = np.zeros((3, layers, 4), dtype=np.uint64)
+    eng.check(eng.lib.p2hot_batch_paths(handle, idx.ctypes.data, 3, paths.ctypes.data))
+    for q, i in enumerate(idx):
+        assert (paths[q] == ora.merkle_prove(int(i), N, cap, o["digests"])).all()
+        assert ora.merkle_verify(rows[q], int(i), o["cap"], paths[q])
+    bad = np.array([N], dtype=np.uint64)
+    assert eng.lib.p2hot_batch_paths(handle, bad.ctypes.data, 1, paths.ctypes.data) != 0
+    eng.lib.p2hot_batch_free(handle)
+    # digests_out = NULL: the digest array never leaves the device, paths still come from the handle
+    handle = C.c_void_p()
+    eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, None, None, None, capv.ctypes.data, C.byref(handle)))
+    eng.check(eng.lib.p2hot_batch_paths(handle, idx.ctypes.data, 3, paths.ctypes.data))
+    assert (paths[1] == ora.merkle_prove(int(idx[1]), N, cap, o["digests"])).all() and (capv == o["cap"]).all()
     eng.lib.p2hot_batch_free(handle)
 
 

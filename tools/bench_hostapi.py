@@ -32,3 +32,20 @@ for want_leaves in (False, True, False, True):
     dt = time.perf_counter() - t0
     print("p2hot_commit W=%d 2^%d rows, leaves_out=%s: %.1f ms  -> %.2f GFE/s PCIe-inclusive"
           % (W, log_n, want_leaves, dt * 1e3, W * N / dt / 1e9))
+
+# digests kept on the device (paths served from the handle by p2hot_batch_paths): only the columns go in and the
+# coefficients + cap come back
+for _ in range(2):
+    handle = C.c_void_p()
+    t0 = time.perf_counter()
+    eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, coeffs.ctypes.data, None, None, capv.ctypes.data,
+                                   C.byref(handle)))
+    dt = time.perf_counter() - t0
+    idx = np.arange(28, dtype=np.uint64) * 12345 % N
+    paths = np.zeros((28, log_n + rb - cap, 4), dtype=np.uint64)
+    t1 = time.perf_counter()
+    eng.check(eng.lib.p2hot_batch_paths(handle, idx.ctypes.data, 28, paths.ctypes.data))
+    dq = time.perf_counter() - t1
+    eng.lib.p2hot_batch_free(handle)
+    print("p2hot_commit W=%d 2^%d rows, digests on device: %.1f ms  -> %.2f GFE/s PCIe-inclusive; 28 paths %.2f ms"
+          % (W, log_n, dt * 1e3, W * N / dt / 1e9, dq * 1e3))
