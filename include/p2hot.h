@@ -171,6 +171,9 @@ int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned log_n, uns
  * recursion: dummy cap observations + challenges up to max_num_query_steps, zero observations up to
  * final_poly_coeff_len) for the NEXT p2hot_fri_commit / p2hot_fri_commit_dev call on this context; 0 = None. */
 int p2hot_fri_set_padding(p2hot_ctx *ctx, unsigned max_num_query_steps, size_t final_poly_coeff_len);
+/* For the NEXT p2hot_fri_commit_dev call on this context: digests_out is a DEVICE buffer (the round trees' digest
+ * arrays stay on the GPU next to their leaves; Merkle paths then come from p2hot_merkle_paths_dev). */
+int p2hot_fri_set_device_digests(p2hot_ctx *ctx, int on);
 /* the same with the coefficients already on the device as two planes [2][n] (component 0, then component 1),
  * e.g. the output of p2hot_fri_final_poly_dev.  d_leaves_out is a DEVICE buffer (or NULL): the round trees' leaf
  * matrices stay on the GPU (same concatenated layout) and the query phase gathers the few rows it opens; the other

@@ -63,6 +63,7 @@ SIGNATURES = {
     "p2hot_eval_polys_dev": (i, [vp, vp, sz, u, vp, sz, vp]),
     "p2hot_merkle_paths_dev": (i, [vp, vp, u, u, vp, sz, vp]),
     "p2hot_partial_products_dev": (i, [vp, vp, sz, vp, sz, vp, u, u, u, vp, vp, u, vp, sz]),
+    "p2hot_fri_set_device_digests": (i, [vp, i]),
     "p2hot_fri_set_padding": (i, [vp, u, sz]),
     "p2hot_fri_pow": (i, [vp, vp, u, C.POINTER(u64)]),
     "p2hot_commit": (i, [vp, C.POINTER(vp), sz, u, u, u, i, vp, vp, vp, vp, C.POINTER(vp)]),

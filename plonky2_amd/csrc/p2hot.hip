@@ -34,6 +34,7 @@ struct p2hot_ctx {
     size_t quad_threshold = (size_t)1 << 15;  // launches with at most this many permutations use the quad kernels
     // starky multi-degree recursion padding of the next FRI commit (prover.rs:125-132, :142-147); 0 = None
     unsigned fri_max_num_query_steps = 0;
+    bool fri_device_digests = false;  // next p2hot_fri_commit_dev: digests_out is a device pointer
     size_t fri_final_poly_coeff_len = 0;  // measured on MI355X: no gain (the sponge's waves fill every CU; the two kernels time-slice)
     unsigned ntt_radix_bits = 3;  // 3: radix-8 rounds / 512 threads, 4: radix-16 / 256 threads
     struct Scratch {
@@ -936,7 +937,10 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
                                  n_leaves, digests.u(), cap.u()));
             const size_t nd = p2hot_num_digests(log_leaves, cap_height);
             if (digests_out) {
-                if (nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, digests.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
+                if (nd)
+                    P2_HIP(ctx, hipMemcpyAsync(digests_out, digests.p, nd * 32,
+                                               ctx->fri_device_digests && leaves_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                               ctx->stream));
                 digests_out += 4 * nd;
             }
             if (caps_out) {
@@ -988,6 +992,7 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
         return P2HOT_OK;
     };
     rc = body();
+    ctx->fri_device_digests = false;
     ctx->fri_max_num_query_steps = 0;
     ctx->fri_final_poly_coeff_len = 0;
     hipError_t e = hipStreamSynchronize(ctx->stream);  // host outputs are complete on return
@@ -1015,6 +1020,13 @@ extern "C" int p2hot_fri_commit_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs_pla
 
 // Option<usize> arguments of fri_committed_trees (prover.rs:89-90) for the NEXT p2hot_fri_commit* call on this
 // context (0 = None); they are consumed (reset to None) by that call.
+// digests_out of the NEXT p2hot_fri_commit_dev call is a DEVICE pointer (the round trees stay on the GPU entirely)
+extern "C" int p2hot_fri_set_device_digests(p2hot_ctx *ctx, int on) {
+    if (!ctx) return P2HOT_EINVAL;
+    ctx->fri_device_digests = on != 0;
+    return P2HOT_OK;
+}
+
 extern "C" int p2hot_fri_set_padding(p2hot_ctx *ctx, unsigned max_num_query_steps, size_t final_poly_coeff_len) {
     if (!ctx) return P2HOT_EINVAL;
     ctx->fri_max_num_query_steps = max_num_query_steps;

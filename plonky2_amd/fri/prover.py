@@ -47,7 +47,9 @@ def _commit(coeffs, planes, log_n, challenger, rate_bits, cap_height, reduction_
     n_leaf_words = max(1, 2 * sum(s[0] for s in sizes))
     # host-coefficient entry: leaves come back to the host; device-plane entry: they stay on the GPU
     leaves = np.zeros(n_leaf_words, dtype=np.uint64) if planes is None else eng.mem.empty(n_leaf_words)
-    digests = np.zeros(max(1, 4 * sum(s[2] for s in sizes)), dtype=np.uint64)
+    n_dig_words = max(1, 4 * sum(s[2] for s in sizes))
+    # device-plane entry: the digest arrays stay on the GPU as well (paths come from p2hot_merkle_paths_dev)
+    digests = np.zeros(n_dig_words, dtype=np.uint64) if planes is None else eng.mem.empty(n_dig_words)
     caps = np.zeros(max(1, 4 * ncap * len(sizes)), dtype=np.uint64)
     betas = np.zeros((max(1, len(sizes)), 2), dtype=np.uint64)
     final = np.zeros((max(1, n_final), 2), dtype=np.uint64)
@@ -57,8 +59,9 @@ def _commit(coeffs, planes, log_n, challenger, rate_bits, cap_height, reduction_
                                            challenger._h, leaves.ctypes.data, digests.ctypes.data, caps.ctypes.data,
                                            betas.ctypes.data, final.ctypes.data))
     else:
+        eng.check(eng.lib.p2hot_fri_set_device_digests(eng.ctx, 1))
         eng.check(eng.lib.p2hot_fri_commit_dev(eng.ctx, eng.ptr(planes), log_n, rate_bits, cap_height, ab, len(arity),
-                                               challenger._h, eng.ptr(leaves), digests.ctypes.data, caps.ctypes.data,
+                                               challenger._h, eng.ptr(leaves), eng.ptr(digests), caps.ctypes.data,
                                                betas.ctypes.data, final.ctypes.data))
     trees, lo, do = [], 0, 0
     for i, (mi, nl, nd) in enumerate(sizes):
@@ -67,9 +70,10 @@ def _commit(coeffs, planes, log_n, challenger, rate_bits, cap_height, reduction_
             tree = MerkleTree(leaves=lv, digests=digests[do:do + 4 * nd].reshape(nd, 4),
                               cap=caps[4 * ncap * i:4 * ncap * (i + 1)].reshape(ncap, 4), cap_height=cap_height)
         else:  # rows are fetched from the device on demand (MerkleTree::get of the few queried leaves)
-            tree = MerkleTree(leaves=None, digests=digests[do:do + 4 * nd].reshape(nd, 4),
+            tree = MerkleTree(leaves=None, digests=digests[do:do + 4 * nd].reshape(nd, 4) if nd else np.zeros((0, 4), np.uint64),
                               cap=caps[4 * ncap * i:4 * ncap * (i + 1)].reshape(ncap, 4), cap_height=cap_height, n_leaves=nl,
-                              leaf_getter=(lambda idx, lv=lv: eng.host(lv[np.asarray(idx, dtype=np.int64)])))
+                              leaf_getter=(lambda idx, lv=lv: eng.host(lv[np.asarray(idx, dtype=np.int64)])),
+                              engine=eng if nd else None)
         trees.append(tree)
         lo += 2 * mi
         do += 4 * nd
