@@ -1112,13 +1112,16 @@ extern "C" int p2hot_eval_polys_dev(p2hot_ctx *ctx, const uint64_t *const *d_pol
     const size_t n_seg = n >> seg_log;
     if (n_seg > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "eval_polys: polynomial too long");
     u64 *part;
-    P2_TRY(scratch_get(ctx, 1, n_polys * n_seg * 16, (void **)&part));
+    const size_t seg = (size_t)1 << seg_log;
+    P2_TRY(scratch_get(ctx, 1, (n_polys * n_seg * 2 + 2 * seg) * 8, (void **)&part));
+    u64 *w0 = part + n_polys * n_seg * 2, *w1 = w0 + seg;  // z^u, u < seg: shared by all segments and polynomials
     ProfScope ps(ctx, "eval_polys");
     for (size_t p = 0; p < n_points; ++p) {
         const gl::ext2 z{gl::canon(points[2 * p]), gl::canon(points[2 * p + 1])};
         const gl::ext2 zs = ext_pow(z, (u64)1 << seg_log);
-        P2HOT_LAUNCH(fri::eval_polys_stage1_kernel, dim3((unsigned)n_polys, (unsigned)n_seg), dim3(256), 0, ctx->stream,
-                     d_poly_table, seg_log, z, ext_pow(z, 256), part);
+        P2HOT_LAUNCH(fri::ext_powers_kernel, dim3(cdiv(seg, 256)), dim3(256), 0, ctx->stream, z, (unsigned)seg, w0, w1);
+        P2HOT_LAUNCH(fri::eval_polys_dot_kernel, dim3((unsigned)n_polys, (unsigned)n_seg), dim3(256), 0, ctx->stream,
+                     d_poly_table, seg_log, (const u64 *)w0, (const u64 *)w1, part);
         P2HOT_LAUNCH(fri::eval_polys_stage2_kernel, dim3((unsigned)n_polys), dim3(256), 0, ctx->stream, (const u64 *)part,
                      n_seg, zs, ext_pow(zs, 256), d_out + 2 * p * n_polys);
         P2_LAUNCH_CHECK(ctx);
