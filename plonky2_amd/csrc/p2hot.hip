@@ -1147,7 +1147,7 @@ extern "C" int p2hot_partial_products_dev(p2hot_ctx *ctx, const uint64_t *d_wire
     const size_t n_chunks = n >> chunk_log, per = (n_chunks + 1023) / 1024;
     // scratch: k_is | chunk denominators [num_chunks][n] | row totals [n] | chunk products | carries | flag
     const size_t words = num_routed + (size_t)num_chunks * n + n + 2 * n_chunks + 1;
-    u64 *base;
+    u64 *base = nullptr;
     P2_TRY(scratch_get(ctx, 0, words * 8, (void **)&base));
     u64 *d_k = base, *dchunk = d_k + num_routed, *total = dchunk + (size_t)num_chunks * n, *prod = total + n,
         *carry = prod + n_chunks;
