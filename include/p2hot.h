@@ -110,9 +110,11 @@ int p2hot_merkle_dev(p2hot_ctx *ctx, const uint64_t *d_leaves, int layout, size_
  * `count` words to d_out: a*b by the compiler-scheduled multiply, by the hand-scheduled single stream, by the 3-way
  * interleaved stream, a+b, a-b (all canonical), and a 0/1 flag that the other two mul3 lanes agreed. */
 int p2hot_field_selftest_dev(p2hot_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t count, uint64_t *d_out);
-/* rows of a column-major matrix: d_out[q][c] = d_colmajor[c * col_stride + d_idx[q]]
- * (PolynomialBatch::get_lde_values / MerkleTree::get, fri/oracle.rs:142-147, merkle_tree.rs:227) */
-int p2hot_gather_rows_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W,
+/* rows of a column-major matrix of `rows` rows: d_out[q][c] = d_colmajor[c * col_stride + d_idx[q]]
+ * (PolynomialBatch::get_lde_values / MerkleTree::get, fri/oracle.rs:142-147, merkle_tree.rs:227).
+ * The indices are device-resident, so they cannot be validated before the launch: an index >= rows reads nothing,
+ * its output row is zero, and the next p2hot_ctx_sync returns P2HOT_EINVAL (the reference panics on the slice index). */
+int p2hot_gather_rows_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t rows, size_t W,
                           const uint64_t *d_idx, size_t m, uint64_t *d_out);
 
 /* ---------------------------------------------------------------- PolynomialBatch (device pointers) */
@@ -165,23 +167,23 @@ int p2hot_challenger_step(p2hot_challenger *ch, const uint64_t *observe, size_t 
  *     final_out    [(m_last >> rate_bits)][2], m_last = N >> sum(arity_bits) */
 int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned log_n, unsigned rate_bits,
                      unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
+                     unsigned max_num_query_steps, size_t final_poly_coeff_len,
                      p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
                      uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out);
-/* The two Option<usize> arguments of fri_committed_trees (fri/prover.rs:89-90, used by starky's multi-degree
- * recursion: dummy cap observations + challenges up to max_num_query_steps, zero observations up to
- * final_poly_coeff_len) for the NEXT p2hot_fri_commit / p2hot_fri_commit_dev call on this context; 0 = None. */
-int p2hot_fri_set_padding(p2hot_ctx *ctx, unsigned max_num_query_steps, size_t final_poly_coeff_len);
-/* For the NEXT p2hot_fri_commit_dev call on this context: digests_out is a DEVICE buffer (the round trees' digest
- * arrays stay on the GPU next to their leaves; Merkle paths then come from p2hot_merkle_paths_dev). */
-int p2hot_fri_set_device_digests(p2hot_ctx *ctx, int on);
+/* max_num_query_steps / final_poly_coeff_len: the two Option<usize> arguments of fri_committed_trees
+ * (fri/prover.rs:89-90, used by starky's multi-degree recursion: dummy cap observations + challenges up to
+ * max_num_query_steps, :122-132, zero observations up to final_poly_coeff_len, :140-147); 0 = None. */
 /* the same with the coefficients already on the device as two planes [2][n] (component 0, then component 1),
  * e.g. the output of p2hot_fri_final_poly_dev.  d_leaves_out is a DEVICE buffer (or NULL): the round trees' leaf
- * matrices stay on the GPU (same concatenated layout) and the query phase gathers the few rows it opens; the other
- * outputs are host pointers as above. */
+ * matrices stay on the GPU (same concatenated layout) and the query phase gathers the few rows it opens.
+ * digests_out is a DEVICE buffer when digests_on_device != 0 (the round trees' digest arrays stay on the GPU next
+ * to their leaves; Merkle paths then come from p2hot_merkle_paths_dev), else a host buffer; the other outputs are
+ * host pointers as above. */
 int p2hot_fri_commit_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs_planar, unsigned log_n, unsigned rate_bits,
                          unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
+                         unsigned max_num_query_steps, size_t final_poly_coeff_len,
                          p2hot_challenger *challenger, uint64_t *d_leaves_out, uint64_t *digests_out,
-                         uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out);
+                         int digests_on_device, uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out);
 /* The final_poly construction of PolynomialBatch::prove_openings (fri/oracle.rs:186-213) on device-resident
  * coefficient polynomials: for every batch i with opening point z_i,
  *   F_i = ReducingFactor::reduce_polys_base(polys of the batch)      (util/reducing.rs:83-95)
@@ -213,7 +215,8 @@ int p2hot_partial_products_dev(p2hot_ctx *ctx, const uint64_t *d_wires, size_t w
                                unsigned degree, const uint64_t *betas, const uint64_t *gammas, unsigned num_challenges,
                                uint64_t *d_out, size_t out_stride);
 /* merkle_tree_prove (hash/merkle_tree.rs:151-190) for m leaf indices from a device-resident digest array
- * (the query phase, fri/prover.rs:204-258): d_out [m][log_leaves - cap_height][4] */
+ * (the query phase, fri/prover.rs:204-258): d_out [m][log_leaves - cap_height][4].  A leaf index
+ * >= 2^log_leaves yields a zero path and P2HOT_EINVAL at the next p2hot_ctx_sync (see p2hot_gather_rows_dev). */
 int p2hot_merkle_paths_dev(p2hot_ctx *ctx, const uint64_t *d_digests, unsigned log_leaves, unsigned cap_height,
                            const uint64_t *d_idx, size_t m, uint64_t *d_out);
 /* fri_proof_of_work (fri/prover.rs:153-202), deterministic: returns the SMALLEST valid witness
@@ -221,25 +224,141 @@ int p2hot_merkle_paths_dev(p2hot_ctx *ctx, const uint64_t *d_digests, unsigned l
  * response like the reference does. */
 int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bits, uint64_t *witness_out);
 
-/* ---------------------------------------------------------------- PolynomialBatch (host pointers) */
-typedef struct p2hot_batch p2hot_batch; /* device-resident PolynomialBatch: coefficients + LDE + tree */
-/* from_values / from_coeffs.  cols: W host pointers to n words each (Vec<PolynomialValues<F>>).
- * coeffs_out [W][n], leaves_out [N][W], digests_out, cap_out: caller-allocated or NULL.
- * handle_out (optional): keeps the device-resident batch (LDE matrix + digests) for p2hot_batch_rows /
- * p2hot_batch_paths; free with p2hot_batch_free. */
+/* ================================================================ prover session (HOST pointers)
+ * What the patched plonky2 crate calls from the prover's main thread with ordinary Vec<F> buffers.  Everything between
+ * the calls stays on the GPU behind opaque handles:
+ *   p2hot_batch       a device-resident PolynomialBatch (fri/oracle.rs:30-37): polynomials (coefficients), the LDE
+ *                     matrix = merkle_tree.leaves, merkle_tree.digests; optionally the input values
+ *   p2hot_cols        a device-resident Vec<PolynomialValues> / Vec<PolynomialCoeffs> ([W][n]) that never visits the host
+ *   p2hot_challenger  the Fiat-Shamir transcript (above)
+ * A context runs ONE host-pointer call at a time; a second thread entering gets P2HOT_EBUSY (plonky2 calls these
+ * from the main thread, outside its rayon closures). */
+#define P2HOT_EBUSY 5        /* another host-pointer call is running on this context */
+#define P2HOT_ECOMM 6        /* collective (RCCL / caller-supplied transport) failure in the multi-GPU mode */
+#define P2HOT_KEEP_VALUES 1u /* from_values: keep the input values on the device (p2hot_batch_values) */
+
+typedef struct p2hot_batch p2hot_batch;
+typedef struct p2hot_cols p2hot_cols;
+
+/* from_values (is_values != 0, fri/oracle.rs:57-79) / from_coeffs (:82-112), blinding = false.
+ * cols: W host pointers to n = 2^log_n words each (Vec<PolynomialValues<F>> / Vec<PolynomialCoeffs<F>>).
+ * coeffs_out [W][n], leaves_out [N][W], digests_out, cap_out: caller-allocated or NULL (anything not asked for is not
+ * copied back: the leaf matrix is 9 GB at the C3 shape, and the query phase needs only a few dozen rows and paths).
+ * handle_out (optional): the device-resident batch for p2hot_batch_rows / _paths / _coeffs, p2hot_eval_openings and
+ * p2hot_prove_openings; free with p2hot_batch_free.  flags: P2HOT_KEEP_VALUES. */
 int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
-                 unsigned cap_height, int is_values, uint64_t *coeffs_out, uint64_t *leaves_out,
+                 unsigned cap_height, int is_values, unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out,
                  uint64_t *digests_out, uint64_t *cap_out, p2hot_batch **handle_out);
+/* the same on a device-resident column set (the output of p2hot_partial_products / p2hot_quotient_chunks, or an upload).
+ * CONSUMES `cols`, on success and on failure: its block becomes the batch's coefficients or kept values, or is released. */
+int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate_bits, unsigned cap_height, int is_values,
+                      unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out,
+                      p2hot_batch **handle_out);
+/* a handle over device buffers the CALLER owns (the outputs of p2hot_commit_dev): nothing is copied, p2hot_batch_free
+ * frees only the handle.  d_coeffs [W][n] stride n, d_lde [W][N] stride N, d_digests the full tree's array. */
+int p2hot_batch_wrap_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, const uint64_t *d_lde, const uint64_t *d_digests, size_t W,
+                         unsigned log_n, unsigned rate_bits, unsigned cap_height, p2hot_batch **out);
+size_t p2hot_batch_width(const p2hot_batch *batch);
+unsigned p2hot_batch_degree_log(const p2hot_batch *batch);
+/* `polynomials[first .. first + count)` (fri/oracle.rs:32), canonical: out [count][n] */
+int p2hot_batch_coeffs(p2hot_batch *batch, size_t first, size_t count, uint64_t *out);
 /* MerkleTree::get for m leaf indices (merkle_tree.rs:227): out [m][W] */
 int p2hot_batch_rows(p2hot_batch *batch, const uint64_t *row_idx, size_t m, uint64_t *out);
 /* merkle_tree_prove (merkle_tree.rs:151-190) for m leaf indices from the batch's device-resident digests:
  * out [m][log2(N) - cap_height][4].  With it the caller may pass digests_out = NULL to p2hot_commit and never copy
- * the digest array (0.54 GB at the C3 shape) to the host: the query phase needs a few dozen paths per tree. */
+ * the digest array (0.54 GB at the C3 shape) to the host. */
 int p2hot_batch_paths(p2hot_batch *batch, const uint64_t *leaf_idx, size_t m, uint64_t *out);
+/* merkle_tree.digests (reference layout, hash/merkle_tree.rs:50-57): out [p2hot_num_digests(log2 N, cap_height)][4] */
+int p2hot_batch_digests(p2hot_batch *batch, uint64_t *out);
+/* the kept input values (P2HOT_KEEP_VALUES) as a BORROWED column set: valid while the batch lives; p2hot_cols_free on
+ * the view leaves the batch's memory alone */
+int p2hot_batch_values(p2hot_batch *batch, p2hot_cols **out);
 /* returns the batch's device blocks to its context's block cache; call it BEFORE p2hot_ctx_destroy of that context
- * (the host-pointer entry points keep their device blocks in a grow-only per-context cache: a fresh allocation of the
- * 9 GB LDE matrix costs up to a second) */
+ * (the host-pointer entry points keep their device blocks in a per-context cache: a fresh allocation of the 9 GB LDE
+ * matrix costs up to a second; p2hot_ctx_trim gives the cached free blocks back to the driver) */
 void p2hot_batch_free(p2hot_batch *batch);
+int p2hot_ctx_trim(p2hot_ctx *ctx);
+
+/* device-resident column sets */
+int p2hot_cols_upload(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, p2hot_cols **out);
+int p2hot_cols_download(p2hot_cols *cols, size_t first, size_t count, uint64_t *out /* [count][n] */);
+size_t p2hot_cols_width(const p2hot_cols *cols);
+unsigned p2hot_cols_degree_log(const p2hot_cols *cols);
+void p2hot_cols_free(p2hot_cols *cols);
+
+/* OpeningSet::new (plonky2/src/plonk/proof.rs:314-327; starky/src/proof.rs StarkOpeningSet): every polynomial of every
+ * listed batch at each extension point.  points [n_points][2].  out: for batch b in order, [n_points][W_b][2], concatenated. */
+int p2hot_eval_openings(p2hot_ctx *ctx, const p2hot_batch *const *batches, size_t n_batches, const uint64_t *points,
+                        size_t n_points, uint64_t *out);
+
+/* FriBatchInfo (fri/structure.rs): an opening point and the polynomials opened there as (oracle_index, polynomial_index) */
+typedef struct {
+    uint64_t point[2];
+    const uint32_t *oracle_index;
+    const uint32_t *poly_index;
+    size_t n_polys;
+} p2hot_fri_batch_info;
+/* FriParams / FriConfig (fri/mod.rs:19-60, :62-104) + the two Option<usize> of prove_openings (0 = None) */
+typedef struct {
+    unsigned rate_bits, cap_height, proof_of_work_bits, num_query_rounds;
+    const unsigned *reduction_arity_bits;
+    unsigned n_reduction_rounds;
+    int hiding;                     /* FriParams::hiding: must be 0 (blinded leaves are not on this path) */
+    unsigned max_num_query_steps;   /* fri/prover.rs:90 */
+    size_t final_poly_coeff_len;    /* fri/prover.rs:89 */
+} p2hot_fri_params;
+/* FriProof (fri/proof.rs:95-110) as flat caller-allocated buffers; Q = num_query_rounds, R = rounds, m_0 = N,
+ * m_{r+1} = m_r >> arity_bits[r]:
+ *   commit_phase_merkle_caps [R][2^cap_height][4]
+ *   final_poly               [m_R >> rate_bits][2]
+ *   pow_witness
+ *   query_indices            [Q] x_index of every query round (optional, may be NULL; the verifier re-derives them)
+ *   query_round_proofs[q].initial_trees_proof.evals_proofs[o] = (leaf, path):
+ *     initial_leaves         [Q][sum_o W_o]   the opened row of every oracle, oracles in order
+ *     initial_paths          [Q][n_oracles][log2(N) - cap_height][4]
+ *   query_round_proofs[q].steps[r] = (evals, merkle_proof):
+ *     step_evals             [Q][sum_r 2 * 2^arity_bits[r]]       evals of round r = 2^arity_bits[r] extension elements
+ *     step_paths             [Q][sum_r (log2(m_r) - arity_bits[r] - cap_height) * 4] */
+typedef struct {
+    uint64_t *commit_phase_merkle_caps;
+    uint64_t *final_poly;
+    uint64_t pow_witness;
+    uint64_t *query_indices;
+    uint64_t *initial_leaves;
+    uint64_t *initial_paths;
+    uint64_t *step_evals;
+    uint64_t *step_paths;
+} p2hot_fri_proof;
+typedef struct {
+    size_t caps_words, final_poly_words, initial_leaves_words, initial_paths_words, step_evals_words, step_paths_words;
+} p2hot_fri_proof_layout;
+int p2hot_fri_proof_sizes(const p2hot_batch *const *oracles, size_t n_oracles, const p2hot_fri_params *params,
+                          p2hot_fri_proof_layout *out);
+/* PolynomialBatch::prove_openings (fri/oracle.rs:176-237) + fri_proof (fri/prover.rs:24-82): alpha, final_poly =
+ * sum_i alpha^(k_i) (F_i - F_i(z_i)) / (X - z_i), its LDE, the commit phase (fri_committed_trees, :84-150), the
+ * proof-of-work grind (:153-202, smallest witness) and the query rounds (:204-258), with the transcript advanced exactly
+ * like the reference.  All oracles must share degree, rate and cap height. */
+int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *batches, size_t n_batches,
+                         const p2hot_batch *const *oracles, size_t n_oracles, p2hot_challenger *challenger,
+                         const p2hot_fri_params *params, p2hot_fri_proof *proof);
+
+/* all_wires_permutation_partial_products (plonk/prover.rs:356-449) on device-resident columns: wires = columns
+ * [wires_first_col, +num_routed) of `wires` (e.g. p2hot_batch_values of the wires commitment), sigmas likewise (the
+ * constants_sigmas commitment's values: sigma_j(w_n^i)).  k_is HOST [num_routed], betas / gammas HOST [num_challenges],
+ * degree = quotient_degree_factor.  Output rows ordered as the prover commits them (prover.rs:224-229): Z of challenge
+ * 0 .. nc-1, then the partial products of challenge 0, 1, ...: out_host [nc * (num_prods + 1)][n] and / or out_cols
+ * (feed it to p2hot_commit_cols(is_values = 1)); either may be NULL. */
+int p2hot_partial_products(p2hot_ctx *ctx, const p2hot_cols *wires, size_t wires_first_col, const p2hot_cols *sigmas,
+                           size_t sigmas_first_col, const uint64_t *k_is, unsigned num_routed, unsigned degree,
+                           const uint64_t *betas, const uint64_t *gammas, unsigned num_challenges, uint64_t *out_host,
+                           p2hot_cols **out_cols);
+/* The gate-independent tail of compute_quotient_polys (plonk/prover.rs:274-289, :810-815): quotient_values[c] are the
+ * values of challenge c's quotient on the coset g*H of size n << ceil(log2(quotient_degree_factor)) (natural order);
+ * coset_ifft, trim to quotient_degree_factor * n coefficients (P2HOT_EINVAL "Quotient has failed ..." if the tail is
+ * not zero, where the reference panics) and split into chunks of n: chunks_out = [nc * quotient_degree_factor][n]
+ * coefficients, ready for p2hot_commit_cols(is_values = 0). */
+int p2hot_quotient_chunks(p2hot_ctx *ctx, const uint64_t *const *quotient_values, unsigned num_challenges,
+                          unsigned degree_bits, unsigned quotient_degree_factor, p2hot_cols **chunks_out);
 
 #ifdef __cplusplus
 }

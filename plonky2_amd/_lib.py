@@ -11,8 +11,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PRODUCT_SO = os.path.join(_HERE, "libp2hot.so")
 
-OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
-_ERR_NAMES = {EINVAL: "EINVAL", ENOMEM: "ENOMEM", EHIP: "EHIP", EUNSUPPORTED: "EUNSUPPORTED"}
+OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED, EBUSY, ECOMM = 0, 1, 2, 3, 4, 5, 6
+_ERR_NAMES = {EINVAL: "EINVAL", ENOMEM: "ENOMEM", EHIP: "EHIP", EUNSUPPORTED: "EUNSUPPORTED", EBUSY: "EBUSY",
+              ECOMM: "ECOMM"}
+KEEP_VALUES = 1
 
 vp = C.c_void_p
 sz = C.c_size_t
@@ -24,6 +26,27 @@ i = C.c_int
 class ChallengerState(C.Structure):
     _fields_ = [("sponge_state", u64 * 12), ("input_buffer", u64 * 8), ("output_buffer", u64 * 8),
                 ("input_len", C.c_uint32), ("output_len", C.c_uint32)]
+
+
+class FriBatchInfo(C.Structure):  # p2hot_fri_batch_info
+    _fields_ = [("point", u64 * 2), ("oracle_index", C.POINTER(C.c_uint32)), ("poly_index", C.POINTER(C.c_uint32)),
+                ("n_polys", sz)]
+
+
+class FriParams(C.Structure):  # p2hot_fri_params
+    _fields_ = [("rate_bits", u), ("cap_height", u), ("proof_of_work_bits", u), ("num_query_rounds", u),
+                ("reduction_arity_bits", C.POINTER(u)), ("n_reduction_rounds", u), ("hiding", i),
+                ("max_num_query_steps", u), ("final_poly_coeff_len", sz)]
+
+
+class FriProof(C.Structure):  # p2hot_fri_proof
+    _fields_ = [("commit_phase_merkle_caps", vp), ("final_poly", vp), ("pow_witness", u64), ("query_indices", vp),
+                ("initial_leaves", vp), ("initial_paths", vp), ("step_evals", vp), ("step_paths", vp)]
+
+
+class FriProofLayout(C.Structure):  # p2hot_fri_proof_layout
+    _fields_ = [("caps_words", sz), ("final_poly_words", sz), ("initial_leaves_words", sz), ("initial_paths_words", sz),
+                ("step_evals_words", sz), ("step_paths_words", sz)]
 
 
 # name -> (restype, argtypes); every symbol include/p2hot.h declares
@@ -50,26 +73,43 @@ SIGNATURES = {
     "p2hot_poseidon_permute_dev": (i, [vp, vp, sz]),
     "p2hot_merkle_dev": (i, [vp, vp, i, sz, sz, u, u, sz, sz, vp, vp]),
     "p2hot_field_selftest_dev": (i, [vp, vp, vp, sz, vp]),
-    "p2hot_gather_rows_dev": (i, [vp, vp, sz, sz, vp, sz, vp]),
+    "p2hot_gather_rows_dev": (i, [vp, vp, sz, sz, sz, vp, sz, vp]),
     "p2hot_commit_dev": (i, [vp, vp, sz, sz, u, u, u, i, sz, sz, vp, sz, vp, sz, vp, vp, vp]),
     "p2hot_challenger_create": (i, [vp, C.POINTER(vp)]),
     "p2hot_challenger_destroy": (None, [vp]),
     "p2hot_challenger_load": (i, [vp, C.POINTER(ChallengerState)]),
     "p2hot_challenger_store": (i, [vp, C.POINTER(ChallengerState)]),
     "p2hot_challenger_step": (i, [vp, vp, sz, vp, sz]),
-    "p2hot_fri_commit": (i, [vp, vp, u, u, u, C.POINTER(u), u, vp, vp, vp, vp, vp, vp]),
-    "p2hot_fri_commit_dev": (i, [vp, vp, u, u, u, C.POINTER(u), u, vp, vp, vp, vp, vp, vp]),
+    "p2hot_fri_commit": (i, [vp, vp, u, u, u, C.POINTER(u), u, u, sz, vp, vp, vp, vp, vp, vp]),
+    "p2hot_fri_commit_dev": (i, [vp, vp, u, u, u, C.POINTER(u), u, u, sz, vp, vp, vp, i, vp, vp, vp]),
     "p2hot_fri_final_poly_dev": (i, [vp, vp, C.POINTER(sz), sz, vp, vp, u, vp]),
     "p2hot_eval_polys_dev": (i, [vp, vp, sz, u, vp, sz, vp]),
     "p2hot_merkle_paths_dev": (i, [vp, vp, u, u, vp, sz, vp]),
     "p2hot_partial_products_dev": (i, [vp, vp, sz, vp, sz, vp, u, u, u, vp, vp, u, vp, sz]),
-    "p2hot_fri_set_device_digests": (i, [vp, i]),
-    "p2hot_fri_set_padding": (i, [vp, u, sz]),
     "p2hot_fri_pow": (i, [vp, vp, u, C.POINTER(u64)]),
-    "p2hot_commit": (i, [vp, C.POINTER(vp), sz, u, u, u, i, vp, vp, vp, vp, C.POINTER(vp)]),
+    "p2hot_commit": (i, [vp, C.POINTER(vp), sz, u, u, u, i, u, vp, vp, vp, vp, C.POINTER(vp)]),
+    "p2hot_commit_cols": (i, [vp, vp, u, u, i, u, vp, vp, vp, vp, C.POINTER(vp)]),
+    "p2hot_batch_wrap_dev": (i, [vp, vp, vp, vp, sz, u, u, u, C.POINTER(vp)]),
+    "p2hot_batch_width": (sz, [vp]),
+    "p2hot_batch_degree_log": (u, [vp]),
+    "p2hot_batch_coeffs": (i, [vp, sz, sz, vp]),
     "p2hot_batch_rows": (i, [vp, vp, sz, vp]),
     "p2hot_batch_paths": (i, [vp, vp, sz, vp]),
+    "p2hot_batch_digests": (i, [vp, vp]),
+    "p2hot_batch_values": (i, [vp, C.POINTER(vp)]),
     "p2hot_batch_free": (None, [vp]),
+    "p2hot_ctx_trim": (i, [vp]),
+    "p2hot_cols_upload": (i, [vp, C.POINTER(vp), sz, u, C.POINTER(vp)]),
+    "p2hot_cols_download": (i, [vp, sz, sz, vp]),
+    "p2hot_cols_width": (sz, [vp]),
+    "p2hot_cols_degree_log": (u, [vp]),
+    "p2hot_cols_free": (None, [vp]),
+    "p2hot_eval_openings": (i, [vp, C.POINTER(vp), sz, vp, sz, vp]),
+    "p2hot_fri_proof_sizes": (i, [C.POINTER(vp), sz, C.POINTER(FriParams), C.POINTER(FriProofLayout)]),
+    "p2hot_prove_openings": (i, [vp, C.POINTER(FriBatchInfo), sz, C.POINTER(vp), sz, vp, C.POINTER(FriParams),
+                                 C.POINTER(FriProof)]),
+    "p2hot_partial_products": (i, [vp, vp, sz, vp, sz, vp, u, u, vp, vp, u, vp, C.POINTER(vp)]),
+    "p2hot_quotient_chunks": (i, [vp, C.POINTER(vp), u, u, u, C.POINTER(vp)]),
 }
 
 

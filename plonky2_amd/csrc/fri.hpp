@@ -301,14 +301,21 @@ __global__ void __launch_bounds__(256) eval_polys_stage2_kernel(const u64 *part,
 
 // merkle_tree_prove (hash/merkle_tree.rs:151-190) for m leaf indices straight from the device-resident
 // digest array: out[q][i] = sibling at layer i.  Lane = (query, layer).
+// A leaf index >= 2^log_leaves (the reference panics) yields a zero path and raises *oob.
 __global__ void merkle_paths_kernel(const u64 *digests, unsigned log_leaves, unsigned cap_height, const u64 *idx,
-                                    size_t m, u64 *out) {
+                                    size_t m, u64 *out, unsigned *oob) {
     const unsigned layers = log_leaves - cap_height;
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (layers == 0 || e >= m * layers) return;
     const size_t q = e / layers;
     const unsigned i = (unsigned)(e % layers);
     const size_t leaf = idx[q];
+    if (leaf >> log_leaves) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) out[4 * e + w] = 0;
+        if (i == 0) atomicOr(oob, 2u);
+        return;
+    }
     const size_t tree_len = 2 * (((size_t)1 << layers) - 1);
     const size_t pair = (leaf & (((size_t)1 << layers) - 1)) >> i;  // pair_index before this layer's shift
     const size_t parity = pair & 1;
@@ -316,6 +323,20 @@ __global__ void merkle_paths_kernel(const u64 *digests, unsigned log_leaves, uns
     const u64 *src = digests + 4 * (tree_len * (leaf >> layers) + 2 * siblings_index + (1 - parity));
 #pragma unroll
     for (int w = 0; w < 4; ++w) out[4 * e + w] = src[w];
+}
+
+// rows of a row-major matrix (the FRI round trees' leaves, MerkleTree::get, merkle_tree.rs:227): out[q][0..w) = in[idx[q]][0..w)
+__global__ void gather_rowmajor_kernel(const u64 *in, size_t w, size_t n_rows, const u64 *idx, size_t m, u64 *out, unsigned *oob) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * w) return;
+    const size_t q = e / w, c = e % w;
+    const u64 r = idx[q];
+    if (r >= n_rows) {
+        out[e] = 0;
+        if (c == 0) atomicOr(oob, 1u);
+        return;
+    }
+    out[e] = gl::canon(in[r * w + c]);
 }
 
 // [count][2] <-> two planes (flatten order extension/mod.rs:128-135)

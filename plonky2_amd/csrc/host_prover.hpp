@@ -1,0 +1,704 @@
+// host_prover.hpp -- the HOST-POINTER layer of libp2hot: what a patched plonky2 crate calls from the prover's main thread
+// with ordinary Vec<F> buffers (include/p2hot.h, "prover session" section).  Included at the end of p2hot.hip (one TU).
+//
+// Reference call sites this layer stands behind:
+//   PolynomialBatch::from_values / from_coeffs   plonky2/src/fri/oracle.rs:57-112      p2hot_commit, p2hot_commit_cols
+//   MerkleTree::get / ::prove                      hash/merkle_tree.rs:227, :231-237     p2hot_batch_rows, p2hot_batch_paths
+//   OpeningSet::new                                plonk/proof.rs:314-327                p2hot_eval_openings
+//   PolynomialBatch::prove_openings + fri_proof    fri/oracle.rs:176-237, fri/prover.rs:24-82, :204-258   p2hot_prove_openings
+//   all_wires_permutation_partial_products         plonk/prover.rs:356-449               p2hot_partial_products
+//   quotient coset_ifft + chunks                   plonk/prover.rs:274-289, :810-815     p2hot_quotient_chunks
+// Everything between the calls stays on the GPU behind opaque handles (p2hot_batch, p2hot_cols, p2hot_challenger).
+#pragma once
+
+#include <atomic>
+
+// one call at a time per context: a second thread entering gets P2HOT_EBUSY instead of a data race on the scratch blocks
+struct CallGuard {
+    p2hot_ctx *ctx;
+    bool ok;
+    explicit CallGuard(p2hot_ctx *c) : ctx(c), ok(false) {
+        if (ctx) ok = !ctx->busy.exchange(true, std::memory_order_acquire);
+    }
+    ~CallGuard() {
+        if (ok) ctx->busy.store(false, std::memory_order_release);
+    }
+};
+#define P2_ENTER(ctx)                                                                                                  \
+    CallGuard guard_(ctx);                                                                                             \
+    if (!(ctx)) return P2HOT_EINVAL;                                                                                   \
+    if (!guard_.ok) return P2HOT_EBUSY /* the context's error text belongs to the call that is running */
+
+static int sync_checked(p2hot_ctx *ctx, int rc, const char *what) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (rc == P2HOT_OK && e != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return rc;
+}
+
+// ------------------------------------------------------------------ device-resident column sets
+extern "C" int p2hot_cols_upload(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, p2hot_cols **out) {
+    P2_ENTER(ctx);
+    if (!out) P2_FAIL(ctx, P2HOT_EINVAL, "cols_upload: null output");
+    *out = nullptr;
+    P2_TRY(check_log(ctx, log_n, "cols_upload"));
+    if (W > 0 && !cols) P2_FAIL(ctx, P2HOT_EINVAL, "cols_upload: null column table");
+    const size_t n = (size_t)1 << log_n;
+    PoolBuf d(ctx);
+    P2_TRY(pool_alloc(ctx, (W ? W : 1) * n * 8, &d.p));
+    for (size_t c = 0; c < W; ++c) {
+        if (!cols[c]) P2_FAIL(ctx, P2HOT_EINVAL, "cols_upload: column %zu is null", c);
+        P2_HIP(ctx, hipMemcpyAsync(d.u() + c * n, cols[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    P2_TRY(sync_checked(ctx, P2HOT_OK, "cols_upload"));
+    *out = new p2hot_cols{ctx, d.u(), W, log_n, true};
+    d.p = nullptr;
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_cols_download(p2hot_cols *c, size_t first, size_t count, uint64_t *out) {
+    if (!c) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = c->ctx;
+    P2_ENTER(ctx);
+    if (first > c->W || count > c->W - first) P2_FAIL(ctx, P2HOT_EINVAL, "cols_download: columns [%zu,+%zu) of %zu", first, count, c->W);
+    if (count == 0) return P2HOT_OK;
+    if (!out) P2_FAIL(ctx, P2HOT_EINVAL, "cols_download: null output");
+    const size_t n = (size_t)1 << c->log_n;
+    P2_HIP(ctx, hipMemcpyAsync(out, c->d + first * n, count * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return sync_checked(ctx, P2HOT_OK, "cols_download");
+}
+
+extern "C" size_t p2hot_cols_width(const p2hot_cols *c) { return c ? c->W : 0; }
+extern "C" unsigned p2hot_cols_degree_log(const p2hot_cols *c) { return c ? c->log_n : 0; }
+
+extern "C" void p2hot_cols_free(p2hot_cols *c) {
+    if (!c) return;
+    if (c->owned) {
+        (void)hipStreamSynchronize(c->ctx->stream);
+        pool_release(c->ctx, c->d);
+    }
+    delete c;
+}
+
+// ------------------------------------------------------------------ from_values / from_coeffs
+static p2hot_batch *make_batch(p2hot_ctx *ctx, PoolBuf &lde, PoolBuf &dig, PoolBuf &coef, PoolBuf *vals, size_t W, unsigned log_n,
+                               unsigned rate_bits, unsigned cap_height) {
+    p2hot_batch *b = new p2hot_batch{ctx, lde.u(), W, ((size_t)1 << log_n) << rate_bits, dig.u(), log_n + rate_bits, cap_height};
+    b->d_coef = coef.u();
+    b->d_vals = vals ? vals->u() : nullptr;
+    b->log_n = log_n;
+    b->rate_bits = rate_bits;
+    lde.p = dig.p = coef.p = nullptr;  // ownership moves to the handle (still live blocks of the context's cache)
+    if (vals) vals->p = nullptr;
+    return b;
+}
+
+extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
+                            unsigned cap_height, int is_values, unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out,
+                            uint64_t *digests_out, uint64_t *cap_out, p2hot_batch **handle_out) {
+    P2_ENTER(ctx);
+    if (handle_out) *handle_out = nullptr;
+    P2_TRY(check_log(ctx, log_n + rate_bits, "commit"));
+    if (W > 0 && !cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit: null column table");
+    if (flags & ~(unsigned)P2HOT_KEEP_VALUES) P2_FAIL(ctx, P2HOT_EINVAL, "commit: unknown flags %#x", flags);
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    const unsigned log_N = log_n + rate_bits;
+    if (cap_height > log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit: cap_height %u > log2(N) %u (merkle_tree.rs:195-200)", cap_height, log_N);
+    for (size_t c = 0; c < W; ++c)
+        if (!cols[c]) P2_FAIL(ctx, P2HOT_EINVAL, "commit: column %zu is null", c);
+    const size_t nd = p2hot_num_digests(log_N, cap_height), cap_words = (size_t)4 << cap_height;
+    const bool keep_vals = is_values && handle_out && (flags & P2HOT_KEEP_VALUES);
+    PoolBuf d_work(ctx), d_vals(ctx), d_lde(ctx), d_leaves(ctx), d_dig(ctx), d_cap(ctx);
+    const size_t Wn = (W ? W : 1) * n * 8, WN = (W ? W : 1) * N * 8;
+    P2_TRY(pool_alloc(ctx, Wn, &d_work.p));  // uploaded columns; becomes the coefficients in place
+    if (keep_vals) P2_TRY(pool_alloc(ctx, Wn, &d_vals.p));
+    P2_TRY(pool_alloc(ctx, WN, &d_lde.p));
+    if (leaves_out) P2_TRY(pool_alloc(ctx, WN, &d_leaves.p));
+    P2_TRY(pool_alloc(ctx, (nd ? nd : 1) * 32, &d_dig.p));
+    P2_TRY(pool_alloc(ctx, cap_words * 8, &d_cap.p));
+    // The PCIe copies run on the side stream beside the compute stream.  Column blocks are uploaded, transformed (iNTT)
+    // and extended (LDE) one after the other -- the upload of block b+1 overlaps the transforms of block b -- and the
+    // coefficient blocks go back to the host while the leaf sponge runs.  Small batches are one block.
+    const size_t kBlockCols = (W >= 32 && W * n >= ((size_t)1 << 22)) ? 16 : (W ? W : 1);
+    const size_t nb = W ? (W + kBlockCols - 1) / kBlockCols : 0;
+    std::vector<hipEvent_t> up, done;
+    hipStream_t copy_stream = ctx->stream;
+#ifndef P2HOT_EMU
+    const bool two_streams = nb > 1;
+    if (two_streams) copy_stream = ctx->side;
+#endif
+    auto body = [&]() -> int {
+#ifndef P2HOT_EMU
+        if (two_streams) {
+            for (size_t b = 0; b < 2 * nb; ++b) {
+                hipEvent_t e;
+                P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                (b < nb ? up : done).push_back(e);
+            }
+            // the side stream must not start before work already queued on the compute stream has finished with the blocks
+            P2_HIP(ctx, hipEventRecord(ctx->join_event, ctx->stream));
+            P2_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->join_event, 0));
+        }
+#endif
+        for (size_t b = 0; b < nb; ++b) {
+            const size_t c0 = b * kBlockCols, cnt = (c0 + kBlockCols <= W ? kBlockCols : W - c0);
+            u64 *blk = d_work.u() + c0 * n;
+            u64 *land = keep_vals ? d_vals.u() + c0 * n : blk;  // where the upload lands
+            for (size_t c = c0; c < c0 + cnt; ++c)
+                P2_HIP(ctx, hipMemcpyAsync(land + (c - c0) * n, cols[c], n * 8, hipMemcpyHostToDevice, copy_stream));
+#ifndef P2HOT_EMU
+            if (two_streams) {
+                P2_HIP(ctx, hipEventRecord(up[b], ctx->side));
+                P2_HIP(ctx, hipStreamWaitEvent(ctx->stream, up[b], 0));
+            }
+#endif
+            if (keep_vals) P2_HIP(ctx, hipMemcpyAsync(blk, land, cnt * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            if (is_values) {  // "IFFT" (oracle.rs:65-69): the block becomes its coefficients in place
+                P2_TRY(ntt_natural(ctx, blk, cnt, n, log_n, true));
+            } else if (coeffs_out) {
+                P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(cnt * n, 256)), dim3(256), 0, ctx->stream, blk, cnt * n);
+                P2_LAUNCH_CHECK(ctx);
+            }
+#ifndef P2HOT_EMU
+            if (two_streams) P2_HIP(ctx, hipEventRecord(done[b], ctx->stream));
+#endif
+            P2_TRY(p2hot_coset_lde_dev(ctx, blk, cnt, n, log_n, rate_bits, gl::COSET_SHIFT, 0, N, d_lde.u() + c0 * N, N));
+        }
+        P2_TRY(p2hot_merkle_dev(ctx, d_lde.u(), 0, N, W, log_N, cap_height, 0, N, d_dig.u(), d_cap.u()));
+        if (leaves_out && W) P2_TRY(p2hot_transpose_dev(ctx, d_lde.u(), N, W, N, d_leaves.u()));
+        // coefficient blocks go back while the leaf sponge runs: queued behind the uploads on the copy stream, each
+        // waiting for its block's transform only
+        if (coeffs_out)
+            for (size_t b = 0; b < nb; ++b) {
+                const size_t c0 = b * kBlockCols, cnt = (c0 + kBlockCols <= W ? kBlockCols : W - c0);
+#ifndef P2HOT_EMU
+                if (two_streams) P2_HIP(ctx, hipStreamWaitEvent(ctx->side, done[b], 0));
+#endif
+                P2_HIP(ctx, hipMemcpyAsync(coeffs_out + c0 * n, d_work.u() + c0 * n, cnt * n * 8, hipMemcpyDeviceToHost, copy_stream));
+            }
+        if (leaves_out && W) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, W * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (digests_out && nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
+        if (cap_out) P2_HIP(ctx, hipMemcpyAsync(cap_out, d_cap.p, cap_words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        return P2HOT_OK;
+    };
+    int rc = body();
+    hipError_t e1 = hipSuccess;
+#ifndef P2HOT_EMU
+    if (two_streams) e1 = hipStreamSynchronize(ctx->side);
+    for (hipEvent_t ev : up) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : done) (void)hipEventDestroy(ev);
+#endif
+    rc = sync_checked(ctx, rc, "commit");
+    if (rc == P2HOT_OK && e1 != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "commit: %s", hipGetErrorString(e1));
+    if (rc == P2HOT_OK && handle_out) *handle_out = make_batch(ctx, d_lde, d_dig, d_work, keep_vals ? &d_vals : nullptr, W, log_n, rate_bits, cap_height);
+    return rc;
+}
+
+// from_values / from_coeffs on a device-resident column set.  CONSUMES `cols` (on success and on failure): its block
+// becomes the batch's coefficients (from_coeffs) or its kept values (from_values with P2HOT_KEEP_VALUES), or is released.
+extern "C" int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate_bits, unsigned cap_height, int is_values,
+                                 unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out,
+                                 uint64_t *cap_out, p2hot_batch **handle_out) {
+    P2_ENTER(ctx);
+    if (handle_out) *handle_out = nullptr;
+    if (!cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: null column set");
+    PoolBuf d_in(ctx);
+    const size_t W = cols->W;
+    const unsigned log_n = cols->log_n;
+    {
+        const bool ok = cols->ctx == ctx && cols->owned;
+        if (ok) d_in.p = cols->d;
+        if (ok) delete cols;  // consumed; the block is now ours (a view or a foreign set is left alone)
+        if (!ok) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: the column set belongs to another context or is a borrowed view");
+    }
+    P2_TRY(check_log(ctx, log_n + rate_bits, "commit_cols"));
+    if (flags & ~(unsigned)P2HOT_KEEP_VALUES) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: unknown flags %#x", flags);
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    const unsigned log_N = log_n + rate_bits;
+    if (cap_height > log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: cap_height %u > log2(N) %u (merkle_tree.rs:195-200)", cap_height, log_N);
+    const size_t nd = p2hot_num_digests(log_N, cap_height), cap_words = (size_t)4 << cap_height;
+    const bool keep_vals = is_values && handle_out && (flags & P2HOT_KEEP_VALUES);
+    PoolBuf d_coef(ctx), d_lde(ctx), d_leaves(ctx), d_dig(ctx), d_cap(ctx);
+    const size_t Wn = (W ? W : 1) * n * 8, WN = (W ? W : 1) * N * 8;
+    if (keep_vals) P2_TRY(pool_alloc(ctx, Wn, &d_coef.p));
+    P2_TRY(pool_alloc(ctx, WN, &d_lde.p));
+    if (leaves_out) P2_TRY(pool_alloc(ctx, WN, &d_leaves.p));
+    P2_TRY(pool_alloc(ctx, (nd ? nd : 1) * 32, &d_dig.p));
+    P2_TRY(pool_alloc(ctx, cap_words * 8, &d_cap.p));
+    auto body = [&]() -> int {
+        u64 *co = d_in.u();
+        if (keep_vals) {
+            P2_HIP(ctx, hipMemcpyAsync(d_coef.p, d_in.p, W * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            co = d_coef.u();
+        }
+        if (is_values) {
+            P2_TRY(ntt_natural(ctx, co, W, n, log_n, true));
+        } else if (W) {
+            P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(W * n, 256)), dim3(256), 0, ctx->stream, co, W * n);
+            P2_LAUNCH_CHECK(ctx);
+        }
+        P2_TRY(p2hot_commit_dev(ctx, co, n, W, log_n, rate_bits, cap_height, 0, 0, N, nullptr, 0, d_lde.u(), N,
+                                leaves_out ? d_leaves.u() : nullptr, d_dig.u(), d_cap.u()));
+        if (coeffs_out && W) P2_HIP(ctx, hipMemcpyAsync(coeffs_out, co, W * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (leaves_out && W) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, W * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (digests_out && nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
+        if (cap_out) P2_HIP(ctx, hipMemcpyAsync(cap_out, d_cap.p, cap_words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        return P2HOT_OK;
+    };
+    int rc = sync_checked(ctx, body(), "commit_cols");
+    if (rc == P2HOT_OK && handle_out) {
+        if (keep_vals)
+            *handle_out = make_batch(ctx, d_lde, d_dig, d_coef, &d_in, W, log_n, rate_bits, cap_height);
+        else
+            *handle_out = make_batch(ctx, d_lde, d_dig, d_in, nullptr, W, log_n, rate_bits, cap_height);
+    }
+    return rc;
+}
+
+// a handle over device buffers the caller owns (the *_dev flow: p2hot_commit_dev outputs); nothing is copied or freed
+extern "C" int p2hot_batch_wrap_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, const uint64_t *d_lde, const uint64_t *d_digests,
+                                    size_t W, unsigned log_n, unsigned rate_bits, unsigned cap_height, p2hot_batch **out) {
+    if (!ctx || !out) return P2HOT_EINVAL;
+    *out = nullptr;
+    P2_TRY(check_log(ctx, log_n + rate_bits, "batch_wrap"));
+    if (cap_height > log_n + rate_bits) P2_FAIL(ctx, P2HOT_EINVAL, "batch_wrap: cap_height > log2(N)");
+    if (W && (!d_coeffs || !d_lde)) P2_FAIL(ctx, P2HOT_EINVAL, "batch_wrap: null buffer");
+    if (p2hot_num_digests(log_n + rate_bits, cap_height) && !d_digests) P2_FAIL(ctx, P2HOT_EINVAL, "batch_wrap: null digests");
+    p2hot_batch *b = new p2hot_batch{ctx, (u64 *)d_lde, W, ((size_t)1 << log_n) << rate_bits, (u64 *)d_digests, log_n + rate_bits, cap_height};
+    b->d_coef = (u64 *)d_coeffs;
+    b->log_n = log_n;
+    b->rate_bits = rate_bits;
+    b->owned = false;
+    *out = b;
+    return P2HOT_OK;
+}
+
+extern "C" size_t p2hot_batch_width(const p2hot_batch *b) { return b ? b->W : 0; }
+extern "C" unsigned p2hot_batch_degree_log(const p2hot_batch *b) { return b ? b->log_n : 0; }
+
+// the kept input values of a from_values batch as a BORROWED column set (valid while the batch lives; free the view
+// with p2hot_cols_free, which leaves the batch's block alone)
+extern "C" int p2hot_batch_values(p2hot_batch *b, p2hot_cols **out) {
+    if (!b || !out) return P2HOT_EINVAL;
+    *out = nullptr;
+    if (!b->d_vals) P2_FAIL(b->ctx, P2HOT_EINVAL, "batch_values: the batch was not committed with P2HOT_KEEP_VALUES");
+    *out = new p2hot_cols{b->ctx, b->d_vals, b->W, b->log_n, false};
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_batch_coeffs(p2hot_batch *b, size_t first, size_t count, uint64_t *out) {
+    if (!b) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = b->ctx;
+    P2_ENTER(ctx);
+    if (first > b->W || count > b->W - first) P2_FAIL(ctx, P2HOT_EINVAL, "batch_coeffs: polynomials [%zu,+%zu) of %zu", first, count, b->W);
+    if (count == 0) return P2HOT_OK;
+    if (!out) P2_FAIL(ctx, P2HOT_EINVAL, "batch_coeffs: null output");
+    const size_t n = (size_t)1 << b->log_n;
+    PoolBuf tmp(ctx);
+    P2_TRY(pool_alloc(ctx, count * n * 8, &tmp.p));
+    P2_HIP(ctx, hipMemcpyAsync(tmp.p, b->d_coef + first * n, count * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(count * n, 256)), dim3(256), 0, ctx->stream, tmp.u(), count * n);
+    P2_LAUNCH_CHECK(ctx);
+    P2_HIP(ctx, hipMemcpyAsync(out, tmp.p, count * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return sync_checked(ctx, P2HOT_OK, "batch_coeffs");
+}
+
+extern "C" int p2hot_batch_digests(p2hot_batch *b, uint64_t *out) {
+    if (!b) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = b->ctx;
+    P2_ENTER(ctx);
+    const size_t nd = p2hot_num_digests(b->log_N, b->cap_height);
+    if (nd == 0) return P2HOT_OK;
+    if (!out) P2_FAIL(ctx, P2HOT_EINVAL, "batch_digests: null output");
+    P2_HIP(ctx, hipMemcpyAsync(out, b->d_dig, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
+    return sync_checked(ctx, P2HOT_OK, "batch_digests");
+}
+
+extern "C" int p2hot_batch_rows(p2hot_batch *b, const uint64_t *row_idx, size_t m, uint64_t *out) {
+    if (!b) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = b->ctx;
+    P2_ENTER(ctx);
+    if (m == 0 || b->W == 0) return P2HOT_OK;
+    if (!row_idx || !out) P2_FAIL(ctx, P2HOT_EINVAL, "batch_rows: null buffer");
+    for (size_t i = 0; i < m; ++i)
+        if (row_idx[i] >= b->N) P2_FAIL(ctx, P2HOT_EINVAL, "batch_rows: index %llu out of range", (unsigned long long)row_idx[i]);
+    PoolBuf d_idx(ctx), d_out(ctx);
+    P2_TRY(pool_alloc(ctx, m * 8, &d_idx.p));
+    P2_TRY(pool_alloc(ctx, m * b->W * 8, &d_out.p));
+    auto body = [&]() -> int {
+        P2_HIP(ctx, hipMemcpyAsync(d_idx.p, row_idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
+        P2_TRY(p2hot_gather_rows_dev(ctx, b->d_lde, b->N, b->N, b->W, d_idx.u(), m, d_out.u()));
+        P2_HIP(ctx, hipMemcpyAsync(out, d_out.p, m * b->W * 8, hipMemcpyDeviceToHost, ctx->stream));
+        return P2HOT_OK;
+    };
+    return sync_checked(ctx, body(), "batch_rows");
+}
+
+extern "C" int p2hot_batch_paths(p2hot_batch *b, const uint64_t *leaf_idx, size_t m, uint64_t *out) {
+    if (!b) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = b->ctx;
+    P2_ENTER(ctx);
+    const unsigned layers = b->log_N - b->cap_height;
+    if (m == 0 || layers == 0) return P2HOT_OK;
+    if (!leaf_idx || !out) P2_FAIL(ctx, P2HOT_EINVAL, "batch_paths: null buffer");
+    for (size_t i = 0; i < m; ++i)
+        if (leaf_idx[i] >= b->N) P2_FAIL(ctx, P2HOT_EINVAL, "batch_paths: index %llu out of range", (unsigned long long)leaf_idx[i]);
+    PoolBuf d_idx(ctx), d_out(ctx);
+    P2_TRY(pool_alloc(ctx, m * 8, &d_idx.p));
+    P2_TRY(pool_alloc(ctx, m * layers * 32, &d_out.p));
+    auto body = [&]() -> int {
+        P2_HIP(ctx, hipMemcpyAsync(d_idx.p, leaf_idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
+        P2_TRY(p2hot_merkle_paths_dev(ctx, b->d_dig, b->log_N, b->cap_height, d_idx.u(), m, d_out.u()));
+        P2_HIP(ctx, hipMemcpyAsync(out, d_out.p, m * layers * 32, hipMemcpyDeviceToHost, ctx->stream));
+        return P2HOT_OK;
+    };
+    return sync_checked(ctx, body(), "batch_paths");
+}
+
+extern "C" void p2hot_batch_free(p2hot_batch *b) {
+    if (!b) return;
+    if (b->owned) {
+        (void)hipStreamSynchronize(b->ctx->stream);
+        pool_release(b->ctx, b->d_lde);
+        pool_release(b->ctx, b->d_dig);
+        pool_release(b->ctx, b->d_coef);
+        pool_release(b->ctx, b->d_vals);
+    }
+    delete b;
+}
+
+// returns the cached free blocks of the host-pointer entry points to the driver (the cache is grow-only otherwise)
+extern "C" int p2hot_ctx_trim(p2hot_ctx *ctx) {
+    P2_ENTER(ctx);
+    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &blk : ctx->pool_free) (void)hipFree(blk.first);
+    ctx->pool_free.clear();
+    return P2HOT_OK;
+}
+
+// ------------------------------------------------------------------ OpeningSet::new (plonk/proof.rs:314-327)
+// device table of pointers to every polynomial of the listed batches, in order
+static int poly_table(p2hot_ctx *ctx, const p2hot_batch *const *batches, size_t n_batches, unsigned *log_n, PoolBuf &d_table,
+                      size_t *total) {
+    std::vector<const u64 *> ptrs;
+    for (size_t b = 0; b < n_batches; ++b) {
+        const p2hot_batch *B = batches[b];
+        if (!B || B->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "oracle %zu is null or belongs to another context", b);
+        if (b == 0) *log_n = B->log_n;
+        if (B->log_n != *log_n) P2_FAIL(ctx, P2HOT_EINVAL, "all oracles must have the same degree (oracle %zu: 2^%u vs 2^%u)", b, B->log_n, *log_n);
+        for (size_t j = 0; j < B->W; ++j) ptrs.push_back(B->d_coef + (j << B->log_n));
+    }
+    *total = ptrs.size();
+    P2_TRY(pool_alloc(ctx, (ptrs.size() ? ptrs.size() : 1) * sizeof(u64 *), &d_table.p));
+    if (!ptrs.empty())
+        P2_HIP(ctx, hipMemcpyAsync(d_table.p, ptrs.data(), ptrs.size() * sizeof(u64 *), hipMemcpyHostToDevice, ctx->stream));
+    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `ptrs` is a local
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_eval_openings(p2hot_ctx *ctx, const p2hot_batch *const *batches, size_t n_batches, const uint64_t *points,
+                                   size_t n_points, uint64_t *out) {
+    P2_ENTER(ctx);
+    if (n_batches == 0 || n_points == 0) return P2HOT_OK;
+    if (!batches || !points || !out) P2_FAIL(ctx, P2HOT_EINVAL, "eval_openings: null argument");
+    unsigned log_n = 0;
+    size_t total = 0;
+    PoolBuf d_table(ctx), d_res(ctx);
+    P2_TRY(poly_table(ctx, batches, n_batches, &log_n, d_table, &total));
+    if (total == 0) return P2HOT_OK;
+    P2_TRY(pool_alloc(ctx, n_points * total * 16, &d_res.p));
+    auto body = [&]() -> int {
+        // device layout [n_points][total][2]; the caller's layout is per batch [n_points][W_b][2]
+        P2_TRY(p2hot_eval_polys_dev(ctx, (const uint64_t *const *)d_table.p, total, log_n, points, n_points, d_res.u()));
+        size_t off = 0, out_off = 0;
+        for (size_t b = 0; b < n_batches; ++b) {
+            const size_t Wb = batches[b]->W;
+            for (size_t p = 0; p < n_points && Wb; ++p)
+                P2_HIP(ctx, hipMemcpyAsync(out + out_off + 2 * p * Wb, d_res.u() + 2 * (p * total + off), Wb * 16, hipMemcpyDeviceToHost,
+                                           ctx->stream));
+            off += Wb;
+            out_off += 2 * n_points * Wb;
+        }
+        return P2HOT_OK;
+    };
+    return sync_checked(ctx, body(), "eval_openings");
+}
+
+// ------------------------------------------------------------------ prove_openings + fri_proof
+static int fri_check_params(p2hot_ctx *ctx, const p2hot_fri_params *fp, unsigned log_n) {
+    if (!fp) P2_FAIL(ctx, P2HOT_EINVAL, "null fri params");
+    if (fp->n_reduction_rounds && !fp->reduction_arity_bits) P2_FAIL(ctx, P2HOT_EINVAL, "null reduction_arity_bits");
+    P2_TRY(check_log(ctx, log_n + fp->rate_bits, "fri"));
+    unsigned lm = log_n + fp->rate_bits, ln = log_n;
+    for (unsigned r = 0; r < fp->n_reduction_rounds; ++r) {
+        const unsigned ab = fp->reduction_arity_bits[r];
+        if (ab == 0 || ab > ln) P2_FAIL(ctx, P2HOT_EINVAL, "fri: round %u arity 2^%u does not divide the degree bound", r, ab);
+        if (lm - ab < fp->cap_height) P2_FAIL(ctx, P2HOT_EINVAL, "fri: round %u tree has fewer leaves than the cap (merkle_tree.rs:195-200)", r);
+        lm -= ab;
+        ln -= ab;
+    }
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_fri_proof_sizes(const p2hot_batch *const *oracles, size_t n_oracles, const p2hot_fri_params *fp,
+                                     p2hot_fri_proof_layout *out) {
+    if (!out || !fp || (n_oracles && !oracles) || (fp->n_reduction_rounds && !fp->reduction_arity_bits)) return P2HOT_EINVAL;
+    if (n_oracles == 0 || !oracles[0]) return P2HOT_EINVAL;
+    const unsigned log_n = oracles[0]->log_n, log_N = log_n + fp->rate_bits;
+    size_t w_sum = 0;
+    for (size_t o = 0; o < n_oracles; ++o) {
+        if (!oracles[o]) return P2HOT_EINVAL;
+        w_sum += oracles[o]->W;
+    }
+    const size_t q = fp->num_query_rounds, cap_words = (size_t)4 << fp->cap_height;
+    size_t evals = 0, paths = 0;
+    unsigned lm = log_N;
+    for (unsigned r = 0; r < fp->n_reduction_rounds; ++r) {
+        const unsigned ab = fp->reduction_arity_bits[r];
+        if (ab > lm || lm - ab < fp->cap_height) return P2HOT_EINVAL;
+        evals += (size_t)2 << ab;
+        paths += 4 * (size_t)(lm - ab - fp->cap_height);
+        lm -= ab;
+    }
+    if (lm < fp->rate_bits || log_N < fp->cap_height) return P2HOT_EINVAL;
+    out->caps_words = fp->n_reduction_rounds * cap_words;
+    out->final_poly_words = (size_t)2 << (lm - fp->rate_bits);
+    out->initial_leaves_words = q * w_sum;
+    out->initial_paths_words = q * n_oracles * 4 * (size_t)(log_N - fp->cap_height);
+    out->step_evals_words = q * evals;
+    out->step_paths_words = q * paths;
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *batches, size_t n_batches,
+                                    const p2hot_batch *const *oracles, size_t n_oracles, p2hot_challenger *challenger,
+                                    const p2hot_fri_params *fp, p2hot_fri_proof *proof) {
+    P2_ENTER(ctx);
+    if (!challenger || challenger->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: the challenger belongs to another context");
+    if (!proof || !oracles || n_oracles == 0 || (n_batches && !batches)) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: null argument");
+    if (fp && fp->hiding) P2_FAIL(ctx, P2HOT_EUNSUPPORTED, "prove_openings: hiding = true needs the blinded (salted) leaves of oracle.rs:133-137");
+    for (size_t o = 0; o < n_oracles; ++o)
+        if (!oracles[o] || oracles[o]->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: oracle %zu is null or belongs to another context", o);
+    const unsigned log_n = oracles[0]->log_n;
+    P2_TRY(fri_check_params(ctx, fp, log_n));
+    const unsigned rate_bits = fp->rate_bits, cap_height = fp->cap_height, log_N = log_n + rate_bits, n_rounds = fp->n_reduction_rounds;
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits, Q = fp->num_query_rounds;
+    for (size_t o = 0; o < n_oracles; ++o)
+        if (oracles[o]->log_n != log_n || oracles[o]->rate_bits != rate_bits || oracles[o]->cap_height != cap_height)
+            P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: oracle %zu was committed with another degree / rate / cap height", o);
+    p2hot_fri_proof_layout lay;
+    if (p2hot_fri_proof_sizes(oracles, n_oracles, fp, &lay) != P2HOT_OK) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: inconsistent parameters");
+    if ((lay.caps_words && !proof->commit_phase_merkle_caps) || !proof->final_poly ||
+        (Q && ((lay.initial_leaves_words && !proof->initial_leaves) || (lay.initial_paths_words && !proof->initial_paths) ||
+               (lay.step_evals_words && !proof->step_evals) || (lay.step_paths_words && !proof->step_paths))))
+        P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: a proof buffer is null (size them with p2hot_fri_proof_sizes)");
+    // --- the polynomial table of the instance (FriInstanceInfo.batches, fri/structure.rs): device pointers in batch order
+    std::vector<const u64 *> ptrs;
+    std::vector<size_t> offsets(1, 0);
+    std::vector<u64> points;
+    for (size_t i = 0; i < n_batches; ++i) {
+        const p2hot_fri_batch_info &bi = batches[i];
+        if (bi.n_polys && (!bi.oracle_index || !bi.poly_index)) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: batch %zu has null index arrays", i);
+        for (size_t j = 0; j < bi.n_polys; ++j) {
+            const size_t oi = bi.oracle_index[j], pi = bi.poly_index[j];
+            if (oi >= n_oracles || pi >= oracles[oi]->W)
+                P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: batch %zu opens polynomial (%zu, %zu) which does not exist", i, oi, pi);
+            ptrs.push_back(oracles[oi]->d_coef + (pi << log_n));
+        }
+        offsets.push_back(ptrs.size());
+        points.push_back(bi.point[0]);
+        points.push_back(bi.point[1]);
+    }
+    // --- device blocks: pointer table, final_poly planes, round trees (leaves + digests), query staging
+    size_t leaf_words = 0, dig_words = 0;
+    {
+        size_t m = N;
+        unsigned lm = log_N;
+        for (unsigned r = 0; r < n_rounds; ++r) {
+            const unsigned ab = fp->reduction_arity_bits[r];
+            leaf_words += 2 * m;
+            dig_words += 4 * p2hot_num_digests(lm - ab, cap_height);
+            m >>= ab;
+            lm -= ab;
+        }
+    }
+    const unsigned layers0 = log_N - cap_height;
+    PoolBuf d_table(ctx), d_planes(ctx), d_leaves(ctx), d_dig(ctx), d_q(ctx);
+    P2_TRY(pool_alloc(ctx, (ptrs.size() ? ptrs.size() : 1) * sizeof(u64 *), &d_table.p));
+    P2_TRY(pool_alloc(ctx, 2 * n * 8, &d_planes.p));
+    P2_TRY(pool_alloc(ctx, (leaf_words ? leaf_words : 1) * 8, &d_leaves.p));
+    P2_TRY(pool_alloc(ctx, (dig_words ? dig_words : 1) * 8, &d_dig.p));
+    const size_t q_words = Q * (1 + n_rounds) + lay.initial_leaves_words + lay.initial_paths_words + lay.step_evals_words + lay.step_paths_words;
+    P2_TRY(pool_alloc(ctx, (q_words ? q_words : 1) * 8, &d_q.p));
+    std::vector<u64> idx_host(Q * (1 + (size_t)n_rounds));
+    auto body = [&]() -> int {
+        if (!ptrs.empty())
+            P2_HIP(ctx, hipMemcpyAsync(d_table.p, ptrs.data(), ptrs.size() * sizeof(u64 *), hipMemcpyHostToDevice, ctx->stream));
+        // oracle.rs:186: alpha = challenger.get_extension_challenge()
+        u64 alpha[2];
+        P2_TRY(p2hot_challenger_step(challenger, nullptr, 0, alpha, 2));
+        // oracle.rs:190-213: final_poly = sum_i alpha^(k_i) (F_i - F_i(z_i)) / (X - z_i)
+        P2_TRY(p2hot_fri_final_poly_dev(ctx, (const uint64_t *const *)d_table.p, offsets.data(), n_batches, points.data(), alpha, log_n,
+                                        d_planes.u()));
+        // oracle.rs:215-220 + fri/prover.rs:40-51: final FFT, commit phase; the round trees stay on the device
+        P2_TRY(fri_commit_core(ctx, nullptr, d_planes.u(), log_n, rate_bits, cap_height, fp->reduction_arity_bits, n_rounds,
+                               fp->max_num_query_steps, fp->final_poly_coeff_len, challenger, d_leaves.u(), true, d_dig.u(), true,
+                               proof->commit_phase_merkle_caps, nullptr, proof->final_poly));
+        // fri/prover.rs:53-58: proof of work
+        P2_TRY(p2hot_fri_pow(ctx, challenger, fp->proof_of_work_bits, &proof->pow_witness));
+        if (Q == 0) return P2HOT_OK;
+        // fri/prover.rs:215-220: x_index = rand % n for num_query_rounds challenges
+        P2_TRY(p2hot_challenger_step(challenger, nullptr, 0, idx_host.data(), Q));
+        for (size_t q = 0; q < Q; ++q) {
+            u64 x = idx_host[q] % N;
+            idx_host[q] = x;
+            for (unsigned r = 0; r < n_rounds; ++r) {  // per round: x_index >>= arity_bits (prover.rs:243-253)
+                x >>= fp->reduction_arity_bits[r];
+                idx_host[(1 + (size_t)r) * Q + q] = x;
+            }
+        }
+        if (proof->query_indices) std::copy(idx_host.begin(), idx_host.begin() + Q, proof->query_indices);
+        u64 *d_idx = d_q.u(), *d_il = d_idx + Q * (1 + n_rounds), *d_ip = d_il + lay.initial_leaves_words,
+            *d_se = d_ip + lay.initial_paths_words, *d_sp = d_se + lay.step_evals_words;
+        P2_HIP(ctx, hipMemcpyAsync(d_idx, idx_host.data(), idx_host.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        // prover.rs:238-241: initial_trees_proof = for every oracle (tree.get(x), tree.prove(x)), all queries per launch.
+        // Device staging is oracle-major ([oracle][q][...]); the host layout is query-major (see p2hot.h), fixed by the D2H copies.
+        size_t w_sum = 0;
+        for (size_t o = 0; o < n_oracles; ++o) w_sum += oracles[o]->W;
+        size_t w_off = 0;
+        for (size_t o = 0; o < n_oracles; ++o) {
+            const p2hot_batch *B = oracles[o];
+            P2_TRY(p2hot_gather_rows_dev(ctx, B->d_lde, B->N, B->N, B->W, d_idx, Q, d_il + Q * w_off));
+            P2_TRY(p2hot_merkle_paths_dev(ctx, B->d_dig, log_N, cap_height, d_idx, Q, d_ip + o * Q * 4 * layers0));
+            w_off += B->W;
+        }
+        // prover.rs:242-253: per round (evals = unflatten(tree.get(x >> arity_bits)), tree.prove(x >> arity_bits))
+        size_t ev_off = 0, pa_off = 0, lv = 0, dg = 0, m = N;
+        unsigned lm = log_N;
+        std::vector<size_t> ev_offs, pa_offs, ev_w, pa_w;
+        for (unsigned r = 0; r < n_rounds; ++r) {
+            const unsigned ab = fp->reduction_arity_bits[r];
+            const size_t roww = (size_t)2 << ab, layers = lm - ab - cap_height;
+            P2HOT_LAUNCH(fri::gather_rowmajor_kernel, dim3(cdiv(Q * roww, 256)), dim3(256), 0, ctx->stream, (const u64 *)(d_leaves.u() + lv),
+                         roww, m >> ab, (const u64 *)(d_idx + (1 + (size_t)r) * Q), Q, d_se + Q * ev_off, ctx->d_oob);
+            P2_LAUNCH_CHECK(ctx);
+            if (layers)
+                P2_TRY(p2hot_merkle_paths_dev(ctx, d_dig.u() + dg, lm - ab, cap_height, d_idx + (1 + (size_t)r) * Q, Q, d_sp + Q * pa_off));
+            ev_offs.push_back(ev_off);
+            pa_offs.push_back(pa_off);
+            ev_w.push_back(roww);
+            pa_w.push_back(4 * layers);
+            ev_off += roww;
+            pa_off += 4 * layers;
+            lv += 2 * m;
+            dg += 4 * p2hot_num_digests(lm - ab, cap_height);
+            m >>= ab;
+            lm -= ab;
+        }
+        // D2H: one strided copy per (oracle | round) turns the oracle-major staging into the query-major proof layout
+        w_off = 0;
+        for (size_t o = 0; o < n_oracles; ++o) {
+            const size_t Wb = oracles[o]->W;
+            if (Wb)
+                P2_HIP(ctx, hipMemcpy2DAsync(proof->initial_leaves + w_off, w_sum * 8, d_il + Q * w_off, Wb * 8, Wb * 8, Q,
+                                             hipMemcpyDeviceToHost, ctx->stream));
+            if (layers0)
+                P2_HIP(ctx, hipMemcpy2DAsync(proof->initial_paths + o * 4 * layers0, n_oracles * 4 * layers0 * 8,
+                                             d_ip + o * Q * 4 * layers0, 4 * layers0 * 8, 4 * layers0 * 8, Q, hipMemcpyDeviceToHost,
+                                             ctx->stream));
+            w_off += Wb;
+        }
+        for (unsigned r = 0; r < n_rounds; ++r) {
+            P2_HIP(ctx, hipMemcpy2DAsync(proof->step_evals + ev_offs[r], ev_off * 8, d_se + Q * ev_offs[r], ev_w[r] * 8, ev_w[r] * 8, Q,
+                                         hipMemcpyDeviceToHost, ctx->stream));
+            if (pa_w[r])
+                P2_HIP(ctx, hipMemcpy2DAsync(proof->step_paths + pa_offs[r], pa_off * 8, d_sp + Q * pa_offs[r], pa_w[r] * 8, pa_w[r] * 8, Q,
+                                             hipMemcpyDeviceToHost, ctx->stream));
+        }
+        return P2HOT_OK;
+    };
+    return sync_checked(ctx, body(), "prove_openings");
+}
+
+// ------------------------------------------------------------------ permutation argument (plonk/prover.rs:356-449)
+extern "C" int p2hot_partial_products(p2hot_ctx *ctx, const p2hot_cols *wires, size_t wires_first_col, const p2hot_cols *sigmas,
+                                      size_t sigmas_first_col, const uint64_t *k_is, unsigned num_routed, unsigned degree,
+                                      const uint64_t *betas, const uint64_t *gammas, unsigned num_challenges, uint64_t *out_host,
+                                      p2hot_cols **out_cols) {
+    P2_ENTER(ctx);
+    if (out_cols) *out_cols = nullptr;
+    if (!wires || !sigmas || wires->ctx != ctx || sigmas->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "partial_products: null or foreign column set");
+    if (wires->log_n != sigmas->log_n) P2_FAIL(ctx, P2HOT_EINVAL, "partial_products: wires and sigmas have different lengths");
+    if (wires_first_col > wires->W || num_routed > wires->W - wires_first_col || sigmas_first_col > sigmas->W ||
+        num_routed > sigmas->W - sigmas_first_col)
+        P2_FAIL(ctx, P2HOT_EINVAL, "partial_products: %u routed columns do not fit the column sets", num_routed);
+    // prover.rs:215-218: "When the number of routed wires is smaller that the degree, we should change the logic"
+    if (degree < 2 || !(degree < num_routed)) P2_FAIL(ctx, P2HOT_EINVAL, "partial_products: need 2 <= degree < num_routed");
+    const unsigned log_n = wires->log_n;
+    const size_t n = (size_t)1 << log_n;
+    const unsigned num_prods = (num_routed + degree - 1) / degree - 1;
+    const size_t rows = (size_t)num_challenges * (num_prods + 1);
+    PoolBuf d_out(ctx);
+    P2_TRY(pool_alloc(ctx, (rows ? rows : 1) * n * 8, &d_out.p));
+    auto body = [&]() -> int {
+        P2_TRY(p2hot_partial_products_dev(ctx, wires->d + wires_first_col * n, n, sigmas->d + sigmas_first_col * n, n, k_is, num_routed,
+                                          log_n, degree, betas, gammas, num_challenges, d_out.u(), n));
+        if (out_host && rows) P2_HIP(ctx, hipMemcpyAsync(out_host, d_out.p, rows * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        return P2HOT_OK;
+    };
+    int rc = sync_checked(ctx, body(), "partial_products");
+    if (rc == P2HOT_OK && out_cols) {
+        *out_cols = new p2hot_cols{ctx, d_out.u(), rows, log_n, true};
+        d_out.p = nullptr;
+    }
+    return rc;
+}
+
+// ------------------------------------------------------------------ quotient polynomials -> chunks (plonk/prover.rs:274-289, :810-815)
+extern "C" int p2hot_quotient_chunks(p2hot_ctx *ctx, const uint64_t *const *quotient_values, unsigned num_challenges,
+                                     unsigned degree_bits, unsigned quotient_degree_factor, p2hot_cols **chunks_out) {
+    P2_ENTER(ctx);
+    if (!chunks_out) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_chunks: null output");
+    *chunks_out = nullptr;
+    if (quotient_degree_factor == 0 || (num_challenges && !quotient_values)) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_chunks: bad arguments");
+    unsigned qbits = 0;
+    while ((1u << qbits) < quotient_degree_factor) ++qbits;  // log2_ceil (circuit_data.rs quotient_degree_bits)
+    P2_TRY(check_log(ctx, degree_bits + qbits, "quotient_chunks"));
+    const size_t n = (size_t)1 << degree_bits, m = n << qbits, keep = n * quotient_degree_factor;
+    PoolBuf d_work(ctx), d_chunks(ctx);
+    P2_TRY(pool_alloc(ctx, (num_challenges ? num_challenges : 1) * m * 8 + 8, &d_work.p));
+    P2_TRY(pool_alloc(ctx, (num_challenges ? (size_t)num_challenges * quotient_degree_factor : 1) * n * 8, &d_chunks.p));
+    unsigned nonzero = 0;
+    auto body = [&]() -> int {
+        for (unsigned c = 0; c < num_challenges; ++c) {
+            if (!quotient_values[c]) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_chunks: polynomial %u is null", c);
+            P2_HIP(ctx, hipMemcpyAsync(d_work.u() + c * m, quotient_values[c], m * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
+        // values.coset_ifft(F::coset_shift()) (prover.rs:810-814)
+        P2_TRY(p2hot_coset_ifft_dev(ctx, d_work.u(), num_challenges, m, degree_bits + qbits, gl::COSET_SHIFT));
+        // trim_to_len(quotient_degree_factor * n) (polynomial/mod.rs:164-178) with its divisibility check, then
+        // chunks(degree) (mod.rs:136-142): the kept prefix of polynomial c is chunks c*qdf .. (c+1)*qdf-1
+        unsigned *flag = (unsigned *)(d_work.u() + (size_t)num_challenges * m);
+        P2_HIP(ctx, hipMemsetAsync(flag, 0, 8, ctx->stream));
+        for (unsigned c = 0; c < num_challenges; ++c) {
+            if (keep < m) {
+                P2HOT_LAUNCH(plonk::any_nonzero_kernel, dim3(cdiv(m - keep, 256)), dim3(256), 0, ctx->stream,
+                             (const u64 *)(d_work.u() + c * m + keep), m - keep, flag);
+                P2_LAUNCH_CHECK(ctx);
+            }
+            P2_HIP(ctx, hipMemcpyAsync(d_chunks.u() + (size_t)c * keep, d_work.u() + c * m, keep * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        if (num_challenges) {
+            P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv((size_t)num_challenges * keep, 256)), dim3(256), 0, ctx->stream, d_chunks.u(),
+                         (size_t)num_challenges * keep);
+            P2_LAUNCH_CHECK(ctx);
+        }
+        P2_HIP(ctx, hipMemcpyAsync(&nonzero, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        return P2HOT_OK;
+    };
+    int rc = sync_checked(ctx, body(), "quotient_chunks");
+    if (rc != P2HOT_OK) return rc;
+    if (nonzero) P2_FAIL(ctx, P2HOT_EINVAL, "Quotient has failed, the vanishing polynomial is not divisible by Z_H");
+    *chunks_out = new p2hot_cols{ctx, d_chunks.u(), (size_t)num_challenges * quotient_degree_factor, degree_bits, true};
+    d_chunks.p = nullptr;
+    return P2HOT_OK;
+}

@@ -481,12 +481,21 @@ __global__ void __launch_bounds__(256) transpose_kernel(const u64 *in, size_t st
 }
 
 // out[m][W] = in[c][idx[m]]  (lazy leaf fetch for query openings, oracle.rs:142-147 / merkle_tree.rs:227)
-__global__ void gather_rows_kernel(const u64 *in, size_t stride, unsigned W, const u64 *idx, size_t m, u64 *out) {
+// An index >= rows (the reference would panic on the slice index) reads nothing: the row is zeroed and *oob is raised;
+// the context reports it at the next synchronisation point.
+__global__ void gather_rows_kernel(const u64 *in, size_t stride, size_t rows, unsigned W, const u64 *idx, size_t m, u64 *out,
+                                   unsigned *oob) {
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m * W) return;
     size_t q = e / W;
     unsigned c = (unsigned)(e % W);
-    out[e] = gl::canon(in[(size_t)c * stride + idx[q]]);
+    const u64 r = idx[q];
+    if (r >= rows) {
+        out[e] = 0;
+        if (c == 0) atomicOr(oob, 1u);
+        return;
+    }
+    out[e] = gl::canon(in[(size_t)c * stride + r]);
 }
 
 }  // namespace ntt

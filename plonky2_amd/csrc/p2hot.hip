@@ -3,6 +3,7 @@
 #include "../../include/p2hot.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <map>
 #include <string>
@@ -22,7 +23,9 @@ struct p2hot_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    std::atomic<bool> busy{false};  // a host-pointer entry point is running on this context (see CallGuard)
     u64 *tables = nullptr;  // fwd_lo, fwd_hi, inv_lo, inv_hi (65536 each)
+    unsigned *d_oob = nullptr;  // raised by gathers that were handed an out-of-range row / leaf index (device-resident indices)
     ntt::RootTable fwd{}, inv{};
     u64 *local_fwd = nullptr, *local_inv = nullptr;  // [2^m + e] = w_{2^m}^(+-e), m <= TILE_LOG
     bool use_regpass = true;
@@ -32,10 +35,6 @@ struct p2hot_ctx {
     hipEvent_t join_event = nullptr;
     bool overlap = false;
     size_t quad_threshold = (size_t)1 << 15;  // launches with at most this many permutations use the quad kernels
-    // starky multi-degree recursion padding of the next FRI commit (prover.rs:125-132, :142-147); 0 = None
-    unsigned fri_max_num_query_steps = 0;
-    bool fri_device_digests = false;  // next p2hot_fri_commit_dev: digests_out is a device pointer
-    size_t fri_final_poly_coeff_len = 0;  // measured on MI355X: no gain (the sponge's waves fill every CU; the two kernels time-slice)
     unsigned ntt_radix_bits = 3;  // 3: radix-8 rounds / 512 threads, 4: radix-16 / 256 threads
     struct Scratch {
         void *p = nullptr;
@@ -194,7 +193,9 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     P2_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     P2_HIP(ctx, hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming));
 #endif
-    P2_HIP(ctx, hipMalloc((void **)&ctx->tables, (4 * 65536 + 4 * (1u << ntt::TILE_LOG)) * sizeof(u64)));
+    P2_HIP(ctx, hipMalloc((void **)&ctx->tables, (4 * 65536 + 4 * (1u << ntt::TILE_LOG) + 1) * sizeof(u64)));
+    ctx->d_oob = (unsigned *)(ctx->tables + 4 * 65536 + 4 * (1u << ntt::TILE_LOG));
+    P2_HIP(ctx, hipMemsetAsync(ctx->d_oob, 0, 8, ctx->stream));
     u64 *t = ctx->tables;
     const u64 w = gl::ROOT_2_32, wi = gl::inv(gl::ROOT_2_32);
     P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(256), dim3(256), 0, ctx->stream, t, (size_t)65536, w, (u64)1, (u64)0);
@@ -251,10 +252,23 @@ extern "C" int p2hot_ctx_set_stream(p2hot_ctx *ctx, void *hip_stream) {
     return P2HOT_OK;
 }
 
+// reads and clears the out-of-range flag of the device-index gathers (the stream must be idle)
+static int check_oob(p2hot_ctx *ctx) {
+    unsigned f = 0;
+    P2_HIP(ctx, hipMemcpyAsync(&f, ctx->d_oob, 4, hipMemcpyDeviceToHost, ctx->stream));
+    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (f) {
+        P2_HIP(ctx, hipMemsetAsync(ctx->d_oob, 0, 4, ctx->stream));
+        P2_FAIL(ctx, P2HOT_EINVAL, "an earlier %s was given an index out of range (the reference panics on the slice index); its output rows are zero",
+                (f & 1) ? "p2hot_gather_rows_dev" : "p2hot_merkle_paths_dev");
+    }
+    return P2HOT_OK;
+}
+
 extern "C" int p2hot_ctx_sync(p2hot_ctx *ctx) {
     if (!ctx) return P2HOT_EINVAL;
     P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return P2HOT_OK;
+    return check_oob(ctx);
 }
 
 extern "C" const char *p2hot_last_error(const p2hot_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -605,13 +619,14 @@ extern "C" int p2hot_field_selftest_dev(p2hot_ctx *ctx, const uint64_t *d_a, con
     return P2HOT_OK;
 }
 
-extern "C" int p2hot_gather_rows_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W,
+extern "C" int p2hot_gather_rows_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t rows, size_t W,
                                      const uint64_t *d_idx, size_t m, uint64_t *d_out) {
     if (!ctx) return P2HOT_EINVAL;
     if (W == 0 || m == 0) return P2HOT_OK;
     if (!d_colmajor || !d_idx || !d_out) P2_FAIL(ctx, P2HOT_EINVAL, "gather_rows: null pointer");
-    P2HOT_LAUNCH(ntt::gather_rows_kernel, dim3(cdiv(m * W, 256)), dim3(256), 0, ctx->stream, d_colmajor, col_stride,
-                 (unsigned)W, d_idx, m, d_out);
+    if (rows > col_stride) P2_FAIL(ctx, P2HOT_EINVAL, "gather_rows: rows > col_stride");
+    P2HOT_LAUNCH(ntt::gather_rows_kernel, dim3(cdiv(m * W, 256)), dim3(256), 0, ctx->stream, d_colmajor, col_stride, rows,
+                 (unsigned)W, d_idx, m, d_out, ctx->d_oob);
     P2_LAUNCH_CHECK(ctx);
     return P2HOT_OK;
 }
@@ -862,10 +877,12 @@ extern "C" int p2hot_challenger_step(p2hot_challenger *ch, const uint64_t *obser
 
 // ------------------------------------------------------------------ FRI commit phase
 // coeffs: host [n][2] interleaved, or (d_planar != NULL) device planes [2][n]
+// max_num_query_steps / final_poly_coeff_len: the Option<usize> arguments of fri_committed_trees (prover.rs:89-90), 0 = None
 static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_t *d_planar, unsigned log_n,
                            unsigned rate_bits, unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
+                           unsigned max_num_query_steps, size_t final_poly_coeff_len,
                            p2hot_challenger *challenger, uint64_t *leaves_out, bool leaves_on_device, uint64_t *digests_out,
-                           uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
+                           bool digests_on_device, uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
     if (!ctx || !challenger || challenger->ctx != ctx) return P2HOT_EINVAL;
     P2_TRY(check_log(ctx, log_n + rate_bits, "fri_commit"));
     if ((!coeffs && !d_planar) || (n_rounds && !arity_bits)) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit: null input");
@@ -939,7 +956,7 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
             if (digests_out) {
                 if (nd)
                     P2_HIP(ctx, hipMemcpyAsync(digests_out, digests.p, nd * 32,
-                                               ctx->fri_device_digests && leaves_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                               digests_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                                                ctx->stream));
                 digests_out += 4 * nd;
             }
@@ -968,9 +985,9 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
         }
         // prover.rs:122-132: keep the transcript in sync with a verifier circuit that has more query steps:
         // observe an all-zero cap and draw a dummy challenge per missing step
-        if (ctx->fri_max_num_query_steps > n_rounds) {
+        if (max_num_query_steps > n_rounds) {
             P2_HIP(ctx, hipMemsetAsync(cap.p, 0, cap_words * 8, ctx->stream));
-            for (unsigned k = n_rounds; k < ctx->fri_max_num_query_steps; ++k)
+            for (unsigned k = n_rounds; k < max_num_query_steps; ++k)
                 P2_TRY(challenger_step_dev(challenger, cap.u(), cap_words, beta.u(), 2));
         }
         // prover.rs:135-139: final_poly = the remaining coefficients, observed by the challenger
@@ -980,8 +997,8 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
         P2_TRY(challenger_step_dev(challenger, stage.u(), 2 * cur_n, nullptr, 0));
         if (final_out) P2_HIP(ctx, hipMemcpyAsync(final_out, stage.p, cur_n * 16, hipMemcpyDeviceToHost, ctx->stream));
         // prover.rs:140-147: observe zeros up to the padded final polynomial length
-        if (ctx->fri_final_poly_coeff_len > cur_n) {
-            const size_t extra = 2 * (ctx->fri_final_poly_coeff_len - cur_n);  // extension elements -> words
+        if (final_poly_coeff_len > cur_n) {
+            const size_t extra = 2 * (final_poly_coeff_len - cur_n);  // extension elements -> words
             P2_HIP(ctx, hipMemsetAsync(values.p, 0, (extra < 2 * N ? extra : 2 * N) * 8, ctx->stream));
             for (size_t done = 0; done < extra;) {
                 size_t chunk = extra - done < 2 * N ? extra - done : 2 * N;
@@ -992,9 +1009,6 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
         return P2HOT_OK;
     };
     rc = body();
-    ctx->fri_device_digests = false;
-    ctx->fri_max_num_query_steps = 0;
-    ctx->fri_final_poly_coeff_len = 0;
     hipError_t e = hipStreamSynchronize(ctx->stream);  // host outputs are complete on return
     if (rc == P2HOT_OK && e != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "fri_commit: %s", hipGetErrorString(e));
     return rc;
@@ -1002,36 +1016,24 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
 
 extern "C" int p2hot_fri_commit(p2hot_ctx *ctx, const uint64_t *coeffs, unsigned log_n, unsigned rate_bits,
                                 unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
+                                unsigned max_num_query_steps, size_t final_poly_coeff_len,
                                 p2hot_challenger *challenger, uint64_t *leaves_out, uint64_t *digests_out,
                                 uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
     if (ctx && !coeffs) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit: null coefficients");
-    return fri_commit_core(ctx, coeffs, nullptr, log_n, rate_bits, cap_height, arity_bits, n_rounds, challenger, leaves_out,
-                           false, digests_out, caps_out, betas_out, final_out);
+    return fri_commit_core(ctx, coeffs, nullptr, log_n, rate_bits, cap_height, arity_bits, n_rounds, max_num_query_steps,
+                           final_poly_coeff_len, challenger, leaves_out, false, digests_out, false, caps_out, betas_out,
+                           final_out);
 }
 
 extern "C" int p2hot_fri_commit_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs_planar, unsigned log_n, unsigned rate_bits,
                                     unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
+                                    unsigned max_num_query_steps, size_t final_poly_coeff_len,
                                     p2hot_challenger *challenger, uint64_t *d_leaves_out, uint64_t *digests_out,
-                                    uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
+                                    int digests_on_device, uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
     if (ctx && !d_coeffs_planar) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit_dev: null coefficients");
-    return fri_commit_core(ctx, nullptr, d_coeffs_planar, log_n, rate_bits, cap_height, arity_bits, n_rounds, challenger,
-                           d_leaves_out, true, digests_out, caps_out, betas_out, final_out);
-}
-
-// Option<usize> arguments of fri_committed_trees (prover.rs:89-90) for the NEXT p2hot_fri_commit* call on this
-// context (0 = None); they are consumed (reset to None) by that call.
-// digests_out of the NEXT p2hot_fri_commit_dev call is a DEVICE pointer (the round trees stay on the GPU entirely)
-extern "C" int p2hot_fri_set_device_digests(p2hot_ctx *ctx, int on) {
-    if (!ctx) return P2HOT_EINVAL;
-    ctx->fri_device_digests = on != 0;
-    return P2HOT_OK;
-}
-
-extern "C" int p2hot_fri_set_padding(p2hot_ctx *ctx, unsigned max_num_query_steps, size_t final_poly_coeff_len) {
-    if (!ctx) return P2HOT_EINVAL;
-    ctx->fri_max_num_query_steps = max_num_query_steps;
-    ctx->fri_final_poly_coeff_len = final_poly_coeff_len;
-    return P2HOT_OK;
+    return fri_commit_core(ctx, nullptr, d_coeffs_planar, log_n, rate_bits, cap_height, arity_bits, n_rounds,
+                           max_num_query_steps, final_poly_coeff_len, challenger, d_leaves_out, true, digests_out,
+                           digests_on_device != 0, caps_out, betas_out, final_out);
 }
 
 // ------------------------------------------------------------------ prove_openings prelude
@@ -1203,7 +1205,7 @@ extern "C" int p2hot_merkle_paths_dev(p2hot_ctx *ctx, const uint64_t *d_digests,
     if (m == 0 || layers == 0) return P2HOT_OK;
     if (!d_digests || !d_idx || !d_out) P2_FAIL(ctx, P2HOT_EINVAL, "merkle_paths: null pointer");
     P2HOT_LAUNCH(fri::merkle_paths_kernel, dim3(cdiv(m * layers, 256)), dim3(256), 0, ctx->stream, d_digests, log_leaves,
-                 cap_height, d_idx, m, d_out);
+                 cap_height, d_idx, m, d_out, ctx->d_oob);
     P2_LAUNCH_CHECK(ctx);
     return P2HOT_OK;
 }
@@ -1236,178 +1238,27 @@ extern "C" int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsig
 }
 
 // ------------------------------------------------------------------ PolynomialBatch, host pointers
+// A device-resident PolynomialBatch (fri/oracle.rs:30-37): `polynomials` (coefficients), the LDE matrix (= merkle_tree.leaves,
+// column-major, committed row order) and merkle_tree.digests; optionally the input values (P2HOT_KEEP_VALUES).
 struct p2hot_batch {
     p2hot_ctx *ctx;
     u64 *d_lde;
     size_t W, N;
     u64 *d_dig;  // the tree's digest array (reference layout) stays on the device for p2hot_batch_paths
     unsigned log_N, cap_height;
+    u64 *d_coef = nullptr;  // [W][n], stride n
+    u64 *d_vals = nullptr;  // [W][n] values on H_n, kept on request
+    unsigned log_n = 0, rate_bits = 0;
+    bool owned = true;      // false: a view over caller-owned device buffers (p2hot_batch_wrap_dev)
 };
 
-extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
-                            unsigned cap_height, int is_values, uint64_t *coeffs_out, uint64_t *leaves_out,
-                            uint64_t *digests_out, uint64_t *cap_out, p2hot_batch **handle_out) {
-    if (!ctx) return P2HOT_EINVAL;
-    if (handle_out) *handle_out = nullptr;
-    P2_TRY(check_log(ctx, log_n + rate_bits, "commit"));
-    if (W > 0 && !cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit: null column table");
-    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
-    const unsigned log_N = log_n + rate_bits;
-    if (cap_height > log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit: cap_height %u > log2(N) %u (merkle_tree.rs:195-200)", cap_height, log_N);
-    const size_t nd = p2hot_num_digests(log_N, cap_height), cap_words = (size_t)4 << cap_height;
-    PoolBuf d_cols(ctx), d_coeffs(ctx), d_lde(ctx), d_leaves(ctx), d_dig(ctx), d_cap(ctx);
-    const size_t Wn = (W ? W : 1) * n * 8, WN = (W ? W : 1) * N * 8;
-#ifndef P2HOT_EMU
-    const size_t kBlockCols = 16;  // columns per upload / transform block of the pipelined path
-    const bool pipeline = W >= 2 * kBlockCols && W * n >= ((size_t)1 << 22);
-#else
-    const bool pipeline = false;
-#endif
-    P2_TRY(pool_alloc(ctx, Wn, &d_cols.p));
-    if (is_values && !pipeline) P2_TRY(pool_alloc(ctx, Wn, &d_coeffs.p));  // the pipelined path transforms in place
-    P2_TRY(pool_alloc(ctx, WN, &d_lde.p));
-    if (leaves_out) P2_TRY(pool_alloc(ctx, WN, &d_leaves.p));
-    P2_TRY(pool_alloc(ctx, (nd ? nd : 1) * 32, &d_dig.p));
-    P2_TRY(pool_alloc(ctx, cap_words * 8, &d_cap.p));
-#ifndef P2HOT_EMU
-    // Large batches: the PCIe copies run on the side stream beside the compute stream.  Column blocks are uploaded,
-    // transformed (iNTT) and extended (LDE) one after the other -- the upload of block b+1 overlaps the transforms of
-    // block b -- and the coefficient blocks go back to the host while the leaf sponge runs.
-    if (pipeline) {
-        std::vector<hipEvent_t> up, done;
-        auto pipelined = [&]() -> int {
-            const size_t nb = (W + kBlockCols - 1) / kBlockCols;
-            for (size_t c = 0; c < W; ++c)
-                if (!cols[c]) P2_FAIL(ctx, P2HOT_EINVAL, "commit: column %zu is null", c);
-            for (size_t b = 0; b < 2 * nb; ++b) {
-                hipEvent_t e;
-                P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                (b < nb ? up : done).push_back(e);
-            }
-            // the side stream must not start before work already queued on the compute stream has finished with d_cols
-            P2_HIP(ctx, hipEventRecord(ctx->join_event, ctx->stream));
-            P2_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->join_event, 0));
-            for (size_t b = 0; b < nb; ++b) {
-                const size_t c0 = b * kBlockCols, cnt = (c0 + kBlockCols <= W ? kBlockCols : W - c0);
-                for (size_t c = c0; c < c0 + cnt; ++c)
-                    P2_HIP(ctx, hipMemcpyAsync(d_cols.u() + c * n, cols[c], n * 8, hipMemcpyHostToDevice, ctx->side));
-                P2_HIP(ctx, hipEventRecord(up[b], ctx->side));
-                P2_HIP(ctx, hipStreamWaitEvent(ctx->stream, up[b], 0));
-                u64 *blk = d_cols.u() + c0 * n;  // the block becomes its coefficients in place
-                if (is_values) {
-                    P2_TRY(p2hot_ifft_dev(ctx, blk, cnt, n, log_n));
-                } else if (coeffs_out) {
-                    P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(cnt * n, 256)), dim3(256), 0, ctx->stream, blk, cnt * n);
-                    P2_LAUNCH_CHECK(ctx);
-                }
-                P2_HIP(ctx, hipEventRecord(done[b], ctx->stream));
-                P2_TRY(p2hot_coset_lde_dev(ctx, blk, cnt, n, log_n, rate_bits, gl::COSET_SHIFT, 0, N, d_lde.u() + c0 * N, N));
-            }
-            P2_TRY(p2hot_merkle_dev(ctx, d_lde.u(), 0, N, W, log_N, cap_height, 0, N, d_dig.u(), d_cap.u()));
-            if (leaves_out) P2_TRY(p2hot_transpose_dev(ctx, d_lde.u(), N, W, N, d_leaves.u()));
-            // queued behind the uploads on the side stream; each waits for its block's transform only
-            if (coeffs_out)
-                for (size_t b = 0; b < nb; ++b) {
-                    const size_t c0 = b * kBlockCols, cnt = (c0 + kBlockCols <= W ? kBlockCols : W - c0);
-                    P2_HIP(ctx, hipStreamWaitEvent(ctx->side, done[b], 0));
-                    P2_HIP(ctx, hipMemcpyAsync(coeffs_out + c0 * n, d_cols.u() + c0 * n, cnt * n * 8, hipMemcpyDeviceToHost, ctx->side));
-                }
-            if (leaves_out) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, W * N * 8, hipMemcpyDeviceToHost, ctx->stream));
-            if (digests_out && nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
-            if (cap_out) P2_HIP(ctx, hipMemcpyAsync(cap_out, d_cap.p, cap_words * 8, hipMemcpyDeviceToHost, ctx->stream));
-            return P2HOT_OK;
-        };
-        int prc = pipelined();
-        hipError_t e1 = hipStreamSynchronize(ctx->side), e2 = hipStreamSynchronize(ctx->stream);
-        for (hipEvent_t ev : up) (void)hipEventDestroy(ev);
-        for (hipEvent_t ev : done) (void)hipEventDestroy(ev);
-        if (prc == P2HOT_OK && (e1 != hipSuccess || e2 != hipSuccess))
-            P2_FAIL(ctx, P2HOT_EHIP, "commit: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-        if (prc == P2HOT_OK && handle_out) {
-            *handle_out = new p2hot_batch{ctx, d_lde.u(), W, N, d_dig.u(), log_N, cap_height};
-            d_lde.p = nullptr;  // ownership moves to the handle (still a live block of the context's cache)
-            d_dig.p = nullptr;
-        }
-        return prc;
-    }
-#endif
-    auto body = [&]() -> int {
-        for (size_t c = 0; c < W; ++c) {
-            if (!cols[c]) P2_FAIL(ctx, P2HOT_EINVAL, "commit: column %zu is null", c);
-            P2_HIP(ctx, hipMemcpyAsync(d_cols.u() + c * n, cols[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
-        }
-        P2_TRY(p2hot_commit_dev(ctx, d_cols.u(), n, W, log_n, rate_bits, cap_height, is_values, 0, N, d_coeffs.u(), n,
-                                d_lde.u(), N, d_leaves.u(), d_dig.u(), d_cap.u()));
-        if (coeffs_out && W) {
-            if (is_values) {
-                P2_HIP(ctx, hipMemcpyAsync(coeffs_out, d_coeffs.p, W * n * 8, hipMemcpyDeviceToHost, ctx->stream));
-            } else {
-                P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(W * n, 256)), dim3(256), 0, ctx->stream, d_cols.u(), W * n);
-                P2_LAUNCH_CHECK(ctx);
-                P2_HIP(ctx, hipMemcpyAsync(coeffs_out, d_cols.p, W * n * 8, hipMemcpyDeviceToHost, ctx->stream));
-            }
-        }
-        if (leaves_out && W) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, W * N * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (digests_out && nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
-        if (cap_out) P2_HIP(ctx, hipMemcpyAsync(cap_out, d_cap.p, cap_words * 8, hipMemcpyDeviceToHost, ctx->stream));
-        return P2HOT_OK;
-    };
-    int rc = body();
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (rc == P2HOT_OK && e != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "commit: %s", hipGetErrorString(e));
-    if (rc == P2HOT_OK && handle_out) {
-        *handle_out = new p2hot_batch{ctx, d_lde.u(), W, N, d_dig.u(), log_N, cap_height};
-        d_lde.p = nullptr;  // ownership moves to the handle
-        d_dig.p = nullptr;
-    }
-    return rc;
-}
+// A device-resident column set [W][n] (Vec<PolynomialValues> / Vec<PolynomialCoeffs> that never visits the host)
+struct p2hot_cols {
+    p2hot_ctx *ctx;
+    u64 *d;
+    size_t W;
+    unsigned log_n;
+    bool owned;
+};
 
-extern "C" int p2hot_batch_rows(p2hot_batch *b, const uint64_t *row_idx, size_t m, uint64_t *out) {
-    if (!b) return P2HOT_EINVAL;
-    p2hot_ctx *ctx = b->ctx;
-    if (m == 0 || b->W == 0) return P2HOT_OK;
-    if (!row_idx || !out) P2_FAIL(ctx, P2HOT_EINVAL, "batch_rows: null buffer");
-    for (size_t i = 0; i < m; ++i)
-        if (row_idx[i] >= b->N) P2_FAIL(ctx, P2HOT_EINVAL, "batch_rows: index %llu out of range", (unsigned long long)row_idx[i]);
-    PoolBuf d_idx(ctx), d_out(ctx);
-    P2_TRY(pool_alloc(ctx, m * 8, &d_idx.p));
-    P2_TRY(pool_alloc(ctx, m * b->W * 8, &d_out.p));
-    P2_HIP(ctx, hipMemcpyAsync(d_idx.p, row_idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
-    int rc = p2hot_gather_rows_dev(ctx, b->d_lde, b->N, b->W, d_idx.u(), m, d_out.u());
-    if (rc == P2HOT_OK) {
-        hipError_t e = hipMemcpyAsync(out, d_out.p, m * b->W * 8, hipMemcpyDeviceToHost, ctx->stream);
-        if (e != hipSuccess) rc = P2HOT_EHIP;
-    }
-    (void)hipStreamSynchronize(ctx->stream);
-    return rc;
-}
-
-extern "C" int p2hot_batch_paths(p2hot_batch *b, const uint64_t *leaf_idx, size_t m, uint64_t *out) {
-    if (!b) return P2HOT_EINVAL;
-    p2hot_ctx *ctx = b->ctx;
-    const unsigned layers = b->log_N - b->cap_height;
-    if (m == 0 || layers == 0) return P2HOT_OK;
-    if (!leaf_idx || !out) P2_FAIL(ctx, P2HOT_EINVAL, "batch_paths: null buffer");
-    for (size_t i = 0; i < m; ++i)
-        if (leaf_idx[i] >= b->N) P2_FAIL(ctx, P2HOT_EINVAL, "batch_paths: index %llu out of range", (unsigned long long)leaf_idx[i]);
-    PoolBuf d_idx(ctx), d_out(ctx);
-    P2_TRY(pool_alloc(ctx, m * 8, &d_idx.p));
-    P2_TRY(pool_alloc(ctx, m * layers * 32, &d_out.p));
-    P2_HIP(ctx, hipMemcpyAsync(d_idx.p, leaf_idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
-    int rc = p2hot_merkle_paths_dev(ctx, b->d_dig, b->log_N, b->cap_height, d_idx.u(), m, d_out.u());
-    if (rc == P2HOT_OK) {
-        hipError_t e = hipMemcpyAsync(out, d_out.p, m * layers * 32, hipMemcpyDeviceToHost, ctx->stream);
-        if (e != hipSuccess) rc = P2HOT_EHIP;
-    }
-    (void)hipStreamSynchronize(ctx->stream);
-    return rc;
-}
-
-extern "C" void p2hot_batch_free(p2hot_batch *b) {
-    if (!b) return;
-    (void)hipStreamSynchronize(b->ctx->stream);
-    pool_release(b->ctx, b->d_lde);
-    pool_release(b->ctx, b->d_dig);
-    delete b;
-}
+#include "host_prover.hpp"

@@ -124,4 +124,10 @@ __global__ void pp_scale_kernel(u64 *pp, size_t pp_stride, unsigned num_prods, c
     }
 }
 
+// trim_to_len's divisibility check (field/src/polynomial/mod.rs:164-178): raises *flag when any of v[0..count) is nonzero
+__global__ void any_nonzero_kernel(const u64 *v, size_t count, unsigned *flag) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count && gl::canon(v[i]) != 0) atomicOr(flag, 1u);
+}
+
 }  // namespace plonk

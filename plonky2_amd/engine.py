@@ -63,20 +63,39 @@ class Engine:
         self.lib = lib if lib is not None else _lib.product()
         self.mem = memory if memory is not None else TorchMemory(device_index)
         ctx = C.c_void_p()
-        rc = self.lib.p2hot_ctx_create(device_index, self.mem.stream(), C.byref(ctx))
-        self.ctx = ctx
+        self._stream = self.mem.stream()
+        rc = self.lib.p2hot_ctx_create(device_index, self._stream, C.byref(ctx))
+        self._ctx = ctx
         if rc != _lib.OK:
             msg = self.lib.p2hot_last_error(ctx).decode() if ctx else "context creation failed"
             if ctx:
                 self.lib.p2hot_ctx_destroy(ctx)
-            self.ctx = None
+            self._ctx = None
             raise _lib.P2HotError(rc, msg)
+
+    @property
+    def ctx(self):
+        """The library context, re-bound to the memory backend's CURRENT stream if that changed since the last call
+        (torch.cuda.stream(...) blocks): torch copies / collectives and libp2hot kernels then stay ordered on one
+        stream.  Every library call takes `eng.ctx` as its first argument, so this is the one place to do it."""
+        if self._ctx:
+            st = self.mem.stream()
+            if st != self._stream:
+                rc = self.lib.p2hot_ctx_set_stream(self._ctx, st)  # synchronises the old stream first
+                if rc != _lib.OK:
+                    raise _lib.P2HotError(rc, self.lib.p2hot_last_error(self._ctx).decode())
+                self._stream = st
+        return self._ctx
+
+    @ctx.setter
+    def ctx(self, value):
+        self._ctx = value
 
     # -- plumbing
     def close(self):
-        if getattr(self, "ctx", None):
-            self.lib.p2hot_ctx_destroy(self.ctx)
-            self.ctx = None
+        if getattr(self, "_ctx", None):
+            self.lib.p2hot_ctx_destroy(self._ctx)
+            self._ctx = None
 
     def __del__(self):
         try:
@@ -86,7 +105,7 @@ class Engine:
 
     def check(self, rc):
         if rc != _lib.OK:
-            raise _lib.P2HotError(rc, self.lib.p2hot_last_error(self.ctx).decode())
+            raise _lib.P2HotError(rc, self.lib.p2hot_last_error(self._ctx).decode())
 
     def sync(self):
         self.check(self.lib.p2hot_ctx_sync(self.ctx))
@@ -96,7 +115,11 @@ class Engine:
         return x if self.mem.is_buffer(x) else self.mem.from_host(x)
 
     def host(self, x):
-        return self.mem.to_host(x) if self.mem.is_buffer(x) else np.asarray(x, dtype=np.uint64)
+        if self.mem.is_buffer(x):
+            return self.mem.to_host(x)
+        if hasattr(x, "degree_log") and callable(getattr(x, "host", None)):  # fri.oracle.DeviceColumns
+            return x.host()
+        return np.asarray(x, dtype=np.uint64)
 
     def ptr(self, x):
         return C.c_void_p(self.mem.ptr(x)) if x is not None else None
@@ -167,10 +190,15 @@ class Engine:
 
     def gather_rows(self, colmajor, idx):
         W, stride = colmajor.shape
-        idx = self.dev(np.asarray(idx, dtype=np.uint64))
+        if not self.mem.is_buffer(idx):  # host indices are validated here; device-resident ones by the kernel (p2hot_ctx_sync)
+            idx = np.asarray(idx, dtype=np.uint64)
+            if idx.size and int(idx.max()) >= stride:
+                raise IndexError("gather_rows: row index %d out of range (%d rows)" % (int(idx.max()), stride))
+        idx = self.dev(idx)
         m = idx.shape[0]
         out = self.mem.empty(m, W)
-        self.check(self.lib.p2hot_gather_rows_dev(self.ctx, self.ptr(colmajor), stride, W, self.ptr(idx), m, self.ptr(out)))
+        self.check(self.lib.p2hot_gather_rows_dev(self.ctx, self.ptr(colmajor), stride, stride, W, self.ptr(idx), m,
+                                                  self.ptr(out)))
         return out
 
     def commit(self, cols, log_n, rate_bits, cap_height, is_values, row_begin=0, row_count=None, want_leaves=False,

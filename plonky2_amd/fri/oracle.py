@@ -1,63 +1,145 @@
-"""PolynomialBatch -- mirror of plonky2/src/fri/oracle.rs:30-147 with the pipeline on the GPU.
+"""PolynomialBatch -- mirror of plonky2/src/fri/oracle.rs:30-237 over libp2hot.
 
 from_values / from_coeffs keep the reference's signature (values, rate_bits, blinding, cap_height,
 timing, fft_root_table); `timing` and `fft_root_table` are accepted and ignored (the GPU path has
 its own twiddle tables), `blinding=True` raises (salts come from OsRng in the reference,
-oracle.rs:133-137).  The LDE matrix stays on the GPU in column-major form; `merkle_tree.leaves`
-and `get_lde_values` fetch rows on demand.
+oracle.rs:133-137).  Every batch is a `p2hot_batch` handle of the library: host arrays go through
+the host-pointer entry point (p2hot_commit -- what the Rust shim calls), device buffers through
+p2hot_commit_dev + p2hot_batch_wrap_dev.  The LDE matrix stays on the GPU in column-major form;
+`merkle_tree.leaves` and `get_lde_values` fetch rows on demand.
+
+OpeningSet evaluation and prove_openings are ONE library call each (p2hot_eval_openings,
+p2hot_prove_openings): this module only marshals arguments and reshapes the flat result buffers.
 """
+import ctypes as C
+
 import numpy as np
 
+from .. import _lib
 from ..engine import default_engine
 from ..hash.merkle_tree import MerkleTree
 
+P = 0xFFFFFFFF00000001
+
 
 class PolynomialBatch:
-    def __init__(self, engine, coeffs, lde, digests, cap, degree_log, rate_bits, cap_height, blinding=False):
+    def __init__(self, engine, handle, W, degree_log, rate_bits, cap_height, cap, digests=None, coeffs=None, lde=None,
+                 blinding=False):
         self.engine = engine
-        self._coeffs = coeffs      # device [W][n]
-        self.lde = lde             # device [W][N], rows in committed (bit-reversed) order
+        self._h = handle           # p2hot_batch*
+        self._W = W
+        self._coeffs = coeffs      # device [W][n] when the batch was built from device buffers, else None
+        self.lde = lde             # device [W][N] (same condition)
         self.degree_log = degree_log
         self.rate_bits = rate_bits
+        self.cap_height = cap_height
         self.blinding = blinding
-        W = coeffs.shape[0]
         N = 1 << (degree_log + rate_bits)
-        self.merkle_tree = MerkleTree(None, digests, engine.host(cap), cap_height, n_leaves=N, engine=engine,
-                                      leaf_getter=lambda idx: engine.host(engine.gather_rows(lde, idx)) if W else
-                                      np.zeros((len(idx), 0), dtype=np.uint64))
+        self.merkle_tree = MerkleTree(None, digests, cap, cap_height, n_leaves=N,
+                                      engine=engine if digests is not None and engine.mem.is_buffer(digests) else None,
+                                      leaf_getter=self._rows, path_getter=self._paths if digests is None else None,
+                                      digests_getter=self._digests_host)
+
+    def __del__(self):
+        try:
+            if self._h and getattr(self.engine, "_ctx", None):
+                self.engine.lib.p2hot_batch_free(self._h)
+        except Exception:
+            pass
+        self._h = None
+
+    # -- lazily fetched pieces (MerkleTree::get / ::prove on the device-resident tree)
+    def _rows(self, idx):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.uint64).reshape(-1))
+        out = np.zeros((len(idx), self._W), dtype=np.uint64)
+        if len(idx) and self._W:
+            self.engine.check(self.engine.lib.p2hot_batch_rows(self._h, idx.ctypes.data, len(idx), out.ctypes.data))
+        return out
+
+    def _paths(self, idx):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.uint64).reshape(-1))
+        layers = self.degree_log + self.rate_bits - self.cap_height
+        out = np.zeros((len(idx), layers, 4), dtype=np.uint64)
+        if len(idx) and layers:
+            self.engine.check(self.engine.lib.p2hot_batch_paths(self._h, idx.ctypes.data, len(idx), out.ctypes.data))
+        return out
+
+    def _digests_host(self):
+        nd = self.engine.num_digests(self.degree_log + self.rate_bits, self.cap_height)
+        out = np.zeros((nd, 4), dtype=np.uint64)
+        if nd:
+            self.engine.check(self.engine.lib.p2hot_batch_digests(self._h, out.ctypes.data))
+        return out
 
     @property
     def polynomials(self):
         """coefficient form, host [W][n] (oracle.rs:32), canonical representatives"""
-        a = self.engine.host(self._coeffs)
-        P = np.uint64(0xFFFFFFFF00000001)
-        return np.where(a >= P, a - P, a)
+        out = np.zeros((self._W, 1 << self.degree_log), dtype=np.uint64)
+        if self._W:
+            self.engine.check(self.engine.lib.p2hot_batch_coeffs(self._h, 0, self._W, out.ctypes.data))
+        return out
 
     @classmethod
-    def from_values(cls, values, rate_bits, blinding, cap_height, timing=None, fft_root_table=None, engine=None):
-        """oracle.rs:57-79.  values: [W][n] (host ndarray or device buffer), values on H_n."""
-        return cls._build(values, rate_bits, blinding, cap_height, True, engine)
+    def from_values(cls, values, rate_bits, blinding, cap_height, timing=None, fft_root_table=None, engine=None,
+                    keep_values=False):
+        """oracle.rs:57-79.  values: [W][n] (host ndarray or device buffer), values on H_n.
+        keep_values: keep the values on the device for plonk.prover (P2HOT_KEEP_VALUES)."""
+        return cls._build(values, rate_bits, blinding, cap_height, True, engine, keep_values)
 
     @classmethod
     def from_coeffs(cls, polynomials, rate_bits, blinding, cap_height, timing=None, fft_root_table=None, engine=None):
         """oracle.rs:82-112.  polynomials: [W][n] coefficients."""
-        return cls._build(polynomials, rate_bits, blinding, cap_height, False, engine)
+        return cls._build(polynomials, rate_bits, blinding, cap_height, False, engine, False)
 
     @classmethod
-    def _build(cls, cols, rate_bits, blinding, cap_height, is_values, engine):
+    def _build(cls, cols, rate_bits, blinding, cap_height, is_values, engine, keep_values):
         eng = engine or default_engine()
         if blinding:
             raise NotImplementedError("blinding=True draws salts from OsRng in the reference (oracle.rs:133-137); "
                                       "use the CPU prover for zero-knowledge configs")
-        d_cols = eng.dev(cols)
-        if d_cols.ndim != 2:
+        if isinstance(cols, DeviceColumns):
+            return cls._from_device_columns(cols, rate_bits, cap_height, is_values, eng, keep_values)
+        if not eng.mem.is_buffer(cols):
+            cols = np.asarray(cols, dtype=np.uint64)
+        if cols.ndim != 2:
             raise ValueError("expected [W][n]")
-        W, n = d_cols.shape
+        W, n = cols.shape
         log_n = int(n).bit_length() - 1
         if n != 1 << log_n:
             raise ValueError("polynomial length must be a power of two")  # log2_strict, oracle.rs:88
-        r = eng.commit(d_cols, log_n, rate_bits, cap_height, is_values)
-        return cls(eng, r["coeffs"], r["lde"], r["digests"], r["cap"], log_n, rate_bits, cap_height, blinding)
+        h = C.c_void_p()
+        if eng.mem.is_buffer(cols):
+            # device buffers: the *_dev flow, wrapped into a handle that borrows them
+            r = eng.commit(cols, log_n, rate_bits, cap_height, is_values)
+            eng.check(eng.lib.p2hot_batch_wrap_dev(eng.ctx, eng.ptr(r["coeffs"]), eng.ptr(r["lde"]), eng.ptr(r["digests"]), W,
+                                                   log_n, rate_bits, cap_height, C.byref(h)))
+            return cls(eng, h, W, log_n, rate_bits, cap_height, eng.host(r["cap"]), digests=r["digests"], coeffs=r["coeffs"],
+                       lde=r["lde"])
+        # host arrays: exactly what the Rust shim does -- W column pointers in, the cap out, the rest stays on the GPU
+        cols = np.ascontiguousarray(cols, dtype=np.uint64)
+        ptrs = (C.c_void_p * max(W, 1))(*[cols[c].ctypes.data for c in range(W)])
+        cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+        eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rate_bits, cap_height, 1 if is_values else 0,
+                                       _lib.KEEP_VALUES if (keep_values and is_values) else 0, None, None, None,
+                                       cap.ctypes.data, C.byref(h)))
+        return cls(eng, h, W, log_n, rate_bits, cap_height, cap)
+
+    @classmethod
+    def _from_device_columns(cls, dc, rate_bits, cap_height, is_values, eng, keep_values):
+        W, log_n = dc.width, dc.degree_log
+        cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+        h = C.c_void_p()
+        handle, dc._h = dc._h, None  # consumed by the library
+        eng.check(eng.lib.p2hot_commit_cols(eng.ctx, handle, rate_bits, cap_height, 1 if is_values else 0,
+                                            _lib.KEEP_VALUES if (keep_values and is_values) else 0, None, None, None,
+                                            cap.ctypes.data, C.byref(h)))
+        return cls(eng, h, W, log_n, rate_bits, cap_height, cap)
+
+    def values(self):
+        """the kept input values (keep_values=True) as a borrowed DeviceColumns view"""
+        h = C.c_void_p()
+        self.engine.check(self.engine.lib.p2hot_batch_values(self._h, C.byref(h)))
+        return DeviceColumns(self.engine, h, owner=self)
 
     def get_lde_values(self, index, step=1):
         """oracle.rs:142-147: row reverse_bits(index*step, degree_log + rate_bits) of the leaf matrix"""
@@ -65,6 +147,48 @@ class PolynomialBatch:
         i = index * step
         rev = int(format(i, "0%db" % bits)[::-1], 2) if bits else 0
         return self.merkle_tree.get(rev)
+
+
+class DeviceColumns:
+    """p2hot_cols: a device-resident Vec<PolynomialValues> / Vec<PolynomialCoeffs>"""
+
+    def __init__(self, engine, handle, owner=None):
+        self.engine, self._h, self._owner = engine, handle, owner
+
+    @classmethod
+    def upload(cls, cols, engine=None):
+        eng = engine or default_engine()
+        cols = np.ascontiguousarray(np.asarray(cols, dtype=np.uint64))
+        W, n = cols.shape
+        log_n = int(n).bit_length() - 1
+        if n != 1 << log_n:
+            raise ValueError("column length must be a power of two")
+        ptrs = (C.c_void_p * max(W, 1))(*[cols[c].ctypes.data for c in range(W)])
+        h = C.c_void_p()
+        eng.check(eng.lib.p2hot_cols_upload(eng.ctx, ptrs, W, log_n, C.byref(h)))
+        return cls(eng, h)
+
+    @property
+    def width(self):
+        return self.engine.lib.p2hot_cols_width(self._h)
+
+    @property
+    def degree_log(self):
+        return self.engine.lib.p2hot_cols_degree_log(self._h)
+
+    def host(self):
+        out = np.zeros((self.width, 1 << self.degree_log), dtype=np.uint64)
+        if self.width:
+            self.engine.check(self.engine.lib.p2hot_cols_download(self._h, 0, self.width, out.ctypes.data))
+        return out
+
+    def __del__(self):
+        try:
+            if self._h and getattr(self.engine, "_ctx", None):
+                self.engine.lib.p2hot_cols_free(self._h)
+        except Exception:
+            pass
+        self._h = None
 
 
 # ------------------------------------------------------------------ prove_openings (oracle.rs:176-237)
@@ -76,35 +200,38 @@ class FriBatchInfo:
         self.polynomials = [(int(o), int(p)) for o, p in polynomials]
 
 
+def _handles(oracles):
+    return (C.c_void_p * max(len(oracles), 1))(*[o._h for o in oracles])
+
+
 def eval_openings(oracles, points, engine=None):
     """OpeningSet::new (plonk/proof.rs:314-327): every polynomial of every oracle at each extension point.
     Returns a list (per oracle) of arrays [n_points][W][2]."""
     eng = engine or oracles[0].engine
     pts = np.ascontiguousarray(np.asarray(points, dtype=np.uint64).reshape(-1, 2))
-    out = []
+    total = sum(o._W for o in oracles)
+    flat = np.zeros(max(1, 2 * len(pts) * total), dtype=np.uint64)
+    eng.check(eng.lib.p2hot_eval_openings(eng.ctx, _handles(oracles), len(oracles), pts.ctypes.data, len(pts), flat.ctypes.data))
+    out, off = [], 0
     for o in oracles:
-        co = o._coeffs
-        W, n = co.shape
-        table = eng.dev(np.asarray([eng.mem.ptr(co) + 8 * j * n for j in range(W)] or [0], dtype=np.uint64))
-        res = eng.mem.zeros(len(pts), max(W, 1), 2)
-        eng.check(eng.lib.p2hot_eval_polys_dev(eng.ctx, eng.ptr(table), W, o.degree_log, pts.ctypes.data, len(pts),
-                                               eng.ptr(res)))
-        out.append(eng.host(res)[:, :W])
+        cnt = 2 * len(pts) * o._W
+        out.append(flat[off:off + cnt].reshape(len(pts), o._W, 2))
+        off += cnt
     return out
 
 
 def final_poly_device(batches, oracles, alpha, engine=None):
-    """The final_poly of prove_openings (oracle.rs:186-213) on the GPU: per batch reduce_polys_base, divide_by_linear,
-    shift_poly + accumulate.  Returns device planes [2][n] (component 0 plane, component 1 plane)."""
-    import ctypes as C
+    """The final_poly of prove_openings (oracle.rs:186-213) on the GPU (p2hot_fri_final_poly_dev, the building block
+    p2hot_prove_openings uses): device planes [2][n].  Only for oracles built from device buffers; kept for the
+    stage-level parity test."""
     eng = engine or oracles[0].engine
     n = 1 << oracles[0].degree_log
     ptrs, offsets = [], [0]
     for b in batches:
         for (oi, pi) in b.polynomials:
             co = oracles[oi]._coeffs
-            if co.shape[1] != n:
-                raise ValueError("all oracles must have the same degree")
+            if co is None:
+                raise ValueError("final_poly_device needs oracles committed from device buffers")
             ptrs.append(eng.mem.ptr(co) + 8 * pi * co.shape[1])
         offsets.append(len(ptrs))
     table = eng.dev(np.asarray(ptrs if ptrs else [0], dtype=np.uint64))
@@ -118,52 +245,71 @@ def final_poly_device(batches, oracles, alpha, engine=None):
 
 
 def prove_openings(batches, oracles, challenger, rate_bits, cap_height, reduction_arity_bits, proof_of_work_bits,
-                   num_query_rounds, engine=None, timing=None):
-    """PolynomialBatch::prove_openings + fri_proof (oracle.rs:176-237, fri/prover.rs:24-82) with everything
-    but the transcript bookkeeping on the GPU.  Returns a dict shaped like FriProof:
+                   num_query_rounds, engine=None, timing=None, final_poly_coeff_len=None, max_num_query_steps=None):
+    """PolynomialBatch::prove_openings + fri_proof (oracle.rs:176-237, fri/prover.rs:24-82): one p2hot_prove_openings
+    call.  Returns a dict shaped like FriProof:
       commit_phase_merkle_caps, query_round_proofs [{initial_trees_proof: [(leaf, siblings)...], steps: [(evals, siblings)...]}],
       final_poly [[c0, c1]...], pow_witness.
-    `timing` (a dict, the reference's TimingTree argument): filled with synchronised wall milliseconds per stage."""
+    `timing` (a dict): total synchronised wall milliseconds of the call under "prove_openings"."""
     import time
-    from .prover import fri_committed_trees_device, fri_proof_of_work
     eng = engine or oracles[0].engine
-    t_last = [time.perf_counter()]
-
-    def lap(label):
-        if timing is not None:
-            eng.sync()
-            now = time.perf_counter()
-            timing[label] = timing.get(label, 0.0) + (now - t_last[0]) * 1e3
-            t_last[0] = now
-
-    alpha = challenger.get_extension_challenge()                      # oracle.rs:186
-    planes = final_poly_device(batches, oracles, alpha, eng)
-    lap("reduce + divide_by_linear (final_poly)")
-    log_n = oracles[0].degree_log
-    trees, final, _betas = fri_committed_trees_device(planes, log_n, challenger, rate_bits, cap_height,
-                                                      reduction_arity_bits, eng)   # prover.rs:40-51
-    lap("final FFT + fold codewords in the commitment phase")
-    pow_witness = fri_proof_of_work(challenger, proof_of_work_bits, eng)           # prover.rs:53-58
-    lap("find proof-of-work witness")
-    lde_size = 1 << (log_n + rate_bits)
-    xs = [rand % lde_size for rand in challenger.get_n_challenges(num_query_rounds)]   # prover.rs:215-220
-    # initial trees: one batched row gather and one batched path gather per oracle, on the device (prover.rs:238-241)
-    idx = np.asarray(xs, dtype=np.uint64)
-    init_rows = [o.merkle_tree._getter(idx) if o.merkle_tree._leaves is None else o.merkle_tree.leaves[idx.astype(np.int64)]
-                 for o in oracles]
-    init_paths = [o.merkle_tree.prove_many(idx) for o in oracles]
-    # FRI trees: one batched row fetch + one batched path walk per round (prover.rs:242-253 for all queries at once)
-    step_rows, step_paths, idx_r = [], [], idx.copy()
-    for i, tree in enumerate(trees):
-        idx_r = idx_r >> np.uint64(reduction_arity_bits[i])
-        rows = tree._getter(idx_r) if tree._leaves is None else tree.leaves[idx_r.astype(np.int64)]
-        step_rows.append(np.asarray(rows).reshape(len(xs), -1, 2))
-        step_paths.append(tree.prove_many(idx_r))
+    arity = [int(a) for a in reduction_arity_bits]
+    R, Q = len(arity), int(num_query_rounds)
+    ab = (C.c_uint * max(R, 1))(*arity)
+    fp = _lib.FriParams(rate_bits, cap_height, proof_of_work_bits, Q, ab, R, 0, max_num_query_steps or 0,
+                        final_poly_coeff_len or 0)
+    keep = []  # index arrays referenced by the batch structs
+    infos = (_lib.FriBatchInfo * max(len(batches), 1))()
+    for k, b in enumerate(batches):
+        oi = (C.c_uint32 * max(len(b.polynomials), 1))(*[o for o, _ in b.polynomials])
+        pi = (C.c_uint32 * max(len(b.polynomials), 1))(*[p for _, p in b.polynomials])
+        keep += [oi, pi]
+        infos[k].point[0], infos[k].point[1] = b.point
+        infos[k].oracle_index, infos[k].poly_index, infos[k].n_polys = oi, pi, len(b.polynomials)
+    handles = _handles(oracles)
+    lay = _lib.FriProofLayout()
+    rc = eng.lib.p2hot_fri_proof_sizes(handles, len(oracles), C.byref(fp), C.byref(lay))
+    if rc != _lib.OK:
+        raise _lib.P2HotError(rc, "inconsistent FRI parameters")
+    bufs = {k: np.zeros(max(1, getattr(lay, k + "_words")), dtype=np.uint64)
+            for k in ("caps", "final_poly", "initial_leaves", "initial_paths", "step_evals", "step_paths")}
+    qidx = np.zeros(max(1, Q), dtype=np.uint64)
+    proof = _lib.FriProof(bufs["caps"].ctypes.data, bufs["final_poly"].ctypes.data, 0, qidx.ctypes.data,
+                          bufs["initial_leaves"].ctypes.data, bufs["initial_paths"].ctypes.data,
+                          bufs["step_evals"].ctypes.data, bufs["step_paths"].ctypes.data)
+    t0 = time.perf_counter()
+    eng.check(eng.lib.p2hot_prove_openings(eng.ctx, infos, len(batches), handles, len(oracles), challenger._h, C.byref(fp),
+                                           C.byref(proof)))
+    if timing is not None:
+        timing["prove_openings"] = timing.get("prove_openings", 0.0) + (time.perf_counter() - t0) * 1e3
+    # reshape the flat buffers (layout: include/p2hot.h, p2hot_fri_proof)
+    ncap = 1 << cap_height
+    log_N = oracles[0].degree_log + rate_bits
+    widths = [o._W for o in oracles]
+    wsum = sum(widths)
+    il = bufs["initial_leaves"][:Q * wsum].reshape(Q, wsum) if wsum else np.zeros((Q, 0), dtype=np.uint64)
+    layers0 = log_N - cap_height
+    ip = bufs["initial_paths"][:Q * len(oracles) * layers0 * 4].reshape(Q, len(oracles), layers0, 4)
+    ev_w, pa_w, lm = [], [], log_N
+    for a in arity:
+        ev_w.append(2 << a)
+        pa_w.append(lm - a - cap_height)
+        lm -= a
+    se = bufs["step_evals"][:Q * sum(ev_w)].reshape(Q, sum(ev_w)) if R else None
+    sp = bufs["step_paths"][:Q * 4 * sum(pa_w)].reshape(Q, 4 * sum(pa_w)) if R else None
     queries = []
-    for q in range(len(xs)):
-        initial = [(init_rows[oi][q], init_paths[oi][q]) for oi in range(len(oracles))]
-        steps = [(step_rows[i][q], step_paths[i][q]) for i in range(len(trees))]
+    for q in range(Q):
+        initial, wo = [], 0
+        for oi, w in enumerate(widths):
+            initial.append((il[q, wo:wo + w], ip[q, oi]))
+            wo += w
+        steps, eo, po = [], 0, 0
+        for r in range(R):
+            steps.append((se[q, eo:eo + ev_w[r]].reshape(-1, 2), sp[q, po:po + 4 * pa_w[r]].reshape(pa_w[r], 4)))
+            eo += ev_w[r]
+            po += 4 * pa_w[r]
         queries.append({"initial_trees_proof": initial, "steps": steps})
-    lap("produce batch opening proof: query rounds")
-    return {"commit_phase_merkle_caps": [t.cap.entries for t in trees], "query_round_proofs": queries,
-            "final_poly": final, "pow_witness": pow_witness}
+    return {"commit_phase_merkle_caps": [bufs["caps"][4 * ncap * r:4 * ncap * (r + 1)].reshape(ncap, 4) for r in range(R)],
+            "query_round_proofs": queries,
+            "final_poly": bufs["final_poly"][:lay.final_poly_words].reshape(-1, 2),
+            "pow_witness": int(proof.pow_witness), "query_indices": [int(x) for x in qidx[:Q]]}

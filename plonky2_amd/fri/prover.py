@@ -27,12 +27,12 @@ def fri_committed_trees(coeffs, challenger, rate_bits, cap_height, reduction_ari
     log_n = n.bit_length() - 1
     if n != 1 << log_n:
         raise ValueError("coefficient count must be a power of two")
-    if final_poly_coeff_len or max_num_query_steps:  # prover.rs:89-90 (starky multi-degree recursion)
-        eng.check(eng.lib.p2hot_fri_set_padding(eng.ctx, max_num_query_steps or 0, final_poly_coeff_len or 0))
-    return _commit(coeffs, None, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, eng)
+    return _commit(coeffs, None, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, eng,
+                   max_num_query_steps or 0, final_poly_coeff_len or 0)   # prover.rs:89-90: None -> 0
 
 
-def _commit(coeffs, planes, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, engine):
+def _commit(coeffs, planes, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, engine,
+            max_num_query_steps=0, final_poly_coeff_len=0):
     eng = engine or challenger.engine or default_engine()
     n = 1 << log_n
     arity = [int(a) for a in reduction_arity_bits]
@@ -56,13 +56,12 @@ def _commit(coeffs, planes, log_n, challenger, rate_bits, cap_height, reduction_
     ab = (C.c_uint * max(1, len(arity)))(*arity)
     if planes is None:
         eng.check(eng.lib.p2hot_fri_commit(eng.ctx, coeffs.ctypes.data, log_n, rate_bits, cap_height, ab, len(arity),
-                                           challenger._h, leaves.ctypes.data, digests.ctypes.data, caps.ctypes.data,
-                                           betas.ctypes.data, final.ctypes.data))
+                                           max_num_query_steps, final_poly_coeff_len, challenger._h, leaves.ctypes.data,
+                                           digests.ctypes.data, caps.ctypes.data, betas.ctypes.data, final.ctypes.data))
     else:
-        eng.check(eng.lib.p2hot_fri_set_device_digests(eng.ctx, 1))
         eng.check(eng.lib.p2hot_fri_commit_dev(eng.ctx, eng.ptr(planes), log_n, rate_bits, cap_height, ab, len(arity),
-                                               challenger._h, eng.ptr(leaves), eng.ptr(digests), caps.ctypes.data,
-                                               betas.ctypes.data, final.ctypes.data))
+                                               max_num_query_steps, final_poly_coeff_len, challenger._h, eng.ptr(leaves),
+                                               eng.ptr(digests), 1, caps.ctypes.data, betas.ctypes.data, final.ctypes.data))
     trees, lo, do = [], 0, 0
     for i, (mi, nl, nd) in enumerate(sizes):
         lv = leaves[lo:lo + 2 * mi].reshape(nl, -1)
@@ -80,10 +79,12 @@ def _commit(coeffs, planes, log_n, challenger, rate_bits, cap_height, reduction_
     return trees, final[:n_final], betas[:len(sizes)]
 
 
-def fri_committed_trees_device(planes, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, engine=None):
+def fri_committed_trees_device(planes, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, engine=None,
+                               final_poly_coeff_len=None, max_num_query_steps=None):
     """fri_committed_trees on coefficients that are already on the device as planes [2][n]
     (e.g. plonky2_amd.fri.oracle.final_poly_device)."""
-    return _commit(None, planes, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, engine)
+    return _commit(None, planes, log_n, challenger, rate_bits, cap_height, reduction_arity_bits, engine,
+                   max_num_query_steps or 0, final_poly_coeff_len or 0)
 
 
 def fri_proof_of_work(challenger, proof_of_work_bits, engine=None):

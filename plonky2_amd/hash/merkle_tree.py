@@ -23,11 +23,15 @@ class MerkleTree:
     `leaves` may be given lazily (a callable rows(idx_array) -> [m][w]) when the leaf matrix stays on the GPU.
     """
 
-    def __init__(self, leaves, digests, cap, cap_height, n_leaves=None, leaf_getter=None, engine=None):
+    def __init__(self, leaves, digests, cap, cap_height, n_leaves=None, leaf_getter=None, engine=None, path_getter=None,
+                 digests_getter=None):
         """digests: host array, or a DEVICE buffer (then `engine` must be given): it stays on the GPU, proofs are
-        gathered there (p2hot_merkle_paths_dev) and `.digests` copies it to the host only when somebody asks."""
+        gathered there (p2hot_merkle_paths_dev) and `.digests` copies it to the host only when somebody asks; or None
+        with `path_getter` / `digests_getter` callables when the tree lives inside a p2hot_batch handle."""
         self._leaves = leaves
         self._getter = leaf_getter
+        self._path_getter = path_getter
+        self._digests_getter = digests_getter
         self._engine = engine
         self._digests_dev = digests if engine is not None and engine.mem.is_buffer(digests) else None
         self._digests = None if self._digests_dev is not None else digests
@@ -38,7 +42,7 @@ class MerkleTree:
     @property
     def digests(self):
         if self._digests is None:
-            self._digests = self._engine.host(self._digests_dev)
+            self._digests = self._digests_getter() if self._digests_dev is None else self._engine.host(self._digests_dev)
         return self._digests
 
     @classmethod
@@ -76,6 +80,10 @@ class MerkleTree:
         log_n = n.bit_length() - 1
         num_layers = log_n - self.cap_height
         idx = np.asarray(leaf_indices, dtype=np.uint64).reshape(-1)
+        if idx.size and int(idx.max()) >= n:
+            raise IndexError("leaf index %d out of range (%d leaves)" % (int(idx.max()), n))  # merkle_tree.rs:231 panics
+        if self._path_getter is not None and self._digests is None:
+            return self._path_getter(idx)
         if self._digests_dev is not None and self._digests is None:
             eng = self._engine
             out = eng.mem.zeros(len(idx), max(num_layers, 1), 4)

@@ -16,10 +16,33 @@ def num_partial_products(n, max_degree):
 def all_wires_permutation_partial_products(wires, sigmas, k_is, quotient_degree_factor, betas, gammas, engine=None):
     """all_wires_permutation_partial_products (prover.rs:356-390) followed by the batch ordering of prover.rs:224-229.
 
-    wires, sigmas: [num_routed][n] column-major (host ndarray or device buffer) -- MatrixWitness.wire_values[col][row]
-    and the sigma polynomials' values on the subgroup.  Returns a device buffer [nc * (num_prods + 1)][n]: the Z of every
-    challenge first, then the partial products of challenge 0, 1, ... (`zs_partial_products`)."""
+    wires, sigmas: [num_routed][n] column-major -- MatrixWitness.wire_values[col][row] and the sigma polynomials' values
+    on the subgroup -- as host ndarrays / DeviceColumns (the host-pointer entry point p2hot_partial_products, what the
+    Rust shim calls; returns DeviceColumns) or as device buffers (p2hot_partial_products_dev; returns a device buffer).
+    Result [nc * (num_prods + 1)][n]: the Z of every challenge first, then the partial products of challenge 0, 1, ...
+    (`zs_partial_products`)."""
+    from ..fri.oracle import DeviceColumns
     eng = engine or default_engine()
+    if not (eng.mem.is_buffer(wires) and eng.mem.is_buffer(sigmas)):
+        for x in (wires, sigmas):
+            if not isinstance(x, DeviceColumns) and (np.ndim(x) != 2 or np.shape(x)[1] & (np.shape(x)[1] - 1)):
+                raise ValueError("wires and sigmas must be [num_routed][n] with n a power of two")
+        dw = wires if isinstance(wires, DeviceColumns) else DeviceColumns.upload(eng.host(wires), eng)
+        ds = sigmas if isinstance(sigmas, DeviceColumns) else DeviceColumns.upload(eng.host(sigmas), eng)
+        k = np.ascontiguousarray(np.asarray(k_is, dtype=np.uint64))
+        if dw.degree_log != ds.degree_log or dw.width < len(k) or ds.width < len(k):
+            raise ValueError("wires and sigmas must both be [num_routed][n]")
+        if not quotient_degree_factor < len(k):  # prover.rs:215-218
+            raise ValueError("quotient_degree_factor must be smaller than the number of routed wires")
+        b = np.ascontiguousarray(np.asarray(betas, dtype=np.uint64))
+        g = np.ascontiguousarray(np.asarray(gammas, dtype=np.uint64))
+        if b.shape != g.shape or b.ndim != 1:
+            raise ValueError("betas and gammas must be equally long vectors")
+        h = C.c_void_p()
+        eng.check(eng.lib.p2hot_partial_products(eng.ctx, dw._h, 0, ds._h, 0, k.ctypes.data_as(C.c_void_p), len(k),
+                                                 quotient_degree_factor, b.ctypes.data_as(C.c_void_p),
+                                                 g.ctypes.data_as(C.c_void_p), len(b), None, C.byref(h)))
+        return DeviceColumns(eng, h)
     d_w, d_s = eng.dev(wires), eng.dev(sigmas)
     if d_w.ndim != 2 or d_s.shape != d_w.shape:
         raise ValueError("wires and sigmas must both be [num_routed][n]")
@@ -60,26 +83,21 @@ def quotient_poly_chunks(quotient_values, degree_bits, quotient_degree_factor, e
     arrive as values on the coset g*H of size n << ceil(log2(quotient_degree_factor)) (one row per challenge, natural
     order), are interpolated with coset_ifft, trimmed to quotient_degree_factor * n coefficients (the reference panics
     with "Quotient has failed, the vanishing polynomial is not divisible by Z_H" if the tail is not zero) and split
-    into quotient_degree_factor chunks of n coefficients.  Returns a device buffer
+    into quotient_degree_factor chunks of n coefficients.  Returns DeviceColumns
     [num_challenges * quotient_degree_factor][n] ready for PolynomialBatch.from_coeffs."""
-    from ..engine import COSET_SHIFT
+    from ..fri.oracle import DeviceColumns
     eng = engine or default_engine()
-    d = eng.dev(quotient_values)
-    if d.ndim != 2:
+    # one p2hot_quotient_chunks call (the Rust shim's path: compute_quotient_polys leaves host Vecs)
+    q = np.ascontiguousarray(eng.host(quotient_values))
+    if q.ndim != 2:
         raise ValueError("expected [num_challenges][n << quotient_degree_bits]")
-    nc, m = d.shape
-    n = 1 << degree_bits
-    qbits = max(0, (quotient_degree_factor - 1).bit_length())
-    if m != n << qbits:
+    qb = max(0, (quotient_degree_factor - 1).bit_length())
+    if q.shape[1] != (1 << degree_bits) << qb:
         raise ValueError("quotient values must live on the coset of size n << ceil(log2(quotient_degree_factor))")
-    work = eng.mem.empty(nc, m)
-    work[:] = d                                                             # coset_ifft works in place
-    eng.check(eng.lib.p2hot_coset_ifft_dev(eng.ctx, eng.ptr(work), nc, m, degree_bits + qbits, COSET_SHIFT))
-    keep = n * quotient_degree_factor
-    if keep < m and eng.host(work[:, keep:]).any():                         # trim_to_len (polynomial/mod.rs:164-178)
-        raise ValueError("Quotient has failed, the vanishing polynomial is not divisible by Z_H")
-    out = eng.mem.empty(nc * quotient_degree_factor, n)
-    for ch in range(nc):                                                    # PolynomialCoeffs::chunks (mod.rs:136-142)
-        out[ch * quotient_degree_factor:(ch + 1) * quotient_degree_factor] = \
-            work[ch, :keep].reshape(quotient_degree_factor, n)
-    return out
+    ptrs = (C.c_void_p * max(q.shape[0], 1))(*[q[c].ctypes.data for c in range(q.shape[0])])
+    h = C.c_void_p()
+    rc = eng.lib.p2hot_quotient_chunks(eng.ctx, ptrs, q.shape[0], degree_bits, quotient_degree_factor, C.byref(h))
+    if rc == 1 and b"Quotient has failed" in eng.lib.p2hot_last_error(eng._ctx):
+        raise ValueError(eng.lib.p2hot_last_error(eng._ctx).decode())  # the reference panics (polynomial/mod.rs:164-178)
+    eng.check(rc)
+    return DeviceColumns(eng, h)

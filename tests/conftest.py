@@ -41,7 +41,8 @@ def emu():
 def gpu():
     """The product engine: libp2hot.so (HIP, gfx950) on cuda:0 through the C ABI."""
     import torch
-    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X (run with -m gpu on the GPU box)")
     import __graft_entry__ as ge
     ge.build_product()
     from plonky2_amd import Engine

@@ -104,6 +104,11 @@ static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKi
     memmove(d, s, n);
     return hipSuccess;
 }
+static inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height,
+                                          hipMemcpyKind, hipStream_t) {
+    for (size_t r = 0; r < height; ++r) memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width);
+    return hipSuccess;
+}
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
     memset(d, v, n);
     return hipSuccess;

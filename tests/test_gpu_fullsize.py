@@ -191,7 +191,7 @@ def test_host_pointer_commit_pipelined_path(gpu, ora, is_values, want_leaves):
     digests = np.zeros((nd, 4), dtype=np.uint64)
     capv = np.zeros((1 << cap, 4), dtype=np.uint64)
     handle = C.c_void_p()
-    gpu.check(gpu.lib.p2hot_commit(gpu.ctx, ptrs, W, log_n, rb, cap, 1 if is_values else 0, coeffs.ctypes.data,
+    gpu.check(gpu.lib.p2hot_commit(gpu.ctx, ptrs, W, log_n, rb, cap, 1 if is_values else 0, 0, coeffs.ctypes.data,
                                    leaves.ctypes.data if want_leaves else None, digests.ctypes.data, capv.ctypes.data,
                                    C.byref(handle)))
     o = ora.commit(np.stack(cols), rb, cap, is_values)

@@ -297,7 +297,7 @@ def test_host_pointer_commit_abi(eng, ora):
     digests = np.zeros((nd, 4), dtype=np.uint64)
     capv = np.zeros((1 << cap, 4), dtype=np.uint64)
     handle = C.c_void_p()
-    eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, coeffs.ctypes.data, leaves.ctypes.data,
+    eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, 0, coeffs.ctypes.data, leaves.ctypes.data,
                                    digests.ctypes.data, capv.ctypes.data, C.byref(handle)))
     o = ora.commit(np.stack(cols), rb, cap, True)
     assert (coeffs == o["coeffs"]).all() and (leaves == o["leaves"]).all()
@@ -318,7 +318,7 @@ def test_host_pointer_commit_abi(eng, ora):
     eng.lib.p2hot_batch_free(handle)
     # digests_out = NULL: the digest array never leaves the device, paths still come from the handle
     handle = C.c_void_p()
-    eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, None, None, None, capv.ctypes.data, C.byref(handle)))
+    eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, 0, None, None, None, capv.ctypes.data, C.byref(handle)))
     eng.check(eng.lib.p2hot_batch_paths(handle, idx.ctypes.data, 3, paths.ctypes.data))
     assert (paths[1] == ora.merkle_prove(int(idx[1]), N, cap, o["digests"])).all() and (capv == o["cap"]).all()
     eng.lib.p2hot_batch_free(handle)

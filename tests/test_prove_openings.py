@@ -41,7 +41,10 @@ def test_final_poly_and_prove_openings_vs_oracle(eng, ora, log_n, widths, rb, ca
     rng = np.random.default_rng(log_n * 31 + len(widths))
     n = 1 << log_n
     cols = [rand_field(rng, w, n) for w in widths]
+    # host arrays: p2hot_commit with host pointers only, exactly what the Rust shim calls (the batch lives behind a handle)
     oracles = [PolynomialBatch.from_coeffs(c, rb, False, cap, engine=eng) for c in cols]
+    # device buffers: the *_dev flow wrapped into handles (p2hot_batch_wrap_dev)
+    oracles_dev = [PolynomialBatch.from_coeffs(eng.dev(c), rb, False, cap, engine=eng) for c in cols]
     # two opening batches like plonky2's zeta / g*zeta (plonk_common.rs FRI_ORACLES): all polys at z0, the first oracle at z1
     all_polys = [(oi, pi) for oi, w in enumerate(widths) for pi in range(w)]
     first = [(0, pi) for pi in range(widths[0])]
@@ -50,7 +53,7 @@ def test_final_poly_and_prove_openings_vs_oracle(eng, ora, log_n, widths, rb, ca
     ob = [(z0, all_polys), (z1, first)]
 
     alpha = rand_field(rng, 2)
-    got = eng.host(final_poly_device(batches, oracles, alpha, eng))      # planes [2][n]
+    got = eng.host(final_poly_device(batches, oracles_dev, alpha, eng))  # planes [2][n]
     exp = _oracle_final_poly(ora, ob, cols, alpha)
     assert (got.T == exp).all()
 
@@ -60,7 +63,15 @@ def test_final_poly_and_prove_openings_vs_oracle(eng, ora, log_n, widths, rb, ca
     c.observe_elements(pre)
     oc.observe_elements(pre)
     pow_bits, n_queries = 5, 3
+    c_dev = Challenger(eng)
+    c_dev.observe_elements(pre)
     proof = prove_openings(batches, oracles, c, rb, cap, arity, pow_bits, n_queries, engine=eng)
+    proof_dev = prove_openings(batches, oracles_dev, c_dev, rb, cap, arity, pow_bits, n_queries, engine=eng)
+    assert proof["pow_witness"] == proof_dev["pow_witness"] and proof["query_indices"] == proof_dev["query_indices"]
+    assert (proof["final_poly"] == proof_dev["final_poly"]).all()
+    for qa, qb in zip(proof["query_round_proofs"], proof_dev["query_round_proofs"]):
+        for (la, sa), (lb, sb) in zip(qa["initial_trees_proof"] + qa["steps"], qb["initial_trees_proof"] + qb["steps"]):
+            assert (la == lb).all() and (sa == sb).all()
     a = oc.get_extension_challenge()
     fin = _oracle_final_poly(ora, ob, cols, np.array(a, dtype=np.uint64))
     pad = np.zeros((n << rb, 2), dtype=np.uint64)

@@ -27,7 +27,7 @@ capv = np.zeros((1 << cap, 4), dtype=np.uint64)
 leaves = np.zeros((N, W), dtype=np.uint64)  # touched once here so page faults are not timed
 for want_leaves in (False, True, False, True):
     t0 = time.perf_counter()
-    eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, coeffs.ctypes.data,
+    eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, 0, coeffs.ctypes.data,
                                    leaves.ctypes.data if want_leaves else None, digests.ctypes.data, capv.ctypes.data, None))
     dt = time.perf_counter() - t0
     print("p2hot_commit W=%d 2^%d rows, leaves_out=%s: %.1f ms  -> %.2f GFE/s PCIe-inclusive"
@@ -38,7 +38,7 @@ for want_leaves in (False, True, False, True):
 for _ in range(2):
     handle = C.c_void_p()
     t0 = time.perf_counter()
-    eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, coeffs.ctypes.data, None, None, capv.ctypes.data,
+    eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, 0, coeffs.ctypes.data, None, None, capv.ctypes.data,
                                    C.byref(handle)))
     dt = time.perf_counter() - t0
     idx = np.arange(28, dtype=np.uint64) * 12345 % N

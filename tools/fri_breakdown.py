@@ -19,7 +19,7 @@ import torch
 for variant in ("all","no_leaves","no_outputs","all"):
     ch = Challenger(eng)
     torch.cuda.synchronize(); t0=time.perf_counter()
-    eng.check(eng.lib.p2hot_fri_commit(eng.ctx, co.ctypes.data, log_n, rb, cap, ab, 4, ch._h,
+    eng.check(eng.lib.p2hot_fri_commit(eng.ctx, co.ctypes.data, log_n, rb, cap, ab, 4, 0, 0, ch._h,
         leaves.ctypes.data if variant=="all" else None,
         digests.ctypes.data if variant!="no_outputs" else None,
         caps.ctypes.data if variant!="no_outputs" else None, betas.ctypes.data, final.ctypes.data))
@@ -30,7 +30,7 @@ for variant in ("all","no_leaves","no_outputs","all"):
 eng.profile(True)
 eng.profile_results(reset=True)
 ch = Challenger(eng)
-eng.check(eng.lib.p2hot_fri_commit(eng.ctx, co.ctypes.data, log_n, rb, cap, ab, 4, ch._h, None, None, None, betas.ctypes.data,
+eng.check(eng.lib.p2hot_fri_commit(eng.ctx, co.ctypes.data, log_n, rb, cap, ab, 4, 0, 0, ch._h, None, None, None, betas.ctypes.data,
                                    final.ctypes.data))
 prof = eng.profile_results(reset=True)
 eng.profile(False)

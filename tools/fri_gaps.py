@@ -26,7 +26,7 @@ for it in range(8):
     ch = Challenger(eng)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    eng.check(eng.lib.p2hot_fri_commit(eng.ctx, co.ctypes.data, log_n, rb, cap, ab, 4, ch._h, None, None, None, betas.ctypes.data,
+    eng.check(eng.lib.p2hot_fri_commit(eng.ctx, co.ctypes.data, log_n, rb, cap, ab, 4, 0, 0, ch._h, None, None, None, betas.ctypes.data,
                                        final.ctypes.data))
     dt = (time.perf_counter() - t0) * 1e3
     if it >= 3:
