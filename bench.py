@@ -27,43 +27,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 P = 0xFFFFFFFF00000001
-SEED = 0x9E3779B97F4A7C15
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable float4 copy)
 
 
-def splitmix_columns_torch(torch, device, col_begin, col_count, n):
-    """col[c][i] = splitmix64(SEED ^ (c << 32) ^ i) mod P, generated on the device."""
-    i64 = torch.int64
-
-    def k(v):  # python int -> wrapped int64 constant
-        v &= (1 << 64) - 1
-        return v - (1 << 64) if v >= (1 << 63) else v
-
-    def lsr(z, s):
-        return (z >> s) & ((1 << (64 - s)) - 1)
-
-    c = torch.arange(col_begin, col_begin + col_count, dtype=i64, device=device).unsqueeze(1)
-    i = torch.arange(n, dtype=i64, device=device).unsqueeze(0)
-    z = (c << 32) ^ i ^ k(SEED)
-    z = z + k(0x9E3779B97F4A7C15)
-    z = (z ^ lsr(z, 30)) * k(0xBF58476D1CE4E5B9)
-    z = (z ^ lsr(z, 27)) * k(0x94D049BB133111EB)
-    z = z ^ lsr(z, 31)
-    # unsigned z >= P  <=>  signed z in [-(2^32 - 1), -1]; subtract P == add 2^32 - 1 (mod 2^64)
-    z = torch.where((z < 0) & (z >= -(2**32 - 1)), z + (2**32 - 1), z)
-    return z.contiguous()
-
-
-def splitmix_columns_numpy(col_begin, col_count, n):
-    with np.errstate(over="ignore"):
-        c = np.arange(col_begin, col_begin + col_count, dtype=np.uint64)[:, None]
-        i = np.arange(n, dtype=np.uint64)[None, :]
-        z = (c << np.uint64(32)) ^ i ^ np.uint64(SEED)
-        z = z + np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-        return np.where(z >= np.uint64(P), z - np.uint64(P), z)
+from plonky2_amd.util.synthetic import splitmix_columns_numpy, splitmix_columns_torch  # noqa: E402,F401
 
 
 def algorithmic_bytes(W, log_n, rate_bits, is_values=True):
@@ -104,38 +71,138 @@ def pmc_valu(W, log_n, rb, cap, world):
         return None
 
 
-def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=20.0):
-    """The oracle's C restatement ("port", OpenMP on the host cores) timed on a bounded sample of the
-    same workload: same W / rate / cap, fewer rows.  NOT the Rust prover (no cargo in the image)."""
+def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=45.0, golden_cap=None):
+    """The tuned CPU implementation of the same step (oracle/p2fast.c, "port-tuned": branch-free reduce128, the
+    reference's fast-partial Poseidon with lazily reduced u128 accumulators, cached root tables, coset-by-coset LDE,
+    OpenMP over the host cores this job may use), bit-exact against the faithful oracle (tests/test_fast_oracle.py).
+    The WHOLE 2^log_n-row step is timed when a 1/16 sample predicts it fits the budget, else the largest power-of-two
+    row count that does.  NOT the Rust prover (no cargo in the image)."""
+    from oracle import p2fast as fast
     from oracle import p2oracle as ora
     cores = ora.usable_cores()  # min(affinity, cgroup CPU quota): oversubscribing a quota-limited job throttles it
-    ora.set_num_threads(cores)
-    k = min(12, log_n)
-    cols = splitmix_columns_numpy(0, W, 1 << k)
+    fast.set_num_threads(cores)
+    k = max(0, min(log_n, log_n - 4))
     t0 = time.perf_counter()
-    ora.commit(cols, rate_bits, cap_height, True)
+    fast.commit(splitmix_columns_numpy(0, W, 1 << k), rate_bits, cap_height, True, want_coeffs=False, want_digests=False)
+    probe = time.perf_counter() - t0
+    kk = k
+    while kk < log_n and probe * (1 << (kk + 1 - k)) * 1.1 <= budget_s:
+        kk += 1
+    cols = splitmix_columns_numpy(0, W, 1 << kk)
+    tm = {}
+    t0 = time.perf_counter()
+    r = fast.commit(cols, rate_bits, cap_height, True, want_coeffs=False, want_digests=False, timed=tm)
     dt = time.perf_counter() - t0
-    total = dt
-    # grow the sample while the predicted time stays inside the budget (cost ~ linear in rows)
-    while k < log_n and total + 2.2 * dt <= budget_s:
-        k += 1
-        cols = splitmix_columns_numpy(0, W, 1 << k)
-        tm = {}
-        t0 = time.perf_counter()
-        ora.commit(cols, rate_bits, cap_height, True, timed=tm)
-        dt = time.perf_counter() - t0
-        total += dt
-    fe = W * (1 << (k + rate_bits))
-    out = {"value": fe / dt / 1e9, "unit": "GFE/s", "cores": cores, "kind": "port",
-           "sample": "from_values W=%d, 2^%d rows, rate 1/%d, cap %d (1/%d of the GPU step's rows), %.2f s; "
-                     "restated CPU baseline (oracle/p2oracle.c, OpenMP), not the Rust prover -- the oracle's scalar Poseidon "
-                     "(~10 us per permutation per core on this host) is an order of magnitude slower than the reference's"
-                     % (W, k, 1 << rate_bits, cap_height, 1 << (log_n - k), dt)}
+    fe = W * (1 << (kk + rate_bits))
+    whole = kk == log_n
+    out = {"value": fe / dt / 1e9, "unit": "GFE/s", "cores": cores, "kind": "port-tuned", "seconds": dt,
+           "sample": ("the whole step" if whole else "1/%d of the GPU step's rows" % (1 << (log_n - kk)))
+                     + ": from_values W=%d, 2^%d rows, rate 1/%d, cap %d, %.2f s on %d cores; oracle/p2fast.c (tuned C + OpenMP restatement "
+                       "of the reference algorithm), not the Rust prover (no cargo in the image)" % (W, kk, 1 << rate_bits, cap_height, dt, cores),
+           "stage_seconds": {k_: round(v, 4) for k_, v in tm.items()},  # the reference's TimingTree scopes, fri/oracle.rs:65-103
+           "us_per_permutation_per_core": tm["build Merkle tree"] * cores / (((W + 7) // 8 + 1) * (1 << (kk + rate_bits))) * 1e6}
+    if whole and golden_cap is not None:
+        out["cap_matches_golden"] = r["cap"].tolist() == golden_cap
     out["host"] = "%d logical CPUs visible, %d usable by this job (cgroup quota / affinity)" % (os.cpu_count(), cores)
     try:
         out["cpu_model"] = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         pass
+    return out
+
+
+def golden(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "commit_caps.json")))[name]
+    except Exception:
+        return None
+
+
+def other_configs(eng, torch, reps=3):
+    """Driver-timed lines for the other BASELINE shapes (extra keys of the JSON line; the headline is unchanged):
+    each is `reps` timed repetitions after one warm-up, inputs resident in HBM, synchronised wall time."""
+    from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, eval_openings, prove_openings
+    from plonky2_amd.fri.prover import fri_committed_trees_device
+    from plonky2_amd.iop.challenger import Challenger
+    from plonky2_amd.plonk.prover import all_wires_permutation_partial_products
+    from plonky2_amd.util.synthetic import fibonacci_trace
+    dev = eng.mem.device
+    out = {}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def commit_line(name, W, log_n, rb, cap, is_values, cols, what):
+        ms = timed(lambda: eng.commit(cols, log_n, rb, cap, is_values))
+        g = golden(name)
+        rec = {"workload": what, "ms": ms, "GFE/s": W * (1 << (log_n + rb)) / ms / 1e6}
+        if g is not None:
+            rec["cap_checked"] = eng.host(eng.commit(cols, log_n, rb, cap, is_values)["cap"]).tolist() == g["cap"]
+        out[name] = rec
+
+    commit_line("c2_wires", 135, 16, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 135, 1 << 16),
+                "C2: from_values W=135, 2^16 rows, rate 1/8, cap 4")
+    commit_line("c3_zs_partial_products", 20, 20, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 20, 1 << 20),
+                "C3: from_values W=20 (Zs + partial products), 2^20 rows, rate 1/8, cap 4")
+    commit_line("c3_quotient_chunks", 16, 20, 3, 4, False, splitmix_columns_torch(torch, dev, 0, 16, 1 << 20),
+                "C3: from_coeffs W=16 (quotient chunks), 2^20 rows, rate 1/8, cap 4")
+    commit_line("c4_fibonacci_trace", 2, 22, 1, 4, True, eng.dev(fibonacci_trace(22)),
+                "C4: from_values W=2 (Fibonacci trace), 2^22 rows, rate 1/2, cap 4 (hash_or_noop leaves)")
+    for name, log_n, rb in (("c3_fri_commit_phase", 20, 3), ("c4_fri_commit_phase", 22, 1)):
+        planes = splitmix_columns_torch(torch, dev, 500, 2, 1 << log_n)
+        ch = Challenger(eng)
+        ms = timed(lambda: fri_committed_trees_device(planes, log_n, ch, rb, 4, [4, 4, 4, 4], eng))
+        out[name] = {"workload": "fri_committed_trees, N=2^%d, arity 16 x4, cap 4 (final FFT + 4 round trees + folds, device resident)"
+                                 % (log_n + rb), "ms": ms}
+    # the per-proof path of a 2^20-gate standard_recursion_config proof: every stage of SURVEY section 8 back to back
+    n, rb, cap, arity, nq = 1 << 20, 3, 4, [4, 4, 4, 4], 28
+    wires = splitmix_columns_torch(torch, dev, 0, 135, n)
+    sig = splitmix_columns_torch(torch, dev, 1000, 80, n)
+    quo = splitmix_columns_torch(torch, dev, 2000, 16, n)
+    k_is = [pow(14293326489335486720, j, P) for j in range(80)]
+
+    def path():
+        stage = {}
+        t = [time.perf_counter()]
+
+        def lap(label):
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            stage[label] = (now - t[0]) * 1e3
+            t[0] = now
+        b_w = PolynomialBatch.from_values(wires, rb, False, cap, engine=eng)
+        lap("wires commit (W=135, from_values)")
+        zs = all_wires_permutation_partial_products(wires[:80], sig, k_is, 8, [3, 5], [11, 13], eng)
+        lap("partial products + Zs (80 routed wires, 2 challenges)")
+        b_z = PolynomialBatch.from_values(zs, rb, False, cap, engine=eng)
+        lap("Zs + partial products commit (W=20, from_values)")
+        b_q = PolynomialBatch.from_coeffs(quo, rb, False, cap, engine=eng)
+        lap("quotient chunks commit (W=16, from_coeffs)")
+        oracles = [b_w, b_z, b_q]
+        ch = Challenger(eng)
+        ch.observe_elements(np.arange(8, dtype=np.uint64))
+        zeta = ch.get_extension_challenge()
+        gz = [(zeta[0] * 7) % P, zeta[1]]
+        eval_openings(oracles, [zeta, gz], eng)
+        lap("OpeningSet (171 polynomials at 2 points)")
+        allp = [(oi, pi) for oi, W in enumerate((135, 20, 16)) for pi in range(W)]
+        nxt = [(oi, pi) for oi, W in enumerate((135, 20)) for pi in range(W)]
+        prove_openings([FriBatchInfo(zeta, allp), FriBatchInfo(gz, nxt)], oracles, ch, rb, cap, arity, 16, nq, engine=eng)
+        lap("prove_openings (final_poly, FRI commit, PoW 16 bits, 28 queries)")
+        return stage
+
+    path()
+    stages = [path() for _ in range(reps)]
+    mean = {k: sum(s_[k] for s_ in stages) / reps for k in stages[0]}
+    out["per_proof_path_k20"] = {"workload": "every SURVEY section-8 stage of one 2^20-gate standard_recursion_config proof, back to back "
+                                             "(gate evaluation / witness generation excluded: out of scope)",
+                                 "ms": sum(mean.values()), "stage_ms": {k: round(v, 3) for k, v in mean.items()}}
     return out
 
 
@@ -149,6 +216,7 @@ def main():
     ap.add_argument("--rate-bits", type=int, default=3)
     ap.add_argument("--cap-height", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra driver-timed lines of the other BASELINE shapes")
     args = ap.parse_args()
 
     import torch
@@ -213,6 +281,14 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_results(reset=True)
     eng.profile(False)
+    # what was timed is checked: the cap of the last timed step against the faithful oracle's golden cap of the same
+    # synthetic columns (tests/golden/commit_caps.json; only the headline single-GPU shape has one)
+    g = golden("c3_wires") if (world, W, log_n, rb, cap) == (1, 135, 20, 3, 4) else None
+    cap_checked = None
+    if g is not None:
+        cap_checked = eng.host(job.cap).tolist() == g["cap"]
+        if not cap_checked:
+            raise SystemExit("bench: the Merkle cap of the timed commit differs from the oracle's golden cap")
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.mem.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -270,12 +346,18 @@ def main():
                         / (k["ms_per_launch"] * 1e-3 * k["launches"] / args.steps) / 1e9 / HBM_PEAK_GBS,
                 "note": "HBM-bound by design, measured VALU-bound (about 210 VALU instructions per element-pass, profiles/*_pmc_sq.txt)"})(
                 kern.get("ntt_pass_contig")),
+            "cap_checked": cap_checked,
             "kernels": kern,
             "algorithmic_bytes_per_step": ab,
             "commit_hbm_frac": ab["total"] / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         }
+        if world == 1 and not args.no_extra:
+            del job, cols
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(eng, torch)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, log_n, rb, cap)
+            out["cpu_baseline"] = cpu_baseline(W, log_n, rb, cap, golden_cap=g["cap"] if g else None)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist:
         dist.barrier()

@@ -17,8 +17,8 @@
  *  - `*_dev` functions take DEVICE pointers and only enqueue work on the context's HIP stream;
  *    the others take HOST pointers, stage through device memory owned by the context and return
  *    after the results are in the caller's buffers.
- *  - A context is bound to one GPU and is not thread-safe; use one context per GPU (one process
- *    per GPU in the multi-GPU mode, see plonky2_amd/distributed.py).
+ *  - A context is bound to one GPU and runs one call at a time; use one context per GPU (one process per GPU with
+ *    p2hot_comm_*, or one process for all GPUs with p2hot_group_*, see the multi-GPU section).
  */
 #ifndef P2HOT_H
 #define P2HOT_H
@@ -359,6 +359,65 @@ int p2hot_partial_products(p2hot_ctx *ctx, const p2hot_cols *wires, size_t wires
  * coefficients, ready for p2hot_commit_cols(is_values = 0). */
 int p2hot_quotient_chunks(p2hot_ctx *ctx, const uint64_t *const *quotient_values, unsigned num_challenges,
                           unsigned degree_bits, unsigned quotient_degree_factor, p2hot_cols **chunks_out);
+
+/* ================================================================ multi-GPU: the coset-sharded commit
+ * The rate-1/B LDE is B independent coset transforms and coset j is the contiguous row block bitrev(j) of the
+ * committed order, so rank r of G owns rows [r*N/G, (r+1)*N/G) = whole cosets = whole cap subtrees: it runs the LDE,
+ * the leaf sponge and the Merkle levels of its rows with no data-path exchange.  Exchanges: the coefficients after the
+ * column-sharded iNTT (W*n*8 bytes, pipelined in column chunks beside the transforms), the 2^cap_height cap entries,
+ * and -- on request -- the digest slices.  G <= 2^rate_bits and G <= 2^cap_height, G a power of two.
+ * Two ways to run it:
+ *   one process per GPU   p2hot_comm_create_rccl (RCCL over xGMI; the launcher distributes the unique id) or
+ *                         p2hot_comm_create_callback (the host application's own all-gather), then p2hot_commit_sharded_dev
+ *   one process, N GPUs   p2hot_group_create + p2hot_group_commit: host pointers in, like p2hot_commit -- a patched
+ *                         plonky2 gets every GPU of the node from its main thread
+ * RCCL is bound at run time (dlopen), libp2hot.so has no link-time dependency on it. */
+#define P2HOT_UNIQUE_ID_BYTES 128 /* NCCL_UNIQUE_ID_BYTES, rccl.h:40 */
+typedef struct p2hot_comm p2hot_comm;
+typedef struct p2hot_group p2hot_group;
+typedef struct p2hot_sharded_batch p2hot_sharded_batch;
+/* caller-supplied transport: rank r's slice is `bytes` bytes at d_base + offsets[r] (valid on rank r); on return every
+ * slice must be complete on this rank.  Called on the host with the context's stream idle; return 0 on success. */
+typedef int (*p2hot_allgather_fn)(void *user, void *d_base, const size_t *offsets, int world, size_t bytes, void *hip_stream);
+int p2hot_comm_unique_id(uint8_t out[P2HOT_UNIQUE_ID_BYTES]);               /* ncclGetUniqueId on one rank */
+int p2hot_comm_create_rccl(p2hot_ctx *ctx, int rank, int world, const uint8_t id[P2HOT_UNIQUE_ID_BYTES], p2hot_comm **out);
+int p2hot_comm_create_callback(p2hot_ctx *ctx, int rank, int world, p2hot_allgather_fn fn, void *user, p2hot_comm **out);
+void p2hot_comm_destroy(p2hot_comm *comm);
+int p2hot_comm_rank(const p2hot_comm *comm);
+int p2hot_comm_world(const p2hot_comm *comm);
+/* columns [first, first + count) of W are the ones rank `rank` of `world` transforms in the iNTT stage */
+int p2hot_shard_columns(size_t W, int world, int rank, size_t *first, size_t *count);
+/* from_values / from_coeffs (fri/oracle.rs:57-112) of this rank's share, DEVICE pointers, asynchronous:
+ *   d_cols_local  [count][n] this rank's columns (p2hot_shard_columns), stride col_stride
+ *   d_coeffs_all  [world * ceil(W/world)][n] out: row c = polynomial c for c < W (`polynomials`, complete on every rank)
+ *   d_lde         [W][N/world] out: this rank's rows of the LDE matrix, column-major, stride lde_stride
+ *   d_leaves      [N/world][W] out or NULL
+ *   d_digests, d_cap: FULL-tree arrays; this rank's digest slice [rank * nd/world, +nd/world) and the whole cap are
+ *                 valid on return, the other digest slices only with gather_digests != 0 (a Merkle path below the
+ *                 cap never leaves the cap subtree of its leaf: the owner of a row can always serve its path)
+ *   pipeline_chunks: column chunks of the coefficient exchange (0 / 1 = one blocking exchange; 8 is a good default) */
+int p2hot_commit_sharded_dev(p2hot_ctx *ctx, p2hot_comm *comm, const uint64_t *d_cols_local, size_t col_stride, size_t W,
+                             unsigned log_n, unsigned rate_bits, unsigned cap_height, int is_values, int gather_digests,
+                             unsigned pipeline_chunks, uint64_t *d_coeffs_all, uint64_t *d_lde, size_t lde_stride,
+                             uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap);
+/* one process, n_gpus devices (devices == NULL: 0 .. n_gpus-1), one context + stream per device.  Distinct devices use
+ * RCCL (ncclCommInitAll); a repeated device id (one-GPU test boxes) or P2HOT_GROUP_PEER_COPY=1 uses peer copies. */
+int p2hot_group_create(int n_gpus, const int *devices, p2hot_group **out);
+void p2hot_group_destroy(p2hot_group *group);
+int p2hot_group_size(const p2hot_group *group);
+p2hot_ctx *p2hot_group_ctx(p2hot_group *group, int i);
+int p2hot_group_uses_rccl(const p2hot_group *group);
+const char *p2hot_group_last_error(const p2hot_group *group);
+/* from_values / from_coeffs over every GPU of the group, HOST pointers (the multi-GPU p2hot_commit): each GPU is sent
+ * only the columns it transforms; coeffs_out / leaves_out / digests_out / cap_out (any may be NULL) are assembled from
+ * the owning ranks.  handle_out: the sharded batch for p2hot_sharded_batch_open. */
+int p2hot_group_commit(p2hot_group *group, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
+                       unsigned cap_height, int is_values, unsigned pipeline_chunks, uint64_t *coeffs_out, uint64_t *leaves_out,
+                       uint64_t *digests_out, uint64_t *cap_out, p2hot_sharded_batch **handle_out);
+/* MerkleTree::get + merkle_tree_prove (merkle_tree.rs:227, :151-190) for m leaves, each answered by the rank that owns
+ * the row: rows_out [m][W], paths_out [m][log2(N) - cap_height][4]; either may be NULL */
+int p2hot_sharded_batch_open(p2hot_sharded_batch *batch, const uint64_t *leaf_idx, size_t m, uint64_t *rows_out, uint64_t *paths_out);
+void p2hot_sharded_batch_free(p2hot_sharded_batch *batch);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,9 @@ class FriProofLayout(C.Structure):  # p2hot_fri_proof_layout
                 ("step_evals_words", sz), ("step_paths_words", sz)]
 
 
+# p2hot_allgather_fn: (user, d_base, offsets, world, bytes, hip_stream) -> int
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.POINTER(sz), C.c_int, sz, vp)
+
 # name -> (restype, argtypes); every symbol include/p2hot.h declares
 SIGNATURES = {
     "p2hot_ctx_create": (i, [i, vp, C.POINTER(vp)]),
@@ -110,6 +113,23 @@ SIGNATURES = {
                                  C.POINTER(FriProof)]),
     "p2hot_partial_products": (i, [vp, vp, sz, vp, sz, vp, u, u, vp, vp, u, vp, C.POINTER(vp)]),
     "p2hot_quotient_chunks": (i, [vp, C.POINTER(vp), u, u, u, C.POINTER(vp)]),
+    "p2hot_comm_unique_id": (i, [vp]),
+    "p2hot_comm_create_rccl": (i, [vp, i, i, vp, C.POINTER(vp)]),
+    "p2hot_comm_create_callback": (i, [vp, i, i, ALLGATHER_FN, vp, C.POINTER(vp)]),
+    "p2hot_comm_destroy": (None, [vp]),
+    "p2hot_comm_rank": (i, [vp]),
+    "p2hot_comm_world": (i, [vp]),
+    "p2hot_shard_columns": (i, [sz, i, i, C.POINTER(sz), C.POINTER(sz)]),
+    "p2hot_commit_sharded_dev": (i, [vp, vp, vp, sz, sz, u, u, u, i, i, u, vp, vp, sz, vp, vp, vp]),
+    "p2hot_group_create": (i, [i, C.POINTER(i), C.POINTER(vp)]),
+    "p2hot_group_destroy": (None, [vp]),
+    "p2hot_group_size": (i, [vp]),
+    "p2hot_group_ctx": (vp, [vp, i]),
+    "p2hot_group_uses_rccl": (i, [vp]),
+    "p2hot_group_last_error": (C.c_char_p, [vp]),
+    "p2hot_group_commit": (i, [vp, C.POINTER(vp), sz, u, u, u, i, u, vp, vp, vp, vp, C.POINTER(vp)]),
+    "p2hot_sharded_batch_open": (i, [vp, vp, sz, vp, vp]),
+    "p2hot_sharded_batch_free": (None, [vp]),
 }
 
 

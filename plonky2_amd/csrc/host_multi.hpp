@@ -1,0 +1,668 @@
+// host_multi.hpp -- the coset-sharded PolynomialBatch commit across the GPUs of one node, BEHIND the C ABI
+// (include/p2hot.h "multi-GPU").  Included at the end of p2hot.hip (one TU).
+//
+// The reference has no multi-device mode; this is the MI355X design:
+//   * the rate-1/B LDE is B independent coset transforms, and in the committed (bit-reversed) leaf order coset j is the
+//     contiguous row block bitrev(j); with B = 8 and cap_height = 4 a block is two whole cap subtrees.  Rank r owns rows
+//     [r*N/G, (r+1)*N/G): it runs the LDE, the Poseidon leaf sponge and the Merkle levels of its rows with NO data-path exchange;
+//   * every rank needs all W*n coefficients: the iNTT is column-sharded (ceil(W/G) columns per rank) and followed by an
+//     all-gather of coefficients (W*n*8 bytes in total), pipelined in column chunks on a second stream: chunk k travels
+//     while chunk k+1 runs its iNTT and chunk k-1 its LDE;
+//   * a rank's subtrees are a contiguous slice of the reference digest array, so one all-gather of the cap entries (and,
+//     on request, of the digest slices) reassembles MerkleTree::cap (::digests).  No reductions anywhere.
+// Transports (all move "rank r's slice at base + offsets[r]" to every other rank, in place):
+//   RCCL, one process per GPU   p2hot_comm_create_rccl: ncclCommInitRank; a grouped ncclBroadcast per slice (= an
+//                               all-gather with free placement) on the comm stream over xGMI
+//   RCCL, one process, N GPUs   p2hot_group_create: ncclCommInitAll, the same grouped broadcasts for all local ranks
+//   peer copies                 p2hot_group_create with a repeated device (one-GPU test boxes) or P2HOT_GROUP_PEER_COPY:
+//                               hipMemcpyAsync between the ranks' buffers (xGMI is a full mesh: a direct all-gather)
+//   caller-supplied             p2hot_comm_create_callback: the host application's own collective (the CPU tests use
+//                               torch.distributed/gloo; a Rust prover may bring MPI or its own RCCL communicator)
+// RCCL is bound at run time (dlopen: the copy PyTorch already loaded if there is one, else /opt/rocm's), so libp2hot.so
+// carries no link-time dependency on it and two RCCL copies never meet in one process.
+#pragma once
+
+#ifndef P2HOT_EMU
+#include <dlfcn.h>
+#endif
+
+#include <memory>
+
+// ---- the few RCCL entry points used (rccl.h:40-43, :187, :220, :236, :260, :339, :460, :591, :923-929) ----
+namespace rccl {
+struct UniqueId {
+    char internal[P2HOT_UNIQUE_ID_BYTES];
+};
+typedef void *Comm;
+struct Api {
+    void *lib = nullptr;
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
+    int (*CommInitAll)(Comm *, int, const int *) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+    bool ok = false;
+};
+static const int kUint8 = 1;  // ncclUint8, rccl.h:460
+static Api &api() {
+    static Api a;
+    static bool tried = false;
+    if (tried) return a;
+    tried = true;
+#ifdef P2HOT_EMU
+    a.err = "the kernel emulator build has no RCCL";
+#else
+    const char *names[] = {"librccl.so", "librccl.so.1"};
+    for (const char *n : names)  // the copy this process already uses (PyTorch's), so two RCCLs never meet
+        if (!a.lib) a.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    const char *paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    for (const char *p : paths)
+        if (!a.lib) a.lib = dlopen(p, RTLD_NOW | RTLD_GLOBAL);
+    if (!a.lib) {
+        a.err = std::string("RCCL not found: ") + dlerror();
+        return a;
+    }
+    bool all = true;
+    auto sym = [&](const char *n) {
+        void *s = dlsym(a.lib, n);
+        if (!s) {
+            all = false;
+            a.err = std::string("RCCL symbol missing: ") + n;
+        }
+        return s;
+    };
+    a.GetUniqueId = (int (*)(UniqueId *))sym("ncclGetUniqueId");
+    a.CommInitRank = (int (*)(Comm *, int, UniqueId, int))sym("ncclCommInitRank");
+    a.CommInitAll = (int (*)(Comm *, int, const int *))sym("ncclCommInitAll");
+    a.CommDestroy = (int (*)(Comm))sym("ncclCommDestroy");
+    a.Broadcast = (int (*)(const void *, void *, size_t, int, int, Comm, hipStream_t))sym("ncclBroadcast");
+    a.GroupStart = (int (*)())sym("ncclGroupStart");
+    a.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    a.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+    a.ok = all;
+#endif
+    return a;
+}
+}  // namespace rccl
+
+struct p2hot_group;
+
+struct p2hot_comm {
+    p2hot_ctx *ctx = nullptr;
+    int rank = 0, world = 1;
+    enum Kind { RCCL, CALLBACK, GROUP } kind = CALLBACK;
+    rccl::Comm nccl = nullptr;
+    p2hot_allgather_fn fn = nullptr;
+    void *user = nullptr;
+    p2hot_group *group = nullptr;
+    hipStream_t comm_stream = nullptr;  // collectives run here, beside the transforms on the context's stream
+    std::vector<hipEvent_t> ev_ready, ev_done;  // per pipeline slot: "slice written" (compute -> comm), "gathered" (comm -> compute)
+};
+
+struct p2hot_group {
+    std::vector<p2hot_ctx *> ctx;
+    std::vector<p2hot_comm *> comm;
+    std::vector<int> devices;
+    std::vector<hipStream_t> streams;
+    bool use_rccl = false;
+    std::string err;
+};
+
+#define P2_NCCL(ctx, call)                                                                                   \
+    do {                                                                                                     \
+        int r_ = (call);                                                                                     \
+        if (r_ != 0) P2_FAIL(ctx, P2HOT_ECOMM, "%s: %s", #call, rccl::api().GetErrorString ? rccl::api().GetErrorString(r_) : "?"); \
+    } while (0)
+
+static int comm_events(p2hot_comm *c, size_t slots) {
+#ifndef P2HOT_EMU
+    p2hot_ctx *ctx = c->ctx;
+    P2_HIP(ctx, hipSetDevice(ctx->device));
+    if (!c->comm_stream) P2_HIP(ctx, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    while (c->ev_ready.size() < slots) {
+        hipEvent_t a, b;
+        P2_HIP(ctx, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        P2_HIP(ctx, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        c->ev_ready.push_back(a);
+        c->ev_done.push_back(b);
+    }
+#else
+    (void)c;
+    (void)slots;
+#endif
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_comm_unique_id(uint8_t out[P2HOT_UNIQUE_ID_BYTES]) {
+    if (!out) return P2HOT_EINVAL;
+    rccl::Api &a = rccl::api();
+    if (!a.ok) return P2HOT_ECOMM;
+    rccl::UniqueId id;
+    if (a.GetUniqueId(&id) != 0) return P2HOT_ECOMM;
+    std::copy(id.internal, id.internal + P2HOT_UNIQUE_ID_BYTES, (char *)out);
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_comm_create_rccl(p2hot_ctx *ctx, int rank, int world, const uint8_t id[P2HOT_UNIQUE_ID_BYTES], p2hot_comm **out) {
+    if (!ctx || !out) return P2HOT_EINVAL;
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || !id) P2_FAIL(ctx, P2HOT_EINVAL, "comm_create_rccl: bad rank %d / world %d", rank, world);
+    rccl::Api &a = rccl::api();
+    if (!a.ok) P2_FAIL(ctx, P2HOT_ECOMM, "comm_create_rccl: %s", a.err.c_str());
+    std::unique_ptr<p2hot_comm> c(new p2hot_comm());
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    c->kind = p2hot_comm::RCCL;
+    rccl::UniqueId uid;
+    std::copy(id, id + P2HOT_UNIQUE_ID_BYTES, (uint8_t *)uid.internal);
+    P2_HIP(ctx, hipSetDevice(ctx->device));
+    P2_NCCL(ctx, a.CommInitRank(&c->nccl, world, uid, rank));
+    P2_TRY(comm_events(c.get(), 1));
+    *out = c.release();
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_comm_create_callback(p2hot_ctx *ctx, int rank, int world, p2hot_allgather_fn fn, void *user, p2hot_comm **out) {
+    if (!ctx || !out) return P2HOT_EINVAL;
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || !fn) P2_FAIL(ctx, P2HOT_EINVAL, "comm_create_callback: bad rank %d / world %d or null transport", rank, world);
+    p2hot_comm *c = new p2hot_comm();
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    c->kind = p2hot_comm::CALLBACK;
+    c->fn = fn;
+    c->user = user;
+    *out = c;
+    return P2HOT_OK;
+}
+
+extern "C" void p2hot_comm_destroy(p2hot_comm *c) {
+    if (!c) return;
+#ifndef P2HOT_EMU
+    (void)hipSetDevice(c->ctx->device);
+    if (c->comm_stream) {
+        (void)hipStreamSynchronize(c->comm_stream);
+        (void)hipStreamDestroy(c->comm_stream);
+    }
+    for (auto e : c->ev_ready) (void)hipEventDestroy(e);
+    for (auto e : c->ev_done) (void)hipEventDestroy(e);
+#endif
+    if (c->nccl && rccl::api().ok) (void)rccl::api().CommDestroy(c->nccl);
+    delete c;
+}
+
+extern "C" int p2hot_comm_rank(const p2hot_comm *c) { return c ? c->rank : -1; }
+extern "C" int p2hot_comm_world(const p2hot_comm *c) { return c ? c->world : 0; }
+
+// ------------------------------------------------------------------ the exchange
+// One entry per LOCAL rank (1 in the process-per-GPU mode, world in the single-process group): base[s] is that rank's copy
+// of the buffer; rank r's slice lives at base[s] + offsets[r] (bytes) on every rank and is valid on rank r.
+// slot: which (ev_ready, ev_done) pair orders this exchange against the compute stream; the caller makes the compute
+// stream wait for it with gather_wait before touching the gathered slices.
+static int gather_start(std::vector<p2hot_comm *> &cs, std::vector<u64 *> &base, const std::vector<size_t> &offsets, size_t bytes,
+                        size_t slot) {
+    p2hot_comm *c0 = cs[0];
+    const int world = c0->world;
+    // a one-rank RCCL communicator still issues its (trivial) collectives: the same calls, streams and events as at scale
+    if (bytes == 0 || (world == 1 && c0->kind != p2hot_comm::RCCL)) return P2HOT_OK;
+    if (c0->kind == p2hot_comm::CALLBACK) {  // the host application's collective: synchronous, after the slice is complete
+        p2hot_ctx *ctx = c0->ctx;
+        P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int rc = c0->fn(c0->user, base[0], offsets.data(), world, bytes, (void *)ctx->stream);
+        if (rc != 0) P2_FAIL(ctx, P2HOT_ECOMM, "the caller-supplied all-gather failed (%d)", rc);
+        return P2HOT_OK;
+    }
+#ifndef P2HOT_EMU
+    for (size_t s = 0; s < cs.size(); ++s) {  // slice written on the compute stream -> visible to the comm stream
+        p2hot_ctx *ctx = cs[s]->ctx;
+        P2_HIP(ctx, hipSetDevice(ctx->device));
+        P2_TRY(comm_events(cs[s], slot + 1));
+        P2_HIP(ctx, hipEventRecord(cs[s]->ev_ready[slot], ctx->stream));
+    }
+    const bool rccl_path = c0->kind == p2hot_comm::RCCL || (c0->kind == p2hot_comm::GROUP && c0->group->use_rccl);
+    if (rccl_path) {
+        rccl::Api &a = rccl::api();
+        for (size_t s = 0; s < cs.size(); ++s) {
+            P2_HIP(cs[s]->ctx, hipSetDevice(cs[s]->ctx->device));
+            P2_HIP(cs[s]->ctx, hipStreamWaitEvent(cs[s]->comm_stream, cs[s]->ev_ready[slot], 0));
+        }
+        P2_NCCL(c0->ctx, a.GroupStart());
+        for (size_t s = 0; s < cs.size(); ++s)
+            for (int r = 0; r < world; ++r) {
+                char *p = (char *)base[s] + offsets[r];
+                int rc = a.Broadcast(p, p, bytes, rccl::kUint8, r, cs[s]->nccl, cs[s]->comm_stream);
+                if (rc != 0) {
+                    (void)a.GroupEnd();
+                    P2_FAIL(c0->ctx, P2HOT_ECOMM, "ncclBroadcast: %s", a.GetErrorString(rc));
+                }
+            }
+        P2_NCCL(c0->ctx, a.GroupEnd());
+    } else {  // peer copies inside the single-process group: rank s pulls every other rank's slice
+        for (size_t s = 0; s < cs.size(); ++s) {
+            p2hot_ctx *ctx = cs[s]->ctx;
+            P2_HIP(ctx, hipSetDevice(ctx->device));
+            for (size_t r = 0; r < cs.size(); ++r) {
+                if (r == s) continue;
+                P2_HIP(ctx, hipStreamWaitEvent(cs[s]->comm_stream, cs[r]->ev_ready[slot], 0));
+                P2_HIP(ctx, hipMemcpyAsync((char *)base[s] + offsets[r], (const char *)base[r] + offsets[r], bytes, hipMemcpyDefault,
+                                           cs[s]->comm_stream));
+            }
+        }
+    }
+    for (size_t s = 0; s < cs.size(); ++s) {
+        P2_HIP(cs[s]->ctx, hipSetDevice(cs[s]->ctx->device));
+        P2_HIP(cs[s]->ctx, hipEventRecord(cs[s]->ev_done[slot], cs[s]->comm_stream));
+    }
+#else
+    // emulator: the single-process group copies between the ranks' (host) buffers
+    for (size_t s = 0; s < cs.size(); ++s)
+        for (size_t r = 0; r < cs.size(); ++r)
+            if (r != s) memmove((char *)base[s] + offsets[r], (const char *)base[r] + offsets[r], bytes);
+    (void)slot;
+#endif
+    return P2HOT_OK;
+}
+
+static int gather_wait(std::vector<p2hot_comm *> &cs, size_t slot) {
+#ifndef P2HOT_EMU
+    if ((cs[0]->world == 1 && cs[0]->kind != p2hot_comm::RCCL) || cs[0]->kind == p2hot_comm::CALLBACK) return P2HOT_OK;
+    for (auto *c : cs) {
+        if (slot >= c->ev_done.size()) continue;
+        P2_HIP(c->ctx, hipSetDevice(c->ctx->device));
+        P2_HIP(c->ctx, hipStreamWaitEvent(c->ctx->stream, c->ev_done[slot], 0));
+    }
+#else
+    (void)cs;
+    (void)slot;
+#endif
+    return P2HOT_OK;
+}
+
+// ------------------------------------------------------------------ the sharded commit
+struct ShardArgs {  // per local rank
+    const u64 *cols_local;  // [c1 - c0][n], stride col_stride: this rank's columns (values or coefficients)
+    size_t col_stride;
+    u64 *coeffs_all;        // [world * cols_per_rank][n]: row = global column index; complete on return
+    u64 *lde;               // [W][rows_per_rank], stride lde_stride
+    size_t lde_stride;
+    u64 *leaves;            // [rows_per_rank][W] or NULL
+    u64 *digests, *cap;     // FULL tree arrays
+};
+
+struct ShardPlan {
+    size_t W, n, N, rows_per_rank, cols_per_rank, digests_per_rank, cap_per_rank;
+    unsigned log_n, rate_bits, cap_height, log_N;
+    int world;
+};
+
+static int shard_plan(p2hot_ctx *ctx, size_t W, unsigned log_n, unsigned rate_bits, unsigned cap_height, int world, ShardPlan *p) {
+    P2_TRY(check_log(ctx, log_n + rate_bits, "commit_sharded"));
+    if (world < 1 || (world & (world - 1))) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: world size %d is not a power of two", world);
+    p->W = W;
+    p->log_n = log_n;
+    p->rate_bits = rate_bits;
+    p->cap_height = cap_height;
+    p->log_N = log_n + rate_bits;
+    p->n = (size_t)1 << log_n;
+    p->N = p->n << rate_bits;
+    p->world = world;
+    if (cap_height > p->log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: cap_height > log2(N) (merkle_tree.rs:195-200)");
+    if ((size_t)world > ((size_t)1 << rate_bits)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: world size %d exceeds the %u LDE cosets", world, 1u << rate_bits);
+    if ((size_t)world > ((size_t)1 << cap_height)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: world size %d exceeds the %u cap subtrees", world, 1u << cap_height);
+    p->rows_per_rank = p->N / world;
+    p->cols_per_rank = W ? (W + world - 1) / world : 0;
+    p->digests_per_rank = p2hot_num_digests(p->log_N, cap_height) / world;
+    p->cap_per_rank = ((size_t)1 << cap_height) / world;
+    return P2HOT_OK;
+}
+
+// all local ranks advance phase by phase; everything is enqueued asynchronously on the ranks' streams
+static int sharded_commit_core(std::vector<p2hot_comm *> &cs, std::vector<ShardArgs> &as, const ShardPlan &p, int is_values,
+                               int gather_digests, unsigned pipeline_chunks) {
+    const size_t L = cs.size(), n = p.n, cpr = p.cols_per_rank, W = p.W;
+    const int world = p.world;
+    auto setdev = [&](size_t s) -> int {
+        P2_HIP(cs[s]->ctx, hipSetDevice(cs[s]->ctx->device));
+        return P2HOT_OK;
+    };
+    if (world == 1 && cs[0]->kind != p2hot_comm::RCCL) {
+        P2_TRY(setdev(0));
+        return p2hot_commit_dev(cs[0]->ctx, as[0].cols_local, as[0].col_stride, W, p.log_n, p.rate_bits, p.cap_height, is_values, 0, p.N,
+                                as[0].coeffs_all, n, as[0].lde, as[0].lde_stride, as[0].leaves, as[0].digests, as[0].cap);
+    }
+    // 1 + 2. column chunks: this rank's columns -> coefficient form in its slot, then the exchange of that chunk
+    const size_t K = cpr ? std::max<size_t>(1, std::min<size_t>(pipeline_chunks ? pipeline_chunks : 1, cpr)) : 0;
+    const size_t cpk = K ? (cpr + K - 1) / K : 0;
+    std::vector<std::pair<size_t, size_t>> spans;
+    for (size_t k = 0; k < K; ++k) {
+        const size_t lo = k * cpk, hi = std::min((k + 1) * cpk, cpr);
+        if (hi <= lo) continue;
+        for (size_t s = 0; s < L; ++s) {
+            P2_TRY(setdev(s));
+            p2hot_ctx *ctx = cs[s]->ctx;
+            const size_t rank = (size_t)cs[s]->rank;
+            const size_t c0 = std::min(W, rank * cpr), c1 = std::min(W, c0 + cpr), mine = c1 - c0;
+            const size_t valid = lo < mine ? std::min(hi, mine) - lo : 0;  // my real (non-padding) columns in the chunk
+            u64 *slot = as[s].coeffs_all + (rank * cpr + lo) * n;
+            for (size_t j = 0; j < valid; ++j)
+                P2_HIP(ctx, hipMemcpyAsync(slot + j * n, as[s].cols_local + (lo + j) * as[s].col_stride, n * 8, hipMemcpyDeviceToDevice,
+                                           ctx->stream));
+            if (valid && is_values) P2_TRY(ntt_natural(ctx, slot, valid, n, p.log_n, true));
+        }
+        std::vector<u64 *> base(L);
+        std::vector<size_t> offs((size_t)world);
+        for (size_t s = 0; s < L; ++s) base[s] = as[s].coeffs_all;
+        for (int r = 0; r < world; ++r) offs[(size_t)r] = ((size_t)r * cpr + lo) * n * 8;
+        P2_TRY(gather_start(cs, base, offs, (hi - lo) * n * 8, spans.size()));
+        spans.emplace_back(lo, hi);
+    }
+    // 3. LDE of every gathered chunk for this rank's coset rows
+    for (size_t k = 0; k < spans.size(); ++k) {
+        P2_TRY(gather_wait(cs, k));
+        const size_t lo = spans[k].first, hi = spans[k].second;
+        for (size_t s = 0; s < L; ++s) {
+            P2_TRY(setdev(s));
+            const size_t row_begin = (size_t)cs[s]->rank * p.rows_per_rank;
+            for (int r = 0; r < world; ++r) {
+                const size_t cb = (size_t)r * cpr + lo, ce = std::min(std::min((size_t)r * cpr + hi, W), ((size_t)r + 1) * cpr);
+                if (ce <= cb) continue;
+                P2_TRY(p2hot_coset_lde_dev(cs[s]->ctx, as[s].coeffs_all + cb * n, ce - cb, n, p.log_n, p.rate_bits, gl::COSET_SHIFT, row_begin,
+                                           p.rows_per_rank, as[s].lde + cb * as[s].lde_stride, as[s].lde_stride));
+            }
+        }
+    }
+    // leaf sponge + Merkle levels of this rank's rows (whole cosets, whole cap subtrees), straight from the column-major LDE
+    for (size_t s = 0; s < L; ++s) {
+        P2_TRY(setdev(s));
+        const size_t row_begin = (size_t)cs[s]->rank * p.rows_per_rank;
+        P2_TRY(p2hot_merkle_dev(cs[s]->ctx, as[s].lde, 0, as[s].lde_stride, W, p.log_N, p.cap_height, row_begin, p.rows_per_rank,
+                                as[s].digests, as[s].cap));
+        if (as[s].leaves && W) P2_TRY(p2hot_transpose_dev(cs[s]->ctx, as[s].lde, as[s].lde_stride, W, p.rows_per_rank, as[s].leaves));
+    }
+    // 4. the cap entries (always) and the digest slices (on request): contiguous per-rank slices of the full arrays
+    const size_t slot0 = spans.size();
+    {
+        std::vector<u64 *> base(L);
+        std::vector<size_t> offs((size_t)world);
+        for (size_t s = 0; s < L; ++s) base[s] = as[s].cap;
+        for (int r = 0; r < world; ++r) offs[(size_t)r] = (size_t)r * p.cap_per_rank * 32;
+        P2_TRY(gather_start(cs, base, offs, p.cap_per_rank * 32, slot0));
+        if (gather_digests && p.digests_per_rank) {
+            for (size_t s = 0; s < L; ++s) base[s] = as[s].digests;
+            for (int r = 0; r < world; ++r) offs[(size_t)r] = (size_t)r * p.digests_per_rank * 32;
+            P2_TRY(gather_start(cs, base, offs, p.digests_per_rank * 32, slot0 + 1));
+            P2_TRY(gather_wait(cs, slot0 + 1));
+        }
+        P2_TRY(gather_wait(cs, slot0));
+    }
+    return P2HOT_OK;
+}
+
+// process-per-GPU entry: device pointers, asynchronous on the context's stream (+ the communicator's stream)
+extern "C" int p2hot_commit_sharded_dev(p2hot_ctx *ctx, p2hot_comm *comm, const uint64_t *d_cols_local, size_t col_stride, size_t W,
+                                        unsigned log_n, unsigned rate_bits, unsigned cap_height, int is_values, int gather_digests,
+                                        unsigned pipeline_chunks, uint64_t *d_coeffs_all, uint64_t *d_lde, size_t lde_stride,
+                                        uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap) {
+    if (!ctx) return P2HOT_EINVAL;
+    if (!comm || comm->ctx != ctx || comm->kind == p2hot_comm::GROUP) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: the communicator belongs to another context");
+    ShardPlan p;
+    P2_TRY(shard_plan(ctx, W, log_n, rate_bits, cap_height, comm->world, &p));
+    const size_t c0 = std::min(W, (size_t)comm->rank * p.cols_per_rank), c1 = std::min(W, c0 + p.cols_per_rank);
+    if (W && (!d_coeffs_all || !d_lde || (c1 > c0 && !d_cols_local) || col_stride < p.n || lde_stride < p.rows_per_rank))
+        P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: null buffer or stride too small");
+    if (!d_cap || (p2hot_num_digests(p.log_N, cap_height) && !d_digests)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: null tree output");
+    std::vector<p2hot_comm *> cs{comm};
+    std::vector<ShardArgs> as{ShardArgs{d_cols_local, col_stride, d_coeffs_all, d_lde, lde_stride, d_leaves, d_digests, d_cap}};
+    return sharded_commit_core(cs, as, p, is_values, gather_digests, pipeline_chunks);
+}
+
+extern "C" int p2hot_shard_columns(size_t W, int world, int rank, size_t *first, size_t *count) {
+    if (world < 1 || rank < 0 || rank >= world || !first || !count) return P2HOT_EINVAL;
+    const size_t cpr = W ? (W + (size_t)world - 1) / (size_t)world : 0;
+    const size_t c0 = std::min(W, (size_t)rank * cpr), c1 = std::min(W, c0 + cpr);
+    *first = c0;
+    *count = c1 - c0;
+    return P2HOT_OK;
+}
+
+// ------------------------------------------------------------------ single process, all GPUs of the node (the Rust prover's mode)
+extern "C" int p2hot_group_create(int n_gpus, const int *devices, p2hot_group **out) {
+    if (!out || n_gpus < 1 || (n_gpus & (n_gpus - 1))) return P2HOT_EINVAL;
+    *out = nullptr;
+    std::unique_ptr<p2hot_group> g(new p2hot_group());
+    bool distinct = true;
+    for (int i = 0; i < n_gpus; ++i) {
+        g->devices.push_back(devices ? devices[i] : i);
+        for (int j = 0; j < i; ++j) distinct = distinct && g->devices[(size_t)j] != g->devices[(size_t)i];
+    }
+    auto fail = [&](int rc) {
+        for (auto *c : g->comm) p2hot_comm_destroy(c);
+        for (auto *c : g->ctx) p2hot_ctx_destroy(c);
+#ifndef P2HOT_EMU
+        for (auto s : g->streams)
+            if (s) (void)hipStreamDestroy(s);
+#endif
+        return rc;
+    };
+    for (int i = 0; i < n_gpus; ++i) {
+        hipStream_t st = nullptr;
+#ifndef P2HOT_EMU
+        if (hipSetDevice(g->devices[(size_t)i]) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(P2HOT_EHIP);
+#endif
+        g->streams.push_back(st);
+        p2hot_ctx *c = nullptr;
+        int rc = p2hot_ctx_create(g->devices[(size_t)i], st, &c);
+        if (c) g->ctx.push_back(c);
+        if (rc != P2HOT_OK) return fail(rc);
+        p2hot_comm *cm = new p2hot_comm();
+        cm->ctx = c;
+        cm->rank = i;
+        cm->world = n_gpus;
+        cm->kind = p2hot_comm::GROUP;
+        cm->group = g.get();
+        g->comm.push_back(cm);
+    }
+    // distinct devices: RCCL over xGMI (ncclCommInitAll); a repeated device (one-GPU test boxes) or P2HOT_GROUP_PEER_COPY=1: peer copies
+    const char *env = getenv("P2HOT_GROUP_PEER_COPY");
+    g->use_rccl = n_gpus > 1 && distinct && !(env && env[0] == '1');
+    if (g->use_rccl) {
+        rccl::Api &a = rccl::api();
+        if (!a.ok) {
+            g->ctx[0]->err = "group_create: " + a.err;
+            return fail(P2HOT_ECOMM);
+        }
+        std::vector<rccl::Comm> comms((size_t)n_gpus);
+        if (a.CommInitAll(comms.data(), n_gpus, g->devices.data()) != 0) return fail(P2HOT_ECOMM);
+        for (int i = 0; i < n_gpus; ++i) g->comm[(size_t)i]->nccl = comms[(size_t)i];
+    }
+#ifndef P2HOT_EMU
+    if (!g->use_rccl && distinct)
+        for (int i = 0; i < n_gpus; ++i) {  // peer copies between distinct devices need peer access
+            (void)hipSetDevice(g->devices[(size_t)i]);
+            for (int j = 0; j < n_gpus; ++j)
+                if (j != i) (void)hipDeviceEnablePeerAccess(g->devices[(size_t)j], 0);
+            (void)hipGetLastError();
+        }
+#endif
+    *out = g.release();
+    return P2HOT_OK;
+}
+
+extern "C" void p2hot_group_destroy(p2hot_group *g) {
+    if (!g) return;
+    for (auto *c : g->comm) p2hot_comm_destroy(c);
+    for (auto *c : g->ctx) p2hot_ctx_destroy(c);
+#ifndef P2HOT_EMU
+    for (size_t i = 0; i < g->streams.size(); ++i)
+        if (g->streams[i]) {
+            (void)hipSetDevice(g->devices[i]);
+            (void)hipStreamDestroy(g->streams[i]);
+        }
+#endif
+    delete g;
+}
+
+extern "C" int p2hot_group_size(const p2hot_group *g) { return g ? (int)g->ctx.size() : 0; }
+extern "C" p2hot_ctx *p2hot_group_ctx(p2hot_group *g, int i) { return (g && i >= 0 && (size_t)i < g->ctx.size()) ? g->ctx[(size_t)i] : nullptr; }
+extern "C" int p2hot_group_uses_rccl(const p2hot_group *g) { return g && g->use_rccl ? 1 : 0; }
+extern "C" const char *p2hot_group_last_error(const p2hot_group *g) {
+    if (!g) return "null group";
+    for (auto *c : g->ctx)
+        if (!c->err.empty()) return c->err.c_str();
+    return "";
+}
+
+// a PolynomialBatch whose LDE rows and cap subtrees are spread over the group's GPUs; rank r = rows [r*N/G, (r+1)*N/G)
+struct p2hot_sharded_batch {
+    p2hot_group *g;
+    ShardPlan plan;
+    std::vector<u64 *> coeffs_all, lde, digests;  // per rank; every rank holds ALL coefficients
+};
+
+extern "C" void p2hot_sharded_batch_free(p2hot_sharded_batch *b) {
+    if (!b) return;
+    for (size_t s = 0; s < b->g->ctx.size(); ++s) {
+        p2hot_ctx *ctx = b->g->ctx[s];
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        pool_release(ctx, b->coeffs_all[s]);
+        pool_release(ctx, b->lde[s]);
+        pool_release(ctx, b->digests[s]);
+    }
+    delete b;
+}
+
+// from_values / from_coeffs over all GPUs of the group, HOST pointers (what p2hot_commit is for one GPU).
+// coeffs_out [W][n], leaves_out [N][W], digests_out, cap_out: caller-allocated or NULL; assembled from the owning ranks.
+extern "C" int p2hot_group_commit(p2hot_group *g, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
+                                  unsigned cap_height, int is_values, unsigned pipeline_chunks, uint64_t *coeffs_out, uint64_t *leaves_out,
+                                  uint64_t *digests_out, uint64_t *cap_out, p2hot_sharded_batch **handle_out) {
+    if (!g) return P2HOT_EINVAL;
+    p2hot_ctx *ctx0 = g->ctx[0];
+    P2_ENTER(ctx0);
+    if (handle_out) *handle_out = nullptr;
+    const int world = (int)g->ctx.size();
+    ShardPlan p;
+    P2_TRY(shard_plan(ctx0, W, log_n, rate_bits, cap_height, world, &p));
+    if (W && !cols) P2_FAIL(ctx0, P2HOT_EINVAL, "group_commit: null column table");
+    for (size_t c = 0; c < W; ++c)
+        if (!cols[c]) P2_FAIL(ctx0, P2HOT_EINVAL, "group_commit: column %zu is null", c);
+    const size_t n = p.n, nd = p2hot_num_digests(p.log_N, cap_height), cap_words = (size_t)4 << cap_height;
+    const size_t L = (size_t)world;
+    std::vector<std::unique_ptr<PoolBuf>> b_cols, b_co, b_lde, b_leaves, b_dig, b_cap;
+    std::vector<ShardArgs> as(L);
+    auto alloc = [&](std::vector<std::unique_ptr<PoolBuf>> &v, p2hot_ctx *ctx, size_t bytes) -> int {
+        v.emplace_back(new PoolBuf(ctx));
+        return pool_alloc(ctx, bytes, &v.back()->p);
+    };
+    int rc = P2HOT_OK;
+    auto body = [&]() -> int {
+        for (size_t s = 0; s < L; ++s) {
+            p2hot_ctx *ctx = g->ctx[s];
+            P2_HIP(ctx, hipSetDevice(ctx->device));
+            const size_t c0 = std::min(W, s * p.cols_per_rank), c1 = std::min(W, c0 + p.cols_per_rank);
+            P2_TRY(alloc(b_cols, ctx, std::max<size_t>(1, c1 - c0) * n * 8));
+            P2_TRY(alloc(b_co, ctx, std::max<size_t>(1, L * p.cols_per_rank) * n * 8));
+            P2_TRY(alloc(b_lde, ctx, std::max<size_t>(1, W) * p.rows_per_rank * 8));
+            P2_TRY(alloc(b_leaves, ctx, leaves_out ? std::max<size_t>(1, W) * p.rows_per_rank * 8 : 8));
+            P2_TRY(alloc(b_dig, ctx, std::max<size_t>(1, nd) * 32));
+            P2_TRY(alloc(b_cap, ctx, cap_words * 8));
+            for (size_t c = c0; c < c1; ++c)  // each GPU receives only the columns it transforms
+                P2_HIP(ctx, hipMemcpyAsync(b_cols[s]->u() + (c - c0) * n, cols[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
+            as[s] = ShardArgs{b_cols[s]->u(), n, b_co[s]->u(), b_lde[s]->u(), p.rows_per_rank, leaves_out ? b_leaves[s]->u() : nullptr,
+                              b_dig[s]->u(), b_cap[s]->u()};
+        }
+        P2_TRY(sharded_commit_core(g->comm, as, p, is_values, /*gather_digests=*/0, pipeline_chunks ? pipeline_chunks : 8));
+        // results: the coefficients and the cap from rank 0 (complete everywhere), digests / leaves from their owners
+        P2_HIP(ctx0, hipSetDevice(ctx0->device));
+        if (coeffs_out && W) {
+            if (!is_values) {
+                P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(W * n, 256)), dim3(256), 0, ctx0->stream, as[0].coeffs_all, W * n);
+                P2_LAUNCH_CHECK(ctx0);
+            }
+            P2_HIP(ctx0, hipMemcpyAsync(coeffs_out, as[0].coeffs_all, W * n * 8, hipMemcpyDeviceToHost, ctx0->stream));
+        }
+        if (cap_out) P2_HIP(ctx0, hipMemcpyAsync(cap_out, as[0].cap, cap_words * 8, hipMemcpyDeviceToHost, ctx0->stream));
+        for (size_t s = 0; s < L; ++s) {
+            p2hot_ctx *ctx = g->ctx[s];
+            P2_HIP(ctx, hipSetDevice(ctx->device));
+            if (digests_out && p.digests_per_rank)
+                P2_HIP(ctx, hipMemcpyAsync(digests_out + 4 * s * p.digests_per_rank, as[s].digests + 4 * s * p.digests_per_rank,
+                                           p.digests_per_rank * 32, hipMemcpyDeviceToHost, ctx->stream));
+            if (leaves_out && W)
+                P2_HIP(ctx, hipMemcpyAsync(leaves_out + s * p.rows_per_rank * W, as[s].leaves, p.rows_per_rank * W * 8, hipMemcpyDeviceToHost,
+                                           ctx->stream));
+        }
+        return P2HOT_OK;
+    };
+    rc = body();
+    for (size_t s = 0; s < L; ++s) {  // every rank's work is complete (and its pool blocks reusable) on return
+        p2hot_ctx *ctx = g->ctx[s];
+        (void)hipSetDevice(ctx->device);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+#ifndef P2HOT_EMU
+        if (g->comm[s]->comm_stream) (void)hipStreamSynchronize(g->comm[s]->comm_stream);
+#endif
+        if (rc == P2HOT_OK && e != hipSuccess) {
+            ctx0->err = std::string("group_commit: ") + hipGetErrorString(e);
+            rc = P2HOT_EHIP;
+        }
+        if (rc == P2HOT_OK && ctx != ctx0 && !ctx->err.empty()) ctx0->err = ctx->err;
+    }
+    if (rc != P2HOT_OK && ctx0->err.empty())
+        for (auto *c : g->ctx)
+            if (!c->err.empty()) ctx0->err = c->err;
+    if (rc == P2HOT_OK && handle_out) {
+        p2hot_sharded_batch *b = new p2hot_sharded_batch{g, p, {}, {}, {}};
+        for (size_t s = 0; s < L; ++s) {
+            b->coeffs_all.push_back(b_co[s]->u());
+            b->lde.push_back(b_lde[s]->u());
+            b->digests.push_back(b_dig[s]->u());
+            b_co[s]->p = b_lde[s]->p = b_dig[s]->p = nullptr;
+        }
+        *handle_out = b;
+    }
+    return rc;
+}
+
+// MerkleTree::get + merkle_tree_prove for m leaves of a sharded batch: every query is answered by the rank that owns the row
+// (a Merkle path below the cap never leaves the cap subtree of its leaf).  rows_out [m][W], paths_out [m][log2(N) - cap][4]; either may be NULL.
+extern "C" int p2hot_sharded_batch_open(p2hot_sharded_batch *b, const uint64_t *leaf_idx, size_t m, uint64_t *rows_out, uint64_t *paths_out) {
+    if (!b) return P2HOT_EINVAL;
+    p2hot_group *g = b->g;
+    p2hot_ctx *ctx0 = g->ctx[0];
+    P2_ENTER(ctx0);
+    const ShardPlan &p = b->plan;
+    if (m == 0) return P2HOT_OK;
+    if (!leaf_idx) P2_FAIL(ctx0, P2HOT_EINVAL, "sharded_batch_open: null indices");
+    const unsigned layers = p.log_N - p.cap_height;
+    for (size_t q = 0; q < m; ++q) {
+        const u64 x = leaf_idx[q];
+        if (x >= p.N) P2_FAIL(ctx0, P2HOT_EINVAL, "sharded_batch_open: index %llu out of range", (unsigned long long)x);
+        const size_t owner = x / p.rows_per_rank;
+        p2hot_ctx *ctx = g->ctx[owner];
+        P2_HIP(ctx, hipSetDevice(ctx->device));
+        PoolBuf d_idx(ctx), d_row(ctx), d_path(ctx);
+        P2_TRY(pool_alloc(ctx, 16, &d_idx.p));
+        P2_TRY(pool_alloc(ctx, std::max<size_t>(1, p.W) * 8, &d_row.p));
+        P2_TRY(pool_alloc(ctx, std::max<size_t>(1, layers) * 32, &d_path.p));
+        const u64 idx2[2] = {x - owner * p.rows_per_rank, x};  // local row in the owner's LDE block, global leaf for the path
+        P2_HIP(ctx, hipMemcpyAsync(d_idx.p, idx2, 16, hipMemcpyHostToDevice, ctx->stream));
+        if (rows_out && p.W) {
+            P2_TRY(p2hot_gather_rows_dev(ctx, b->lde[owner], p.rows_per_rank, p.rows_per_rank, p.W, d_idx.u(), 1, d_row.u()));
+            P2_HIP(ctx, hipMemcpyAsync(rows_out + q * p.W, d_row.p, p.W * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (paths_out && layers) {
+            P2_TRY(p2hot_merkle_paths_dev(ctx, b->digests[owner], p.log_N, p.cap_height, d_idx.u() + 1, 1, d_path.u()));
+            P2_HIP(ctx, hipMemcpyAsync(paths_out + q * layers * 4, d_path.p, layers * 32, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return P2HOT_OK;
+}

@@ -1262,3 +1262,4 @@ struct p2hot_cols {
 };
 
 #include "host_prover.hpp"
+#include "host_multi.hpp"

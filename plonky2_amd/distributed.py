@@ -1,36 +1,33 @@
-"""Coset-sharded PolynomialBatch commit across the GPUs of one node (one process per GPU).
+"""Coset-sharded PolynomialBatch commit across the GPUs of one node -- a thin caller of the library's multi-GPU
+entry points (include/p2hot.h "multi-GPU", plonky2_amd/csrc/host_multi.hpp).
 
-The reference has no multi-device mode; this is the MI355X design of SURVEY.md 8(e):
+The sharding, the pipelined coefficient exchange and the cap / digest exchange all live in libp2hot
+(`p2hot_commit_sharded_dev`, `p2hot_group_commit`); this module only
+  * restates the shard arithmetic (`ShardPlan`, testable without devices),
+  * builds the communicator: RCCL inside the library when the job runs one process per GPU under
+    torch.distributed's "nccl" backend (the unique id travels through torch.distributed), or the library's
+    caller-supplied-transport hook bound to torch.distributed/gloo in the CPU tests,
+  * owns the device buffers of a rank (`ShardedCommit`) and wraps the single-process mode (`GroupCommit`).
 
-  * the rate-1/B LDE is B independent coset transforms, and in the committed (bit-reversed) leaf
-    order coset j is the contiguous row block bitrev(j); with B = 8 and cap_height = 4 a block is
-    two whole cap subtrees.  Rank r therefore owns rows [r*N/G, (r+1)*N/G): it runs the LDE, the
-    Poseidon leaf sponge and the Merkle levels of its rows with NO data-path exchange;
-  * every rank needs all W*n coefficients: the iNTT is column-sharded (ceil(W/G) columns per
-    rank) and followed by ONE all-gather of coefficients (W*n*8 bytes in total);
-  * the digests of a rank's subtrees are a contiguous slice of the reference digest array, so ONE
-    all-gather of digests (+ cap entries) reassembles MerkleTree::digests / ::cap on every rank.  That digest
-    exchange is optional (`gather_digests=False`): a Merkle path below the cap never leaves the cap subtree of its
-    leaf, i.e. the slice of the rank that owns the row, so with only the 2^cap_height cap entries all-gathered every
-    query can still be answered by the owner (`ShardedCommit.owner` / `.prove_local`), SURVEY 8(e) collective (2).
-
-  * the coefficient all-gather is pipelined in column chunks: chunk k is gathered asynchronously (RCCL runs on its
-    own stream) while chunk k+1 goes through the iNTT and chunk k-1 through the LDE, so most of the W*n*8-byte
-    exchange hides behind the NTT work; the leaf sponge starts when the last chunk's LDE is done.
-
-Collectives are torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs; "gloo" in the
-CPU tests).  There is no reduction anywhere, only all-gathers.  P2HOT_SYNC_COLLECTIVES=1 selects the
-unpipelined variant (one blocking all-gather of all coefficients).
+The reference has no multi-device mode.  Design: the rate-1/B LDE is B independent coset transforms and coset j is the
+contiguous row block bitrev(j) of the committed order; with B = 8 and cap_height = 4 a block is two whole cap subtrees,
+so rank r owns rows [r*N/G, (r+1)*N/G) and runs the LDE, the leaf sponge and the Merkle levels of its rows with no
+data-path exchange.  Exchanges: the coefficients after the column-sharded iNTT (W*n*8 bytes, pipelined in column
+chunks), the cap entries, and -- optionally -- the digest slices (`gather_digests`; a Merkle path below the cap never
+leaves the cap subtree of its leaf, so the owner of a row can always serve its path: `owner`, `prove_local`).
 """
+import ctypes as C
 import os
 
 import numpy as np
+
+from . import _lib
 
 COSET_SHIFT = 14293326489335486720
 
 
 class ShardPlan:
-    """Pure arithmetic of the sharding (testable without devices)."""
+    """Pure arithmetic of the sharding (mirrors shard_plan() of csrc/host_multi.hpp; testable without devices)."""
 
     def __init__(self, W, log_n, rate_bits, cap_height, world):
         if world < 1 or world & (world - 1):
@@ -67,11 +64,70 @@ class ShardPlan:
         return [int(format(b, "0%db" % rb)[::-1], 2) if rb else 0 for b in range(b0, b0 + nb)]
 
 
+def _gloo_transport(dist, rank):
+    """p2hot_allgather_fn over torch.distributed with HOST buffers (the CPU test tier: the kernel emulator's "device"
+    memory is host memory).  Rank r's slice is `nbytes` bytes at base + offsets[r]."""
+    import torch
+
+    def fn(_user, d_base, offsets, world, nbytes, _stream):
+        try:
+            view = lambda r: np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(d_base + offsets[r]))  # noqa: E731
+            outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(outs, torch.from_numpy(view(rank).copy()))
+            for r in range(world):
+                if r != rank:
+                    view(r)[:] = outs[r].numpy()
+            return 0
+        except Exception as e:  # an exception must not unwind through the C frames
+            print("p2hot transport callback failed:", repr(e), flush=True)
+            return 1
+    return _lib.ALLGATHER_FN(fn)
+
+
+class Communicator:
+    """p2hot_comm: this rank's end of the library's exchange.  transport: "rccl" (inside libp2hot, one process per GPU),
+    "gloo" (caller-supplied hook over torch.distributed, host buffers) or None = pick by the process group's backend."""
+
+    def __init__(self, engine, rank, world, dist=None, transport=None):
+        self.engine, self.rank, self.world = engine, rank, world
+        self._cb = None
+        h = C.c_void_p()
+        if transport is None:
+            transport = "none" if world == 1 or dist is None else ("rccl" if dist.get_backend() == "nccl" else "gloo")
+        self.transport = transport
+        if transport == "rccl":
+            import torch
+            uid = np.zeros(128, dtype=np.uint8)
+            if rank == 0:
+                engine.check(engine.lib.p2hot_comm_unique_id(uid.ctypes.data))
+            if world > 1:  # the launcher's job: hand rank 0's id to everybody
+                dev = engine.mem.device if dist.get_backend() == "nccl" else "cpu"
+                t = torch.from_numpy(uid).to(dev)
+                dist.broadcast(t, src=0)
+                uid = t.cpu().numpy()
+            engine.check(engine.lib.p2hot_comm_create_rccl(engine.ctx, rank, world, uid.ctypes.data, C.byref(h)))
+        else:
+            self._cb = _gloo_transport(dist, rank) if transport == "gloo" else _lib.ALLGATHER_FN(lambda *a: 1)
+            engine.check(engine.lib.p2hot_comm_create_callback(engine.ctx, rank, world, self._cb, None, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h and getattr(self.engine, "_ctx", None):
+            self.engine.lib.p2hot_comm_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedCommit:
-    """from_values / from_coeffs over `world` ranks.  Buffers are allocated once and reused."""
+    """from_values / from_coeffs over `world` ranks, one process per GPU.  Buffers are allocated once and reused."""
 
     def __init__(self, engine, W, log_n, rate_bits, cap_height, is_values=True, rank=0, world=1, dist=None,
-                 want_leaves=False, pipeline_chunks=None, gather_digests=True):
+                 want_leaves=False, pipeline_chunks=None, gather_digests=True, transport=None):
         self.eng, self.dist, self.rank, self.world = engine, dist, rank, world
         if pipeline_chunks is None:
             pipeline_chunks = 1 if os.environ.get("P2HOT_SYNC_COLLECTIVES") == "1" else 8
@@ -82,9 +138,10 @@ class ShardedCommit:
         mem = engine.mem
         self.column_range = p.columns(rank)
         self.row_begin, self.row_count = p.rows(rank)
-        # coefficient buffer, padded to world * cols_per_rank columns so the all-gather is uniform
+        self.comm = Communicator(engine, rank, world, dist, transport)
+        # coefficient buffer, padded to world * cols_per_rank columns so every rank's slot has the same size
         self.coeffs_all = mem.empty(max(1, world * p.cols_per_rank), p.n)
-        self.lde = mem.empty(W, self.row_count)
+        self.lde = mem.empty(max(W, 1), self.row_count)
         self.leaves = mem.empty(self.row_count, W) if want_leaves else None
         self.digests = mem.zeros(max(1, p.num_digests), 4)
         self.cap = mem.zeros(1 << cap_height, 4)
@@ -94,38 +151,15 @@ class ShardedCommit:
         Returns dict(coeffs [W][n], lde [W][rows of this rank], digests, cap), all device buffers;
         digests / cap are the FULL tree's arrays on every rank (with gather_digests=False only this rank's slice
         [rank * digests_per_rank, (rank + 1) * digests_per_rank) of `digests` is filled; cap is always complete)."""
-        eng, p, lib = self.eng, self.plan, self.eng.lib
-        c0, c1 = self.column_range
+        eng, p = self.eng, self.plan
         W = p.W
-        if self.world == 1:
-            eng.check(lib.p2hot_commit_dev(
-                eng.ctx, eng.ptr(cols_local), cols_local.shape[1] if W else p.n, W, p.log_n, p.rate_bits, p.cap_height,
-                1 if self.is_values else 0, 0, p.N, eng.ptr(self.coeffs_all), p.n, eng.ptr(self.lde), self.row_count,
-                eng.ptr(self.leaves), eng.ptr(self.digests), eng.ptr(self.cap)))
-        elif self.pipeline_chunks > 1 and p.cols_per_rank > 1:
-            self._run_pipelined(cols_local)
-        else:
-            # 1. this rank's columns -> coefficient form, in its slot of the padded buffer
-            slot = self.coeffs_all[self.rank * p.cols_per_rank:(self.rank + 1) * p.cols_per_rank]
-            if c1 > c0:
-                slot[:c1 - c0] = cols_local
-                if self.is_values:
-                    eng.ifft(slot[:c1 - c0], p.log_n)
-            # 2. all-gather of coefficients (W*n*8 bytes over xGMI)
-            self._all_gather(self.coeffs_all, slot)
-            # 3. LDE + leaf sponge + Merkle levels of this rank's rows (whole cosets, whole cap subtrees)
-            eng.check(lib.p2hot_commit_dev(
-                eng.ctx, eng.ptr(self.coeffs_all), p.n, W, p.log_n, p.rate_bits, p.cap_height, 0, self.row_begin,
-                self.row_count, None, 0, eng.ptr(self.lde), self.row_count, eng.ptr(self.leaves), eng.ptr(self.digests),
-                eng.ptr(self.cap)))
-        if self.world > 1:
-            # 4. all-gather of this rank's contiguous digest slice and cap entries
-            if p.digests_per_rank and self.gather_digests:
-                d = self.digests[self.rank * p.digests_per_rank:(self.rank + 1) * p.digests_per_rank]
-                self._all_gather(self.digests[:p.num_digests], d)
-            k = self.cap[self.rank * p.cap_per_rank:(self.rank + 1) * p.cap_per_rank]
-            self._all_gather(self.cap, k)
-        return {"coeffs": self.coeffs_all[:W], "lde": self.lde, "leaves": self.leaves,
+        stride = cols_local.shape[1] if (cols_local is not None and cols_local.ndim == 2 and cols_local.shape[0]) else p.n
+        eng.check(eng.lib.p2hot_commit_sharded_dev(
+            eng.ctx, self.comm._h, eng.ptr(cols_local) if cols_local is not None else None, stride, W, p.log_n, p.rate_bits,
+            p.cap_height, 1 if self.is_values else 0, 1 if self.gather_digests else 0, self.pipeline_chunks,
+            eng.ptr(self.coeffs_all), eng.ptr(self.lde), self.row_count, eng.ptr(self.leaves), eng.ptr(self.digests),
+            eng.ptr(self.cap)))
+        return {"coeffs": self.coeffs_all[:W], "lde": self.lde[:W], "leaves": self.leaves,
                 "digests": self.digests[:p.num_digests], "cap": self.cap}
 
     def owner(self, leaf_index):
@@ -144,52 +178,69 @@ class ShardedCommit:
         d_idx = eng.dev(idx if len(idx) else np.zeros(1, dtype=np.uint64))
         eng.check(eng.lib.p2hot_merkle_paths_dev(eng.ctx, eng.ptr(self.digests), p.log_N, p.cap_height, eng.ptr(d_idx),
                                                  len(idx), eng.ptr(paths)))
-        rows = eng.gather_rows(self.lde, idx - np.uint64(self.row_begin)) if len(idx) and p.W else \
+        rows = eng.gather_rows(self.lde[:p.W], idx - np.uint64(self.row_begin)) if len(idx) and p.W else \
             np.zeros((len(idx), p.W), dtype=np.uint64)
         return eng.host(rows), eng.host(paths)[:len(idx), :layers]
 
-    def _run_pipelined(self, cols_local):
-        """steps 1-3 with the coefficient exchange hidden behind the NTTs (see the module docstring)"""
-        eng, p, lib, mem = self.eng, self.plan, self.eng.lib, self.eng.mem
-        c0, c1 = self.column_range
-        cpr, W = p.cols_per_rank, p.W
-        K = min(self.pipeline_chunks, cpr)
-        cpk = -(-cpr // K)
-        mine = c1 - c0
-        mem.collective_fence()
-        works, spans = [], []
-        for k in range(K):
-            lo, hi = k * cpk, min((k + 1) * cpk, cpr)            # rows of every rank's slot in this chunk
-            if hi <= lo:
-                continue
-            my = self.coeffs_all[self.rank * cpr + lo:self.rank * cpr + hi]
-            valid = max(0, min(hi, mine) - lo)                   # my real (non-padding) columns in the chunk
-            if valid:
-                my[:valid] = cols_local[lo:lo + valid]
-                if self.is_values:
-                    eng.ifft(my[:valid], p.log_n)
-            outs = [mem.as_torch(self.coeffs_all[r * cpr + lo:r * cpr + hi]) for r in range(self.world)]
-            works.append(self.dist.all_gather(outs, mem.as_torch(my).clone(), async_op=True))
-            spans.append((lo, hi))
-        for w, (lo, hi) in zip(works, spans):
-            w.wait()                                             # NCCL: the compute stream waits, the host does not
-            for r in range(self.world):
-                cb = r * cpr + lo
-                cnt = max(0, min(r * cpr + hi, W, (r + 1) * cpr) - cb)
-                if cnt:                                          # LDE of these columns for this rank's coset rows
-                    eng.check(lib.p2hot_coset_lde_dev(
-                        eng.ctx, eng.ptr(self.coeffs_all[cb:cb + cnt]), cnt, p.n, p.log_n, p.rate_bits, COSET_SHIFT,
-                        self.row_begin, self.row_count, eng.ptr(self.lde[cb:cb + cnt]), self.row_count))
-        # leaf sponge + Merkle levels of this rank's rows, straight from the column-major LDE
-        eng.check(lib.p2hot_merkle_dev(eng.ctx, eng.ptr(self.lde), 0, self.row_count, W, p.log_N, p.cap_height,
-                                       self.row_begin, self.row_count, eng.ptr(self.digests), eng.ptr(self.cap)))
-        if self.leaves is not None:
-            eng.check(lib.p2hot_transpose_dev(eng.ctx, eng.ptr(self.lde), self.row_count, W, self.row_count,
-                                              eng.ptr(self.leaves)))
 
-    def _all_gather(self, full, mine):
-        mem = self.eng.mem
-        out = mem.as_torch(full).reshape(-1)
-        inp = mem.as_torch(mine).reshape(-1).clone()  # not in place: the slice aliases `full`
-        mem.collective_fence()
-        self.dist.all_gather_into_tensor(out, inp)
+class GroupCommit:
+    """p2hot_group: ONE process driving `n_gpus` devices -- what a patched plonky2 (a single Rust process) uses.
+    `devices` may repeat a device id (one-GPU boxes, the kernel emulator): the ranks then exchange by copies."""
+
+    def __init__(self, lib, n_gpus, devices=None):
+        self.lib = lib
+        h = C.c_void_p()
+        dv = (C.c_int * n_gpus)(*(devices if devices is not None else range(n_gpus)))
+        rc = lib.p2hot_group_create(n_gpus, dv, C.byref(h))
+        if rc != _lib.OK:
+            raise _lib.P2HotError(rc, "p2hot_group_create failed")
+        self._h, self.n_gpus = h, n_gpus
+
+    @property
+    def uses_rccl(self):
+        return bool(self.lib.p2hot_group_uses_rccl(self._h))
+
+    def _check(self, rc):
+        if rc != _lib.OK:
+            raise _lib.P2HotError(rc, self.lib.p2hot_group_last_error(self._h).decode())
+
+    def commit(self, cols, rate_bits, cap_height, is_values=True, want_leaves=False, want_digests=True, pipeline_chunks=8):
+        """cols: host [W][n].  Returns dict(coeffs, leaves, digests, cap) host arrays + an opener for rows / paths."""
+        cols = np.ascontiguousarray(np.asarray(cols, dtype=np.uint64))
+        W, n = cols.shape
+        log_n = int(n).bit_length() - 1
+        N, ncap = n << rate_bits, 1 << cap_height
+        ptrs = (C.c_void_p * max(W, 1))(*[cols[c].ctypes.data for c in range(W)])
+        coeffs = np.zeros((W, n), dtype=np.uint64)
+        leaves = np.zeros((N, W), dtype=np.uint64) if want_leaves else None
+        digests = np.zeros((max(0, 2 * (N - ncap)), 4), dtype=np.uint64) if want_digests else None
+        cap = np.zeros((ncap, 4), dtype=np.uint64)
+        bh = C.c_void_p()
+        self._check(self.lib.p2hot_group_commit(
+            self._h, ptrs, W, log_n, rate_bits, cap_height, 1 if is_values else 0, pipeline_chunks, coeffs.ctypes.data,
+            leaves.ctypes.data if want_leaves else None, digests.ctypes.data if want_digests else None, cap.ctypes.data,
+            C.byref(bh)))
+        lib, group = self.lib, self
+
+        def open_(leaf_idx):
+            idx = np.ascontiguousarray(np.asarray(leaf_idx, dtype=np.uint64).reshape(-1))
+            layers = log_n + rate_bits - cap_height
+            rows = np.zeros((len(idx), W), dtype=np.uint64)
+            paths = np.zeros((len(idx), layers, 4), dtype=np.uint64)
+            group._check(lib.p2hot_sharded_batch_open(bh, idx.ctypes.data, len(idx), rows.ctypes.data, paths.ctypes.data))
+            return rows, paths
+
+        def free():
+            lib.p2hot_sharded_batch_free(bh)
+        return {"coeffs": coeffs, "leaves": leaves, "digests": digests, "cap": cap, "open": open_, "free": free}
+
+    def close(self):
+        if self._h:
+            self.lib.p2hot_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

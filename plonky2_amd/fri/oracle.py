@@ -22,11 +22,53 @@ from ..hash.merkle_tree import MerkleTree
 P = 0xFFFFFFFF00000001
 
 
+class _BatchHandle:
+    """Owns one p2hot_batch* and the lazy fetches on it.  PolynomialBatch and its MerkleTree both point HERE, not at
+    each other: no reference cycle, so a dropped batch returns its 9 GB LDE block immediately (refcount, not the
+    cycle collector) -- a cycle cost a fresh hipMalloc of the LDE matrix per commit (310 ms instead of 67)."""
+
+    def __init__(self, engine, handle, W, degree_log, rate_bits, cap_height, keepalive=()):
+        self.engine, self.h, self.W = engine, handle, W
+        self.degree_log, self.rate_bits, self.cap_height = degree_log, rate_bits, cap_height
+        self.keepalive = keepalive  # device buffers a wrapped (borrowing) handle points into
+
+    def __del__(self):
+        try:
+            if self.h and getattr(self.engine, "_ctx", None):
+                self.engine.lib.p2hot_batch_free(self.h)
+        except Exception:
+            pass
+        self.h = None
+
+    # MerkleTree::get / ::prove / .digests on the device-resident tree
+    def rows(self, idx):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.uint64).reshape(-1))
+        out = np.zeros((len(idx), self.W), dtype=np.uint64)
+        if len(idx) and self.W:
+            self.engine.check(self.engine.lib.p2hot_batch_rows(self.h, idx.ctypes.data, len(idx), out.ctypes.data))
+        return out
+
+    def paths(self, idx):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.uint64).reshape(-1))
+        layers = self.degree_log + self.rate_bits - self.cap_height
+        out = np.zeros((len(idx), layers, 4), dtype=np.uint64)
+        if len(idx) and layers:
+            self.engine.check(self.engine.lib.p2hot_batch_paths(self.h, idx.ctypes.data, len(idx), out.ctypes.data))
+        return out
+
+    def digests(self):
+        nd = self.engine.num_digests(self.degree_log + self.rate_bits, self.cap_height)
+        out = np.zeros((nd, 4), dtype=np.uint64)
+        if nd:
+            self.engine.check(self.engine.lib.p2hot_batch_digests(self.h, out.ctypes.data))
+        return out
+
+
 class PolynomialBatch:
     def __init__(self, engine, handle, W, degree_log, rate_bits, cap_height, cap, digests=None, coeffs=None, lde=None,
                  blinding=False):
         self.engine = engine
-        self._h = handle           # p2hot_batch*
+        self._owner = _BatchHandle(engine, handle, W, degree_log, rate_bits, cap_height, keepalive=(coeffs, lde, digests))
         self._W = W
         self._coeffs = coeffs      # device [W][n] when the batch was built from device buffers, else None
         self.lde = lde             # device [W][N] (same condition)
@@ -35,41 +77,15 @@ class PolynomialBatch:
         self.cap_height = cap_height
         self.blinding = blinding
         N = 1 << (degree_log + rate_bits)
+        own = self._owner
         self.merkle_tree = MerkleTree(None, digests, cap, cap_height, n_leaves=N,
                                       engine=engine if digests is not None and engine.mem.is_buffer(digests) else None,
-                                      leaf_getter=self._rows, path_getter=self._paths if digests is None else None,
-                                      digests_getter=self._digests_host)
+                                      leaf_getter=own.rows, path_getter=own.paths if digests is None else None,
+                                      digests_getter=own.digests)
 
-    def __del__(self):
-        try:
-            if self._h and getattr(self.engine, "_ctx", None):
-                self.engine.lib.p2hot_batch_free(self._h)
-        except Exception:
-            pass
-        self._h = None
-
-    # -- lazily fetched pieces (MerkleTree::get / ::prove on the device-resident tree)
-    def _rows(self, idx):
-        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.uint64).reshape(-1))
-        out = np.zeros((len(idx), self._W), dtype=np.uint64)
-        if len(idx) and self._W:
-            self.engine.check(self.engine.lib.p2hot_batch_rows(self._h, idx.ctypes.data, len(idx), out.ctypes.data))
-        return out
-
-    def _paths(self, idx):
-        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.uint64).reshape(-1))
-        layers = self.degree_log + self.rate_bits - self.cap_height
-        out = np.zeros((len(idx), layers, 4), dtype=np.uint64)
-        if len(idx) and layers:
-            self.engine.check(self.engine.lib.p2hot_batch_paths(self._h, idx.ctypes.data, len(idx), out.ctypes.data))
-        return out
-
-    def _digests_host(self):
-        nd = self.engine.num_digests(self.degree_log + self.rate_bits, self.cap_height)
-        out = np.zeros((nd, 4), dtype=np.uint64)
-        if nd:
-            self.engine.check(self.engine.lib.p2hot_batch_digests(self._h, out.ctypes.data))
-        return out
+    @property
+    def _h(self):
+        return self._owner.h
 
     @property
     def polynomials(self):

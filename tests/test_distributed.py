@@ -130,3 +130,62 @@ def test_shard_plan():
         ShardPlan(2, 22, 1, 4, 4)  # starky rate 1/2: only two cosets
     with pytest.raises(ValueError):
         ShardPlan(2, 10, 3, 1, 4)  # fewer cap subtrees than ranks
+
+
+@pytest.mark.parametrize("world,W,log_n,rb,cap,is_values,chunks", [
+    (2, 5, 5, 3, 4, True, 1), (4, 135, 3, 3, 4, True, 4), (8, 20, 4, 3, 4, True, 2), (2, 3, 6, 1, 2, False, 3),
+    (8, 9, 3, 3, 3, False, 8), (1, 6, 4, 2, 1, True, 2)])
+def test_group_commit_single_process(ora, world, W, log_n, rb, cap, is_values, chunks):
+    """p2hot_group_commit -- ONE process driving `world` ranks (a patched plonky2's mode), host pointers in and out:
+    coefficients, leaves, the full digest array and the cap equal the oracle's; rows / paths are served by the owning
+    rank.  The emulator's ranks share one "device", so the exchange runs as copies (on a node: RCCL over xGMI)."""
+    from plonky2_amd.distributed import GroupCommit
+    from tests.emu_backend import emu_lib
+    rng = np.random.default_rng(world * 1000 + W)
+    cols = rand_field(rng, W, 1 << log_n, noncanonical=True)
+    g = GroupCommit(emu_lib(), world, [0] * world)
+    assert not g.uses_rccl
+    for _ in range(2):  # pool blocks are reused by the second call
+        r = g.commit(cols, rb, cap, is_values, want_leaves=True, pipeline_chunks=chunks)
+        o = ora.commit(cols, rb, cap, is_values)
+        assert (r["coeffs"] == o["coeffs"] % np.uint64(0xFFFFFFFF00000001)).all()
+        assert (r["cap"] == o["cap"]).all()
+        assert (r["digests"] == o["digests"]).all()
+        assert (r["leaves"] == o["leaves"]).all()
+        N = 1 << (log_n + rb)
+        xs = [0, N - 1] + [int(x) for x in rng.integers(0, N, 6)]
+        rows, paths = r["open"](xs)
+        for x, row, path in zip(xs, rows, paths):
+            assert (row == o["leaves"][x]).all()
+            assert (path == ora.merkle_prove(x, N, cap, o["digests"])).all()
+        with pytest.raises(Exception):
+            r["open"]([N])
+        r["free"]()
+    g.close()
+
+
+def test_group_and_comm_argument_errors():
+    import ctypes as C
+    from plonky2_amd import _lib
+    from plonky2_amd.distributed import GroupCommit
+    from tests.emu_backend import emu_engine, emu_lib
+    lib = emu_lib()
+    with pytest.raises(_lib.P2HotError):
+        GroupCommit(lib, 3, [0, 0, 0])                      # not a power of two
+    g = GroupCommit(lib, 4, [0] * 4)
+    cols = np.ones((2, 16), dtype=np.uint64)
+    with pytest.raises(_lib.P2HotError, match="LDE cosets"):
+        g.commit(cols, 1, 4)                                # starky rate 1/2: only two cosets
+    with pytest.raises(_lib.P2HotError, match="cap subtrees"):
+        g.commit(cols, 3, 1)
+    g.close()
+    eng = emu_engine()
+    h = C.c_void_p()
+    assert lib.p2hot_comm_create_rccl(eng.ctx, 0, 1, np.zeros(128, dtype=np.uint8).ctypes.data, C.byref(h)) == _lib.ECOMM  # no RCCL in the emulator
+    first, count = C.c_size_t(), C.c_size_t()
+    from plonky2_amd.distributed import ShardPlan
+    for (W, world) in ((135, 8), (20, 4), (3, 8), (0, 2)):
+        p = ShardPlan(W, 10, 3, 4, world)
+        for r in range(world):
+            assert lib.p2hot_shard_columns(W, world, r, C.byref(first), C.byref(count)) == 0
+            assert (first.value, first.value + count.value) == p.columns(r)

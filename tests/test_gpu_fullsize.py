@@ -36,6 +36,70 @@ def _check_properties(gpu, ora, cols_dev, r, W, log_n, rb, cap, rng, n_paths=24,
         assert pyref.eval_poly(coeffs, pow(pyref.root_of_unity(log_n), i, P)) == int(gpu.host(cols_dev[c, i:i + 1])[0]) % P
 
 
+def _sha_device_matrix(gpu, mat):
+    """SHA-256 of a device matrix [rows][cols] in row order, copied back one row (= one column of the LDE) at a time"""
+    import hashlib
+    h = hashlib.sha256()
+    for r in range(mat.shape[0]):
+        h.update(gpu.host(mat[r]).tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("name", ["c2_wires", "c3_wires", "c3_zs_partial_products", "c3_quotient_chunks", "c4_fibonacci_trace"])
+def test_baseline_commits_bit_exact_vs_oracle_goldens(gpu, name):
+    """Every full-size commit of BASELINE.json's configs -- C2, the three C3 commits (W = 135 / 20 from_values, 16
+    from_coeffs; 2^20 rows, rate 1/8, cap 4: W = 135 is the bench workload) and the C4 trace commit (W = 2, 2^22 rows,
+    rate 1/2) -- against the bytes the FAITHFUL CPU oracle produced for the same inputs (tests/golden/commit_caps.json,
+    tools/gen_golden_caps.py): the cap, and SHA-256 of the coefficient matrix, of the whole digest array (reference
+    layout) and of the whole LDE matrix (= MerkleTree::leaves, column-major committed order).
+    Reference: fri/oracle.rs:57-112, hash/merkle_tree.rs:193-224."""
+    import hashlib
+    import json
+    import os
+    import torch
+    from plonky2_amd.util.synthetic import fibonacci_trace, splitmix_columns_torch
+    from tests.conftest import ROOT
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "commit_caps.json")))[name]
+    W, log_n, rb, cap, is_values = g["W"], g["log_n"], g["rate_bits"], g["cap_height"], g["is_values"]
+    if g["input"] == "splitmix":
+        cols = splitmix_columns_torch(torch, gpu.mem.device, 0, W, 1 << log_n)
+    else:
+        cols = gpu.dev(fibonacci_trace(log_n))
+    r = gpu.commit(cols, log_n, rb, cap, is_values)
+    assert gpu.host(r["cap"]).tolist() == g["cap"], "Merkle cap differs from the oracle"
+    assert hashlib.sha256(gpu.host(r["digests"]).tobytes()).hexdigest() == g["sha256_digests"], "digest array differs"
+    co = gpu.host(r["coeffs"])
+    assert hashlib.sha256(np.where(co >= np.uint64(P), co - np.uint64(P), co).tobytes()).hexdigest() == g["sha256_coeffs"]
+    assert _sha_device_matrix(gpu, r["lde"]) == g["sha256_lde"], "LDE matrix (leaves) differs"
+    del r, cols
+    torch.cuda.empty_cache()
+
+
+def test_c3_wires_host_pointer_commit_equals_golden(gpu):
+    """the same C3 wires commit through the host-pointer entry point the Rust shim calls (p2hot_commit, pipelined
+    PCIe copies): cap and digest array equal the oracle's golden bytes"""
+    import ctypes as C
+    import hashlib
+    import json
+    import os
+    from plonky2_amd.util.synthetic import splitmix_columns_numpy
+    from tests.conftest import ROOT
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "commit_caps.json")))["c3_wires"]
+    W, log_n, rb, cap = g["W"], g["log_n"], g["rate_bits"], g["cap_height"]
+    cols = splitmix_columns_numpy(0, W, 1 << log_n)
+    ptrs = (C.c_void_p * W)(*[cols[c].ctypes.data for c in range(W)])
+    nd = gpu.num_digests(log_n + rb, cap)
+    digests = np.zeros((nd, 4), dtype=np.uint64)
+    capv = np.zeros((1 << cap, 4), dtype=np.uint64)
+    coeffs = np.zeros((W, 1 << log_n), dtype=np.uint64)
+    gpu.check(gpu.lib.p2hot_commit(gpu.ctx, ptrs, W, log_n, rb, cap, 1, 0, coeffs.ctypes.data, None, digests.ctypes.data,
+                                   capv.ctypes.data, None))
+    assert capv.tolist() == g["cap"]
+    assert hashlib.sha256(digests.tobytes()).hexdigest() == g["sha256_digests"]
+    assert hashlib.sha256(coeffs.tobytes()).hexdigest() == g["sha256_coeffs"]
+    gpu.check(gpu.lib.p2hot_ctx_trim(gpu.ctx))
+
+
 def test_c2_commit_bit_exact_vs_oracle(gpu, ora):
     """C2: W = 135, 2^16 rows, rate 1/8, cap 4 -- everything compared with the oracle"""
     rng = np.random.default_rng(2)
@@ -105,73 +169,49 @@ def test_fri_commit_phase_full_size_vs_oracle(gpu, ora, log_n, rb, arity):
     assert c.get_n_challenges(2) == oc.get_n_challenges(2)
 
 
-class _LoopbackDist:
-    """single-process stand-in for torch.distributed: rank r's all-gather input is written into slot r of the
-    output and the other slots are filled from what the other simulated ranks deposited earlier"""
-
-    def __init__(self, world):
-        self.world, self.rank, self.store = world, 0, {}
-        self.calls = 0
-
-    def all_gather_into_tensor(self, out, inp):
-        key = self.calls
-        self.calls += 1
-        self.store.setdefault(key, {})[self.rank] = inp.clone()
-        chunk = inp.numel()
-        for r, t in self.store[key].items():
-            out[r * chunk:(r + 1) * chunk] = t
-
-    def all_gather(self, outs, inp, async_op=False):
-        key = self.calls
-        self.calls += 1
-        self.store.setdefault(key, {})[self.rank] = inp.clone()
-        for r, t in self.store[key].items():
-            outs[r].copy_(t)
-
-        class _Done:
-            def wait(self):
-                return True
-        return _Done()
+@pytest.mark.parametrize("world,W,log_n,chunks", [(2, 9, 12, 3), (4, 20, 14, 8), (8, 135, 12, 4)])
+def test_group_commit_ranks_on_one_gpu(gpu, ora, world, W, log_n, chunks):
+    """p2hot_group_commit on the real GPU: `world` ranks of ONE process, all on device 0 (the box has one GPU), exchanging
+    by copies on their communicator streams; coefficients, leaves, the whole digest array and the cap equal the oracle's,
+    and the owner of a row serves its Merkle path"""
+    from plonky2_amd.distributed import GroupCommit
+    rng = np.random.default_rng(9 + world)
+    rb, cap = 3, 4
+    cols = rand_field(rng, W, 1 << log_n, noncanonical=True)
+    o = ora.commit(cols, rb, cap, True)
+    g = GroupCommit(gpu.lib, world, [0] * world)
+    assert not g.uses_rccl          # a repeated device cannot carry an RCCL communicator
+    for _ in range(2):
+        r = g.commit(cols, rb, cap, True, want_leaves=True, pipeline_chunks=chunks)
+        assert (r["coeffs"] == o["coeffs"]).all() and (r["cap"] == o["cap"]).all()
+        assert (r["digests"] == o["digests"]).all() and (r["leaves"] == o["leaves"]).all()
+        N = 1 << (log_n + rb)
+        xs = [0, N - 1, N // world, N // world - 1] + [int(x) for x in rng.integers(0, N, 8)]
+        rows, paths = r["open"](xs)
+        for x, row, path in zip(xs, rows, paths):
+            assert (row == o["leaves"][x]).all() and ora.merkle_verify(row, x, o["cap"], path)
+        r["free"]()
+    g.close()
 
 
-@pytest.mark.parametrize("chunks,gather", [(1, True), (3, True), (3, False)])
-def test_sharded_commit_ranks_on_one_gpu(gpu, ora, chunks, gather):
-    """the world > 1 branch of plonky2_amd.distributed on the real GPU: both ranks of a 2-rank job are
-    run one after the other with a loopback all-gather; rank 1 then holds the full tree"""
+@pytest.mark.parametrize("chunks,gather", [(1, True), (5, False)])
+def test_rccl_communicator_one_rank(gpu, ora, chunks, gather):
+    """The in-library RCCL transport on the real GPU with a one-rank communicator (all this box can host):
+    ncclGetUniqueId / ncclCommInitRank / grouped ncclBroadcast on the communicator stream, ordered against the compute
+    stream by events -- the same calls p2hot_commit_sharded_dev issues at 2 / 4 / 8 ranks; result vs the oracle"""
     from plonky2_amd.distributed import ShardedCommit
-    rng = np.random.default_rng(9)
-    W, log_n, rb, cap = 9, 12, 3, 4
+    rng = np.random.default_rng(77)
+    W, log_n, rb, cap = 11, 12, 3, 4
     cols = rand_field(rng, W, 1 << log_n)
     o = ora.commit(cols, rb, cap, True)
-    dist = _LoopbackDist(2)
-    jobs = [ShardedCommit(gpu, W, log_n, rb, cap, is_values=True, rank=r, world=2, dist=dist, want_leaves=True,
-                          pipeline_chunks=chunks, gather_digests=gather) for r in range(2)]
-    out = None
-    for _pass in range(2):  # second sweep: every rank's deposits are present, like a real collective
-        dist.calls = 0
-        for r, job in enumerate(jobs):
-            dist.rank = r
-            base = dist.calls
-            c0, c1 = job.column_range
-            out = job.run(gpu.dev(cols[c0:c1]))
-            if r == 0:
-                dist.calls = base  # rank 1 replays the same sequence of collectives
-    r0, rc = jobs[1].plan.rows(1)
-    assert (gpu.host(out["coeffs"]) == o["coeffs"]).all()
-    assert (gpu.host(out["leaves"]) == o["leaves"][r0:r0 + rc]).all()
-    assert (gpu.host(out["cap"]) == o["cap"]).all()
-    if gather:
-        assert (gpu.host(out["digests"]) == o["digests"]).all()
-    else:  # digests stay with the row owner: rank 1's slice is filled, and it answers the queries that fall into its rows
-        p = jobs[1].plan
-        d0, d1 = p.digests_per_rank, 2 * p.digests_per_rank
-        assert (gpu.host(out["digests"])[d0:d1] == o["digests"][d0:d1]).all()
-        mine = [r0, r0 + 5, r0 + rc - 1]
-        rows, paths = jobs[1].prove_local(mine)
-        for x, row, path in zip(mine, rows, paths):
-            assert (row == o["leaves"][x]).all()
-            assert (path == ora.merkle_prove(x, p.N, cap, o["digests"])).all()
-            assert ora.merkle_verify(row, x, o["cap"], path)
+    job = ShardedCommit(gpu, W, log_n, rb, cap, is_values=True, rank=0, world=1, dist=None, want_leaves=True,
+                        pipeline_chunks=chunks, gather_digests=gather, transport="rccl")
+    for _ in range(2):
+        out = job.run(gpu.dev(cols))
+        gpu.sync()
+        assert (gpu.host(out["coeffs"]) == o["coeffs"]).all() and (gpu.host(out["cap"]) == o["cap"]).all()
+        assert (gpu.host(out["digests"]) == o["digests"]).all() and (gpu.host(out["leaves"]) == o["leaves"]).all()
+    job.comm.close()
 
 
 @pytest.mark.gpu

@@ -14,7 +14,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from bench import splitmix_columns_torch  # noqa: E402
+from plonky2_amd.util.synthetic import splitmix_columns_torch  # noqa: E402
 from plonky2_amd import Engine  # noqa: E402
 from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, eval_openings, prove_openings  # noqa: E402
 from plonky2_amd.iop.challenger import Challenger  # noqa: E402

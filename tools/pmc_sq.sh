@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 CNT="${1:-GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU}"
 rm -rf $R/gpurun_out/pmc_sq
-timeout 600 rocprofv3 --pmc $CNT --output-format csv -d $R/gpurun_out/pmc_sq -o p2hot -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/pmc_sq.err
+timeout 600 rocprofv3 --pmc $CNT --output-format csv -d $R/gpurun_out/pmc_sq -o p2hot -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> $R/gpurun_out/pmc_sq.err
 echo rc=$?
 python - <<'P'
 import csv,glob,collections,os
