@@ -1,0 +1,754 @@
+//! `crate::p2hot` -- the plonky2 side of libp2hot (include/p2hot.h): the MI355X implementation of the
+//! PolynomialBatch LDE + Poseidon-Merkle commit pipeline, the FRI commit phase and `prove_openings`.
+//!
+//! This file is added to the crate as `plonky2/src/p2hot.rs` by `integration/plonky2_p2hot.patch`
+//! (feature `p2hot`).  With the feature on and `F = GoldilocksField`, `C::Hasher = PoseidonHash`, `D = 2`,
+//! `blinding = false`, the bodies of
+//!   `PolynomialBatch::from_values` / `from_coeffs`   (fri/oracle.rs:57-112)
+//!   `PolynomialBatch::prove_openings`                 (fri/oracle.rs:176-237)
+//!   `fri_committed_trees`                             (fri/prover.rs:84-150)
+//!   `MerkleTree::get` / `::prove`                     (hash/merkle_tree.rs:227, :231-237)
+//! call into the library; every other instantiation takes the unchanged CPU path.  Signatures, struct fields
+//! and results are unchanged, so `CircuitBuilder::build`, `prove`, starky's `prove`, serialization and the
+//! verifier are untouched.
+//!
+//! Environment:
+//!   P2HOT_LIB_DIR   directory of libp2hot.so (build.rs adds it to the link search path)
+//!   P2HOT_DEVICE    GPU index of the single-GPU context (default 0)
+//!   P2HOT_LEAVES    "host" (default): the leaf matrix of every commitment is copied back, so code that reads
+//!                   `merkle_tree.leaves` directly (the CPU quotient evaluation through `get_lde_values`, wire
+//!                   formats) works unchanged; "device": `leaves` stays empty, rows and Merkle paths are fetched from
+//!                   the GPU on demand (`MerkleTree::get` / `::prove`) -- 9 GB less PCIe traffic per wires commit.
+//!
+//! This image has no Rust toolchain: the file is checked against include/p2hot.h symbol by symbol
+//! (tests/test_integration_files.py) but has not been compiled here.
+#![allow(non_camel_case_types, clippy::missing_safety_doc, clippy::too_many_arguments)]
+
+use core::any::TypeId;
+use core::ffi::{c_char, c_int, c_uint, c_void};
+use std::collections::HashMap;
+use std::sync::{Mutex, OnceLock};
+
+use crate::field::extension::Extendable;
+use crate::field::goldilocks_field::GoldilocksField;
+use crate::field::polynomial::{PolynomialCoeffs, PolynomialValues};
+use crate::field::types::Field;
+use crate::fri::oracle::PolynomialBatch;
+use crate::fri::proof::{FriInitialTreeProof, FriProof, FriQueryRound, FriQueryStep};
+use crate::fri::structure::FriInstanceInfo;
+use crate::fri::FriParams;
+use crate::hash::hash_types::RichField;
+use crate::hash::hashing::PlonkyPermutation;
+use crate::hash::merkle_proofs::MerkleProof;
+use crate::hash::merkle_tree::{MerkleCap, MerkleTree};
+use crate::hash::poseidon::PoseidonHash;
+use crate::iop::challenger::Challenger;
+use crate::plonk::config::{GenericConfig, Hasher};
+use crate::util::log2_strict;
+
+// ------------------------------------------------------------------------------------------------
+// Raw bindings: one declaration per symbol of include/p2hot.h, same order.
+// ------------------------------------------------------------------------------------------------
+#[repr(C)]
+pub struct P2hotCtx {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct P2hotChallenger {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct P2hotBatch {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct P2hotCols {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct P2hotComm {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct P2hotGroup {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct P2hotShardedBatch {
+    _private: [u8; 0],
+}
+
+/// p2hot_challenger_state: the Fiat-Shamir sponge (iop/challenger.rs:16-20) as plain words
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct P2hotChallengerState {
+    pub sponge_state: [u64; 12],
+    pub input_buffer: [u64; 8],
+    pub output_buffer: [u64; 8],
+    pub input_len: u32,
+    pub output_len: u32,
+}
+
+/// p2hot_fri_batch_info: FriBatchInfo (fri/structure.rs)
+#[repr(C)]
+pub struct P2hotFriBatchInfo {
+    pub point: [u64; 2],
+    pub oracle_index: *const u32,
+    pub poly_index: *const u32,
+    pub n_polys: usize,
+}
+
+/// p2hot_fri_params: FriParams / FriConfig (fri/mod.rs:31-46, :103-118) + the two Option<usize> of prove_openings
+#[repr(C)]
+pub struct P2hotFriParams {
+    pub rate_bits: c_uint,
+    pub cap_height: c_uint,
+    pub proof_of_work_bits: c_uint,
+    pub num_query_rounds: c_uint,
+    pub reduction_arity_bits: *const c_uint,
+    pub n_reduction_rounds: c_uint,
+    pub hiding: c_int,
+    pub max_num_query_steps: c_uint,
+    pub final_poly_coeff_len: usize,
+}
+
+/// p2hot_fri_proof: FriProof (fri/proof.rs:95-110) as flat caller-allocated buffers (layout: include/p2hot.h)
+#[repr(C)]
+pub struct P2hotFriProof {
+    pub commit_phase_merkle_caps: *mut u64,
+    pub final_poly: *mut u64,
+    pub pow_witness: u64,
+    pub query_indices: *mut u64,
+    pub initial_leaves: *mut u64,
+    pub initial_paths: *mut u64,
+    pub step_evals: *mut u64,
+    pub step_paths: *mut u64,
+}
+
+#[repr(C)]
+#[derive(Default)]
+pub struct P2hotFriProofLayout {
+    pub caps_words: usize,
+    pub final_poly_words: usize,
+    pub initial_leaves_words: usize,
+    pub initial_paths_words: usize,
+    pub step_evals_words: usize,
+    pub step_paths_words: usize,
+}
+
+/// p2hot_allgather_fn
+pub type P2hotAllgatherFn = Option<
+    unsafe extern "C" fn(user: *mut c_void, d_base: *mut c_void, offsets: *const usize, world: c_int, bytes: usize, hip_stream: *mut c_void) -> c_int,
+>;
+
+pub const P2HOT_OK: c_int = 0;
+pub const P2HOT_KEEP_VALUES: c_uint = 1;
+
+#[link(name = "p2hot")]
+extern "C" {
+    // ---- context
+    pub fn p2hot_ctx_create(device: c_int, hip_stream: *mut c_void, out: *mut *mut P2hotCtx) -> c_int;
+    pub fn p2hot_ctx_destroy(ctx: *mut P2hotCtx);
+    pub fn p2hot_ctx_set_stream(ctx: *mut P2hotCtx, hip_stream: *mut c_void) -> c_int;
+    pub fn p2hot_ctx_sync(ctx: *mut P2hotCtx) -> c_int;
+    pub fn p2hot_last_error(ctx: *const P2hotCtx) -> *const c_char;
+    pub fn p2hot_version() -> *const c_char;
+    pub fn p2hot_is_emulated() -> c_int;
+    pub fn p2hot_profile_enable(ctx: *mut P2hotCtx, on: c_int) -> c_int;
+    pub fn p2hot_tune_ntt(ctx: *mut P2hotCtx, radix_bits: c_int) -> c_int;
+    pub fn p2hot_tune_overlap(ctx: *mut P2hotCtx, on: c_int) -> c_int;
+    pub fn p2hot_tune_quad(ctx: *mut P2hotCtx, max_perms: usize) -> c_int;
+    pub fn p2hot_profile_json(ctx: *mut P2hotCtx, reset: c_int) -> *const c_char;
+    pub fn p2hot_num_digests(log_leaves: c_uint, cap_height: c_uint) -> usize;
+    // ---- primitives (device pointers)
+    pub fn p2hot_fft_dev(ctx: *mut P2hotCtx, d_data: *mut u64, batch: usize, poly_stride: usize, log_n: c_uint) -> c_int;
+    pub fn p2hot_ifft_dev(ctx: *mut P2hotCtx, d_data: *mut u64, batch: usize, poly_stride: usize, log_n: c_uint) -> c_int;
+    pub fn p2hot_coset_ifft_dev(ctx: *mut P2hotCtx, d_data: *mut u64, batch: usize, poly_stride: usize, log_n: c_uint, shift: u64) -> c_int;
+    pub fn p2hot_coset_lde_dev(
+        ctx: *mut P2hotCtx, d_coeffs: *const u64, W: usize, coeff_stride: usize, log_n: c_uint, rate_bits: c_uint, shift: u64,
+        row_begin: usize, row_count: usize, d_lde: *mut u64, lde_stride: usize,
+    ) -> c_int;
+    pub fn p2hot_transpose_dev(ctx: *mut P2hotCtx, d_colmajor: *const u64, col_stride: usize, W: usize, rows: usize, d_rowmajor: *mut u64) -> c_int;
+    pub fn p2hot_reverse_index_bits_dev(ctx: *mut P2hotCtx, d_in: *const u64, d_out: *mut u64, batch: usize, poly_stride: usize, log_n: c_uint) -> c_int;
+    pub fn p2hot_poseidon_permute_dev(ctx: *mut P2hotCtx, d_states: *mut u64, count: usize) -> c_int;
+    pub fn p2hot_merkle_dev(
+        ctx: *mut P2hotCtx, d_leaves: *const u64, layout: c_int, leaf_stride: usize, W: usize, log_leaves: c_uint, cap_height: c_uint,
+        leaf_begin: usize, leaf_count: usize, d_digests: *mut u64, d_cap: *mut u64,
+    ) -> c_int;
+    pub fn p2hot_field_selftest_dev(ctx: *mut P2hotCtx, d_a: *const u64, d_b: *const u64, count: usize, d_out: *mut u64) -> c_int;
+    pub fn p2hot_gather_rows_dev(
+        ctx: *mut P2hotCtx, d_colmajor: *const u64, col_stride: usize, rows: usize, W: usize, d_idx: *const u64, m: usize, d_out: *mut u64,
+    ) -> c_int;
+    pub fn p2hot_commit_dev(
+        ctx: *mut P2hotCtx, d_cols: *const u64, col_stride: usize, W: usize, log_n: c_uint, rate_bits: c_uint, cap_height: c_uint,
+        is_values: c_int, row_begin: usize, row_count: usize, d_coeffs: *mut u64, coeff_stride: usize, d_lde: *mut u64, lde_stride: usize,
+        d_leaves: *mut u64, d_digests: *mut u64, d_cap: *mut u64,
+    ) -> c_int;
+    // ---- Challenger
+    pub fn p2hot_challenger_create(ctx: *mut P2hotCtx, out: *mut *mut P2hotChallenger) -> c_int;
+    pub fn p2hot_challenger_destroy(ch: *mut P2hotChallenger);
+    pub fn p2hot_challenger_load(ch: *mut P2hotChallenger, host_state: *const P2hotChallengerState) -> c_int;
+    pub fn p2hot_challenger_store(ch: *mut P2hotChallenger, host_state: *mut P2hotChallengerState) -> c_int;
+    pub fn p2hot_challenger_step(ch: *mut P2hotChallenger, observe: *const u64, n_observe: usize, challenges: *mut u64, n_challenges: usize) -> c_int;
+    // ---- FRI commit phase and its building blocks
+    pub fn p2hot_fri_commit(
+        ctx: *mut P2hotCtx, coeffs: *const u64, log_n: c_uint, rate_bits: c_uint, cap_height: c_uint, arity_bits: *const c_uint,
+        n_rounds: c_uint, max_num_query_steps: c_uint, final_poly_coeff_len: usize, challenger: *mut P2hotChallenger, leaves_out: *mut u64,
+        digests_out: *mut u64, caps_out: *mut u64, betas_out: *mut u64, final_out: *mut u64,
+    ) -> c_int;
+    pub fn p2hot_fri_commit_dev(
+        ctx: *mut P2hotCtx, d_coeffs_planar: *const u64, log_n: c_uint, rate_bits: c_uint, cap_height: c_uint, arity_bits: *const c_uint,
+        n_rounds: c_uint, max_num_query_steps: c_uint, final_poly_coeff_len: usize, challenger: *mut P2hotChallenger, d_leaves_out: *mut u64,
+        digests_out: *mut u64, digests_on_device: c_int, caps_out: *mut u64, betas_out: *mut u64, final_out: *mut u64,
+    ) -> c_int;
+    pub fn p2hot_fri_final_poly_dev(
+        ctx: *mut P2hotCtx, d_poly_table: *const *const u64, batch_offsets: *const usize, n_batches: usize, points: *const u64,
+        alpha: *const u64, log_n: c_uint, d_final: *mut u64,
+    ) -> c_int;
+    pub fn p2hot_eval_polys_dev(
+        ctx: *mut P2hotCtx, d_poly_table: *const *const u64, n_polys: usize, log_n: c_uint, points: *const u64, n_points: usize, d_out: *mut u64,
+    ) -> c_int;
+    pub fn p2hot_partial_products_dev(
+        ctx: *mut P2hotCtx, d_wires: *const u64, wires_stride: usize, d_sigmas: *const u64, sigmas_stride: usize, k_is: *const u64,
+        num_routed: c_uint, log_n: c_uint, degree: c_uint, betas: *const u64, gammas: *const u64, num_challenges: c_uint, d_out: *mut u64,
+        out_stride: usize,
+    ) -> c_int;
+    pub fn p2hot_merkle_paths_dev(
+        ctx: *mut P2hotCtx, d_digests: *const u64, log_leaves: c_uint, cap_height: c_uint, d_idx: *const u64, m: usize, d_out: *mut u64,
+    ) -> c_int;
+    pub fn p2hot_fri_pow(ctx: *mut P2hotCtx, challenger: *mut P2hotChallenger, pow_bits: c_uint, witness_out: *mut u64) -> c_int;
+    // ---- prover session (host pointers)
+    pub fn p2hot_commit(
+        ctx: *mut P2hotCtx, cols: *const *const u64, W: usize, log_n: c_uint, rate_bits: c_uint, cap_height: c_uint, is_values: c_int,
+        flags: c_uint, coeffs_out: *mut u64, leaves_out: *mut u64, digests_out: *mut u64, cap_out: *mut u64, handle_out: *mut *mut P2hotBatch,
+    ) -> c_int;
+    pub fn p2hot_commit_cols(
+        ctx: *mut P2hotCtx, cols: *mut P2hotCols, rate_bits: c_uint, cap_height: c_uint, is_values: c_int, flags: c_uint, coeffs_out: *mut u64,
+        leaves_out: *mut u64, digests_out: *mut u64, cap_out: *mut u64, handle_out: *mut *mut P2hotBatch,
+    ) -> c_int;
+    pub fn p2hot_batch_wrap_dev(
+        ctx: *mut P2hotCtx, d_coeffs: *const u64, d_lde: *const u64, d_digests: *const u64, W: usize, log_n: c_uint, rate_bits: c_uint,
+        cap_height: c_uint, out: *mut *mut P2hotBatch,
+    ) -> c_int;
+    pub fn p2hot_batch_width(batch: *const P2hotBatch) -> usize;
+    pub fn p2hot_batch_degree_log(batch: *const P2hotBatch) -> c_uint;
+    pub fn p2hot_batch_coeffs(batch: *mut P2hotBatch, first: usize, count: usize, out: *mut u64) -> c_int;
+    pub fn p2hot_batch_rows(batch: *mut P2hotBatch, row_idx: *const u64, m: usize, out: *mut u64) -> c_int;
+    pub fn p2hot_batch_paths(batch: *mut P2hotBatch, leaf_idx: *const u64, m: usize, out: *mut u64) -> c_int;
+    pub fn p2hot_batch_digests(batch: *mut P2hotBatch, out: *mut u64) -> c_int;
+    pub fn p2hot_batch_values(batch: *mut P2hotBatch, out: *mut *mut P2hotCols) -> c_int;
+    pub fn p2hot_batch_free(batch: *mut P2hotBatch);
+    pub fn p2hot_ctx_trim(ctx: *mut P2hotCtx) -> c_int;
+    pub fn p2hot_cols_upload(ctx: *mut P2hotCtx, cols: *const *const u64, W: usize, log_n: c_uint, out: *mut *mut P2hotCols) -> c_int;
+    pub fn p2hot_cols_download(cols: *mut P2hotCols, first: usize, count: usize, out: *mut u64) -> c_int;
+    pub fn p2hot_cols_width(cols: *const P2hotCols) -> usize;
+    pub fn p2hot_cols_degree_log(cols: *const P2hotCols) -> c_uint;
+    pub fn p2hot_cols_free(cols: *mut P2hotCols);
+    pub fn p2hot_eval_openings(
+        ctx: *mut P2hotCtx, batches: *const *const P2hotBatch, n_batches: usize, points: *const u64, n_points: usize, out: *mut u64,
+    ) -> c_int;
+    pub fn p2hot_fri_proof_sizes(
+        oracles: *const *const P2hotBatch, n_oracles: usize, params: *const P2hotFriParams, out: *mut P2hotFriProofLayout,
+    ) -> c_int;
+    pub fn p2hot_prove_openings(
+        ctx: *mut P2hotCtx, batches: *const P2hotFriBatchInfo, n_batches: usize, oracles: *const *const P2hotBatch, n_oracles: usize,
+        challenger: *mut P2hotChallenger, params: *const P2hotFriParams, proof: *mut P2hotFriProof,
+    ) -> c_int;
+    pub fn p2hot_partial_products(
+        ctx: *mut P2hotCtx, wires: *const P2hotCols, wires_first_col: usize, sigmas: *const P2hotCols, sigmas_first_col: usize,
+        k_is: *const u64, num_routed: c_uint, degree: c_uint, betas: *const u64, gammas: *const u64, num_challenges: c_uint,
+        out_host: *mut u64, out_cols: *mut *mut P2hotCols,
+    ) -> c_int;
+    pub fn p2hot_quotient_chunks(
+        ctx: *mut P2hotCtx, quotient_values: *const *const u64, num_challenges: c_uint, degree_bits: c_uint, quotient_degree_factor: c_uint,
+        chunks_out: *mut *mut P2hotCols,
+    ) -> c_int;
+    // ---- multi-GPU
+    pub fn p2hot_comm_unique_id(out: *mut u8) -> c_int;
+    pub fn p2hot_comm_create_rccl(ctx: *mut P2hotCtx, rank: c_int, world: c_int, id: *const u8, out: *mut *mut P2hotComm) -> c_int;
+    pub fn p2hot_comm_create_callback(
+        ctx: *mut P2hotCtx, rank: c_int, world: c_int, r#fn: P2hotAllgatherFn, user: *mut c_void, out: *mut *mut P2hotComm,
+    ) -> c_int;
+    pub fn p2hot_comm_destroy(comm: *mut P2hotComm);
+    pub fn p2hot_comm_rank(comm: *const P2hotComm) -> c_int;
+    pub fn p2hot_comm_world(comm: *const P2hotComm) -> c_int;
+    pub fn p2hot_shard_columns(W: usize, world: c_int, rank: c_int, first: *mut usize, count: *mut usize) -> c_int;
+    pub fn p2hot_commit_sharded_dev(
+        ctx: *mut P2hotCtx, comm: *mut P2hotComm, d_cols_local: *const u64, col_stride: usize, W: usize, log_n: c_uint, rate_bits: c_uint,
+        cap_height: c_uint, is_values: c_int, gather_digests: c_int, pipeline_chunks: c_uint, d_coeffs_all: *mut u64, d_lde: *mut u64,
+        lde_stride: usize, d_leaves: *mut u64, d_digests: *mut u64, d_cap: *mut u64,
+    ) -> c_int;
+    pub fn p2hot_group_create(n_gpus: c_int, devices: *const c_int, out: *mut *mut P2hotGroup) -> c_int;
+    pub fn p2hot_group_destroy(group: *mut P2hotGroup);
+    pub fn p2hot_group_size(group: *const P2hotGroup) -> c_int;
+    pub fn p2hot_group_ctx(group: *mut P2hotGroup, i: c_int) -> *mut P2hotCtx;
+    pub fn p2hot_group_uses_rccl(group: *const P2hotGroup) -> c_int;
+    pub fn p2hot_group_last_error(group: *const P2hotGroup) -> *const c_char;
+    pub fn p2hot_group_commit(
+        group: *mut P2hotGroup, cols: *const *const u64, W: usize, log_n: c_uint, rate_bits: c_uint, cap_height: c_uint, is_values: c_int,
+        pipeline_chunks: c_uint, coeffs_out: *mut u64, leaves_out: *mut u64, digests_out: *mut u64, cap_out: *mut u64,
+        handle_out: *mut *mut P2hotShardedBatch,
+    ) -> c_int;
+    pub fn p2hot_sharded_batch_open(batch: *mut P2hotShardedBatch, leaf_idx: *const u64, m: usize, rows_out: *mut u64, paths_out: *mut u64) -> c_int;
+    pub fn p2hot_sharded_batch_free(batch: *mut P2hotShardedBatch);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layout facts the casts below rely on
+// ------------------------------------------------------------------------------------------------
+// GoldilocksField is #[repr(transparent)] over u64 (field/src/goldilocks_field.rs:23-25): &[F] <-> *const u64.
+static_assertions::assert_eq_size!(GoldilocksField, u64);
+static_assertions::assert_eq_align!(GoldilocksField, u64);
+// HashOut<F> { elements: [F; 4] } (hash/hash_types.rs:25-27) is a single-field struct: 32 bytes, 4 words.
+static_assertions::assert_eq_size!(crate::hash::hash_types::HashOut<GoldilocksField>, [u64; 4]);
+static_assertions::assert_eq_align!(crate::hash::hash_types::HashOut<GoldilocksField>, u64);
+// the degree-2 extension is [F; 2] (field/src/extension/quadratic.rs:13): [a0, a1] per element at the ABI
+static_assertions::assert_eq_size!(<GoldilocksField as Extendable<2>>::Extension, [u64; 2]);
+
+// ------------------------------------------------------------------------------------------------
+// The process-wide context
+// ------------------------------------------------------------------------------------------------
+struct CtxPtr(*mut P2hotCtx);
+// The library serialises host-pointer calls per context (P2HOT_EBUSY) and plonky2 calls them from the prover's
+// main thread, outside its rayon closures; the Mutex makes that explicit on this side.
+unsafe impl Send for CtxPtr {}
+
+static CTX: OnceLock<Mutex<CtxPtr>> = OnceLock::new();
+
+fn with_ctx<R>(f: impl FnOnce(*mut P2hotCtx) -> R) -> R {
+    let m = CTX.get_or_init(|| {
+        let device = std::env::var("P2HOT_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
+        let mut ctx: *mut P2hotCtx = core::ptr::null_mut();
+        let rc = unsafe { p2hot_ctx_create(device, core::ptr::null_mut(), &mut ctx) };
+        if rc != P2HOT_OK {
+            let msg = error_text(ctx);
+            unsafe { p2hot_ctx_destroy(ctx) };
+            panic!("p2hot_ctx_create(device {device}) failed: {msg}"); // no silent CPU fallback once the feature is on
+        }
+        Mutex::new(CtxPtr(ctx))
+    });
+    let guard = m.lock().expect("p2hot context poisoned");
+    f(guard.0)
+}
+
+fn error_text(ctx: *const P2hotCtx) -> String {
+    unsafe { std::ffi::CStr::from_ptr(p2hot_last_error(ctx)) }.to_string_lossy().into_owned()
+}
+
+/// The reference panics on shape violations (fft.rs:171, oracle.rs:128, merkle_tree.rs:195); so does the shim.
+fn check(ctx: *const P2hotCtx, rc: c_int, what: &str) {
+    if rc != P2HOT_OK {
+        panic!("libp2hot {what} failed ({rc}): {}", error_text(ctx));
+    }
+}
+
+fn leaves_on_device() -> bool {
+    matches!(std::env::var("P2HOT_LEAVES").as_deref(), Ok("device"))
+}
+
+/// Does the GPU path apply to this instantiation?  (TypeId / size checks instead of a plugin trait.)
+pub fn applies<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(blinding: bool) -> bool {
+    !blinding
+        && D == 2
+        && TypeId::of::<F>() == TypeId::of::<GoldilocksField>()
+        && TypeId::of::<C::Hasher>() == TypeId::of::<PoseidonHash>()
+        && core::mem::size_of::<<C::Hasher as Hasher<F>>::Hash>() == 32
+}
+
+#[inline]
+fn words<F: Field>(s: &[F]) -> *const u64 {
+    debug_assert_eq!(core::mem::size_of::<F>(), 8);
+    s.as_ptr() as *const u64
+}
+
+/// A Vec<T> of `len` elements filled through its raw u64 view (T is F or H::Hash: plain words, see the assertions above)
+fn vec_from_words<T>(len: usize, fill: impl FnOnce(*mut u64)) -> Vec<T> {
+    let mut v: Vec<T> = Vec::with_capacity(len);
+    fill(v.as_mut_ptr() as *mut u64);
+    unsafe { v.set_len(len) }; // SAFETY: `fill` initialised len * size_of::<T>() bytes of plain integers
+    v
+}
+
+/// The output-buffer idiom of MerkleTree::new (merkle_tree.rs:203-219): reserve, let the library fill the spare
+/// capacity through the raw pointer, then `set_len`.  `ptr` is null for a buffer that is not wanted.
+struct Out<T> {
+    v: Vec<T>,
+    len: usize,
+}
+impl<T> Out<T> {
+    fn new(len: usize, wanted: bool) -> Self {
+        Out { v: Vec::with_capacity(if wanted { len } else { 0 }), len: if wanted { len } else { 0 } }
+    }
+    fn ptr(&mut self) -> *mut u64 {
+        if self.len == 0 {
+            core::ptr::null_mut()
+        } else {
+            self.v.as_mut_ptr() as *mut u64
+        }
+    }
+    /// SAFETY: the library call that received `ptr()` returned P2HOT_OK, i.e. it wrote all `len` elements
+    unsafe fn finish(mut self) -> Vec<T> {
+        self.v.set_len(self.len);
+        self.v
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-resident tree: what MerkleTree::get / ::prove read when `leaves` / `digests` stayed on the GPU
+// ------------------------------------------------------------------------------------------------
+pub struct DeviceTree<F: RichField> {
+    batch: *mut P2hotBatch,
+    width: usize,
+    num_layers: usize,
+    /// rows fetched so far: `get` hands out `&[F]`, so fetched rows are kept (never moved) for the tree's lifetime
+    rows: Mutex<HashMap<usize, Box<[F]>>>,
+}
+unsafe impl<F: RichField> Send for DeviceTree<F> {}
+unsafe impl<F: RichField> Sync for DeviceTree<F> {}
+
+impl<F: RichField> DeviceTree<F> {
+    pub fn raw(&self) -> *const P2hotBatch {
+        self.batch
+    }
+
+    /// MerkleTree::get (merkle_tree.rs:227)
+    pub fn row(&self, i: usize) -> &[F] {
+        let mut cache = self.rows.lock().unwrap();
+        if !cache.contains_key(&i) {
+            let idx = [i as u64];
+            let row: Vec<F> = vec_from_words(self.width, |p| {
+                let rc = unsafe { p2hot_batch_rows(self.batch, idx.as_ptr(), 1, p) };
+                with_ctx(|c| check(c, rc, "p2hot_batch_rows"));
+            });
+            cache.insert(i, row.into_boxed_slice());
+        }
+        let r: &[F] = &cache[&i];
+        // SAFETY: the boxed slice is never removed or moved while `self` lives; only the map's buckets move.
+        unsafe { core::slice::from_raw_parts(r.as_ptr(), r.len()) }
+    }
+
+    /// merkle_tree_prove (merkle_tree.rs:151-190)
+    pub fn path<H: Hasher<F>>(&self, leaf_index: usize) -> Vec<H::Hash> {
+        let idx = [leaf_index as u64];
+        vec_from_words(self.num_layers, |p| {
+            let rc = unsafe { p2hot_batch_paths(self.batch, idx.as_ptr(), 1, p) };
+            with_ctx(|c| check(c, rc, "p2hot_batch_paths"));
+        })
+    }
+}
+
+impl<F: RichField> Drop for DeviceTree<F> {
+    fn drop(&mut self) {
+        // returns the LDE matrix, the digests and the coefficients to the context's block cache
+        unsafe { p2hot_batch_free(self.batch) };
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PolynomialBatch::from_values / from_coeffs (fri/oracle.rs:57-112)
+// ------------------------------------------------------------------------------------------------
+/// `cols`: the W input vectors (values on H_n, or coefficients), each of length n.
+pub fn commit<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(
+    cols: &[&[F]],
+    rate_bits: usize,
+    cap_height: usize,
+    is_values: bool,
+) -> PolynomialBatch<F, C, D> {
+    let w = cols.len();
+    let n = cols[0].len(); // polynomials[0].len(), oracle.rs:90
+    let log_n = log2_strict(n);
+    assert!(cols.iter().all(|c| c.len() == n));
+    let big_n = n << rate_bits;
+    let num_digests = 2 * (big_n - (1usize << cap_height));
+    let ptrs: Vec<*const u64> = cols.iter().map(|c| words(c)).collect();
+    let on_device = leaves_on_device();
+    let mut handle: *mut P2hotBatch = core::ptr::null_mut();
+    // `polynomials` always comes back (W * n words): the quotient evaluation and the openings read it on the host
+    let mut coeffs = Out::<F>::new(w * n, true);
+    let mut cap = Out::<<C::Hasher as Hasher<F>>::Hash>::new(1 << cap_height, true);
+    let mut digests = Out::<<C::Hasher as Hasher<F>>::Hash>::new(num_digests, !on_device);
+    let mut flat_leaves = Out::<F>::new(big_n * w, !on_device);
+    with_ctx(|ctx| {
+        let rc = unsafe {
+            p2hot_commit(
+                ctx, ptrs.as_ptr(), w, log_n as c_uint, rate_bits as c_uint, cap_height as c_uint, is_values as c_int, 0, coeffs.ptr(),
+                flat_leaves.ptr(), digests.ptr(), cap.ptr(), &mut handle,
+            )
+        };
+        check(ctx, rc, "p2hot_commit");
+    });
+    let (coeffs, cap, digests, flat_leaves) = unsafe { (coeffs.finish(), cap.finish(), digests.finish(), flat_leaves.finish()) };
+    let polynomials = coeffs.chunks_exact(n.max(1)).map(|c| PolynomialCoeffs::new(c.to_vec())).collect();
+    // merkle_tree.leaves: N rows of W (oracle.rs:97-98); empty when the matrix stays on the GPU
+    let leaves: Vec<Vec<F>> = if on_device { Vec::new() } else { flat_leaves.chunks_exact(w.max(1)).map(|r| r.to_vec()).collect() };
+    let device = std::sync::Arc::new(DeviceTree {
+        batch: handle,
+        width: w,
+        num_layers: log_n + rate_bits - cap_height,
+        rows: Mutex::new(HashMap::new()),
+    });
+    PolynomialBatch {
+        polynomials,
+        merkle_tree: MerkleTree { leaves, digests, cap: MerkleCap(cap), device: Some(device) },
+        degree_log: log_n,
+        rate_bits,
+        blinding: false,
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Challenger <-> p2hot_challenger (iop/challenger.rs:16-153)
+// ------------------------------------------------------------------------------------------------
+struct DeviceChallenger(*mut P2hotChallenger);
+impl Drop for DeviceChallenger {
+    fn drop(&mut self) {
+        unsafe { p2hot_challenger_destroy(self.0) };
+    }
+}
+
+fn challenger_to_device<F: RichField, H: Hasher<F>>(ctx: *mut P2hotCtx, ch: &mut Challenger<F, H>) -> DeviceChallenger {
+    let (state, input, output) = ch.p2hot_parts();
+    let mut st = P2hotChallengerState::default();
+    for (d, s) in st.sponge_state.iter_mut().zip(state.as_ref()) {
+        *d = s.to_canonical_u64();
+    }
+    for (d, s) in st.input_buffer.iter_mut().zip(input.iter()) {
+        *d = s.to_canonical_u64();
+    }
+    for (d, s) in st.output_buffer.iter_mut().zip(output.iter()) {
+        *d = s.to_canonical_u64();
+    }
+    st.input_len = input.len() as u32;
+    st.output_len = output.len() as u32;
+    let mut h: *mut P2hotChallenger = core::ptr::null_mut();
+    check(ctx, unsafe { p2hot_challenger_create(ctx, &mut h) }, "p2hot_challenger_create");
+    check(ctx, unsafe { p2hot_challenger_load(h, &st) }, "p2hot_challenger_load");
+    DeviceChallenger(h)
+}
+
+fn challenger_from_device<F: RichField, H: Hasher<F>>(ctx: *mut P2hotCtx, dev: &DeviceChallenger, ch: &mut Challenger<F, H>) {
+    let mut st = P2hotChallengerState::default();
+    check(ctx, unsafe { p2hot_challenger_store(dev.0, &mut st) }, "p2hot_challenger_store");
+    let (state, input, output) = ch.p2hot_parts();
+    state.set_from_iter(st.sponge_state.iter().map(|&x| F::from_canonical_u64(x)), 0);
+    input.clear();
+    input.extend(st.input_buffer[..st.input_len as usize].iter().map(|&x| F::from_canonical_u64(x)));
+    output.clear();
+    output.extend(st.output_buffer[..st.output_len as usize].iter().map(|&x| F::from_canonical_u64(x)));
+}
+
+fn fri_params_c(fri_params: &FriParams, arity: &[c_uint], final_poly_coeff_len: Option<usize>, max_num_query_steps: Option<usize>) -> P2hotFriParams {
+    P2hotFriParams {
+        rate_bits: fri_params.config.rate_bits as c_uint,
+        cap_height: fri_params.config.cap_height as c_uint,
+        proof_of_work_bits: fri_params.config.proof_of_work_bits as c_uint,
+        num_query_rounds: fri_params.config.num_query_rounds as c_uint,
+        reduction_arity_bits: arity.as_ptr(),
+        n_reduction_rounds: arity.len() as c_uint,
+        hiding: fri_params.hiding as c_int,
+        max_num_query_steps: max_num_query_steps.unwrap_or(0) as c_uint, // 0 = None: a Some(0) pads nothing either
+        final_poly_coeff_len: final_poly_coeff_len.unwrap_or(0),
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fri_committed_trees (fri/prover.rs:84-150): used by starky and by plonky2 when an oracle has no device handle
+// ------------------------------------------------------------------------------------------------
+pub fn fri_committed_trees<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(
+    coeffs: &PolynomialCoeffs<F::Extension>,
+    challenger: &mut Challenger<F, C::Hasher>,
+    fri_params: &FriParams,
+    final_poly_coeff_len: Option<usize>,
+    max_num_query_steps: Option<usize>,
+) -> (Vec<MerkleTree<F, C::Hasher>>, PolynomialCoeffs<F::Extension>) {
+    let big_n = coeffs.len();
+    let rate_bits = fri_params.config.rate_bits;
+    let cap_height = fri_params.config.cap_height;
+    let n = big_n >> rate_bits; // "Only the first 1/rate coefficients are non-zero" (prover.rs:27)
+    let arity: Vec<c_uint> = fri_params.reduction_arity_bits.iter().map(|&a| a as c_uint).collect();
+    // output sizes per round (include/p2hot.h, p2hot_fri_commit)
+    let mut m = big_n;
+    let mut shapes = Vec::new(); // (leaves, row width, digests)
+    for &ab in &fri_params.reduction_arity_bits {
+        let n_leaves = m >> ab;
+        shapes.push((n_leaves, 2usize << ab, 2 * (n_leaves - (1usize << cap_height))));
+        m >>= ab;
+    }
+    let n_final = m >> rate_bits;
+    let leaf_words: usize = shapes.iter().map(|s| s.0 * s.1).sum();
+    let digest_count: usize = shapes.iter().map(|s| s.2).sum();
+    let cap_len = 1usize << cap_height;
+    let mut leaves_flat = Out::<F>::new(leaf_words, true);
+    let mut digests_flat = Out::<<C::Hasher as Hasher<F>>::Hash>::new(digest_count, true);
+    let mut caps_flat = Out::<<C::Hasher as Hasher<F>>::Hash>::new(cap_len * shapes.len(), true);
+    let mut final_coeffs = Out::<F::Extension>::new(n_final, true);
+    with_ctx(|ctx| {
+        let dev = challenger_to_device(ctx, challenger);
+        let rc = unsafe {
+            p2hot_fri_commit(
+                ctx, coeffs.coeffs.as_ptr() as *const u64, log2_strict(n.max(1)) as c_uint, rate_bits as c_uint, cap_height as c_uint,
+                arity.as_ptr(), arity.len() as c_uint, max_num_query_steps.unwrap_or(0) as c_uint, final_poly_coeff_len.unwrap_or(0), dev.0,
+                leaves_flat.ptr(), digests_flat.ptr(), caps_flat.ptr(), core::ptr::null_mut(), final_coeffs.ptr(),
+            )
+        };
+        check(ctx, rc, "p2hot_fri_commit");
+        challenger_from_device(ctx, &dev, challenger);
+    });
+    let (leaves_flat, digests_flat, caps_flat, final_coeffs) =
+        unsafe { (leaves_flat.finish(), digests_flat.finish(), caps_flat.finish(), final_coeffs.finish()) };
+    let mut trees = Vec::with_capacity(shapes.len());
+    let (mut lo, mut dg) = (0usize, 0usize);
+    for (i, &(n_leaves, width, nd)) in shapes.iter().enumerate() {
+        let leaves = leaves_flat[lo..lo + n_leaves * width].chunks_exact(width).map(|r| r.to_vec()).collect();
+        trees.push(MerkleTree {
+            leaves,
+            digests: digests_flat[dg..dg + nd].to_vec(),
+            cap: MerkleCap(caps_flat[i * cap_len..(i + 1) * cap_len].to_vec()),
+            device: None,
+        });
+        lo += n_leaves * width;
+        dg += nd;
+    }
+    (trees, PolynomialCoeffs::new(final_coeffs))
+}
+
+// ------------------------------------------------------------------------------------------------
+// PolynomialBatch::prove_openings + fri_proof (fri/oracle.rs:176-237, fri/prover.rs:24-82, :204-258)
+// ------------------------------------------------------------------------------------------------
+/// One library call when every oracle carries a device handle; `None` sends the caller down the CPU path.
+pub fn prove_openings<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(
+    instance: &FriInstanceInfo<F, D>,
+    oracles: &[&PolynomialBatch<F, C, D>],
+    challenger: &mut Challenger<F, C::Hasher>,
+    fri_params: &FriParams,
+    final_poly_coeff_len: Option<usize>,
+    max_num_query_steps: Option<usize>,
+) -> Option<FriProof<F, C::Hasher, D>> {
+    if fri_params.hiding || !applies::<F, C, D>(false) {
+        return None;
+    }
+    let handles: Option<Vec<*const P2hotBatch>> = oracles.iter().map(|o| o.merkle_tree.device.as_ref().map(|d| d.raw())).collect();
+    let handles = handles?;
+    let arity: Vec<c_uint> = fri_params.reduction_arity_bits.iter().map(|&a| a as c_uint).collect();
+    let params = fri_params_c(fri_params, &arity, final_poly_coeff_len, max_num_query_steps);
+    // FriInstanceInfo.batches -> flat index arrays
+    let idx: Vec<(Vec<u32>, Vec<u32>)> = instance
+        .batches
+        .iter()
+        .map(|b| (b.polynomials.iter().map(|p| p.oracle_index as u32).collect(), b.polynomials.iter().map(|p| p.polynomial_index as u32).collect()))
+        .collect();
+    let infos: Vec<P2hotFriBatchInfo> = instance
+        .batches
+        .iter()
+        .zip(&idx)
+        .map(|(b, (oi, pi))| {
+            let pt = b.point.to_basefield_array();
+            P2hotFriBatchInfo { point: [pt[0].to_canonical_u64(), pt[1].to_canonical_u64()], oracle_index: oi.as_ptr(), poly_index: pi.as_ptr(), n_polys: oi.len() }
+        })
+        .collect();
+    let mut lay = P2hotFriProofLayout::default();
+    assert_eq!(unsafe { p2hot_fri_proof_sizes(handles.as_ptr(), handles.len(), &params, &mut lay) }, P2HOT_OK);
+    let q = fri_params.config.num_query_rounds;
+    let cap_len = 1usize << fri_params.config.cap_height;
+    let mut caps = vec![0u64; lay.caps_words];
+    let mut final_poly = vec![0u64; lay.final_poly_words];
+    let mut initial_leaves = vec![0u64; lay.initial_leaves_words];
+    let mut initial_paths = vec![0u64; lay.initial_paths_words];
+    let mut step_evals = vec![0u64; lay.step_evals_words];
+    let mut step_paths = vec![0u64; lay.step_paths_words];
+    let mut proof = P2hotFriProof {
+        commit_phase_merkle_caps: caps.as_mut_ptr(),
+        final_poly: final_poly.as_mut_ptr(),
+        pow_witness: 0,
+        query_indices: core::ptr::null_mut(),
+        initial_leaves: initial_leaves.as_mut_ptr(),
+        initial_paths: initial_paths.as_mut_ptr(),
+        step_evals: step_evals.as_mut_ptr(),
+        step_paths: step_paths.as_mut_ptr(),
+    };
+    with_ctx(|ctx| {
+        let dev = challenger_to_device(ctx, challenger);
+        let rc = unsafe { p2hot_prove_openings(ctx, infos.as_ptr(), infos.len(), handles.as_ptr(), handles.len(), dev.0, &params, &mut proof) };
+        check(ctx, rc, "p2hot_prove_openings");
+        challenger_from_device(ctx, &dev, challenger);
+    });
+    // flat buffers -> FriProof (layout: include/p2hot.h, p2hot_fri_proof)
+    let f = |x: u64| F::from_canonical_u64(x);
+    let hash = |w: &[u64]| -> <C::Hasher as Hasher<F>>::Hash { vec_from_words::<<C::Hasher as Hasher<F>>::Hash>(1, |p| unsafe { core::ptr::copy_nonoverlapping(w.as_ptr(), p, 4) })[0] };
+    let ext = |w: &[u64]| F::Extension::from_basefield_array({
+        let mut a = [F::ZERO; D];
+        a[0] = f(w[0]);
+        a[1] = f(w[1]);
+        a
+    });
+    let degree_bits = oracles[0].degree_log;
+    let layers0 = degree_bits + fri_params.config.rate_bits - fri_params.config.cap_height;
+    let widths: Vec<usize> = oracles.iter().map(|o| o.polynomials.len()).collect();
+    let wsum: usize = widths.iter().sum();
+    let mut ev_w = Vec::new();
+    let mut pa_w = Vec::new();
+    let mut lm = degree_bits + fri_params.config.rate_bits;
+    for &ab in &fri_params.reduction_arity_bits {
+        ev_w.push(2usize << ab);
+        pa_w.push(lm - ab - fri_params.config.cap_height);
+        lm -= ab;
+    }
+    let (ev_sum, pa_sum): (usize, usize) = (ev_w.iter().sum(), pa_w.iter().sum());
+    let query_round_proofs = (0..q)
+        .map(|qi| {
+            let mut wo = 0usize;
+            let evals_proofs = widths
+                .iter()
+                .enumerate()
+                .map(|(oi, &w)| {
+                    let row = &initial_leaves[qi * wsum + wo..qi * wsum + wo + w];
+                    wo += w;
+                    let base = (qi * oracles.len() + oi) * layers0 * 4;
+                    let siblings = (0..layers0).map(|l| hash(&initial_paths[base + 4 * l..base + 4 * l + 4])).collect();
+                    (row.iter().map(|&x| f(x)).collect::<Vec<F>>(), MerkleProof { siblings })
+                })
+                .collect();
+            let (mut eo, mut po) = (0usize, 0usize);
+            let steps = ev_w
+                .iter()
+                .zip(&pa_w)
+                .map(|(&ew, &pw)| {
+                    let e = &step_evals[qi * ev_sum + eo..qi * ev_sum + eo + ew];
+                    let p = &step_paths[qi * pa_sum * 4 + po..qi * pa_sum * 4 + po + 4 * pw];
+                    eo += ew;
+                    po += 4 * pw;
+                    FriQueryStep { evals: e.chunks_exact(2).map(ext).collect(), merkle_proof: MerkleProof { siblings: p.chunks_exact(4).map(hash).collect() } }
+                })
+                .collect();
+            FriQueryRound { initial_trees_proof: FriInitialTreeProof { evals_proofs }, steps }
+        })
+        .collect();
+    Some(FriProof {
+        commit_phase_merkle_caps: caps.chunks_exact(4 * cap_len).map(|c| MerkleCap(c.chunks_exact(4).map(hash).collect())).collect(),
+        query_round_proofs,
+        final_poly: PolynomialCoeffs::new(final_poly.chunks_exact(2).map(ext).collect()),
+        pow_witness: f(proof.pow_witness),
+    })
+}
+
+/// PolynomialValues -> column slices for `commit`
+pub fn value_slices<F: Field>(values: &[PolynomialValues<F>]) -> Vec<&[F]> {
+    values.iter().map(|v| v.values.as_slice()).collect()
+}
+pub fn coeff_slices<F: Field>(polys: &[PolynomialCoeffs<F>]) -> Vec<&[F]> {
+    polys.iter().map(|p| p.coeffs.as_slice()).collect()
+}
+
+// MerkleTree derives Clone / Debug / Eq / PartialEq (hash/merkle_tree.rs:45); the device copy is a cache of the same
+// tree, not part of its value: two trees are equal when leaves, digests and cap are.
+impl<F: RichField> core::fmt::Debug for DeviceTree<F> {
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
+        write!(f, "DeviceTree({:p}, width {}, {} layers)", self.batch, self.width, self.num_layers)
+    }
+}
+impl<F: RichField> PartialEq for DeviceTree<F> {
+    fn eq(&self, _other: &Self) -> bool {
+        true
+    }
+}
+impl<F: RichField> Eq for DeviceTree<F> {}

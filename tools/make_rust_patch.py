@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Regenerates integration/plonky2_p2hot.patch against the reference tree (/root/reference).
+
+The patch is the Rust side of the drop-in boundary: Cargo feature `p2hot`, the module
+`plonky2/src/p2hot.rs` (= integration/p2hot.rs, verbatim) and the feature-gated early returns in
+  fri/oracle.rs        from_values / from_coeffs / get_lde_values / prove_openings
+  fri/prover.rs        fri_committed_trees
+  hash/merkle_tree.rs  `device` handle on MerkleTree, get / prove
+  iop/challenger.rs    accessor for the transcript state
+  util/serialization   the one other MerkleTree struct literal
+It is built by anchored edits of a scratch copy, so this script holds only the NEW lines and short
+anchors -- no reference source is stored in the repository beyond the diff context of the patch itself.
+
+    python tools/make_rust_patch.py        (build container only: needs /root/reference and `diff`)
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("P2_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "integration", "plonky2_p2hot.patch")
+
+FILES = ["plonky2/Cargo.toml", "plonky2/src/lib.rs", "plonky2/src/fri/oracle.rs", "plonky2/src/fri/prover.rs",
+         "plonky2/src/hash/merkle_tree.rs", "plonky2/src/iop/challenger.rs", "plonky2/src/util/serialization/mod.rs"]
+
+
+def edit(path, pairs):
+    s = open(path).read()
+    for old, new in pairs:
+        if s.count(old) != 1:
+            sys.exit("anchor not unique in %s (%d hits): %r" % (path, s.count(old), old[:60]))
+        s = s.replace(old, new)
+    open(path, "w").write(s)
+
+
+GATE = '''        #[cfg(feature = "p2hot")]
+        if crate::p2hot::applies::<F, C, D>(blinding) {
+            // MI355X path (include/p2hot.h): iNTT + coset LDE + Poseidon leaf sponge + Merkle levels in one call
+            return timed!(
+                timing,
+                "p2hot commit",
+                crate::p2hot::commit::<F, C, D>(&crate::p2hot::%s(&%s), rate_bits, cap_height, %s)
+            );
+        }
+'''
+
+
+def main():
+    top = tempfile.mkdtemp(prefix="p2hot_patch_")
+    a, b = os.path.join(top, "a"), os.path.join(top, "b")
+    for f in FILES:
+        for d in (a, b):
+            os.makedirs(os.path.dirname(os.path.join(d, f)), exist_ok=True)
+            shutil.copy(os.path.join(REF, f), os.path.join(d, f))
+    # ---- Cargo feature + build script + module
+    edit(os.path.join(b, "plonky2/Cargo.toml"), [
+        ('timing = ["std", "dep:web-time"]\n',
+         'timing = ["std", "dep:web-time"]\n'
+         '# MI355X hot path through libp2hot (include/p2hot.h); set P2HOT_LIB_DIR to the directory of libp2hot.so\n'
+         'p2hot = ["std"]\n')])
+    with open(os.path.join(b, "plonky2/build.rs"), "w") as f:
+        f.write('''//! Link search path of libp2hot.so for the `p2hot` feature (the MI355X hot path, see src/p2hot.rs).
+fn main() {
+    println!("cargo:rerun-if-env-changed=P2HOT_LIB_DIR");
+    if std::env::var_os("CARGO_FEATURE_P2HOT").is_some() {
+        if let Some(dir) = std::env::var_os("P2HOT_LIB_DIR") {
+            println!("cargo:rustc-link-search=native={}", dir.to_string_lossy());
+            println!("cargo:rustc-link-arg=-Wl,-rpath,{}", dir.to_string_lossy());
+        }
+    }
+}
+''')
+    edit(os.path.join(b, "plonky2/src/lib.rs"), [
+        ("pub mod iop;\n", "pub mod iop;\n#[cfg(feature = \"p2hot\")]\npub mod p2hot;\n")])
+    shutil.copy(os.path.join(ROOT, "integration", "p2hot.rs"), os.path.join(b, "plonky2/src/p2hot.rs"))
+    # ---- PolynomialBatch
+    edit(os.path.join(b, "plonky2/src/fri/oracle.rs"), [
+        ('''        fft_root_table: Option<&FftRootTable<F>>,
+    ) -> Self {
+        let coeffs = timed!(
+''', '''        fft_root_table: Option<&FftRootTable<F>>,
+    ) -> Self {
+''' + GATE % ("value_slices", "values", "true") + '''        let coeffs = timed!(
+'''),
+        ('''        fft_root_table: Option<&FftRootTable<F>>,
+    ) -> Self {
+        let degree = polynomials[0].len();
+''', '''        fft_root_table: Option<&FftRootTable<F>>,
+    ) -> Self {
+''' + GATE % ("coeff_slices", "polynomials", "false") + '''        let degree = polynomials[0].len();
+'''),
+        ('''        let slice = &self.merkle_tree.leaves[index];
+        &slice[..slice.len() - if self.blinding { SALT_SIZE } else { 0 }]
+''', '''        // `get` instead of `leaves[index]`: with the `p2hot` feature the leaf matrix may live on the GPU
+        let slice = self.merkle_tree.get(index);
+        &slice[..slice.len() - if self.blinding { SALT_SIZE } else { 0 }]
+'''),
+        ('''        assert!(D > 1, "Not implemented for D=1.");
+        let alpha = challenger.get_extension_challenge::<D>();
+''', '''        assert!(D > 1, "Not implemented for D=1.");
+        #[cfg(feature = "p2hot")]
+        if let Some(proof) = timed!(
+            timing,
+            "p2hot prove_openings",
+            crate::p2hot::prove_openings::<F, C, D>(
+                instance,
+                oracles,
+                challenger,
+                fri_params,
+                final_poly_coeff_len,
+                max_num_query_steps
+            )
+        ) {
+            // alpha, final_poly, its LDE, the commit phase, the grind and the query rounds ran on the GPU
+            return proof;
+        }
+        let alpha = challenger.get_extension_challenge::<D>();
+''')])
+    # ---- FRI commit phase
+    edit(os.path.join(b, "plonky2/src/fri/prover.rs"), [
+        ('''    max_num_query_steps: Option<usize>,
+) -> FriCommitedTrees<F, C, D> {
+    let mut trees = Vec::with_capacity(fri_params.reduction_arity_bits.len());
+''', '''    max_num_query_steps: Option<usize>,
+) -> FriCommitedTrees<F, C, D> {
+    #[cfg(feature = "p2hot")]
+    if !fri_params.hiding && crate::p2hot::applies::<F, C, D>(false) {
+        // every round (tree, challenge, fold, coset NTT) on the GPU; `values` is recomputed there from `coeffs`
+        return crate::p2hot::fri_committed_trees::<F, C, D>(
+            &coeffs,
+            challenger,
+            fri_params,
+            final_poly_coeff_len,
+            max_num_query_steps,
+        );
+    }
+    let mut trees = Vec::with_capacity(fri_params.reduction_arity_bits.len());
+''')])
+    # ---- MerkleTree
+    edit(os.path.join(b, "plonky2/src/hash/merkle_tree.rs"), [
+        ('''    /// The Merkle cap.
+    pub cap: MerkleCap<F, H>,
+}
+''', '''    /// The Merkle cap.
+    pub cap: MerkleCap<F, H>,
+
+    /// With the `p2hot` feature: the device-resident copy of this tree (LDE matrix = leaves, digests). When
+    /// `leaves` / `digests` are empty (P2HOT_LEAVES=device), `get` / `prove` fetch from it.
+    #[cfg(feature = "p2hot")]
+    pub device: Option<std::sync::Arc<crate::p2hot::DeviceTree<F>>>,
+}
+'''),
+        ('''            digests: Vec::new(),
+            cap: MerkleCap::default(),
+        }
+''', '''            digests: Vec::new(),
+            cap: MerkleCap::default(),
+            #[cfg(feature = "p2hot")]
+            device: None,
+        }
+'''),
+        ('''            digests,
+            cap: MerkleCap(cap),
+        }
+    }
+
+    pub fn get(&self, i: usize) -> &[F] {
+        &self.leaves[i]
+    }
+''', '''            digests,
+            cap: MerkleCap(cap),
+            #[cfg(feature = "p2hot")]
+            device: None,
+        }
+    }
+
+    pub fn get(&self, i: usize) -> &[F] {
+        #[cfg(feature = "p2hot")]
+        if self.leaves.is_empty() {
+            if let Some(device) = &self.device {
+                return device.row(i);
+            }
+        }
+        &self.leaves[i]
+    }
+'''),
+        ('''        let cap_height = log2_strict(self.cap.len());
+        let siblings =
+''', '''        let cap_height = log2_strict(self.cap.len());
+        #[cfg(feature = "p2hot")]
+        if self.digests.is_empty() {
+            if let Some(device) = &self.device {
+                return MerkleProof {
+                    siblings: device.path::<H>(leaf_index),
+                };
+            }
+        }
+        let siblings =
+''')])
+    edit(os.path.join(b, "plonky2/src/util/serialization/mod.rs"), [
+        ('''        Ok(MerkleTree {
+            leaves,
+            digests,
+            cap,
+        })
+''', '''        Ok(MerkleTree {
+            leaves,
+            digests,
+            cap,
+            #[cfg(feature = "p2hot")]
+            device: None,
+        })
+''')])
+    # ---- Challenger
+    edit(os.path.join(b, "plonky2/src/iop/challenger.rs"), [
+        ('''    pub fn compact(&mut self) -> H::Permutation {
+''', '''    /// The transcript state for `crate::p2hot` (the sponge moves to the GPU for the FRI rounds and back).
+    #[cfg(feature = "p2hot")]
+    pub(crate) fn p2hot_parts(&mut self) -> (&mut H::Permutation, &mut Vec<F>, &mut Vec<F>) {
+        (
+            &mut self.sponge_state,
+            &mut self.input_buffer,
+            &mut self.output_buffer,
+        )
+    }
+
+    pub fn compact(&mut self) -> H::Permutation {
+''')])
+    # ---- diff (a/ b/ prefixes, no timestamps, /dev/null for the two new files): `git apply` / `patch -p1` format
+    r = subprocess.run(["diff", "-ruN", "a", "b"], capture_output=True, text=True, cwd=top)
+    out = []
+    for line in r.stdout.splitlines(keepends=True):
+        if line.startswith("--- a/") or line.startswith("+++ b/"):
+            name = line.split("\t")[0].rstrip("\n")
+            if line.startswith("--- a/") and not os.path.exists(os.path.join(top, name[4:])):
+                name = "--- /dev/null"
+            out.append(name + "\n")
+        else:
+            out.append(line)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    with open(OUT, "w") as f:
+        f.write("".join(out))
+    shutil.rmtree(top)
+    print("wrote", OUT, len(out), "lines")
+
+
+if __name__ == "__main__":
+    main()
