@@ -184,9 +184,10 @@ __global__ void __launch_bounds__(1024) horner_carries_kernel(const u64 *p0, con
 }
 
 __global__ void horner_emit_kernel(const u64 *c0, const u64 *c1, unsigned chunk_log, size_t n_chunks, gl::ext2 z,
-                                   const u64 *t0, const u64 *t1, gl::ext2 shift, int accumulate, u64 *a0, u64 *a1) {
+                                   const u64 *t0, const u64 *t1, const u64 *shift_ptr, int accumulate, u64 *a0, u64 *a1) {
     size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_chunks) return;
+    const gl::ext2 shift{shift_ptr[0], shift_ptr[1]};  // alpha^(#polys of the batch), device-resident (alpha never visits the host)
     gl::ext2 acc{t0[m], t1[m]};
     const size_t base = m << chunk_log, n = n_chunks << chunk_log;
     for (size_t i = (size_t)1 << chunk_log; i-- > 0;) {
@@ -231,6 +232,36 @@ __device__ __forceinline__ gl::ext2 block_weighted_sum(gl::ext2 acc, gl::ext2 z,
         __syncthreads();
     }
     return gl::ext2{s0[0], s1[0]};
+}
+
+// out[j] = alpha^j as [2] words for j < count, alpha read from device memory: base.powers() of ReducingFactor
+// (util/reducing.rs:88-89) and, at index J, the shift_poly factor alpha^J (reducing.rs:103-106)
+__global__ void alpha_powers_kernel(const u64 *alpha, size_t count, u64 *out) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    gl::ext2 w{1, 0}, b{gl::canon(alpha[0]), gl::canon(alpha[1])};
+    for (size_t e = j; e; e >>= 1) {
+        if (e & 1) w = gl::ext_mul(w, b);
+        b = gl::ext_mul(b, b);
+    }
+    out[2 * j] = gl::canon(w.a0);
+    out[2 * j + 1] = gl::canon(w.a1);
+}
+
+// fri_prover_query_rounds (fri/prover.rs:215-220, :243-253): x_index = rand % N per query, then x_index >>= arity_bits per
+// round.  idx[0][q] = x_index, idx[1 + r][q] = x_index after round r's shift; rand are the challenger's outputs on the device.
+struct ArityBits {
+    unsigned char b[32];
+};
+__global__ void query_indices_kernel(const u64 *rand, size_t n_queries, unsigned log_n_total, ArityBits ab, unsigned n_rounds, u64 *idx) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_queries) return;
+    u64 x = gl::canon(rand[q]) & ((((u64)1) << log_n_total) - 1);  // rand.to_canonical_u64() as usize % n, n = 2^log_n_total
+    idx[q] = x;
+    for (unsigned r = 0; r < n_rounds; ++r) {
+        x >>= ab.b[r];
+        idx[(1 + (size_t)r) * n_queries + q] = x;
+    }
 }
 
 // w0[u] + X w1[u] = z^u for u < count (the power table of one segment, shared by every segment of every polynomial)
@@ -360,6 +391,9 @@ __global__ void __launch_bounds__(256) pow_kernel(const Challenger *ch, unsigned
                                                  unsigned long long *best) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
+    // a witness below `start` was found by an earlier chunk: the chunks are enqueued back to back without host round
+    // trips, the later ones retire here (kernel boundaries order this load after the earlier chunk's atomicMin)
+    if (*best < (unsigned long long)start) return;
     u64 s[12];
     const u32 n_in = ch->n_in;
 #pragma unroll

@@ -527,43 +527,54 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
     P2_TRY(pool_alloc(ctx, 2 * n * 8, &d_planes.p));
     P2_TRY(pool_alloc(ctx, (leaf_words ? leaf_words : 1) * 8, &d_leaves.p));
     P2_TRY(pool_alloc(ctx, (dig_words ? dig_words : 1) * 8, &d_dig.p));
-    const size_t q_words = Q * (1 + n_rounds) + lay.initial_leaves_words + lay.initial_paths_words + lay.step_evals_words + lay.step_paths_words;
-    P2_TRY(pool_alloc(ctx, (q_words ? q_words : 1) * 8, &d_q.p));
-    std::vector<u64> idx_host(Q * (1 + (size_t)n_rounds));
-    auto body = [&]() -> int {
+    // query staging: indices [1 + R][Q] | initial leaves | initial paths | step evals | step paths | rand [Q] | alpha [2] | best | resp | saved challenger
+    const size_t ch_words = (sizeof(fri::Challenger) + 7) / 8;
+    const size_t q_words = Q * (1 + n_rounds) + lay.initial_leaves_words + lay.initial_paths_words + lay.step_evals_words +
+                           lay.step_paths_words + Q + 2 + 1 + 1 + ch_words;
+    P2_TRY(pool_alloc(ctx, q_words * 8, &d_q.p));
+    u64 *d_idx = d_q.u(), *d_il = d_idx + Q * (1 + n_rounds), *d_ip = d_il + lay.initial_leaves_words,
+        *d_se = d_ip + lay.initial_paths_words, *d_sp = d_se + lay.step_evals_words, *d_rand = d_sp + lay.step_paths_words,
+        *d_alpha = d_rand + Q, *d_best = d_alpha + 2, *d_resp = d_best + 1, *d_chsave = d_resp + 1;
+    fri::ArityBits ab{};
+    if (n_rounds > 32) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: more than 32 reduction rounds");
+    for (unsigned r = 0; r < n_rounds; ++r) ab.b[r] = (unsigned char)fp->reduction_arity_bits[r];
+    size_t w_sum = 0;
+    for (size_t o = 0; o < n_oracles; ++o) w_sum += oracles[o]->W;
+    unsigned long long best = ~0ull;
+    u64 pow_next = 0;
+    // Everything below is enqueued without waiting for the GPU: alpha, beta_i, the PoW witness and the query indices
+    // stay on the device (the challenger is device-resident), results reach the caller's buffers by asynchronous copies
+    // and ONE synchronisation ends the call.
+    auto head = [&]() -> int {
         if (!ptrs.empty())
             P2_HIP(ctx, hipMemcpyAsync(d_table.p, ptrs.data(), ptrs.size() * sizeof(u64 *), hipMemcpyHostToDevice, ctx->stream));
         // oracle.rs:186: alpha = challenger.get_extension_challenge()
-        u64 alpha[2];
-        P2_TRY(p2hot_challenger_step(challenger, nullptr, 0, alpha, 2));
+        P2_TRY(challenger_step_dev(challenger, nullptr, 0, d_alpha, 2));
         // oracle.rs:190-213: final_poly = sum_i alpha^(k_i) (F_i - F_i(z_i)) / (X - z_i)
-        P2_TRY(p2hot_fri_final_poly_dev(ctx, (const uint64_t *const *)d_table.p, offsets.data(), n_batches, points.data(), alpha, log_n,
-                                        d_planes.u()));
+        P2_TRY(final_poly_core(ctx, (const uint64_t *const *)d_table.p, offsets.data(), n_batches, points.data(), nullptr, d_alpha, log_n,
+                               d_planes.u()));
         // oracle.rs:215-220 + fri/prover.rs:40-51: final FFT, commit phase; the round trees stay on the device
         P2_TRY(fri_commit_core(ctx, nullptr, d_planes.u(), log_n, rate_bits, cap_height, fp->reduction_arity_bits, n_rounds,
                                fp->max_num_query_steps, fp->final_poly_coeff_len, challenger, d_leaves.u(), true, d_dig.u(), true,
-                               proof->commit_phase_merkle_caps, nullptr, proof->final_poly));
-        // fri/prover.rs:53-58: proof of work
-        P2_TRY(p2hot_fri_pow(ctx, challenger, fp->proof_of_work_bits, &proof->pow_witness));
+                               proof->commit_phase_merkle_caps, nullptr, proof->final_poly, /*defer_sync=*/true));
+        // fri/prover.rs:53-58: proof of work, searched on the device; the transcript state before it is kept for the
+        // (practically unreachable) case that the searched range holds no witness
+        P2_HIP(ctx, hipMemcpyAsync(d_chsave, challenger->d, sizeof(fri::Challenger), hipMemcpyDeviceToDevice, ctx->stream));
+        return pow_search_dev(ctx, challenger, fp->proof_of_work_bits, (unsigned long long *)d_best, &pow_next);
+    };
+    auto tail = [&]() -> int {
+        // prover.rs:197-198: observe the witness, draw the response
+        P2_TRY(challenger_step_dev(challenger, d_best, 1, d_resp, 1));
+        P2_HIP(ctx, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
         if (Q == 0) return P2HOT_OK;
-        // fri/prover.rs:215-220: x_index = rand % n for num_query_rounds challenges
-        P2_TRY(p2hot_challenger_step(challenger, nullptr, 0, idx_host.data(), Q));
-        for (size_t q = 0; q < Q; ++q) {
-            u64 x = idx_host[q] % N;
-            idx_host[q] = x;
-            for (unsigned r = 0; r < n_rounds; ++r) {  // per round: x_index >>= arity_bits (prover.rs:243-253)
-                x >>= fp->reduction_arity_bits[r];
-                idx_host[(1 + (size_t)r) * Q + q] = x;
-            }
-        }
-        if (proof->query_indices) std::copy(idx_host.begin(), idx_host.begin() + Q, proof->query_indices);
-        u64 *d_idx = d_q.u(), *d_il = d_idx + Q * (1 + n_rounds), *d_ip = d_il + lay.initial_leaves_words,
-            *d_se = d_ip + lay.initial_paths_words, *d_sp = d_se + lay.step_evals_words;
-        P2_HIP(ctx, hipMemcpyAsync(d_idx, idx_host.data(), idx_host.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        // fri/prover.rs:215-220: x_index = rand % n for num_query_rounds challenges; per round x_index >>= arity_bits (:243-253)
+        P2_TRY(challenger_step_dev(challenger, nullptr, 0, d_rand, Q));
+        P2HOT_LAUNCH(fri::query_indices_kernel, dim3(cdiv(Q, 256)), dim3(256), 0, ctx->stream, (const u64 *)d_rand, Q, log_N, ab, n_rounds,
+                     d_idx);
+        P2_LAUNCH_CHECK(ctx);
+        if (proof->query_indices) P2_HIP(ctx, hipMemcpyAsync(proof->query_indices, d_idx, Q * 8, hipMemcpyDeviceToHost, ctx->stream));
         // prover.rs:238-241: initial_trees_proof = for every oracle (tree.get(x), tree.prove(x)), all queries per launch.
         // Device staging is oracle-major ([oracle][q][...]); the host layout is query-major (see p2hot.h), fixed by the D2H copies.
-        size_t w_sum = 0;
-        for (size_t o = 0; o < n_oracles; ++o) w_sum += oracles[o]->W;
         size_t w_off = 0;
         for (size_t o = 0; o < n_oracles; ++o) {
             const p2hot_batch *B = oracles[o];
@@ -576,13 +587,13 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
         unsigned lm = log_N;
         std::vector<size_t> ev_offs, pa_offs, ev_w, pa_w;
         for (unsigned r = 0; r < n_rounds; ++r) {
-            const unsigned ab = fp->reduction_arity_bits[r];
-            const size_t roww = (size_t)2 << ab, layers = lm - ab - cap_height;
+            const unsigned abr = fp->reduction_arity_bits[r];
+            const size_t roww = (size_t)2 << abr, layers = lm - abr - cap_height;
             P2HOT_LAUNCH(fri::gather_rowmajor_kernel, dim3(cdiv(Q * roww, 256)), dim3(256), 0, ctx->stream, (const u64 *)(d_leaves.u() + lv),
-                         roww, m >> ab, (const u64 *)(d_idx + (1 + (size_t)r) * Q), Q, d_se + Q * ev_off, ctx->d_oob);
+                         roww, m >> abr, (const u64 *)(d_idx + (1 + (size_t)r) * Q), Q, d_se + Q * ev_off, ctx->d_oob);
             P2_LAUNCH_CHECK(ctx);
             if (layers)
-                P2_TRY(p2hot_merkle_paths_dev(ctx, d_dig.u() + dg, lm - ab, cap_height, d_idx + (1 + (size_t)r) * Q, Q, d_sp + Q * pa_off));
+                P2_TRY(p2hot_merkle_paths_dev(ctx, d_dig.u() + dg, lm - abr, cap_height, d_idx + (1 + (size_t)r) * Q, Q, d_sp + Q * pa_off));
             ev_offs.push_back(ev_off);
             pa_offs.push_back(pa_off);
             ev_w.push_back(roww);
@@ -590,9 +601,9 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
             ev_off += roww;
             pa_off += 4 * layers;
             lv += 2 * m;
-            dg += 4 * p2hot_num_digests(lm - ab, cap_height);
-            m >>= ab;
-            lm -= ab;
+            dg += 4 * p2hot_num_digests(lm - abr, cap_height);
+            m >>= abr;
+            lm -= abr;
         }
         // D2H: one strided copy per (oracle | round) turns the oracle-major staging into the query-major proof layout
         w_off = 0;
@@ -616,7 +627,18 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
         }
         return P2HOT_OK;
     };
-    return sync_checked(ctx, body(), "prove_openings");
+    int rc = head();
+    if (rc == P2HOT_OK) rc = tail();
+    rc = sync_checked(ctx, rc, "prove_openings");
+    if (rc == P2HOT_OK && best == ~0ull) {
+        // no witness among the first 2^(pow_bits + 5) candidates (probability e^-32): rewind the transcript to before the
+        // grind, search the rest of the range with a host check per chunk, and replay the tail
+        P2_HIP(ctx, hipMemcpyAsync(challenger->d, d_chsave, sizeof(fri::Challenger), hipMemcpyDeviceToDevice, ctx->stream));
+        P2_TRY(pow_continue_host(ctx, challenger, fp->proof_of_work_bits, (unsigned long long *)d_best, pow_next, &best));
+        rc = sync_checked(ctx, tail(), "prove_openings");
+    }
+    if (rc == P2HOT_OK) proof->pow_witness = best;
+    return rc;
 }
 
 // ------------------------------------------------------------------ permutation argument (plonk/prover.rs:356-449)

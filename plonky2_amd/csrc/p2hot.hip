@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <tuple>
@@ -23,6 +24,7 @@ struct p2hot_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    u64 alpha_stage[2] = {0, 0};   // host staging of an extension challenge (outlives the asynchronous copy)
     std::atomic<bool> busy{false};  // a host-pointer entry point is running on this context (see CallGuard)
     u64 *tables = nullptr;  // fwd_lo, fwd_hi, inv_lo, inv_hi (65536 each)
     unsigned *d_oob = nullptr;  // raised by gathers that were handed an out-of-range row / leaf index (device-resident indices)
@@ -882,7 +884,8 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
                            unsigned rate_bits, unsigned cap_height, const unsigned *arity_bits, unsigned n_rounds,
                            unsigned max_num_query_steps, size_t final_poly_coeff_len,
                            p2hot_challenger *challenger, uint64_t *leaves_out, bool leaves_on_device, uint64_t *digests_out,
-                           bool digests_on_device, uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out) {
+                           bool digests_on_device, uint64_t *caps_out, uint64_t *betas_out, uint64_t *final_out,
+                           bool defer_sync = false) {
     if (!ctx || !challenger || challenger->ctx != ctx) return P2HOT_EINVAL;
     P2_TRY(check_log(ctx, log_n + rate_bits, "fri_commit"));
     if ((!coeffs && !d_planar) || (n_rounds && !arity_bits)) P2_FAIL(ctx, P2HOT_EINVAL, "fri_commit: null input");
@@ -1009,6 +1012,7 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
         return P2HOT_OK;
     };
     rc = body();
+    if (defer_sync) return rc;  // the caller synchronises once, after everything it enqueues behind this (p2hot_prove_openings)
     hipError_t e = hipStreamSynchronize(ctx->stream);  // host outputs are complete on return
     if (rc == P2HOT_OK && e != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "fri_commit: %s", hipGetErrorString(e));
     return rc;
@@ -1047,12 +1051,12 @@ static gl::ext2 ext_pow(gl::ext2 b, u64 e) {
     return r;
 }
 
-extern "C" int p2hot_fri_final_poly_dev(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, const size_t *batch_offsets,
-                                        size_t n_batches, const uint64_t *points, const uint64_t alpha[2], unsigned log_n,
-                                        uint64_t *d_final) {
-    if (!ctx) return P2HOT_EINVAL;
+// alpha: host words (alpha_host) or two device words (d_alpha); exactly one is non-null.  Nothing here waits for the GPU.
+static int final_poly_core(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, const size_t *batch_offsets, size_t n_batches,
+                           const uint64_t *points, const uint64_t *alpha_host, const uint64_t *d_alpha, unsigned log_n,
+                           uint64_t *d_final) {
     P2_TRY(check_log(ctx, log_n, "fri_final_poly"));
-    if (!batch_offsets || !points || !alpha || !d_final || (n_batches && !d_poly_table))
+    if (!batch_offsets || !points || (!alpha_host && !d_alpha) || !d_final || (n_batches && !d_poly_table))
         P2_FAIL(ctx, P2HOT_EINVAL, "fri_final_poly: null argument");
     const size_t n = (size_t)1 << log_n;
     const unsigned chunk_log = log_n < 6 ? log_n : 6;
@@ -1062,24 +1066,24 @@ extern "C" int p2hot_fri_final_poly_dev(p2hot_ctx *ctx, const uint64_t *const *d
         if (batch_offsets[i + 1] < batch_offsets[i]) P2_FAIL(ctx, P2HOT_EINVAL, "fri_final_poly: offsets must ascend");
         max_j = std::max(max_j, batch_offsets[i + 1] - batch_offsets[i]);
     }
-    // scratch: composition planes [2][n], chunk totals [2][n_chunks], carries [2][n_chunks], alpha powers [max_j][2]
+    // scratch: composition planes [2][n], chunk totals [2][n_chunks], carries [2][n_chunks], alpha powers [max_j + 1][2], alpha [2]
     u64 *sc = nullptr;
-    P2_TRY(scratch_get(ctx, 1, (2 * n + 4 * n_chunks + 2 * max_j) * 8, (void **)&sc));
+    P2_TRY(scratch_get(ctx, 1, (2 * n + 4 * n_chunks + 2 * (max_j + 1) + 2) * 8, (void **)&sc));
     u64 *c0 = sc, *c1 = sc + n, *p0 = sc + 2 * n, *p1 = p0 + n_chunks, *t0 = p1 + n_chunks, *t1 = t0 + n_chunks;
-    u64 *d_apow = t1 + n_chunks;
-    const gl::ext2 a{gl::canon(alpha[0]), gl::canon(alpha[1])};
+    u64 *d_apow = t1 + n_chunks, *d_a = d_apow + 2 * (max_j + 1);
+    if (alpha_host) {
+        ctx->alpha_stage[0] = gl::canon(alpha_host[0]);
+        ctx->alpha_stage[1] = gl::canon(alpha_host[1]);
+        P2_HIP(ctx, hipMemcpyAsync(d_a, ctx->alpha_stage, 16, hipMemcpyHostToDevice, ctx->stream));
+        d_alpha = d_a;
+    }
     if (n_batches == 0) P2_HIP(ctx, hipMemsetAsync(d_final, 0, n * 16, ctx->stream));
-    std::vector<u64> apow(2 * max_j);
+    // base.powers() restarts at 1 for every batch (reducing.rs:88-89): one table alpha^0 .. alpha^max_j serves all of them,
+    // and entry J is the batch's shift_poly factor (reducing.rs:103-106)
+    P2HOT_LAUNCH(fri::alpha_powers_kernel, dim3(cdiv(max_j + 1, 256)), dim3(256), 0, ctx->stream, d_alpha, max_j + 1, d_apow);
+    P2_LAUNCH_CHECK(ctx);
     for (size_t i = 0; i < n_batches; ++i) {
         const size_t J = batch_offsets[i + 1] - batch_offsets[i];
-        gl::ext2 pw{1, 0};
-        for (size_t j = 0; j < J; ++j) {  // base.powers() restarts at 1 for every batch (reducing.rs:88-89)
-            apow[2 * j] = gl::canon(pw.a0);
-            apow[2 * j + 1] = gl::canon(pw.a1);
-            pw = gl::ext_mul(pw, a);
-        }
-        if (J) P2_HIP(ctx, hipMemcpyAsync(d_apow, apow.data(), J * 16, hipMemcpyHostToDevice, ctx->stream));
-        P2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // apow is reused by the next batch
         {
             ProfScope ps(ctx, "reduce_polys_base");
             P2HOT_LAUNCH(fri::reduce_polys_base_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream,
@@ -1089,17 +1093,24 @@ extern "C" int p2hot_fri_final_poly_dev(p2hot_ctx *ctx, const uint64_t *const *d
         ProfScope ps(ctx, "divide_by_linear");
         const gl::ext2 z{gl::canon(points[2 * i]), gl::canon(points[2 * i + 1])};
         const gl::ext2 zL = ext_pow(z, (u64)1 << chunk_log);
-        const gl::ext2 shift = ext_pow(a, J);  // ReducingFactor::shift_poly: final_poly *= alpha^count (reducing.rs:103-106)
         P2HOT_LAUNCH(fri::horner_chunk_totals_kernel, dim3(cdiv(n_chunks, 256)), dim3(256), 0, ctx->stream, (const u64 *)c0,
                      (const u64 *)c1, chunk_log, n_chunks, z, p0, p1);
         P2HOT_LAUNCH(fri::horner_carries_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u64 *)p0, (const u64 *)p1,
                      n_chunks, per, zL, t0, t1);
         P2HOT_LAUNCH(fri::horner_emit_kernel, dim3(cdiv(n_chunks, 256)), dim3(256), 0, ctx->stream, (const u64 *)c0,
-                     (const u64 *)c1, chunk_log, n_chunks, z, (const u64 *)t0, (const u64 *)t1, shift, i > 0 ? 1 : 0, d_final,
-                     d_final + n);
+                     (const u64 *)c1, chunk_log, n_chunks, z, (const u64 *)t0, (const u64 *)t1, (const u64 *)(d_apow + 2 * J),
+                     i > 0 ? 1 : 0, d_final, d_final + n);
         P2_LAUNCH_CHECK(ctx);
     }
     return P2HOT_OK;
+}
+
+extern "C" int p2hot_fri_final_poly_dev(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, const size_t *batch_offsets,
+                                        size_t n_batches, const uint64_t *points, const uint64_t alpha[2], unsigned log_n,
+                                        uint64_t *d_final) {
+    if (!ctx) return P2HOT_EINVAL;
+    if (!alpha) P2_FAIL(ctx, P2HOT_EINVAL, "fri_final_poly: null argument");
+    return final_poly_core(ctx, d_poly_table, batch_offsets, n_batches, points, alpha, nullptr, log_n, d_final);
 }
 
 extern "C" int p2hot_eval_polys_dev(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, size_t n_polys, unsigned log_n,
@@ -1210,28 +1221,60 @@ extern "C" int p2hot_merkle_paths_dev(p2hot_ctx *ctx, const uint64_t *d_digests,
     return P2HOT_OK;
 }
 
+// fri_proof_of_work (fri/prover.rs:153-202) without a host round trip: chunks of candidates (doubling from 2^14) are
+// enqueued back to back up to 2^(pow_bits + 5) candidates; a chunk retires at once when an earlier one has found a
+// witness.  d_best (8 bytes, device) receives the SMALLEST witness, or stays ~0 if none was found in that range
+// (probability e^-32: the caller then continues with pow_continue_host).  Returns the first candidate NOT covered.
+static int pow_search_dev(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bits, unsigned long long *d_best, u64 *next_start) {
+    P2_HIP(ctx, hipMemsetAsync(d_best, 0xFF, 8, ctx->stream));
+    // P2HOT_POW_RANGE_LOG (tests): log2 of the searched range relative to the expected 2^pow_bits trials, default 5
+    int extra = 5;
+    if (const char *e = getenv("P2HOT_POW_RANGE_LOG")) extra = atoi(e);
+    const int lg = (int)pow_bits + extra;
+    const u64 limit = lg >= 63 ? gl::P : std::min<u64>(gl::P, (u64)1 << (lg < 0 ? 0 : lg));
+    u64 chunk = (u64)1 << 14, start = 0;
+    while (start < limit) {
+        const u64 count = std::min(limit - start, chunk);
+        P2HOT_LAUNCH(fri::pow_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, challenger->d, pow_bits, start, count, d_best);
+        P2_LAUNCH_CHECK(ctx);
+        start += count;
+        if (chunk < ((u64)1 << 24)) chunk <<= 1;
+    }
+    *next_start = start;
+    return P2HOT_OK;
+}
+
+// the rest of the candidate range, chunk by chunk with a host check after each (only reached when pow_search_dev's range held no witness)
+static int pow_continue_host(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bits, unsigned long long *d_best, u64 start,
+                             unsigned long long *best_out) {
+    unsigned long long best = ~0ull;
+    u64 chunk = (u64)1 << 16;
+    while (start < gl::P) {  // candidates 0 ..= P-1 in the reference (prover.rs:182)
+        const u64 count = std::min(gl::P - start, chunk);
+        if (chunk < ((u64)1 << 24)) chunk <<= 1;
+        P2HOT_LAUNCH(fri::pow_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, challenger->d, pow_bits, start, count, d_best);
+        P2_LAUNCH_CHECK(ctx);
+        P2_HIP(ctx, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+        P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (best != ~0ull) break;
+        start += count;
+    }
+    if (best == ~0ull) P2_FAIL(ctx, P2HOT_EUNSUPPORTED, "fri_pow: no witness found");
+    *best_out = best;
+    return P2HOT_OK;
+}
+
 extern "C" int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bits, uint64_t *witness_out) {
     if (!ctx || !challenger || challenger->ctx != ctx || !witness_out) return P2HOT_EINVAL;
     if (pow_bits > 64) P2_FAIL(ctx, P2HOT_EINVAL, "fri_pow: pow_bits > 64");
     u64 *io;
     P2_TRY(challenger_io(challenger, 8, &io));
     unsigned long long best = ~0ull;
-    P2_HIP(ctx, hipMemcpyAsync(io, &best, 8, hipMemcpyHostToDevice, ctx->stream));
-    // candidates 0 ..= P-1 in the reference (prover.rs:182); expected hit after ~2^pow_bits tries.
-    // Chunks double from 2^14 so that small grinds do not pay for a large launch.
-    u64 chunk = (u64)1 << 14;
-    for (u64 start = 0; start < gl::P;) {
-        u64 count = gl::P - start < chunk ? gl::P - start : chunk;
-        P2HOT_LAUNCH(fri::pow_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, challenger->d, pow_bits, start,
-                     count, (unsigned long long *)io);
-        P2_LAUNCH_CHECK(ctx);
-        P2_HIP(ctx, hipMemcpyAsync(&best, io, 8, hipMemcpyDeviceToHost, ctx->stream));
-        P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (best != ~0ull) break;
-        start += count;
-        if (chunk < ((u64)1 << 24)) chunk <<= 1;
-    }
-    if (best == ~0ull) P2_FAIL(ctx, P2HOT_EUNSUPPORTED, "fri_pow: no witness found");
+    u64 next = 0;
+    P2_TRY(pow_search_dev(ctx, challenger, pow_bits, (unsigned long long *)io, &next));
+    P2_HIP(ctx, hipMemcpyAsync(&best, io, 8, hipMemcpyDeviceToHost, ctx->stream));
+    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (best == ~0ull) P2_TRY(pow_continue_host(ctx, challenger, pow_bits, (unsigned long long *)io, next, &best));
     *witness_out = best;
     u64 w = best, resp;
     return p2hot_challenger_step(challenger, &w, 1, &resp, 1);  // prover.rs:197-198

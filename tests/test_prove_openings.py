@@ -252,3 +252,124 @@ def test_fri_proof_passes_the_reference_verifier(eng, ora, log_n, widths, rb, ca
     bad["pow_witness"] = int(bad["pow_witness"]) + 1   # almost surely not a valid witness, and it shifts the query indices
     with pytest.raises(fv.VerificationError):
         verify(bad)
+
+
+def test_host_session_handles_and_errors(eng, ora):
+    """The host-pointer session objects: kept values (P2HOT_KEEP_VALUES) feed the permutation argument, a committed
+    column set is consumed, handles of another context / bad indices / hiding are refused with the reference's wording"""
+    import ctypes as C
+    from plonky2_amd import _lib
+    from plonky2_amd.fri.oracle import DeviceColumns, FriBatchInfo, PolynomialBatch, eval_openings, prove_openings
+    from plonky2_amd.iop.challenger import Challenger
+    from plonky2_amd.plonk.prover import all_wires_permutation_partial_products
+    rng = np.random.default_rng(1)
+    n, W = 32, 6
+    vals = rand_field(rng, W, n, noncanonical=True)
+    b = PolynomialBatch.from_values(vals, 2, False, 1, engine=eng, keep_values=True)
+    o = ora.commit(vals, 2, 1, True)
+    assert (b.polynomials == o["coeffs"]).all() and (b.merkle_tree.cap.entries == o["cap"]).all()
+    assert (b.merkle_tree.digests == o["digests"]).all() and (b.merkle_tree.leaves == o["leaves"]).all()
+    assert (b.get_lde_values(3, 2) == o["leaves"][int(format(6, "07b")[::-1], 2)]).all()       # oracle.rs:142-147
+    # the kept values are the inputs, and they drive p2hot_partial_products without another upload
+    v = b.values()
+    assert (v.host() == vals % np.uint64(P)).all() or (v.host() == vals).all()
+    sig = DeviceColumns.upload(rand_field(rng, W, n), eng)
+    k = np.array([pow(7, j, P) for j in range(W)], dtype=np.uint64)
+    zs = all_wires_permutation_partial_products(v, sig, k, 2, [3], [5], eng)
+    exp = ora.partial_products(vals, sig.host(), k, 2, 3, 5)
+    got = zs.host()
+    assert (got[0] == exp[-1]).all() and (got[1:] == exp[:-1]).all()
+    zb = PolynomialBatch.from_values(zs, 2, False, 1, engine=eng)          # p2hot_commit_cols consumes the column set
+    assert zs._h is None and (zb.merkle_tree.cap.entries == ora.commit(got, 2, 1, True)["cap"]).all()
+    with pytest.raises(_lib.P2HotError, match="KEEP_VALUES"):
+        zb.values()
+    # argument validation of p2hot_prove_openings / p2hot_eval_openings
+    ch = Challenger(eng)
+    with pytest.raises(_lib.P2HotError, match="does not exist"):
+        prove_openings([FriBatchInfo([1, 2], [(0, W)])], [b], ch, 2, 1, [1], 0, 1, engine=eng)
+    with pytest.raises(_lib.P2HotError, match="another degree / rate / cap"):
+        prove_openings([FriBatchInfo([1, 2], [(0, 0)])], [b], ch, 3, 1, [1], 0, 1, engine=eng)
+    with pytest.raises(_lib.P2HotError):
+        prove_openings([FriBatchInfo([1, 2], [(0, 0)])], [b], ch, 2, 1, [6], 0, 1, engine=eng)   # arity > degree
+    other = PolynomialBatch.from_values(rand_field(rng, 2, 16), 2, False, 1, engine=eng)
+    with pytest.raises(_lib.P2HotError, match="same degree"):
+        eval_openings([b, other], [[1, 2]], eng)
+    fp = _lib.FriParams(2, 1, 0, 1, (C.c_uint * 1)(1), 1, 1, 0, 0)                               # hiding = 1
+    lay = _lib.FriProofLayout()
+    h = (C.c_void_p * 1)(b._h)
+    assert eng.lib.p2hot_fri_proof_sizes(h, 1, C.byref(fp), C.byref(lay)) == _lib.OK
+    bufs = [np.zeros(max(1, x), dtype=np.uint64) for x in (lay.caps_words, lay.final_poly_words, lay.initial_leaves_words,
+                                                          lay.initial_paths_words, lay.step_evals_words, lay.step_paths_words)]
+    pr = _lib.FriProof(bufs[0].ctypes.data, bufs[1].ctypes.data, 0, None, bufs[2].ctypes.data, bufs[3].ctypes.data,
+                       bufs[4].ctypes.data, bufs[5].ctypes.data)
+    info = (_lib.FriBatchInfo * 1)()
+    assert eng.lib.p2hot_prove_openings(eng.ctx, info, 0, h, 1, ch._h, C.byref(fp), C.byref(pr)) == _lib.EUNSUPPORTED
+    assert eng.lib.p2hot_ctx_trim(eng.ctx) == _lib.OK
+
+
+def test_starky_padding_arguments_reach_the_transcript(eng, ora):
+    """final_poly_coeff_len / max_num_query_steps (fri/prover.rs:89-90, :122-147) as arguments of p2hot_prove_openings:
+    the transcript advances like the reference's (dummy zero caps + challenges, zero coefficients observed)"""
+    from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, prove_openings
+    from plonky2_amd.iop.challenger import Challenger
+    rng = np.random.default_rng(3)
+    n, rb, cap, arity = 64, 1, 2, [2]
+    co = rand_field(rng, 2, n)
+    b = PolynomialBatch.from_coeffs(co, rb, False, cap, engine=eng)
+    c, oc = Challenger(eng), ora.Challenger()
+    z = [5, 9]
+    proof = prove_openings([FriBatchInfo(z, [(0, 0), (0, 1)])], [b], c, rb, cap, arity, 0, 2, engine=eng,
+                           final_poly_coeff_len=40, max_num_query_steps=3)
+    # oracle side: the same steps with the padding spelled out
+    alpha = oc.get_extension_challenge()
+    comp = ora.reduce_polys_base(co, np.array(alpha, dtype=np.uint64))
+    quo = ora.divide_by_linear(comp, z)
+    pad = np.zeros((n << rb, 2), dtype=np.uint64)
+    pad[:n] = quo
+    o = ora.fri_commit(pad, rb, cap, arity, oc.clone())
+    assert (proof["final_poly"] == o["final"]).all() and (proof["commit_phase_merkle_caps"][0] == o["caps"][0]).all()
+    # replay the reference order by hand: round cap + beta, 2 dummy steps, final poly, zero padding
+    oc.observe_cap(o["caps"][0])
+    oc.get_extension_challenge()
+    for _ in range(len(arity), 3):
+        oc.observe_elements(np.zeros(4 << cap, dtype=np.uint64))
+        oc.get_extension_challenge()
+    oc.observe_elements(o["final"].reshape(-1))
+    oc.observe_elements(np.zeros(2 * (40 - len(o["final"])), dtype=np.uint64))
+    assert proof["pow_witness"] == ora.fri_pow(oc, 0)
+    assert proof["query_indices"] == [r % (n << rb) for r in oc.get_n_challenges(2)]
+
+
+def test_pow_witness_outside_the_first_search_range(eng, ora, monkeypatch):
+    """The grind searches 2^(pow_bits + 5) candidates on the device without a host round trip; if none is valid
+    (probability e^-32) p2hot_prove_openings rewinds the transcript and continues with host-checked chunks.  Forced here
+    by shrinking the range (P2HOT_POW_RANGE_LOG): witness, query indices and the rest of the proof are unchanged."""
+    from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, prove_openings
+    from plonky2_amd.iop.challenger import Challenger
+    rng = np.random.default_rng(11)
+    co = rand_field(rng, 3, 32)
+    b = PolynomialBatch.from_coeffs(co, 2, False, 1, engine=eng)
+    inst = [FriBatchInfo([3, 4], [(0, 0), (0, 1), (0, 2)])]
+    proofs = []
+    for rng_log in (None, "-6"):          # pow_bits 9: 2^3 candidates hold a witness with probability 1.5 %
+        if rng_log is None:
+            monkeypatch.delenv("P2HOT_POW_RANGE_LOG", raising=False)
+        else:
+            monkeypatch.setenv("P2HOT_POW_RANGE_LOG", rng_log)
+        c = Challenger(eng)
+        c.observe_elements(np.arange(5, dtype=np.uint64))
+        proofs.append((prove_openings(inst, [b], c, 2, 1, [2], 9, 3, engine=eng), c.get_n_challenges(3)))
+    (p0, t0), (p1, t1) = proofs
+    assert p0["pow_witness"] == p1["pow_witness"] and p0["pow_witness"] >= 8
+    assert p0["query_indices"] == p1["query_indices"] and t0 == t1
+    for qa, qb in zip(p0["query_round_proofs"], p1["query_round_proofs"]):
+        for (la, sa), (lb, sb) in zip(qa["initial_trees_proof"] + qa["steps"], qb["initial_trees_proof"] + qb["steps"]):
+            assert (la == lb).all() and (sa == sb).all()
+    oc = ora.Challenger()
+    oc.observe_elements(np.arange(5, dtype=np.uint64))
+    a = oc.get_extension_challenge()
+    quo = ora.divide_by_linear(ora.reduce_polys_base(co, np.array(a, dtype=np.uint64)), [3, 4])
+    pad = np.zeros((32 << 2, 2), dtype=np.uint64)
+    pad[:32] = quo
+    ora.fri_commit(pad, 2, 1, [2], oc)
+    assert ora.fri_pow(oc, 9) == p0["pow_witness"]
