@@ -160,49 +160,54 @@ def other_configs(eng, torch, reps=3):
         ms = timed(lambda: fri_committed_trees_device(planes, log_n, ch, rb, 4, [4, 4, 4, 4], eng))
         out[name] = {"workload": "fri_committed_trees, N=2^%d, arity 16 x4, cap 4 (final FFT + 4 round trees + folds, device resident)"
                                  % (log_n + rb), "ms": ms}
-    # the per-proof path of a 2^20-gate standard_recursion_config proof: every stage of SURVEY section 8 back to back
-    n, rb, cap, arity, nq = 1 << 20, 3, 4, [4, 4, 4, 4], 28
-    wires = splitmix_columns_torch(torch, dev, 0, 135, n)
-    sig = splitmix_columns_torch(torch, dev, 1000, 80, n)
-    quo = splitmix_columns_torch(torch, dev, 2000, 16, n)
-    k_is = [pow(14293326489335486720, j, P) for j in range(80)]
+    # the per-proof path of a standard_recursion_config proof: every stage of SURVEY section 8 back to back, at the
+    # headline size (2^20 gates) and at recursion size (2^12 gates: the two recursive proofs of bench_recursion's chain)
+    def path_line(name, log_n, arity):
+        n, rb, cap, nq = 1 << log_n, 3, 4, 28
+        wires = splitmix_columns_torch(torch, dev, 0, 135, n)
+        sig = splitmix_columns_torch(torch, dev, 1000, 80, n)
+        quo = splitmix_columns_torch(torch, dev, 2000, 16, n)
+        k_is = [pow(14293326489335486720, j, P) for j in range(80)]
 
-    def path():
-        stage = {}
-        t = [time.perf_counter()]
+        def path():
+            stage = {}
+            t = [time.perf_counter()]
 
-        def lap(label):
-            torch.cuda.synchronize()
-            now = time.perf_counter()
-            stage[label] = (now - t[0]) * 1e3
-            t[0] = now
-        b_w = PolynomialBatch.from_values(wires, rb, False, cap, engine=eng)
-        lap("wires commit (W=135, from_values)")
-        zs = all_wires_permutation_partial_products(wires[:80], sig, k_is, 8, [3, 5], [11, 13], eng)
-        lap("partial products + Zs (80 routed wires, 2 challenges)")
-        b_z = PolynomialBatch.from_values(zs, rb, False, cap, engine=eng)
-        lap("Zs + partial products commit (W=20, from_values)")
-        b_q = PolynomialBatch.from_coeffs(quo, rb, False, cap, engine=eng)
-        lap("quotient chunks commit (W=16, from_coeffs)")
-        oracles = [b_w, b_z, b_q]
-        ch = Challenger(eng)
-        ch.observe_elements(np.arange(8, dtype=np.uint64))
-        zeta = ch.get_extension_challenge()
-        gz = [(zeta[0] * 7) % P, zeta[1]]
-        eval_openings(oracles, [zeta, gz], eng)
-        lap("OpeningSet (171 polynomials at 2 points)")
-        allp = [(oi, pi) for oi, W in enumerate((135, 20, 16)) for pi in range(W)]
-        nxt = [(oi, pi) for oi, W in enumerate((135, 20)) for pi in range(W)]
-        prove_openings([FriBatchInfo(zeta, allp), FriBatchInfo(gz, nxt)], oracles, ch, rb, cap, arity, 16, nq, engine=eng)
-        lap("prove_openings (final_poly, FRI commit, PoW 16 bits, 28 queries)")
-        return stage
+            def lap(label):
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                stage[label] = (now - t[0]) * 1e3
+                t[0] = now
+            b_w = PolynomialBatch.from_values(wires, rb, False, cap, engine=eng)
+            lap("wires commit (W=135, from_values)")
+            zs = all_wires_permutation_partial_products(wires[:80], sig, k_is, 8, [3, 5], [11, 13], eng)
+            lap("partial products + Zs (80 routed wires, 2 challenges)")
+            b_z = PolynomialBatch.from_values(zs, rb, False, cap, engine=eng)
+            lap("Zs + partial products commit (W=20, from_values)")
+            b_q = PolynomialBatch.from_coeffs(quo, rb, False, cap, engine=eng)
+            lap("quotient chunks commit (W=16, from_coeffs)")
+            oracles = [b_w, b_z, b_q]
+            ch = Challenger(eng)
+            ch.observe_elements(np.arange(8, dtype=np.uint64))
+            zeta = ch.get_extension_challenge()
+            gz = [(zeta[0] * 7) % P, zeta[1]]
+            eval_openings(oracles, [zeta, gz], eng)
+            lap("OpeningSet (171 polynomials at 2 points)")
+            allp = [(oi, pi) for oi, W in enumerate((135, 20, 16)) for pi in range(W)]
+            nxt = [(oi, pi) for oi, W in enumerate((135, 20)) for pi in range(W)]
+            prove_openings([FriBatchInfo(zeta, allp), FriBatchInfo(gz, nxt)], oracles, ch, rb, cap, arity, 16, nq, engine=eng)
+            lap("prove_openings (final_poly, FRI commit, PoW 16 bits, 28 queries)")
+            return stage
 
-    path()
-    stages = [path() for _ in range(reps)]
-    mean = {k: sum(s_[k] for s_ in stages) / reps for k in stages[0]}
-    out["per_proof_path_k20"] = {"workload": "every SURVEY section-8 stage of one 2^20-gate standard_recursion_config proof, back to back "
-                                             "(gate evaluation / witness generation excluded: out of scope)",
-                                 "ms": sum(mean.values()), "stage_ms": {k: round(v, 3) for k, v in mean.items()}}
+        path()
+        stages = [path() for _ in range(reps)]
+        mean = {k: sum(s_[k] for s_ in stages) / reps for k in stages[0]}
+        out[name] = {"workload": "every SURVEY section-8 stage of one 2^%d-gate standard_recursion_config proof, back to back "
+                                 "(gate evaluation / witness generation excluded: out of scope)" % log_n,
+                     "ms": sum(mean.values()), "stage_ms": {k: round(v, 3) for k, v in mean.items()}}
+
+    path_line("per_proof_path_k20", 20, [4, 4, 4, 4])
+    path_line("per_proof_path_k12", 12, [4, 4])
     return out
 
 

@@ -412,8 +412,15 @@ const char *p2hot_group_last_error(const p2hot_group *group);
  * only the columns it transforms; coeffs_out / leaves_out / digests_out / cap_out (any may be NULL) are assembled from
  * the owning ranks.  handle_out: the sharded batch for p2hot_sharded_batch_open. */
 int p2hot_group_commit(p2hot_group *group, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
-                       unsigned cap_height, int is_values, unsigned pipeline_chunks, uint64_t *coeffs_out, uint64_t *leaves_out,
-                       uint64_t *digests_out, uint64_t *cap_out, p2hot_sharded_batch **handle_out);
+                       unsigned cap_height, int is_values, int shard_mode, unsigned pipeline_chunks, uint64_t *coeffs_out,
+                       uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out, p2hot_sharded_batch **handle_out);
+/* shard_mode: P2HOT_SHARD_COSETS (default design, above) or P2HOT_SHARD_COLUMNS -- the fallback of SURVEY 8e's last row:
+ * each rank runs the iNTT and the WHOLE LDE of its ceil(W/G) columns, then the LDE matrix is re-partitioned to row blocks
+ * by an all-to-all of strided peer copies (the leaf sponge chains across the columns of a row) before hashing.  It moves
+ * W*N*8 bytes instead of W*n*8 (2^rate_bits times more) but needs no G <= 2^rate_bits: starky's rate-1/2 traces can use
+ * 4 or 8 GPUs.  Same results bit for bit. */
+#define P2HOT_SHARD_COSETS 0
+#define P2HOT_SHARD_COLUMNS 1
 /* MerkleTree::get + merkle_tree_prove (merkle_tree.rs:227, :151-190) for m leaves, each answered by the rank that owns
  * the row: rows_out [m][W], paths_out [m][log2(N) - cap_height][4]; either may be NULL */
 int p2hot_sharded_batch_open(p2hot_sharded_batch *batch, const uint64_t *leaf_idx, size_t m, uint64_t *rows_out, uint64_t *paths_out);

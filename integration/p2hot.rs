@@ -286,7 +286,7 @@ extern "C" {
     pub fn p2hot_group_last_error(group: *const P2hotGroup) -> *const c_char;
     pub fn p2hot_group_commit(
         group: *mut P2hotGroup, cols: *const *const u64, W: usize, log_n: c_uint, rate_bits: c_uint, cap_height: c_uint, is_values: c_int,
-        pipeline_chunks: c_uint, coeffs_out: *mut u64, leaves_out: *mut u64, digests_out: *mut u64, cap_out: *mut u64,
+        shard_mode: c_int, pipeline_chunks: c_uint, coeffs_out: *mut u64, leaves_out: *mut u64, digests_out: *mut u64, cap_out: *mut u64,
         handle_out: *mut *mut P2hotShardedBatch,
     ) -> c_int;
     pub fn p2hot_sharded_batch_open(batch: *mut P2hotShardedBatch, leaf_idx: *const u64, m: usize, rows_out: *mut u64, paths_out: *mut u64) -> c_int;

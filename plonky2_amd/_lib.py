@@ -127,7 +127,7 @@ SIGNATURES = {
     "p2hot_group_ctx": (vp, [vp, i]),
     "p2hot_group_uses_rccl": (i, [vp]),
     "p2hot_group_last_error": (C.c_char_p, [vp]),
-    "p2hot_group_commit": (i, [vp, C.POINTER(vp), sz, u, u, u, i, u, vp, vp, vp, vp, C.POINTER(vp)]),
+    "p2hot_group_commit": (i, [vp, C.POINTER(vp), sz, u, u, u, i, i, u, vp, vp, vp, vp, C.POINTER(vp)]),
     "p2hot_sharded_batch_open": (i, [vp, vp, sz, vp, vp]),
     "p2hot_sharded_batch_free": (None, [vp]),
 }

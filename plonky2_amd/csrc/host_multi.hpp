@@ -301,7 +301,8 @@ struct ShardPlan {
     int world;
 };
 
-static int shard_plan(p2hot_ctx *ctx, size_t W, unsigned log_n, unsigned rate_bits, unsigned cap_height, int world, ShardPlan *p) {
+static int shard_plan(p2hot_ctx *ctx, size_t W, unsigned log_n, unsigned rate_bits, unsigned cap_height, int world, ShardPlan *p,
+                      bool by_columns = false) {
     P2_TRY(check_log(ctx, log_n + rate_bits, "commit_sharded"));
     if (world < 1 || (world & (world - 1))) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: world size %d is not a power of two", world);
     p->W = W;
@@ -313,7 +314,7 @@ static int shard_plan(p2hot_ctx *ctx, size_t W, unsigned log_n, unsigned rate_bi
     p->N = p->n << rate_bits;
     p->world = world;
     if (cap_height > p->log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: cap_height > log2(N) (merkle_tree.rs:195-200)");
-    if ((size_t)world > ((size_t)1 << rate_bits)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: world size %d exceeds the %u LDE cosets", world, 1u << rate_bits);
+    if (!by_columns && (size_t)world > ((size_t)1 << rate_bits)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: world size %d exceeds the %u LDE cosets", world, 1u << rate_bits);
     if ((size_t)world > ((size_t)1 << cap_height)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: world size %d exceeds the %u cap subtrees", world, 1u << cap_height);
     p->rows_per_rank = p->N / world;
     p->cols_per_rank = W ? (W + world - 1) / world : 0;
@@ -431,6 +432,81 @@ extern "C" int p2hot_shard_columns(size_t W, int world, int rank, size_t *first,
     return P2HOT_OK;
 }
 
+// ------------------------------------------------------------------ the column-sharded fallback (last row)
+// Columns are the unit, as BASELINE's north_star words it: rank r runs the iNTT AND the whole rate-1/B LDE (all N rows)
+// of its ceil(W/G) columns, then the LDE matrix is re-partitioned to row blocks by an all-to-all (the leaf sponge chains
+// across the columns of a row, hash/hashing.rs:118-141, so a rank needs every column of the rows it hashes) and each rank
+// hashes its rows and builds its cap subtrees as in the coset scheme.  Exchange: W*N*8 bytes (2^rate_bits times the
+// coset scheme's W*n*8 of coefficients) -- strictly more traffic, which is why it is the fallback, not the default.  In
+// return it has no constraint G <= 2^rate_bits: starky's rate-1/2 traces (two cosets) can use 4 or 8 GPUs.
+// Implemented for the single-process group, where the all-to-all is a set of strided peer copies over xGMI.
+struct ColShardArgs {        // per local rank
+    const u64 *cols_local;   // [cnt][n]
+    u64 *coeffs_local;       // [cnt][n] out: this rank's columns in coefficient form
+    u64 *lde_cols;           // [cnt][N] scratch: this rank's columns over ALL rows
+    u64 *lde;                // [W][rows_per_rank] out: all columns over this rank's rows
+    u64 *leaves, *digests, *cap;
+};
+
+static int sharded_commit_columns_core(std::vector<p2hot_comm *> &cs, std::vector<ColShardArgs> &as, const ShardPlan &p, int is_values) {
+    const size_t L = cs.size(), n = p.n, N = p.N, cpr = p.cols_per_rank, W = p.W, rpr = p.rows_per_rank;
+    auto cols_of = [&](size_t r, size_t *c0, size_t *cnt) {
+        *c0 = std::min(W, r * cpr);
+        *cnt = std::min(W, *c0 + cpr) - *c0;
+    };
+    for (size_t s = 0; s < L; ++s) {  // iNTT + full LDE of the rank's own columns
+        p2hot_ctx *ctx = cs[s]->ctx;
+        P2_HIP(ctx, hipSetDevice(ctx->device));
+        size_t c0, cnt;
+        cols_of(s, &c0, &cnt);
+        if (cnt == 0) continue;
+        P2_HIP(ctx, hipMemcpyAsync(as[s].coeffs_local, as[s].cols_local, cnt * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (is_values) P2_TRY(ntt_natural(ctx, as[s].coeffs_local, cnt, n, p.log_n, true));
+        P2_TRY(p2hot_coset_lde_dev(ctx, as[s].coeffs_local, cnt, n, p.log_n, p.rate_bits, gl::COSET_SHIFT, 0, N, as[s].lde_cols, N));
+    }
+    // all-to-all: rank d pulls, from every rank r, the rows [d*rpr, (d+1)*rpr) of r's columns into lde[c0_r ..][0 .. rpr)
+#ifndef P2HOT_EMU
+    for (size_t s = 0; s < L; ++s) {
+        P2_HIP(cs[s]->ctx, hipSetDevice(cs[s]->ctx->device));
+        P2_TRY(comm_events(cs[s], 1));
+        P2_HIP(cs[s]->ctx, hipEventRecord(cs[s]->ev_ready[0], cs[s]->ctx->stream));
+    }
+#endif
+    for (size_t d = 0; d < L; ++d) {
+        p2hot_ctx *ctx = cs[d]->ctx;
+        P2_HIP(ctx, hipSetDevice(ctx->device));
+        for (size_t r = 0; r < L; ++r) {
+            size_t c0, cnt;
+            cols_of(r, &c0, &cnt);
+            if (cnt == 0) continue;
+            hipStream_t st = ctx->stream;
+#ifndef P2HOT_EMU
+            st = cs[d]->comm_stream;
+            P2_HIP(ctx, hipStreamWaitEvent(st, cs[r]->ev_ready[0], 0));
+#endif
+            P2_HIP(ctx, hipMemcpy2DAsync(as[d].lde + c0 * rpr, rpr * 8, as[r].lde_cols + d * rpr, N * 8, rpr * 8, cnt, hipMemcpyDefault, st));
+        }
+#ifndef P2HOT_EMU
+        P2_HIP(ctx, hipEventRecord(cs[d]->ev_done[0], cs[d]->comm_stream));
+        P2_HIP(ctx, hipStreamWaitEvent(ctx->stream, cs[d]->ev_done[0], 0));
+#endif
+    }
+    for (size_t s = 0; s < L; ++s) {  // leaf sponge + Merkle levels of the rank's rows
+        p2hot_ctx *ctx = cs[s]->ctx;
+        P2_HIP(ctx, hipSetDevice(ctx->device));
+        P2_TRY(p2hot_merkle_dev(ctx, as[s].lde, 0, rpr, W, p.log_N, p.cap_height, s * rpr, rpr, as[s].digests, as[s].cap));
+        if (as[s].leaves && W) P2_TRY(p2hot_transpose_dev(ctx, as[s].lde, rpr, W, rpr, as[s].leaves));
+    }
+    std::vector<u64 *> base(L);
+    std::vector<size_t> offs(L);
+    for (size_t s = 0; s < L; ++s) {
+        base[s] = as[s].cap;
+        offs[s] = s * p.cap_per_rank * 32;
+    }
+    P2_TRY(gather_start(cs, base, offs, p.cap_per_rank * 32, 1));
+    return gather_wait(cs, 1);
+}
+
 // ------------------------------------------------------------------ single process, all GPUs of the node (the Rust prover's mode)
 extern "C" int p2hot_group_create(int n_gpus, const int *devices, p2hot_group **out) {
     if (!out || n_gpus < 1 || (n_gpus & (n_gpus - 1))) return P2HOT_EINVAL;
@@ -541,22 +617,25 @@ extern "C" void p2hot_sharded_batch_free(p2hot_sharded_batch *b) {
 // from_values / from_coeffs over all GPUs of the group, HOST pointers (what p2hot_commit is for one GPU).
 // coeffs_out [W][n], leaves_out [N][W], digests_out, cap_out: caller-allocated or NULL; assembled from the owning ranks.
 extern "C" int p2hot_group_commit(p2hot_group *g, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
-                                  unsigned cap_height, int is_values, unsigned pipeline_chunks, uint64_t *coeffs_out, uint64_t *leaves_out,
-                                  uint64_t *digests_out, uint64_t *cap_out, p2hot_sharded_batch **handle_out) {
+                                  unsigned cap_height, int is_values, int shard_mode, unsigned pipeline_chunks, uint64_t *coeffs_out,
+                                  uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out, p2hot_sharded_batch **handle_out) {
     if (!g) return P2HOT_EINVAL;
     p2hot_ctx *ctx0 = g->ctx[0];
     P2_ENTER(ctx0);
     if (handle_out) *handle_out = nullptr;
     const int world = (int)g->ctx.size();
+    if (shard_mode != P2HOT_SHARD_COSETS && shard_mode != P2HOT_SHARD_COLUMNS) P2_FAIL(ctx0, P2HOT_EINVAL, "group_commit: unknown shard mode %d", shard_mode);
+    const bool by_columns = shard_mode == P2HOT_SHARD_COLUMNS && world > 1;
     ShardPlan p;
-    P2_TRY(shard_plan(ctx0, W, log_n, rate_bits, cap_height, world, &p));
+    P2_TRY(shard_plan(ctx0, W, log_n, rate_bits, cap_height, world, &p, by_columns));
     if (W && !cols) P2_FAIL(ctx0, P2HOT_EINVAL, "group_commit: null column table");
     for (size_t c = 0; c < W; ++c)
         if (!cols[c]) P2_FAIL(ctx0, P2HOT_EINVAL, "group_commit: column %zu is null", c);
     const size_t n = p.n, nd = p2hot_num_digests(p.log_N, cap_height), cap_words = (size_t)4 << cap_height;
     const size_t L = (size_t)world;
-    std::vector<std::unique_ptr<PoolBuf>> b_cols, b_co, b_lde, b_leaves, b_dig, b_cap;
+    std::vector<std::unique_ptr<PoolBuf>> b_cols, b_co, b_lde, b_leaves, b_dig, b_cap, b_ldecols;
     std::vector<ShardArgs> as(L);
+    std::vector<ColShardArgs> cas(L);
     auto alloc = [&](std::vector<std::unique_ptr<PoolBuf>> &v, p2hot_ctx *ctx, size_t bytes) -> int {
         v.emplace_back(new PoolBuf(ctx));
         return pool_alloc(ctx, bytes, &v.back()->p);
@@ -568,7 +647,8 @@ extern "C" int p2hot_group_commit(p2hot_group *g, const uint64_t *const *cols, s
             P2_HIP(ctx, hipSetDevice(ctx->device));
             const size_t c0 = std::min(W, s * p.cols_per_rank), c1 = std::min(W, c0 + p.cols_per_rank);
             P2_TRY(alloc(b_cols, ctx, std::max<size_t>(1, c1 - c0) * n * 8));
-            P2_TRY(alloc(b_co, ctx, std::max<size_t>(1, L * p.cols_per_rank) * n * 8));
+            P2_TRY(alloc(b_co, ctx, std::max<size_t>(1, by_columns ? p.cols_per_rank : L * p.cols_per_rank) * n * 8));
+            P2_TRY(alloc(b_ldecols, ctx, by_columns ? std::max<size_t>(1, c1 - c0) * p.N * 8 : 8));
             P2_TRY(alloc(b_lde, ctx, std::max<size_t>(1, W) * p.rows_per_rank * 8));
             P2_TRY(alloc(b_leaves, ctx, leaves_out ? std::max<size_t>(1, W) * p.rows_per_rank * 8 : 8));
             P2_TRY(alloc(b_dig, ctx, std::max<size_t>(1, nd) * 32));
@@ -577,11 +657,29 @@ extern "C" int p2hot_group_commit(p2hot_group *g, const uint64_t *const *cols, s
                 P2_HIP(ctx, hipMemcpyAsync(b_cols[s]->u() + (c - c0) * n, cols[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
             as[s] = ShardArgs{b_cols[s]->u(), n, b_co[s]->u(), b_lde[s]->u(), p.rows_per_rank, leaves_out ? b_leaves[s]->u() : nullptr,
                               b_dig[s]->u(), b_cap[s]->u()};
+            cas[s] = ColShardArgs{b_cols[s]->u(), b_co[s]->u(), b_ldecols[s]->u(), b_lde[s]->u(), leaves_out ? b_leaves[s]->u() : nullptr,
+                                  b_dig[s]->u(), b_cap[s]->u()};
         }
-        P2_TRY(sharded_commit_core(g->comm, as, p, is_values, /*gather_digests=*/0, pipeline_chunks ? pipeline_chunks : 8));
+        if (by_columns) {
+            P2_TRY(sharded_commit_columns_core(g->comm, cas, p, is_values));
+            // the coefficients live with the rank that owns the column
+            for (size_t s = 0; s < L && coeffs_out; ++s) {
+                p2hot_ctx *ctx = g->ctx[s];
+                P2_HIP(ctx, hipSetDevice(ctx->device));
+                const size_t c0 = std::min(W, s * p.cols_per_rank), c1 = std::min(W, c0 + p.cols_per_rank);
+                if (c1 == c0) continue;
+                if (!is_values) {
+                    P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv((c1 - c0) * n, 256)), dim3(256), 0, ctx->stream, cas[s].coeffs_local, (c1 - c0) * n);
+                    P2_LAUNCH_CHECK(ctx);
+                }
+                P2_HIP(ctx, hipMemcpyAsync(coeffs_out + c0 * n, cas[s].coeffs_local, (c1 - c0) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+            }
+        } else {
+            P2_TRY(sharded_commit_core(g->comm, as, p, is_values, /*gather_digests=*/0, pipeline_chunks ? pipeline_chunks : 8));
+        }
         // results: the coefficients and the cap from rank 0 (complete everywhere), digests / leaves from their owners
         P2_HIP(ctx0, hipSetDevice(ctx0->device));
-        if (coeffs_out && W) {
+        if (coeffs_out && W && !by_columns) {
             if (!is_values) {
                 P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(W * n, 256)), dim3(256), 0, ctx0->stream, as[0].coeffs_all, W * n);
                 P2_LAUNCH_CHECK(ctx0);

@@ -204,8 +204,11 @@ class GroupCommit:
         if rc != _lib.OK:
             raise _lib.P2HotError(rc, self.lib.p2hot_group_last_error(self._h).decode())
 
-    def commit(self, cols, rate_bits, cap_height, is_values=True, want_leaves=False, want_digests=True, pipeline_chunks=8):
-        """cols: host [W][n].  Returns dict(coeffs, leaves, digests, cap) host arrays + an opener for rows / paths."""
+    def commit(self, cols, rate_bits, cap_height, is_values=True, want_leaves=False, want_digests=True, pipeline_chunks=8,
+               by_columns=False):
+        """cols: host [W][n].  Returns dict(coeffs, leaves, digests, cap) host arrays + an opener for rows / paths.
+        by_columns: the column-sharded fallback (P2HOT_SHARD_COLUMNS: whole-column LDEs + an all-to-all of the LDE matrix;
+        no world <= 2^rate_bits constraint)."""
         cols = np.ascontiguousarray(np.asarray(cols, dtype=np.uint64))
         W, n = cols.shape
         log_n = int(n).bit_length() - 1
@@ -217,7 +220,8 @@ class GroupCommit:
         cap = np.zeros((ncap, 4), dtype=np.uint64)
         bh = C.c_void_p()
         self._check(self.lib.p2hot_group_commit(
-            self._h, ptrs, W, log_n, rate_bits, cap_height, 1 if is_values else 0, pipeline_chunks, coeffs.ctypes.data,
+            self._h, ptrs, W, log_n, rate_bits, cap_height, 1 if is_values else 0, 1 if by_columns else 0, pipeline_chunks,
+            coeffs.ctypes.data,
             leaves.ctypes.data if want_leaves else None, digests.ctypes.data if want_digests else None, cap.ctypes.data,
             C.byref(bh)))
         lib, group = self.lib, self

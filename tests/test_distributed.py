@@ -189,3 +189,27 @@ def test_group_and_comm_argument_errors():
         for r in range(world):
             assert lib.p2hot_shard_columns(W, world, r, C.byref(first), C.byref(count)) == 0
             assert (first.value, first.value + count.value) == p.columns(r)
+
+
+@pytest.mark.parametrize("world,W,log_n,rb,cap,is_values", [
+    (2, 5, 5, 3, 4, True), (4, 135, 3, 3, 4, True), (8, 20, 4, 3, 4, False),
+    (4, 2, 6, 1, 4, True), (8, 2, 5, 1, 3, True),     # starky: rate 1/2 has two cosets, columns still shard over 4 / 8 ranks
+    (8, 3, 4, 3, 3, True)])                            # fewer columns than ranks: some ranks transform nothing, all hash
+def test_group_commit_column_sharded_fallback(ora, world, W, log_n, rb, cap, is_values):
+    """P2HOT_SHARD_COLUMNS (last row): whole-column LDEs per rank, an all-to-all of the LDE matrix to row
+    blocks, then the same per-rank hashing -- bit-identical to the oracle and therefore to the coset scheme"""
+    from plonky2_amd.distributed import GroupCommit
+    from tests.emu_backend import emu_lib
+    rng = np.random.default_rng(world * 77 + W)
+    cols = rand_field(rng, W, 1 << log_n, noncanonical=True)
+    o = ora.commit(cols, rb, cap, is_values)
+    g = GroupCommit(emu_lib(), world, [0] * world)
+    r = g.commit(cols, rb, cap, is_values, want_leaves=True, by_columns=True)
+    assert (r["coeffs"] == o["coeffs"] % np.uint64(0xFFFFFFFF00000001)).all()
+    assert (r["cap"] == o["cap"]).all() and (r["digests"] == o["digests"]).all() and (r["leaves"] == o["leaves"]).all()
+    N = 1 << (log_n + rb)
+    rows, paths = r["open"]([0, N - 1, N // 2])
+    for x, row, path in zip([0, N - 1, N // 2], rows, paths):
+        assert (row == o["leaves"][x]).all() and ora.merkle_verify(row, x, o["cap"], path)
+    r["free"]()
+    g.close()

@@ -169,8 +169,9 @@ def test_fri_commit_phase_full_size_vs_oracle(gpu, ora, log_n, rb, arity):
     assert c.get_n_challenges(2) == oc.get_n_challenges(2)
 
 
-@pytest.mark.parametrize("world,W,log_n,chunks", [(2, 9, 12, 3), (4, 20, 14, 8), (8, 135, 12, 4)])
-def test_group_commit_ranks_on_one_gpu(gpu, ora, world, W, log_n, chunks):
+@pytest.mark.parametrize("world,W,log_n,chunks,by_columns", [(2, 9, 12, 3, False), (4, 20, 14, 8, False), (8, 135, 12, 4, False),
+                                                             (4, 20, 13, 1, True), (8, 135, 11, 1, True)])
+def test_group_commit_ranks_on_one_gpu(gpu, ora, world, W, log_n, chunks, by_columns):
     """p2hot_group_commit on the real GPU: `world` ranks of ONE process, all on device 0 (the box has one GPU), exchanging
     by copies on their communicator streams; coefficients, leaves, the whole digest array and the cap equal the oracle's,
     and the owner of a row serves its Merkle path"""
@@ -182,7 +183,7 @@ def test_group_commit_ranks_on_one_gpu(gpu, ora, world, W, log_n, chunks):
     g = GroupCommit(gpu.lib, world, [0] * world)
     assert not g.uses_rccl          # a repeated device cannot carry an RCCL communicator
     for _ in range(2):
-        r = g.commit(cols, rb, cap, True, want_leaves=True, pipeline_chunks=chunks)
+        r = g.commit(cols, rb, cap, True, want_leaves=True, pipeline_chunks=chunks, by_columns=by_columns)
         assert (r["coeffs"] == o["coeffs"]).all() and (r["cap"] == o["cap"]).all()
         assert (r["digests"] == o["digests"]).all() and (r["leaves"] == o["leaves"]).all()
         N = 1 << (log_n + rb)
