@@ -73,8 +73,9 @@ def pmc_valu(W, log_n, rb, cap, world):
 
 def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=45.0, golden_cap=None):
     """The tuned CPU implementation of the same step (oracle/p2fast.c, "port-tuned": branch-free reduce128, the
-    reference's fast-partial Poseidon with lazily reduced u128 accumulators, cached root tables, coset-by-coset LDE,
-    OpenMP over the host cores this job may use), bit-exact against the faithful oracle (tests/test_fast_oracle.py).
+    reference's fast-partial Poseidon, eight rows per AVX-512 instruction stream in the leaf sponge / tree levels / NTT
+    layers when the CPU has AVX-512, cached root tables, coset-by-coset LDE, OpenMP over the host cores this job may
+    use), bit-exact against the faithful oracle (tests/test_fast_oracle.py).
     The WHOLE 2^log_n-row step is timed when a 1/16 sample predicts it fits the budget, else the largest power-of-two
     row count that does.  NOT the Rust prover (no cargo in the image)."""
     from oracle import p2fast as fast
@@ -97,8 +98,8 @@ def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=45.0, golden_cap=None
     whole = kk == log_n
     out = {"value": fe / dt / 1e9, "unit": "GFE/s", "cores": cores, "kind": "port-tuned", "seconds": dt,
            "sample": ("the whole step" if whole else "1/%d of the GPU step's rows" % (1 << (log_n - kk)))
-                     + ": from_values W=%d, 2^%d rows, rate 1/%d, cap %d, %.2f s on %d cores; oracle/p2fast.c (tuned C + OpenMP restatement "
-                       "of the reference algorithm), not the Rust prover (no cargo in the image)" % (W, kk, 1 << rate_bits, cap_height, dt, cores),
+                     + ": from_values W=%d, 2^%d rows, rate 1/%d, cap %d, %.2f s on %d cores; oracle/p2fast.c (tuned C + OpenMP + AVX-512 "
+                       "restatement of the reference algorithm), not the Rust prover (no cargo in the image)" % (W, kk, 1 << rate_bits, cap_height, dt, cores),
            "stage_seconds": {k_: round(v, 4) for k_, v in tm.items()},  # the reference's TimingTree scopes, fri/oracle.rs:65-103
            "us_per_permutation_per_core": tm["build Merkle tree"] * cores / (((W + 7) // 8 + 1) * (1 << (kk + rate_bits))) * 1e6}
     if whole and golden_cap is not None:

@@ -25,6 +25,10 @@
  *    so the working set is one [W][n] block instead of the [W][N] matrix.
  *  - "transpose LDEs": cache-blocked, per coset block; "build Merkle tree": flat-parallel leaf sponge,
  *    then level-parallel inner nodes.
+ *  - AVX-512 (F + DQ, checked at run time, P2FAST_SCALAR=1 disables it): the leaf sponge and the tree levels hash eight
+ *    rows / nodes per instruction stream (one 64-bit lane per state, 64 x 64 products from four vpmuludq), the NTT layers
+ *    run eight butterflies per stream like the reference's packed fft_classic_simd (fft.rs:95-157).  The reference's own
+ *    Poseidon is scalar on x86, so this baseline is, per core, faster than what the Rust prover would show.
  * OpenMP over columns / rows / nodes mirrors the reference's rayon fork-join points.
  * seconds[] reports the reference's TimingTree scopes (fri/oracle.rs:65-103): "IFFT",
  * "FFT + blinding", "transpose LDEs", "build Merkle tree".
@@ -180,9 +184,14 @@ static void poseidon(u64 s[12]) { /* poseidon.rs:767-777 */
     for (int k = 0; k < 4; ++k) full_round(s, round++);
 }
 
+static int have_avx512(void);
+static void permute8(u64 *states);
 void fast_poseidon(u64 *states, size_t count) {
+    const size_t groups = have_avx512() ? count / 8 : 0;
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < count; ++i) {
+    for (size_t g = 0; g < groups; ++g) permute8(states + 96 * g);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 8 * groups; i < count; ++i) {
         u64 *s = states + 12 * i;
         poseidon(s);
         for (int k = 0; k < 12; ++k) s[k] = canon(s[k]);
@@ -209,9 +218,188 @@ INL void two_to_one(const u64 *l, const u64 *r, u64 out[4]) { /* hashing.rs:97-1
     for (int i = 0; i < 4; ++i) out[i] = canon(s[i]);
 }
 
-void fast_hash_rows(const u64 *rows, size_t n_rows, size_t w, u64 *out) {
+static void hash_rows_any(const u64 *rows, size_t n_rows, size_t w, u64 *out);
+void fast_hash_rows(const u64 *rows, size_t n_rows, size_t w, u64 *out) { hash_rows_any(rows, n_rows, w, out); }
+
+/* ------------------------------------------------------------------ AVX-512: eight permutations per instruction stream
+ * The reference's Poseidon is scalar on x86 (its AVX2 variant is commented out, hash/poseidon_goldilocks.rs:250-262), but
+ * a leaf sponge over millions of independent rows vectorises across rows: one 64-bit lane per row, eight rows per zmm
+ * register, the 12-word state in 12 registers.  A 64 x 64 -> 128 product is four vpmuludq (32 x 32 -> 64) partial
+ * products; the reduction is the same reduce128 with mask registers for the borrow / carry corrections.  Used when the CPU
+ * has AVX-512 F + DQ (checked at run time; the scalar path above is the fallback and the bit-exact cross-check). */
+#include <immintrin.h>
+typedef __m512i V;
+#define VT __attribute__((target("avx512f,avx512dq"), always_inline)) static inline
+#define VK(x) _mm512_set1_epi64((long long)(x))
+
+VT V vred(V lo, V hi) { /* reduce128, goldilocks_field.rs:402-415 */
+    const V E = VK(EPS);
+    V hh = _mm512_srli_epi64(hi, 32), hl = _mm512_and_si512(hi, E);
+    V t0 = _mm512_sub_epi64(lo, hh);
+    __mmask8 b = _mm512_cmplt_epu64_mask(lo, hh);
+    t0 = _mm512_mask_sub_epi64(t0, b, t0, E);
+    V t1 = _mm512_sub_epi64(_mm512_slli_epi64(hl, 32), hl);
+    V t2 = _mm512_add_epi64(t0, t1);
+    __mmask8 c = _mm512_cmplt_epu64_mask(t2, t1);
+    return _mm512_mask_add_epi64(t2, c, t2, E);
+}
+VT V vmul(V a, V b) {
+    const V M = VK(EPS);
+    V ah = _mm512_srli_epi64(a, 32), bh = _mm512_srli_epi64(b, 32);
+    V ll = _mm512_mul_epu32(a, b), lh = _mm512_mul_epu32(a, bh), hl = _mm512_mul_epu32(ah, b), hh = _mm512_mul_epu32(ah, bh);
+    V mid = _mm512_add_epi64(lh, _mm512_srli_epi64(ll, 32));   /* < 2^64: (2^32-1)^2 + 2^32 - 1 */
+    V mid2 = _mm512_add_epi64(hl, _mm512_and_si512(mid, M));
+    V lo = _mm512_or_si512(_mm512_slli_epi64(mid2, 32), _mm512_and_si512(ll, M));
+    V hi = _mm512_add_epi64(hh, _mm512_add_epi64(_mm512_srli_epi64(mid, 32), _mm512_srli_epi64(mid2, 32)));
+    return vred(lo, hi);
+}
+VT V vadd(V a, V b) { /* any representatives: two wrap corrections */
+    const V E = VK(EPS);
+    V s = _mm512_add_epi64(a, b);
+    __mmask8 c = _mm512_cmplt_epu64_mask(s, a);
+    V s2 = _mm512_mask_add_epi64(s, c, s, E);
+    __mmask8 c2 = _mm512_mask_cmplt_epu64_mask(c, s2, E);
+    return _mm512_mask_add_epi64(s2, c2, s2, E);
+}
+VT V vadd_canon(V a, V k) { /* k canonical (< P): one correction is enough */
+    V s = _mm512_add_epi64(a, k);
+    __mmask8 c = _mm512_cmplt_epu64_mask(s, a);
+    return _mm512_mask_add_epi64(s, c, s, VK(EPS));
+}
+VT V vsbox(V x) {
+    V x2 = vmul(x, x), x4 = vmul(x2, x2), x3 = vmul(x, x2);
+    return vmul(x3, x4);
+}
+VT void vmds(V s[12]) { /* poseidon.rs:180-199, :271-290 on the 32-bit halves, one row at a time */
+    V hi[12], out[12];
+    const V E = VK(EPS);
+    for (int i = 0; i < 12; ++i) hi[i] = _mm512_srli_epi64(s[i], 32);
+    for (int r = 0; r < 12; ++r) {
+        V al = _mm512_setzero_si512(), ah = _mm512_setzero_si512();
+        for (int i = 0; i < 12; ++i) {
+            const V c = VK(P2_POSEIDON_MDS_CIRC[i]);
+            const int j = r + i >= 12 ? r + i - 12 : r + i;
+            al = _mm512_add_epi64(al, _mm512_mul_epu32(s[j], c)); /* vpmuludq reads the low 32 bits of s[j] */
+            ah = _mm512_add_epi64(ah, _mm512_mul_epu32(hi[j], c));
+        }
+        if (r == 0) {
+            const V d = VK(P2_POSEIDON_MDS_DIAG[0]);
+            al = _mm512_add_epi64(al, _mm512_mul_epu32(s[0], d));
+            ah = _mm512_add_epi64(ah, _mm512_mul_epu32(hi[0], d));
+        }
+        /* al + ah * 2^32 (< 2^75): lo64 with its carry, the bits above 2^64 fold with 2^64 = EPS */
+        V sh = _mm512_slli_epi64(ah, 32);
+        V lo = _mm512_add_epi64(al, sh);
+        __mmask8 c = _mm512_cmplt_epu64_mask(lo, sh);
+        V top = _mm512_mask_add_epi64(_mm512_srli_epi64(ah, 32), c, _mm512_srli_epi64(ah, 32), VK(1)); /* < 2^11 */
+        V t = _mm512_sub_epi64(_mm512_slli_epi64(top, 32), top);                                    /* top * EPS */
+        V y = _mm512_add_epi64(lo, t);
+        __mmask8 c2 = _mm512_cmplt_epu64_mask(y, t);
+        out[r] = _mm512_mask_add_epi64(y, c2, y, E);
+    }
+    for (int r = 0; r < 12; ++r) s[r] = out[r];
+}
+VT void vfull_round(V s[12], unsigned round) {
+    for (int i = 0; i < 12; ++i) s[i] = vsbox(vadd_canon(s[i], VK(P2_POSEIDON_ALL_ROUND_CONSTANTS[12 * round + i])));
+    vmds(s);
+}
+__attribute__((target("avx512f,avx512dq"))) static void poseidon8(V s[12]) { /* poseidon.rs:767-777, eight states */
+    unsigned round = 0;
+    for (int k = 0; k < 4; ++k) vfull_round(s, round++);
+    for (int i = 0; i < 12; ++i) s[i] = vadd_canon(s[i], VK(P2_POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT[i]));
+    {   /* mds_partial_layer_init (poseidon.rs:415-441) */
+        V t[11];
+        for (int c = 0; c < 11; ++c) {
+            V acc = vmul(s[1], VK(P2_POSEIDON_FAST_PARTIAL_ROUND_INITIAL_MATRIX[c]));
+            for (int r = 2; r < 12; ++r) acc = vadd(acc, vmul(s[r], VK(P2_POSEIDON_FAST_PARTIAL_ROUND_INITIAL_MATRIX[(r - 1) * 11 + c])));
+            t[c] = acc;
+        }
+        for (int c = 0; c < 11; ++c) s[c + 1] = t[c];
+    }
+    const V m00 = VK(P2_POSEIDON_MDS_CIRC[0] + P2_POSEIDON_MDS_DIAG[0]);
+    for (int i = 0; i < 22; ++i) { /* poseidon.rs:752-764, :516-542 */
+        const u64 *wh = P2_POSEIDON_FAST_PARTIAL_ROUND_W_HATS + 11 * i, *vs = P2_POSEIDON_FAST_PARTIAL_ROUND_VS + 11 * i;
+        const V s0 = vadd_canon(vsbox(s[0]), VK(P2_POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[i]));
+        V d = vmul(s0, m00);
+        for (int j = 1; j < 12; ++j) d = vadd(d, vmul(s[j], VK(wh[j - 1])));
+        for (int j = 1; j < 12; ++j) s[j] = vadd(s[j], vmul(s0, VK(vs[j - 1])));
+        s[0] = d;
+    }
+    round += 22;
+    for (int k = 0; k < 4; ++k) vfull_round(s, round++);
+}
+VT V vcanon(V x) {
+    __mmask8 ge = _mm512_cmpge_epu64_mask(x, VK(P));
+    return _mm512_mask_sub_epi64(x, ge, x, VK(P));
+}
+
+static int have_avx512(void) {
+    static int v = -1;
+    if (v < 0) v = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && !getenv("P2FAST_SCALAR");
+    return v;
+}
+
+/* hash_or_noop of 8 rows at once (w > 4): rows r0 .. r0+7 of a row-major matrix with row stride `stride` words */
+__attribute__((target("avx512f,avx512dq"))) static void hash8(const u64 *rows, size_t stride, size_t w, u64 *out /* [8][4] */) {
+    const V idx = _mm512_mullo_epi64(_mm512_set_epi64(7, 6, 5, 4, 3, 2, 1, 0), VK(stride));
+    V s[12];
+    for (int i = 0; i < 12; ++i) s[i] = _mm512_setzero_si512();
+    for (size_t off = 0; off < w; off += 8) {
+        const size_t c = w - off < 8 ? w - off : 8;
+        for (size_t i = 0; i < c; ++i) s[i] = _mm512_i64gather_epi64(idx, (const long long *)(rows + off + i), 8);
+        poseidon8(s);
+    }
+    const V oidx = _mm512_set_epi64(28, 24, 20, 16, 12, 8, 4, 0);
+    for (int i = 0; i < 4; ++i) _mm512_i64scatter_epi64((long long *)(out + i), oidx, vcanon(s[i]), 8);
+}
+/* two_to_one of 8 sibling pairs: pairs[k] = {l[4], r[4]} contiguous (8 words per node), out [8][4] */
+__attribute__((target("avx512f,avx512dq"))) static void two_to_one8(const u64 *pairs, u64 *out) {
+    const V idx = _mm512_set_epi64(56, 48, 40, 32, 24, 16, 8, 0);
+    V s[12];
+    for (int i = 0; i < 8; ++i) s[i] = _mm512_i64gather_epi64(idx, (const long long *)(pairs + i), 8);
+    for (int i = 8; i < 12; ++i) s[i] = _mm512_setzero_si512();
+    poseidon8(s);
+    const V oidx = _mm512_set_epi64(28, 24, 20, 16, 12, 8, 4, 0);
+    for (int i = 0; i < 4; ++i) _mm512_i64scatter_epi64((long long *)(out + i), oidx, vcanon(s[i]), 8);
+}
+__attribute__((target("avx512f,avx512dq"))) static void permute8(u64 *states /* [8][12] */) {
+    const V idx = _mm512_set_epi64(84, 72, 60, 48, 36, 24, 12, 0);
+    V s[12];
+    for (int i = 0; i < 12; ++i) s[i] = _mm512_i64gather_epi64(idx, (const long long *)(states + i), 8);
+    poseidon8(s);
+    for (int i = 0; i < 12; ++i) _mm512_i64scatter_epi64((long long *)(states + i), idx, vcanon(s[i]), 8);
+}
+
+/* leaf digests of n_rows rows (row-major, width w): the AVX-512 path on groups of 8 rows, scalar for the rest */
+static void hash_rows_any(const u64 *rows, size_t n_rows, size_t w, u64 *out) {
+    const size_t groups = (have_avx512() && w > 4) ? n_rows / 8 : 0;
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < n_rows; ++i) hash_or_noop(rows + i * w, w, out + 4 * i);
+    for (size_t g = 0; g < groups; ++g) hash8(rows + 8 * g * w, w, w, out + 32 * g);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 8 * groups; i < n_rows; ++i) hash_or_noop(rows + i * w, w, out + 4 * i);
+}
+
+VT V vsub(V a, V b) { /* any representatives */
+    const V E = VK(EPS);
+    V d = _mm512_sub_epi64(a, b);
+    __mmask8 c = _mm512_cmplt_epu64_mask(a, b);
+    V d2 = _mm512_mask_sub_epi64(d, c, d, E);
+    __mmask8 c2 = _mm512_mask_cmplt_epu64_mask(c, d, E);
+    return _mm512_mask_sub_epi64(d2, c2, d2, E);
+}
+/* one DIF layer on blocks of m = 2 * half >= 16 points, eight butterflies per instruction stream (the reference's
+ * fft_classic_simd, field/src/fft.rs:95-157, does the same with its packed field type) */
+__attribute__((target("avx512f,avx512dq"))) static void dif_layer_avx512(u64 *v, size_t n, size_t half, size_t stride, const u64 *tw) {
+    const V step = _mm512_mullo_epi64(_mm512_set_epi64(7, 6, 5, 4, 3, 2, 1, 0), VK(stride));
+    for (size_t k = 0; k < n; k += 2 * half) {
+        u64 *a = v + k, *b = v + k + half;
+        for (size_t j = 0; j < half; j += 8) {
+            const V x = _mm512_loadu_si512((const void *)(a + j)), y = _mm512_loadu_si512((const void *)(b + j));
+            const V w = stride == 1 ? _mm512_loadu_si512((const void *)(tw + j)) : _mm512_i64gather_epi64(step, (const long long *)(tw + j * stride), 8);
+            _mm512_storeu_si512((void *)(a + j), vadd(x, y));
+            _mm512_storeu_si512((void *)(b + j), vmul(vsub(x, y), w));
+        }
+    }
 }
 
 /* ------------------------------------------------------------------ NTT (field/src/fft.rs) */
@@ -247,7 +435,9 @@ static void ntt_dif(u64 *v, unsigned log_n, const u64 *tw) {
     const size_t n = (size_t)1 << log_n;
     for (unsigned lg_m = log_n; lg_m >= 1; --lg_m) {
         const size_t m = (size_t)1 << lg_m, half = m >> 1, stride = n >> lg_m;
-        if (half >= 4) {
+        if (half >= 8 && have_avx512()) {
+            dif_layer_avx512(v, n, half, stride, tw);
+        } else if (half >= 4) {
             for (size_t k = 0; k < n; k += m) {
                 u64 *a = v + k, *b = v + k + half;
                 for (size_t j = 0; j < half; ++j) {
@@ -338,8 +528,7 @@ int fast_commit(const u64 *cols, size_t W, unsigned log_n, unsigned rate_bits, u
             }
         double t3 = now_s();
         /* "build Merkle tree", leaves (merkle_tree.rs:86-113 fill_subtree's leaf case) */
-#pragma omp parallel for schedule(static)
-        for (size_t q = 0; q < n; ++q) hash_or_noop(r + q * W, W, leaf_dig + 4 * (b * n + q));
+        hash_rows_any(r, n, W, leaf_dig + 4 * b * n);
         double t4 = now_s();
         t_fft += t2 - t1;
         t_tr += t3 - t2;
@@ -358,18 +547,19 @@ int fast_commit(const u64 *cols, size_t W, unsigned log_n, unsigned rate_bits, u
         if (!nxt || !dig) return -2;
         for (unsigned lvl = 0; lvl < h; ++lvl) {
             const size_t per = sub_leaves >> lvl; /* nodes of this level per subtree */
+            const size_t parents = n_cap * per / 2;
+            u64 *dst = (lvl + 1 == h) ? cap_out : nxt; /* parent g's digest goes to dst + 4 g (at the top level g = subtree) */
 #pragma omp parallel for schedule(static)
-            for (size_t g = 0; g < n_cap * per / 2; ++g) { /* g = parent index over the whole forest */
+            for (size_t g = 0; g < parents; ++g) { /* g = parent index over the whole forest; its children are cur[2g], cur[2g+1] */
                 const size_t sidx = g / (per / 2), jp = g % (per / 2);
-                const u64 *l = cur + 4 * (sidx * per + 2 * jp), *rr = l + 4;
                 u64 *slot = dig + 4 * (sidx * sub_digests + 2 * ((jp << (lvl + 1)) + ((size_t)1 << lvl) - 1));
-                memcpy(slot, l, 32);
-                memcpy(slot + 4, rr, 32);
-                if (lvl + 1 == h)
-                    two_to_one(l, rr, cap_out + 4 * sidx);
-                else
-                    two_to_one(l, rr, nxt + 4 * g);
+                memcpy(slot, cur + 8 * g, 64);
             }
+            const size_t groups = have_avx512() ? parents / 8 : 0;
+#pragma omp parallel for schedule(static)
+            for (size_t q = 0; q < groups; ++q) two_to_one8(cur + 64 * q, dst + 32 * q);
+#pragma omp parallel for schedule(static)
+            for (size_t g = 8 * groups; g < parents; ++g) two_to_one(cur + 8 * g, cur + 8 * g + 4, dst + 4 * g);
             if (lvl == 0) {
                 cur = nxt;
                 nxt = (u64 *)malloc(N * 8 > 32 ? N * 8 : 32);

@@ -76,3 +76,23 @@ def test_golden_caps_file_matches_the_oracle_on_the_small_config(ora):
     assert [[int(x) for x in row] for row in f["cap"]] == r["cap"]
     assert hashlib.sha256(f["digests"].tobytes()).hexdigest() == r["sha256_digests"]
     assert hashlib.sha256(f["coeffs"].tobytes()).hexdigest() == r["sha256_coeffs"]
+
+
+def test_fast_scalar_and_avx512_paths_agree(ora):
+    """oracle/p2fast.c picks its AVX-512 leaf sponge (eight rows per instruction stream) at run time; P2FAST_SCALAR=1
+    forces the scalar path.  Both must produce the faithful oracle's bytes -- run the scalar one in a fresh process (the
+    choice is cached per process)."""
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from oracle import p2fast as f, p2oracle as o\n"
+            "rng = np.random.default_rng(5)\n"
+            "c = rng.integers(0, 2**64 - 1, size=(19, 64), dtype=np.uint64)\n"
+            "a, b = f.commit(c, 3, 2, True, want_leaves=True), o.commit(c, 3, 2, True)\n"
+            "assert (a['digests'] == b['digests']).all() and (a['cap'] == b['cap']).all() and (a['leaves'] == b['leaves']).all()\n"
+            "st = rng.integers(0, 2**64 - 1, size=(21, 12), dtype=np.uint64)\n"
+            "assert (f.poseidon(st) == np.stack([o.poseidon(s) for s in st])).all()\n"
+            "print('ok')\n" % ROOT)
+    for env in ({"P2FAST_SCALAR": "1"}, {}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, **env})
+        assert r.returncode == 0 and "ok" in r.stdout, r.stderr
