@@ -10,7 +10,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import splitmix_columns_numpy  # noqa: E402
+from plonky2_amd.util.synthetic import splitmix_columns_numpy  # noqa: E402
 from plonky2_amd import Engine  # noqa: E402
 
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
