@@ -24,15 +24,15 @@
 //! (tests/test_integration_files.py) but has not been compiled here.
 #![allow(non_camel_case_types, clippy::missing_safety_doc, clippy::too_many_arguments)]
 
-use core::any::TypeId;
+use core::any::type_name;
 use core::ffi::{c_char, c_int, c_uint, c_void};
 use std::collections::HashMap;
 use std::sync::{Mutex, OnceLock};
 
-use crate::field::extension::Extendable;
+use crate::field::extension::{Extendable, FieldExtension};
 use crate::field::goldilocks_field::GoldilocksField;
 use crate::field::polynomial::{PolynomialCoeffs, PolynomialValues};
-use crate::field::types::Field;
+use crate::field::types::{Field, PrimeField64};
 use crate::fri::oracle::PolynomialBatch;
 use crate::fri::proof::{FriInitialTreeProof, FriProof, FriQueryRound, FriQueryStep};
 use crate::fri::structure::FriInstanceInfo;
@@ -346,12 +346,14 @@ fn leaves_on_device() -> bool {
     matches!(std::env::var("P2HOT_LEAVES").as_deref(), Ok("device"))
 }
 
-/// Does the GPU path apply to this instantiation?  (TypeId / size checks instead of a plugin trait.)
+/// Does the GPU path apply to this instantiation?  (type / size checks instead of a plugin trait;
+/// `type_name` rather than `TypeId` because the config's associated types carry no `'static` bound.)
 pub fn applies<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(blinding: bool) -> bool {
     !blinding
         && D == 2
-        && TypeId::of::<F>() == TypeId::of::<GoldilocksField>()
-        && TypeId::of::<C::Hasher>() == TypeId::of::<PoseidonHash>()
+        && type_name::<F>() == type_name::<GoldilocksField>()
+        && type_name::<C::Hasher>() == type_name::<PoseidonHash>()
+        && core::mem::size_of::<F>() == 8
         && core::mem::size_of::<<C::Hasher as Hasher<F>>::Hash>() == 32
 }
 
@@ -417,8 +419,7 @@ impl<F: RichField> DeviceTree<F> {
         if !cache.contains_key(&i) {
             let idx = [i as u64];
             let row: Vec<F> = vec_from_words(self.width, |p| {
-                let rc = unsafe { p2hot_batch_rows(self.batch, idx.as_ptr(), 1, p) };
-                with_ctx(|c| check(c, rc, "p2hot_batch_rows"));
+                with_ctx(|c| check(c, unsafe { p2hot_batch_rows(self.batch, idx.as_ptr(), 1, p) }, "p2hot_batch_rows"));
             });
             cache.insert(i, row.into_boxed_slice());
         }
@@ -431,8 +432,7 @@ impl<F: RichField> DeviceTree<F> {
     pub fn path<H: Hasher<F>>(&self, leaf_index: usize) -> Vec<H::Hash> {
         let idx = [leaf_index as u64];
         vec_from_words(self.num_layers, |p| {
-            let rc = unsafe { p2hot_batch_paths(self.batch, idx.as_ptr(), 1, p) };
-            with_ctx(|c| check(c, rc, "p2hot_batch_paths"));
+            with_ctx(|c| check(c, unsafe { p2hot_batch_paths(self.batch, idx.as_ptr(), 1, p) }, "p2hot_batch_paths"));
         })
     }
 }
@@ -440,7 +440,7 @@ impl<F: RichField> DeviceTree<F> {
 impl<F: RichField> Drop for DeviceTree<F> {
     fn drop(&mut self) {
         // returns the LDE matrix, the digests and the coefficients to the context's block cache
-        unsafe { p2hot_batch_free(self.batch) };
+        with_ctx(|_| unsafe { p2hot_batch_free(self.batch) });
     }
 }
 

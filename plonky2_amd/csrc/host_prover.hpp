@@ -537,6 +537,7 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
         *d_alpha = d_rand + Q, *d_best = d_alpha + 2, *d_resp = d_best + 1, *d_chsave = d_resp + 1;
     fri::ArityBits ab{};
     if (n_rounds > 32) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: more than 32 reduction rounds");
+    if (fp->proof_of_work_bits > 64) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: proof_of_work_bits > 64");
     for (unsigned r = 0; r < n_rounds; ++r) ab.b[r] = (unsigned char)fp->reduction_arity_bits[r];
     size_t w_sum = 0;
     for (size_t o = 0; o < n_oracles; ++o) w_sum += oracles[o]->W;

@@ -1230,8 +1230,10 @@ static int pow_search_dev(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned
     // P2HOT_POW_RANGE_LOG (tests): log2 of the searched range relative to the expected 2^pow_bits trials, default 5
     int extra = 5;
     if (const char *e = getenv("P2HOT_POW_RANGE_LOG")) extra = atoi(e);
-    const int lg = (int)pow_bits + extra;
-    const u64 limit = lg >= 63 ? gl::P : std::min<u64>(gl::P, (u64)1 << (lg < 0 ? 0 : lg));
+    // never more than 2^34 candidates (about 1100 launches) without looking at the result: a grind that large is
+    // continued by pow_continue_host, which checks after every chunk
+    const int lg = std::min((int)pow_bits + extra, 34);
+    const u64 limit = (u64)1 << (lg < 0 ? 0 : lg);
     u64 chunk = (u64)1 << 14, start = 0;
     while (start < limit) {
         const u64 count = std::min(limit - start, chunk);

@@ -88,3 +88,36 @@ def test_memory_backends_have_the_same_surface():
     pub = lambda c: {m for m in dir(c) if not m.startswith("_")}
     assert pub(HostMemory) <= pub(TorchMemory) | {"DevArray"}, pub(HostMemory) - pub(TorchMemory)
     assert pub(TorchMemory) <= pub(HostMemory), pub(TorchMemory) - pub(HostMemory)
+
+
+def test_one_host_call_at_a_time_per_context(emu):
+    """A context runs one host-pointer call at a time: a second thread entering while a commit runs gets P2HOT_EBUSY
+    (no data race on the context's scratch blocks), and the context works normally afterwards."""
+    import threading
+    import time
+    from plonky2_amd import _lib
+    rng = np.random.default_rng(0)
+    W, log_n = 48, 9
+    cols = rng.integers(0, 2**63, size=(W, 1 << log_n), dtype=np.uint64)
+    ptrs = (C.c_void_p * W)(*[cols[c].ctypes.data for c in range(W)])
+    cap = np.zeros((4, 4), dtype=np.uint64)
+    rc_a = []
+
+    def worker():
+        rc_a.append(emu.lib.p2hot_commit(emu.ctx, ptrs, W, log_n, 3, 2, 1, 0, None, None, None, cap.ctypes.data, None))
+
+    t = threading.Thread(target=worker)
+    t.start()
+    seen_busy = False
+    deadline = time.time() + 60
+    while t.is_alive() and time.time() < deadline:
+        rc = emu.lib.p2hot_ctx_trim(emu.ctx)          # ctypes releases the GIL: this really runs beside the commit
+        if rc == _lib.EBUSY:
+            seen_busy = True
+            break
+        time.sleep(0.001)
+    t.join(120)
+    assert rc_a == [_lib.OK]
+    assert seen_busy, "the second caller was never refused while the commit was running"
+    assert emu.lib.p2hot_ctx_trim(emu.ctx) == _lib.OK
+    assert cap.any()
