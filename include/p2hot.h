@@ -425,6 +425,18 @@ int p2hot_group_commit(p2hot_group *group, const uint64_t *const *cols, size_t W
  * the row: rows_out [m][W], paths_out [m][log2(N) - cap_height][4]; either may be NULL */
 int p2hot_sharded_batch_open(p2hot_sharded_batch *batch, const uint64_t *leaf_idx, size_t m, uint64_t *rows_out, uint64_t *paths_out);
 void p2hot_sharded_batch_free(p2hot_sharded_batch *batch);
+/* OpeningSet::new, p2hot_fri_proof_sizes and PolynomialBatch::prove_openings + fri_proof (see the single-GPU entry points
+ * above) over sharded oracles of one group, coset mode only (every rank then holds all coefficients): rank 0 runs what
+ * needs the polynomials -- the evaluations, final_poly, the FRI commit phase (tiny after round 0), the grind --
+ * and the rows and Merkle paths of the initial trees come from the ranks that own them.  `challenger` belongs to
+ * p2hot_group_ctx(group, 0).  Same proof, bit for bit, as the single-GPU path on the same polynomials. */
+int p2hot_group_eval_openings(p2hot_group *group, const p2hot_sharded_batch *const *oracles, size_t n_oracles, const uint64_t *points,
+                              size_t n_points, uint64_t *out);
+int p2hot_group_fri_proof_sizes(const p2hot_sharded_batch *const *oracles, size_t n_oracles, const p2hot_fri_params *params,
+                                p2hot_fri_proof_layout *out);
+int p2hot_group_prove_openings(p2hot_group *group, const p2hot_fri_batch_info *batches, size_t n_batches,
+                               const p2hot_sharded_batch *const *oracles, size_t n_oracles, p2hot_challenger *challenger,
+                               const p2hot_fri_params *params, p2hot_fri_proof *proof);
 
 #ifdef __cplusplus
 }

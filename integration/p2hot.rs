@@ -291,6 +291,16 @@ extern "C" {
     ) -> c_int;
     pub fn p2hot_sharded_batch_open(batch: *mut P2hotShardedBatch, leaf_idx: *const u64, m: usize, rows_out: *mut u64, paths_out: *mut u64) -> c_int;
     pub fn p2hot_sharded_batch_free(batch: *mut P2hotShardedBatch);
+    pub fn p2hot_group_eval_openings(
+        group: *mut P2hotGroup, oracles: *const *const P2hotShardedBatch, n_oracles: usize, points: *const u64, n_points: usize, out: *mut u64,
+    ) -> c_int;
+    pub fn p2hot_group_fri_proof_sizes(
+        oracles: *const *const P2hotShardedBatch, n_oracles: usize, params: *const P2hotFriParams, out: *mut P2hotFriProofLayout,
+    ) -> c_int;
+    pub fn p2hot_group_prove_openings(
+        group: *mut P2hotGroup, batches: *const P2hotFriBatchInfo, n_batches: usize, oracles: *const *const P2hotShardedBatch, n_oracles: usize,
+        challenger: *mut P2hotChallenger, params: *const P2hotFriParams, proof: *mut P2hotFriProof,
+    ) -> c_int;
 }
 
 // ------------------------------------------------------------------------------------------------

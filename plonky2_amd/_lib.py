@@ -130,6 +130,10 @@ SIGNATURES = {
     "p2hot_group_commit": (i, [vp, C.POINTER(vp), sz, u, u, u, i, i, u, vp, vp, vp, vp, C.POINTER(vp)]),
     "p2hot_sharded_batch_open": (i, [vp, vp, sz, vp, vp]),
     "p2hot_sharded_batch_free": (None, [vp]),
+    "p2hot_group_eval_openings": (i, [vp, C.POINTER(vp), sz, vp, sz, vp]),
+    "p2hot_group_fri_proof_sizes": (i, [C.POINTER(vp), sz, C.POINTER(FriParams), C.POINTER(FriProofLayout)]),
+    "p2hot_group_prove_openings": (i, [vp, C.POINTER(FriBatchInfo), sz, C.POINTER(vp), sz, vp, C.POINTER(FriParams),
+                                       C.POINTER(FriProof)]),
 }
 
 

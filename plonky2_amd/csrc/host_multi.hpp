@@ -598,7 +598,8 @@ extern "C" const char *p2hot_group_last_error(const p2hot_group *g) {
 struct p2hot_sharded_batch {
     p2hot_group *g;
     ShardPlan plan;
-    std::vector<u64 *> coeffs_all, lde, digests;  // per rank; every rank holds ALL coefficients
+    std::vector<u64 *> coeffs_all, lde, digests;  // per rank; in the coset mode every rank holds ALL coefficients
+    bool by_columns = false;                       // column-sharded: rank r holds only its own columns' coefficients
 };
 
 extern "C" void p2hot_sharded_batch_free(p2hot_sharded_batch *b) {
@@ -717,7 +718,7 @@ extern "C" int p2hot_group_commit(p2hot_group *g, const uint64_t *const *cols, s
         for (auto *c : g->ctx)
             if (!c->err.empty()) ctx0->err = c->err;
     if (rc == P2HOT_OK && handle_out) {
-        p2hot_sharded_batch *b = new p2hot_sharded_batch{g, p, {}, {}, {}};
+        p2hot_sharded_batch *b = new p2hot_sharded_batch{g, p, {}, {}, {}, by_columns};
         for (size_t s = 0; s < L; ++s) {
             b->coeffs_all.push_back(b_co[s]->u());
             b->lde.push_back(b_lde[s]->u());
@@ -730,37 +731,142 @@ extern "C" int p2hot_group_commit(p2hot_group *g, const uint64_t *const *cols, s
 }
 
 // MerkleTree::get + merkle_tree_prove for m leaves of a sharded batch: every query is answered by the rank that owns the row
-// (a Merkle path below the cap never leaves the cap subtree of its leaf).  rows_out [m][W], paths_out [m][log2(N) - cap][4]; either may be NULL.
-extern "C" int p2hot_sharded_batch_open(p2hot_sharded_batch *b, const uint64_t *leaf_idx, size_t m, uint64_t *rows_out, uint64_t *paths_out) {
-    if (!b) return P2HOT_EINVAL;
+// (a Merkle path below the cap never leaves the cap subtree of its leaf).  One gather + one copy per owning rank.
+// rows_out: row q at rows_out + q * row_pitch (W words); paths_out: path q at paths_out + q * path_pitch (layers * 4 words).
+static int sharded_open(p2hot_sharded_batch *b, const u64 *leaf_idx, size_t m, u64 *rows_out, size_t row_pitch, u64 *paths_out,
+                        size_t path_pitch) {
     p2hot_group *g = b->g;
     p2hot_ctx *ctx0 = g->ctx[0];
-    P2_ENTER(ctx0);
     const ShardPlan &p = b->plan;
-    if (m == 0) return P2HOT_OK;
-    if (!leaf_idx) P2_FAIL(ctx0, P2HOT_EINVAL, "sharded_batch_open: null indices");
     const unsigned layers = p.log_N - p.cap_height;
-    for (size_t q = 0; q < m; ++q) {
-        const u64 x = leaf_idx[q];
-        if (x >= p.N) P2_FAIL(ctx0, P2HOT_EINVAL, "sharded_batch_open: index %llu out of range", (unsigned long long)x);
-        const size_t owner = x / p.rows_per_rank;
+    for (size_t q = 0; q < m; ++q)
+        if (leaf_idx[q] >= p.N) P2_FAIL(ctx0, P2HOT_EINVAL, "sharded_batch_open: index %llu out of range", (unsigned long long)leaf_idx[q]);
+    for (size_t owner = 0; owner < g->ctx.size(); ++owner) {
+        std::vector<size_t> mine;
+        std::vector<u64> idx2;  // [local rows ...][global leaves ...]
+        for (size_t q = 0; q < m; ++q)
+            if (leaf_idx[q] / p.rows_per_rank == owner) mine.push_back(q);
+        if (mine.empty()) continue;
+        for (size_t q : mine) idx2.push_back(leaf_idx[q] - owner * p.rows_per_rank);
+        for (size_t q : mine) idx2.push_back(leaf_idx[q]);
+        const size_t k = mine.size();
         p2hot_ctx *ctx = g->ctx[owner];
         P2_HIP(ctx, hipSetDevice(ctx->device));
         PoolBuf d_idx(ctx), d_row(ctx), d_path(ctx);
-        P2_TRY(pool_alloc(ctx, 16, &d_idx.p));
-        P2_TRY(pool_alloc(ctx, std::max<size_t>(1, p.W) * 8, &d_row.p));
-        P2_TRY(pool_alloc(ctx, std::max<size_t>(1, layers) * 32, &d_path.p));
-        const u64 idx2[2] = {x - owner * p.rows_per_rank, x};  // local row in the owner's LDE block, global leaf for the path
-        P2_HIP(ctx, hipMemcpyAsync(d_idx.p, idx2, 16, hipMemcpyHostToDevice, ctx->stream));
-        if (rows_out && p.W) {
-            P2_TRY(p2hot_gather_rows_dev(ctx, b->lde[owner], p.rows_per_rank, p.rows_per_rank, p.W, d_idx.u(), 1, d_row.u()));
-            P2_HIP(ctx, hipMemcpyAsync(rows_out + q * p.W, d_row.p, p.W * 8, hipMemcpyDeviceToHost, ctx->stream));
+        P2_TRY(pool_alloc(ctx, 2 * k * 8, &d_idx.p));
+        P2_TRY(pool_alloc(ctx, std::max<size_t>(1, k * p.W) * 8, &d_row.p));
+        P2_TRY(pool_alloc(ctx, std::max<size_t>(1, k * layers) * 32, &d_path.p));
+        std::vector<u64> rows(k * p.W), paths(k * layers * 4);
+        int rc = P2HOT_OK;
+        auto body = [&]() -> int {
+            P2_HIP(ctx, hipMemcpyAsync(d_idx.p, idx2.data(), 2 * k * 8, hipMemcpyHostToDevice, ctx->stream));
+            if (rows_out && p.W) {
+                P2_TRY(p2hot_gather_rows_dev(ctx, b->lde[owner], p.rows_per_rank, p.rows_per_rank, p.W, d_idx.u(), k, d_row.u()));
+                P2_HIP(ctx, hipMemcpyAsync(rows.data(), d_row.p, k * p.W * 8, hipMemcpyDeviceToHost, ctx->stream));
+            }
+            if (paths_out && layers) {
+                P2_TRY(p2hot_merkle_paths_dev(ctx, b->digests[owner], p.log_N, p.cap_height, d_idx.u() + k, k, d_path.u()));
+                P2_HIP(ctx, hipMemcpyAsync(paths.data(), d_path.p, k * layers * 32, hipMemcpyDeviceToHost, ctx->stream));
+            }
+            return P2HOT_OK;
+        };
+        rc = body();
+        hipError_t e = hipStreamSynchronize(ctx->stream);  // the local vectors and pool blocks are released below
+        if (rc != P2HOT_OK) {
+            if (ctx != ctx0) ctx0->err = ctx->err;
+            return rc;
         }
-        if (paths_out && layers) {
-            P2_TRY(p2hot_merkle_paths_dev(ctx, b->digests[owner], p.log_N, p.cap_height, d_idx.u() + 1, 1, d_path.u()));
-            P2_HIP(ctx, hipMemcpyAsync(paths_out + q * layers * 4, d_path.p, layers * 32, hipMemcpyDeviceToHost, ctx->stream));
+        if (e != hipSuccess) P2_FAIL(ctx0, P2HOT_EHIP, "sharded_batch_open: %s", hipGetErrorString(e));
+        for (size_t t = 0; t < k; ++t) {
+            if (rows_out && p.W) std::copy(rows.begin() + t * p.W, rows.begin() + (t + 1) * p.W, rows_out + mine[t] * row_pitch);
+            if (paths_out && layers)
+                std::copy(paths.begin() + t * layers * 4, paths.begin() + (t + 1) * layers * 4, paths_out + mine[t] * path_pitch);
         }
-        P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return P2HOT_OK;
+}
+
+extern "C" int p2hot_sharded_batch_open(p2hot_sharded_batch *b, const uint64_t *leaf_idx, size_t m, uint64_t *rows_out, uint64_t *paths_out) {
+    if (!b) return P2HOT_EINVAL;
+    p2hot_ctx *ctx0 = b->g->ctx[0];
+    P2_ENTER(ctx0);
+    if (m == 0) return P2HOT_OK;
+    if (!leaf_idx) P2_FAIL(ctx0, P2HOT_EINVAL, "sharded_batch_open: null indices");
+    const unsigned layers = b->plan.log_N - b->plan.cap_height;
+    return sharded_open(b, leaf_idx, m, rows_out, b->plan.W, paths_out, (size_t)layers * 4);
+}
+
+// ------------------------------------------------------------------ openings and prove_openings over sharded batches
+// In the coset mode every rank holds all coefficients, so rank 0 runs what needs the polynomials -- the OpeningSet
+// evaluations, final_poly, the FRI commit phase (after round 0 it is tiny) and the grind -- and the rows and paths
+// of the initial trees come from the ranks that own them.
+static int sharded_views(p2hot_group *g, const p2hot_sharded_batch *const *oracles, size_t n_oracles, std::vector<OracleView> *views,
+                         unsigned *log_n) {
+    p2hot_ctx *ctx0 = g->ctx[0];
+    if (!oracles || n_oracles == 0) P2_FAIL(ctx0, P2HOT_EINVAL, "group openings: null oracle list");
+    for (size_t o = 0; o < n_oracles; ++o) {
+        const p2hot_sharded_batch *B = oracles[o];
+        if (!B || B->g != g) P2_FAIL(ctx0, P2HOT_EINVAL, "group openings: oracle %zu is null or belongs to another group", o);
+        if (B->by_columns) P2_FAIL(ctx0, P2HOT_EUNSUPPORTED, "group openings: oracle %zu was committed column-sharded (no rank holds all coefficients)", o);
+        if (o == 0) *log_n = B->plan.log_n;
+        if (B->plan.log_n != *log_n) P2_FAIL(ctx0, P2HOT_EINVAL, "group openings: all oracles must have the same degree");
+        views->push_back(OracleView{B->coeffs_all[0], nullptr, nullptr, B->plan.W, B->plan.N});
+    }
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_group_eval_openings(p2hot_group *g, const p2hot_sharded_batch *const *oracles, size_t n_oracles, const uint64_t *points,
+                                         size_t n_points, uint64_t *out) {
+    if (!g) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = g->ctx[0];
+    P2_ENTER(ctx);
+    if (n_oracles == 0 || n_points == 0) return P2HOT_OK;
+    if (!points || !out) P2_FAIL(ctx, P2HOT_EINVAL, "group_eval_openings: null argument");
+    std::vector<OracleView> views;
+    unsigned log_n = 0;
+    P2_TRY(sharded_views(g, oracles, n_oracles, &views, &log_n));
+    P2_HIP(ctx, hipSetDevice(ctx->device));
+    return eval_openings_core(ctx, views, log_n, points, n_points, out);
+}
+
+extern "C" int p2hot_group_fri_proof_sizes(const p2hot_sharded_batch *const *oracles, size_t n_oracles, const p2hot_fri_params *fp,
+                                           p2hot_fri_proof_layout *out) {
+    if (!oracles || n_oracles == 0 || !oracles[0]) return P2HOT_EINVAL;
+    std::vector<size_t> widths;
+    for (size_t o = 0; o < n_oracles; ++o) {
+        if (!oracles[o]) return P2HOT_EINVAL;
+        widths.push_back(oracles[o]->plan.W);
+    }
+    return fri_proof_layout(widths.data(), n_oracles, oracles[0]->plan.log_n, fp, out);
+}
+
+// PolynomialBatch::prove_openings + fri_proof over sharded oracles; `challenger` belongs to p2hot_group_ctx(group, 0).
+extern "C" int p2hot_group_prove_openings(p2hot_group *g, const p2hot_fri_batch_info *batches, size_t n_batches,
+                                          const p2hot_sharded_batch *const *oracles, size_t n_oracles, p2hot_challenger *challenger,
+                                          const p2hot_fri_params *fp, p2hot_fri_proof *proof) {
+    if (!g) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = g->ctx[0];
+    std::vector<OracleView> views;
+    unsigned log_n = 0;
+    {
+        P2_ENTER(ctx);
+        P2_TRY(sharded_views(g, oracles, n_oracles, &views, &log_n));
+        for (size_t o = 0; o < n_oracles && fp; ++o)
+            if (oracles[o]->plan.rate_bits != fp->rate_bits || oracles[o]->plan.cap_height != fp->cap_height)
+                P2_FAIL(ctx, P2HOT_EINVAL, "group_prove_openings: oracle %zu was committed with another rate / cap height", o);
+        P2_HIP(ctx, hipSetDevice(ctx->device));
+        size_t w_sum = 0;
+        for (auto &v : views) w_sum += v.W;
+        const unsigned layers0 = fp ? log_n + fp->rate_bits - fp->cap_height : 0;
+        InitialOpener opener = [&](const u64 *idx, size_t Q, u64 *leaves_out, u64 *paths_out) -> int {
+            size_t w_off = 0;
+            for (size_t o = 0; o < n_oracles; ++o) {  // query-major layout: row q of oracle o at [q][w_off ..), path at [q][o][..]
+                P2_TRY(sharded_open(const_cast<p2hot_sharded_batch *>(oracles[o]), idx, Q, leaves_out + w_off, w_sum,
+                                    paths_out + o * 4 * layers0, n_oracles * 4 * (size_t)layers0));
+                w_off += views[o].W;
+            }
+            return P2HOT_OK;
+        };
+        return prove_openings_core(ctx, batches, n_batches, views, log_n, challenger, fp, proof, &opener);
+    }
 }

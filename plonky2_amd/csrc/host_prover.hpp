@@ -12,6 +12,7 @@
 #pragma once
 
 #include <atomic>
+#include <functional>
 
 // one call at a time per context: a second thread entering gets P2HOT_EBUSY instead of a data race on the scratch blocks
 struct CallGuard {
@@ -376,51 +377,62 @@ extern "C" int p2hot_ctx_trim(p2hot_ctx *ctx) {
 }
 
 // ------------------------------------------------------------------ OpeningSet::new (plonk/proof.rs:314-327)
-// device table of pointers to every polynomial of the listed batches, in order
-static int poly_table(p2hot_ctx *ctx, const p2hot_batch *const *batches, size_t n_batches, unsigned *log_n, PoolBuf &d_table,
-                      size_t *total) {
-    std::vector<const u64 *> ptrs;
-    for (size_t b = 0; b < n_batches; ++b) {
-        const p2hot_batch *B = batches[b];
-        if (!B || B->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "oracle %zu is null or belongs to another context", b);
-        if (b == 0) *log_n = B->log_n;
-        if (B->log_n != *log_n) P2_FAIL(ctx, P2HOT_EINVAL, "all oracles must have the same degree (oracle %zu: 2^%u vs 2^%u)", b, B->log_n, *log_n);
-        for (size_t j = 0; j < B->W; ++j) ptrs.push_back(B->d_coef + (j << B->log_n));
-    }
-    *total = ptrs.size();
-    P2_TRY(pool_alloc(ctx, (ptrs.size() ? ptrs.size() : 1) * sizeof(u64 *), &d_table.p));
-    if (!ptrs.empty())
-        P2_HIP(ctx, hipMemcpyAsync(d_table.p, ptrs.data(), ptrs.size() * sizeof(u64 *), hipMemcpyHostToDevice, ctx->stream));
-    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `ptrs` is a local
-    return P2HOT_OK;
-}
+// What prove_openings needs to know about an oracle: its coefficient polynomials on THIS context, and -- when the tree
+// lives on this context too -- its LDE matrix and digest array.  d_lde == NULL: the rows and paths of the initial trees
+// are served elsewhere (a sharded batch: by the rank that owns the row) through `open_initial`.
+struct OracleView {
+    const u64 *d_coef, *d_lde, *d_dig;
+    size_t W, N;
+};
+// fills proof->initial_leaves / initial_paths (query-major layout) for the Q host-resident query indices
+typedef std::function<int(const u64 *idx, size_t Q, u64 *leaves_out, u64 *paths_out)> InitialOpener;
+
+// OpeningSet::new for oracles given as views: a device table of pointers to every polynomial in order, one
+// p2hot_eval_polys_dev call, then per-oracle copies into the caller's layout ([n_points][W_o][2] per oracle)
+static int eval_openings_core(p2hot_ctx *ctx, const std::vector<OracleView> &views, unsigned log_n, const uint64_t *points, size_t n_points,
+                              uint64_t *out);
 
 extern "C" int p2hot_eval_openings(p2hot_ctx *ctx, const p2hot_batch *const *batches, size_t n_batches, const uint64_t *points,
                                    size_t n_points, uint64_t *out) {
     P2_ENTER(ctx);
     if (n_batches == 0 || n_points == 0) return P2HOT_OK;
     if (!batches || !points || !out) P2_FAIL(ctx, P2HOT_EINVAL, "eval_openings: null argument");
-    unsigned log_n = 0;
-    size_t total = 0;
-    PoolBuf d_table(ctx), d_res(ctx);
-    P2_TRY(poly_table(ctx, batches, n_batches, &log_n, d_table, &total));
+    std::vector<OracleView> views;
+    for (size_t b = 0; b < n_batches; ++b) {
+        const p2hot_batch *B = batches[b];
+        if (!B || B->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "oracle %zu is null or belongs to another context", b);
+        if (B->log_n != batches[0]->log_n)
+            P2_FAIL(ctx, P2HOT_EINVAL, "all oracles must have the same degree (oracle %zu: 2^%u vs 2^%u)", b, B->log_n, batches[0]->log_n);
+        views.push_back(OracleView{B->d_coef, B->d_lde, B->d_dig, B->W, B->N});
+    }
+    return eval_openings_core(ctx, views, batches[0]->log_n, points, n_points, out);
+}
+
+static int eval_openings_core(p2hot_ctx *ctx, const std::vector<OracleView> &views, unsigned log_n, const uint64_t *points, size_t n_points,
+                              uint64_t *out) {
+    std::vector<const u64 *> ptrs;
+    for (auto &v : views)
+        for (size_t j = 0; j < v.W; ++j) ptrs.push_back(v.d_coef + (j << log_n));
+    const size_t total = ptrs.size();
     if (total == 0) return P2HOT_OK;
+    PoolBuf d_table(ctx), d_res(ctx);
+    P2_TRY(pool_alloc(ctx, total * sizeof(u64 *), &d_table.p));
     P2_TRY(pool_alloc(ctx, n_points * total * 16, &d_res.p));
     auto body = [&]() -> int {
-        // device layout [n_points][total][2]; the caller's layout is per batch [n_points][W_b][2]
+        P2_HIP(ctx, hipMemcpyAsync(d_table.p, ptrs.data(), total * sizeof(u64 *), hipMemcpyHostToDevice, ctx->stream));
+        // device layout [n_points][total][2]; the caller's layout is per oracle [n_points][W_o][2]
         P2_TRY(p2hot_eval_polys_dev(ctx, (const uint64_t *const *)d_table.p, total, log_n, points, n_points, d_res.u()));
         size_t off = 0, out_off = 0;
-        for (size_t b = 0; b < n_batches; ++b) {
-            const size_t Wb = batches[b]->W;
-            for (size_t p = 0; p < n_points && Wb; ++p)
-                P2_HIP(ctx, hipMemcpyAsync(out + out_off + 2 * p * Wb, d_res.u() + 2 * (p * total + off), Wb * 16, hipMemcpyDeviceToHost,
+        for (auto &v : views) {
+            for (size_t p = 0; p < n_points && v.W; ++p)
+                P2_HIP(ctx, hipMemcpyAsync(out + out_off + 2 * p * v.W, d_res.u() + 2 * (p * total + off), v.W * 16, hipMemcpyDeviceToHost,
                                            ctx->stream));
-            off += Wb;
-            out_off += 2 * n_points * Wb;
+            off += v.W;
+            out_off += 2 * n_points * v.W;
         }
         return P2HOT_OK;
     };
-    return sync_checked(ctx, body(), "eval_openings");
+    return sync_checked(ctx, body(), "eval_openings");  // `ptrs` outlives the copy: the stream is idle on return
 }
 
 // ------------------------------------------------------------------ prove_openings + fri_proof
@@ -439,16 +451,12 @@ static int fri_check_params(p2hot_ctx *ctx, const p2hot_fri_params *fp, unsigned
     return P2HOT_OK;
 }
 
-extern "C" int p2hot_fri_proof_sizes(const p2hot_batch *const *oracles, size_t n_oracles, const p2hot_fri_params *fp,
-                                     p2hot_fri_proof_layout *out) {
-    if (!out || !fp || (n_oracles && !oracles) || (fp->n_reduction_rounds && !fp->reduction_arity_bits)) return P2HOT_EINVAL;
-    if (n_oracles == 0 || !oracles[0]) return P2HOT_EINVAL;
-    const unsigned log_n = oracles[0]->log_n, log_N = log_n + fp->rate_bits;
+// sizes of the flat FriProof buffers for oracles of the given widths (include/p2hot.h, p2hot_fri_proof)
+static int fri_proof_layout(const size_t *widths, size_t n_oracles, unsigned log_n, const p2hot_fri_params *fp, p2hot_fri_proof_layout *out) {
+    if (!out || !fp || n_oracles == 0 || (fp->n_reduction_rounds && !fp->reduction_arity_bits)) return P2HOT_EINVAL;
+    const unsigned log_N = log_n + fp->rate_bits;
     size_t w_sum = 0;
-    for (size_t o = 0; o < n_oracles; ++o) {
-        if (!oracles[o]) return P2HOT_EINVAL;
-        w_sum += oracles[o]->W;
-    }
+    for (size_t o = 0; o < n_oracles; ++o) w_sum += widths[o];
     const size_t q = fp->num_query_rounds, cap_words = (size_t)4 << fp->cap_height;
     size_t evals = 0, paths = 0;
     unsigned lm = log_N;
@@ -469,28 +477,57 @@ extern "C" int p2hot_fri_proof_sizes(const p2hot_batch *const *oracles, size_t n
     return P2HOT_OK;
 }
 
+extern "C" int p2hot_fri_proof_sizes(const p2hot_batch *const *oracles, size_t n_oracles, const p2hot_fri_params *fp,
+                                     p2hot_fri_proof_layout *out) {
+    if (!oracles || n_oracles == 0 || !oracles[0]) return P2HOT_EINVAL;
+    std::vector<size_t> widths;
+    for (size_t o = 0; o < n_oracles; ++o) {
+        if (!oracles[o]) return P2HOT_EINVAL;
+        widths.push_back(oracles[o]->W);
+    }
+    return fri_proof_layout(widths.data(), n_oracles, oracles[0]->log_n, fp, out);
+}
+
+static int prove_openings_core(p2hot_ctx *ctx, const p2hot_fri_batch_info *batches, size_t n_batches, const std::vector<OracleView> &views,
+                               unsigned log_n, p2hot_challenger *challenger, const p2hot_fri_params *fp, p2hot_fri_proof *proof,
+                               const InitialOpener *open_initial);
+
 extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *batches, size_t n_batches,
                                     const p2hot_batch *const *oracles, size_t n_oracles, p2hot_challenger *challenger,
                                     const p2hot_fri_params *fp, p2hot_fri_proof *proof) {
     P2_ENTER(ctx);
-    if (!challenger || challenger->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: the challenger belongs to another context");
-    if (!proof || !oracles || n_oracles == 0 || (n_batches && !batches)) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: null argument");
-    if (fp && fp->hiding) P2_FAIL(ctx, P2HOT_EUNSUPPORTED, "prove_openings: hiding = true needs the blinded (salted) leaves of oracle.rs:133-137");
-    for (size_t o = 0; o < n_oracles; ++o)
+    if (!oracles || n_oracles == 0) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: null argument");
+    std::vector<OracleView> views;
+    for (size_t o = 0; o < n_oracles; ++o) {
         if (!oracles[o] || oracles[o]->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: oracle %zu is null or belongs to another context", o);
-    const unsigned log_n = oracles[0]->log_n;
+        if (oracles[o]->log_n != oracles[0]->log_n || (fp && (oracles[o]->rate_bits != fp->rate_bits || oracles[o]->cap_height != fp->cap_height)))
+            P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: oracle %zu was committed with another degree / rate / cap height", o);
+        views.push_back(OracleView{oracles[o]->d_coef, oracles[o]->d_lde, oracles[o]->d_dig, oracles[o]->W, oracles[o]->N});
+    }
+    return prove_openings_core(ctx, batches, n_batches, views, oracles[0]->log_n, challenger, fp, proof, nullptr);
+}
+
+static int prove_openings_core(p2hot_ctx *ctx, const p2hot_fri_batch_info *batches, size_t n_batches, const std::vector<OracleView> &views,
+                               unsigned log_n, p2hot_challenger *challenger, const p2hot_fri_params *fp, p2hot_fri_proof *proof,
+                               const InitialOpener *open_initial) {
+    const size_t n_oracles = views.size();
+    if (!challenger || challenger->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: the challenger belongs to another context");
+    if (!proof || (n_batches && !batches)) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: null argument");
+    if (fp && fp->hiding) P2_FAIL(ctx, P2HOT_EUNSUPPORTED, "prove_openings: hiding = true needs the blinded (salted) leaves of oracle.rs:133-137");
     P2_TRY(fri_check_params(ctx, fp, log_n));
     const unsigned rate_bits = fp->rate_bits, cap_height = fp->cap_height, log_N = log_n + rate_bits, n_rounds = fp->n_reduction_rounds;
     const size_t n = (size_t)1 << log_n, N = n << rate_bits, Q = fp->num_query_rounds;
-    for (size_t o = 0; o < n_oracles; ++o)
-        if (oracles[o]->log_n != log_n || oracles[o]->rate_bits != rate_bits || oracles[o]->cap_height != cap_height)
-            P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: oracle %zu was committed with another degree / rate / cap height", o);
     p2hot_fri_proof_layout lay;
-    if (p2hot_fri_proof_sizes(oracles, n_oracles, fp, &lay) != P2HOT_OK) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: inconsistent parameters");
+    {
+        std::vector<size_t> widths;
+        for (auto &v : views) widths.push_back(v.W);
+        if (fri_proof_layout(widths.data(), n_oracles, log_n, fp, &lay) != P2HOT_OK) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: inconsistent parameters");
+    }
     if ((lay.caps_words && !proof->commit_phase_merkle_caps) || !proof->final_poly ||
         (Q && ((lay.initial_leaves_words && !proof->initial_leaves) || (lay.initial_paths_words && !proof->initial_paths) ||
                (lay.step_evals_words && !proof->step_evals) || (lay.step_paths_words && !proof->step_paths))))
         P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: a proof buffer is null (size them with p2hot_fri_proof_sizes)");
+    const std::vector<OracleView> &oracles = views;
     // --- the polynomial table of the instance (FriInstanceInfo.batches, fri/structure.rs): device pointers in batch order
     std::vector<const u64 *> ptrs;
     std::vector<size_t> offsets(1, 0);
@@ -500,9 +537,9 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
         if (bi.n_polys && (!bi.oracle_index || !bi.poly_index)) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: batch %zu has null index arrays", i);
         for (size_t j = 0; j < bi.n_polys; ++j) {
             const size_t oi = bi.oracle_index[j], pi = bi.poly_index[j];
-            if (oi >= n_oracles || pi >= oracles[oi]->W)
+            if (oi >= n_oracles || pi >= oracles[oi].W)
                 P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: batch %zu opens polynomial (%zu, %zu) which does not exist", i, oi, pi);
-            ptrs.push_back(oracles[oi]->d_coef + (pi << log_n));
+            ptrs.push_back(oracles[oi].d_coef + (pi << log_n));
         }
         offsets.push_back(ptrs.size());
         points.push_back(bi.point[0]);
@@ -540,9 +577,10 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
     if (fp->proof_of_work_bits > 64) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: proof_of_work_bits > 64");
     for (unsigned r = 0; r < n_rounds; ++r) ab.b[r] = (unsigned char)fp->reduction_arity_bits[r];
     size_t w_sum = 0;
-    for (size_t o = 0; o < n_oracles; ++o) w_sum += oracles[o]->W;
+    for (size_t o = 0; o < n_oracles; ++o) w_sum += oracles[o].W;
     unsigned long long best = ~0ull;
     u64 pow_next = 0;
+    std::vector<u64> idx_for_owners;
     // Everything below is enqueued without waiting for the GPU: alpha, beta_i, the PoW witness and the query indices
     // stay on the device (the challenger is device-resident), results reach the caller's buffers by asynchronous copies
     // and ONE synchronisation ends the call.
@@ -574,14 +612,18 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
                      d_idx);
         P2_LAUNCH_CHECK(ctx);
         if (proof->query_indices) P2_HIP(ctx, hipMemcpyAsync(proof->query_indices, d_idx, Q * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (open_initial) {  // the owners of the rows need the indices on the host
+            idx_for_owners.resize(Q);
+            P2_HIP(ctx, hipMemcpyAsync(idx_for_owners.data(), d_idx, Q * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
         // prover.rs:238-241: initial_trees_proof = for every oracle (tree.get(x), tree.prove(x)), all queries per launch.
         // Device staging is oracle-major ([oracle][q][...]); the host layout is query-major (see p2hot.h), fixed by the D2H copies.
         size_t w_off = 0;
-        for (size_t o = 0; o < n_oracles; ++o) {
-            const p2hot_batch *B = oracles[o];
-            P2_TRY(p2hot_gather_rows_dev(ctx, B->d_lde, B->N, B->N, B->W, d_idx, Q, d_il + Q * w_off));
-            P2_TRY(p2hot_merkle_paths_dev(ctx, B->d_dig, log_N, cap_height, d_idx, Q, d_ip + o * Q * 4 * layers0));
-            w_off += B->W;
+        for (size_t o = 0; o < n_oracles && !open_initial; ++o) {
+            const OracleView &B = oracles[o];
+            P2_TRY(p2hot_gather_rows_dev(ctx, B.d_lde, B.N, B.N, B.W, d_idx, Q, d_il + Q * w_off));
+            P2_TRY(p2hot_merkle_paths_dev(ctx, B.d_dig, log_N, cap_height, d_idx, Q, d_ip + o * Q * 4 * layers0));
+            w_off += B.W;
         }
         // prover.rs:242-253: per round (evals = unflatten(tree.get(x >> arity_bits)), tree.prove(x >> arity_bits))
         size_t ev_off = 0, pa_off = 0, lv = 0, dg = 0, m = N;
@@ -608,8 +650,8 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
         }
         // D2H: one strided copy per (oracle | round) turns the oracle-major staging into the query-major proof layout
         w_off = 0;
-        for (size_t o = 0; o < n_oracles; ++o) {
-            const size_t Wb = oracles[o]->W;
+        for (size_t o = 0; o < n_oracles && !open_initial; ++o) {
+            const size_t Wb = oracles[o].W;
             if (Wb)
                 P2_HIP(ctx, hipMemcpy2DAsync(proof->initial_leaves + w_off, w_sum * 8, d_il + Q * w_off, Wb * 8, Wb * 8, Q,
                                              hipMemcpyDeviceToHost, ctx->stream));
@@ -639,6 +681,8 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
         rc = sync_checked(ctx, tail(), "prove_openings");
     }
     if (rc == P2HOT_OK) proof->pow_witness = best;
+    // a sharded batch: the initial trees' rows and paths come from the ranks that own them
+    if (rc == P2HOT_OK && open_initial && Q) rc = (*open_initial)(idx_for_owners.data(), Q, proof->initial_leaves, proof->initial_paths);
     return rc;
 }
 

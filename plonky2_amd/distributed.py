@@ -236,7 +236,65 @@ class GroupCommit:
 
         def free():
             lib.p2hot_sharded_batch_free(bh)
-        return {"coeffs": coeffs, "leaves": leaves, "digests": digests, "cap": cap, "open": open_, "free": free}
+        return {"coeffs": coeffs, "leaves": leaves, "digests": digests, "cap": cap, "open": open_, "free": free, "handle": bh,
+                "W": W, "degree_log": log_n}
+
+    def engine0(self):
+        """an Engine-like view of rank 0's context (for the Challenger of a group proof)"""
+        from .engine import Engine
+        eng = Engine.__new__(Engine)
+        eng.lib, eng._ctx, eng._stream = self.lib, C.c_void_p(self.lib.p2hot_group_ctx(self._h, 0)), None
+
+        class _NoStream:
+            def stream(self_inner):
+                return None
+        eng.mem = _NoStream()
+        eng.close = lambda: None          # the group owns the context
+        return eng
+
+    def eval_openings(self, commits, points):
+        """OpeningSet::new over sharded oracles (p2hot_group_eval_openings): list of [n_points][W][2] per oracle"""
+        pts = np.ascontiguousarray(np.asarray(points, dtype=np.uint64).reshape(-1, 2))
+        hs = (C.c_void_p * len(commits))(*[c["handle"] for c in commits])
+        total = sum(c["W"] for c in commits)
+        flat = np.zeros(max(1, 2 * len(pts) * total), dtype=np.uint64)
+        self._check(self.lib.p2hot_group_eval_openings(self._h, hs, len(commits), pts.ctypes.data, len(pts), flat.ctypes.data))
+        out, off = [], 0
+        for c in commits:
+            cnt = 2 * len(pts) * c["W"]
+            out.append(flat[off:off + cnt].reshape(len(pts), c["W"], 2))
+            off += cnt
+        return out
+
+    def prove_openings(self, batches, commits, challenger, rate_bits, cap_height, reduction_arity_bits, proof_of_work_bits,
+                       num_query_rounds):
+        """p2hot_group_prove_openings: flat proof buffers as a dict (layout: include/p2hot.h, p2hot_fri_proof)"""
+        arity = [int(a) for a in reduction_arity_bits]
+        ab = (C.c_uint * max(len(arity), 1))(*arity)
+        fp = _lib.FriParams(rate_bits, cap_height, proof_of_work_bits, num_query_rounds, ab, len(arity), 0, 0, 0)
+        keep, infos = [], (_lib.FriBatchInfo * max(len(batches), 1))()
+        for k, (point, polys) in enumerate(batches):
+            oi = (C.c_uint32 * max(len(polys), 1))(*[o for o, _ in polys])
+            pi = (C.c_uint32 * max(len(polys), 1))(*[p for _, p in polys])
+            keep += [oi, pi]
+            infos[k].point[0], infos[k].point[1] = int(point[0]), int(point[1])
+            infos[k].oracle_index, infos[k].poly_index, infos[k].n_polys = oi, pi, len(polys)
+        hs = (C.c_void_p * len(commits))(*[c["handle"] for c in commits])
+        lay = _lib.FriProofLayout()
+        rc = self.lib.p2hot_group_fri_proof_sizes(hs, len(commits), C.byref(fp), C.byref(lay))
+        if rc != _lib.OK:
+            raise _lib.P2HotError(rc, "inconsistent FRI parameters")
+        names = ("caps", "final_poly", "initial_leaves", "initial_paths", "step_evals", "step_paths")
+        bufs = {k: np.zeros(max(1, getattr(lay, k + "_words")), dtype=np.uint64) for k in names}
+        qidx = np.zeros(max(1, num_query_rounds), dtype=np.uint64)
+        proof = _lib.FriProof(bufs["caps"].ctypes.data, bufs["final_poly"].ctypes.data, 0, qidx.ctypes.data,
+                              bufs["initial_leaves"].ctypes.data, bufs["initial_paths"].ctypes.data,
+                              bufs["step_evals"].ctypes.data, bufs["step_paths"].ctypes.data)
+        self._check(self.lib.p2hot_group_prove_openings(self._h, infos, len(batches), hs, len(commits), challenger._h,
+                                                        C.byref(fp), C.byref(proof)))
+        out = {k: bufs[k][:getattr(lay, k + "_words")] for k in names}
+        out["pow_witness"], out["query_indices"] = int(proof.pow_witness), [int(x) for x in qidx[:num_query_rounds]]
+        return out
 
     def close(self):
         if self._h:

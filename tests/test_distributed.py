@@ -213,3 +213,66 @@ def test_group_commit_column_sharded_fallback(ora, world, W, log_n, rb, cap, is_
         assert (row == o["leaves"][x]).all() and ora.merkle_verify(row, x, o["cap"], path)
     r["free"]()
     g.close()
+
+
+@pytest.mark.parametrize("world,widths,log_n,rb,cap,arity", [(2, [5, 3], 6, 3, 4, [2, 1]), (4, [7, 2, 2], 5, 3, 3, [2]), (8, [3], 4, 3, 3, [])])
+def test_group_prove_openings_equals_single_context_proof(ora, world, widths, log_n, rb, cap, arity):
+    from tests.emu_backend import emu_engine, emu_lib
+    _group_proof_equals_single_context(emu_lib(), emu_engine(), world, widths, log_n, rb, cap, arity)
+
+
+def _group_proof_equals_single_context(lib, eng, world, widths, log_n, rb, cap, arity):
+    """A whole opening proof over sharded oracles (p2hot_group_eval_openings / p2hot_group_prove_openings): rank 0 runs the
+    polynomial side, the owners of the rows serve the initial trees' openings; every buffer of the proof equals the one
+    the single-context p2hot_prove_openings produces for the same polynomials, and the transcripts end in the same state"""
+    import ctypes as C
+    from plonky2_amd import _lib
+    from plonky2_amd.distributed import GroupCommit
+    from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, eval_openings, prove_openings
+    from plonky2_amd.iop.challenger import Challenger
+    rng = np.random.default_rng(world * 31 + len(widths))
+    cols = [rand_field(rng, w, 1 << log_n) for w in widths]
+    inst = [([3, 4], [(oi, pi) for oi, w in enumerate(widths) for pi in range(w)]), ([9, 1], [(0, pi) for pi in range(widths[0])])]
+    pre = rand_field(rng, 5)
+    # single context
+    oracles = [PolynomialBatch.from_coeffs(c, rb, False, cap, engine=eng) for c in cols]
+    ch = Challenger(eng)
+    ch.observe_elements(pre)
+    ev1 = eval_openings(oracles, [p for p, _ in inst], eng)
+    p1 = prove_openings([FriBatchInfo(p, polys) for p, polys in inst], oracles, ch, rb, cap, arity, 3, 4, engine=eng)
+    # the group
+    g = GroupCommit(lib, world, [0] * world)
+    commits = [g.commit(c, rb, cap, is_values=False, pipeline_chunks=2) for c in cols]
+    for cm, o in zip(commits, oracles):
+        assert (cm["cap"] == o.merkle_tree.cap.entries).all()
+    ch2 = Challenger(g.engine0())
+    ch2.observe_elements(pre)
+    ev2 = g.eval_openings(commits, [p for p, _ in inst])
+    for a, b in zip(ev1, ev2):
+        assert (a == b).all()
+    p2 = g.prove_openings(inst, commits, ch2, rb, cap, arity, 3, 4)
+    assert p2["pow_witness"] == p1["pow_witness"] and p2["query_indices"] == p1["query_indices"]
+    assert (p2["final_poly"].reshape(-1, 2) == p1["final_poly"]).all()
+    flat_caps = np.concatenate([c.reshape(-1) for c in p1["commit_phase_merkle_caps"]]) if arity else np.zeros(0, dtype=np.uint64)
+    assert (p2["caps"] == flat_caps).all()
+    Q, wsum = 4, sum(widths)
+    il = p2["initial_leaves"].reshape(Q, wsum)
+    layers0 = log_n + rb - cap
+    ip = p2["initial_paths"].reshape(Q, len(widths), layers0, 4)
+    for q, qr in enumerate(p1["query_round_proofs"]):
+        wo = 0
+        for oi, (leaf, sib) in enumerate(qr["initial_trees_proof"]):
+            assert (il[q, wo:wo + widths[oi]] == leaf).all() and (ip[q, oi] == sib).all()
+            wo += widths[oi]
+        ev = np.concatenate([e.reshape(-1) for e, _ in qr["steps"]]) if arity else np.zeros(0, dtype=np.uint64)
+        sp = np.concatenate([s_.reshape(-1) for _, s_ in qr["steps"]]) if arity else np.zeros(0, dtype=np.uint64)
+        assert (p2["step_evals"].reshape(Q, -1)[q] == ev).all() and (p2["step_paths"].reshape(Q, -1)[q] == sp).all()
+    assert ch.get_n_challenges(3) == ch2.get_n_challenges(3)
+    # column-sharded oracles cannot serve it: no rank holds all coefficients
+    cm = g.commit(cols[0], rb, cap, is_values=False, by_columns=True)
+    with pytest.raises(_lib.P2HotError, match="column-sharded"):
+        g.eval_openings([cm], [[1, 2]])
+    for c in commits + [cm]:
+        c["free"]()
+    del ch2
+    g.close()

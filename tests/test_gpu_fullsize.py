@@ -195,6 +195,14 @@ def test_group_commit_ranks_on_one_gpu(gpu, ora, world, W, log_n, chunks, by_col
     g.close()
 
 
+@pytest.mark.parametrize("world,widths,log_n,arity", [(2, [9, 4], 10, [4]), (8, [20, 16], 12, [4, 4])])
+def test_group_prove_openings_on_one_gpu(gpu, world, widths, log_n, arity):
+    """p2hot_group_eval_openings / p2hot_group_prove_openings on the real GPU (all ranks on device 0): the proof over the
+    sharded oracles equals the single-context proof buffer by buffer, transcripts included"""
+    from tests.test_distributed import _group_proof_equals_single_context
+    _group_proof_equals_single_context(gpu.lib, gpu, world, widths, log_n, 3, 4, arity)
+
+
 @pytest.mark.parametrize("chunks,gather", [(1, True), (5, False)])
 def test_rccl_communicator_one_rank(gpu, ora, chunks, gather):
     """The in-library RCCL transport on the real GPU with a one-rank communicator (all this box can host):
