@@ -367,6 +367,8 @@ def main():
         print(json.dumps(out))
     if dist:
         dist.barrier()
+        if "job" in dir():
+            job.comm.close()  # the library's RCCL communicator, before torch tears its own down
         dist.destroy_process_group()
 
 

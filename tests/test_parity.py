@@ -458,3 +458,67 @@ def test_quad_and_lane_poseidon_kernels_agree(eng, ora):
                 assert (np.asarray(t.digests).reshape(-1, 4) == digests).all(), (n, w, cap, thr)
     finally:
         eng.check(eng.lib.p2hot_tune_quad(eng.ctx, 20 if not gpu else 1 << 15))
+
+
+def test_host_pointer_commit_random_shapes(eng, ora):
+    """p2hot_commit (host pointers, what the Rust shim calls) over random shapes incl. single-row polynomials, rate 1,
+    all-cap trees, widths around the sponge rate and the no-hash widths, with and without kept values / leaves /
+    digests: every requested output equals the oracle's, and the handle serves rows, paths, digests and coefficients"""
+    import ctypes as C
+    from plonky2_amd import _lib
+    rng = np.random.default_rng(20260924)
+    for trial in range(24):
+        W = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 33]))
+        log_n = int(rng.integers(0, 7))
+        rb = int(rng.integers(0, 4))
+        cap = int(rng.integers(0, log_n + rb + 1))
+        is_values = bool(rng.integers(0, 2))
+        keep = bool(rng.integers(0, 2))
+        n, N = 1 << log_n, 1 << (log_n + rb)
+        cols = rand_field(rng, W, n, noncanonical=True)
+        o = ora.commit(cols, rb, cap, is_values)
+        ptrs = (C.c_void_p * W)(*[cols[c].ctypes.data for c in range(W)])
+        want_leaves, want_dig = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        coeffs = np.zeros((W, n), dtype=np.uint64)
+        leaves = np.zeros((N, W), dtype=np.uint64)
+        nd = eng.num_digests(log_n + rb, cap)
+        digests = np.zeros((max(nd, 1), 4), dtype=np.uint64)
+        capv = np.zeros((1 << cap, 4), dtype=np.uint64)
+        h = C.c_void_p()
+        eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1 if is_values else 0, _lib.KEEP_VALUES if keep else 0,
+                                       coeffs.ctypes.data, leaves.ctypes.data if want_leaves else None,
+                                       digests.ctypes.data if want_dig else None, capv.ctypes.data, C.byref(h)))
+        tag = (trial, W, log_n, rb, cap, is_values)
+        assert (coeffs == o["coeffs"] % np.uint64(P)).all(), tag
+        assert (capv == o["cap"]).all(), tag
+        if want_leaves:
+            assert (leaves == o["leaves"]).all(), tag
+        if want_dig and nd:
+            assert (digests[:nd] == o["digests"]).all(), tag
+        idx = rng.integers(0, N, size=5).astype(np.uint64)
+        rows = np.zeros((5, W), dtype=np.uint64)
+        eng.check(eng.lib.p2hot_batch_rows(h, idx.ctypes.data, 5, rows.ctypes.data))
+        assert (rows == o["leaves"][idx.astype(np.int64)]).all(), tag
+        layers = log_n + rb - cap
+        paths = np.zeros((5, max(layers, 1), 4), dtype=np.uint64)
+        eng.check(eng.lib.p2hot_batch_paths(h, idx.ctypes.data, 5, paths.ctypes.data))
+        for q, x in enumerate(idx):
+            if layers:
+                assert (paths[q][:layers] == ora.merkle_prove(int(x), N, cap, o["digests"])).all(), tag
+        d2 = np.zeros((max(nd, 1), 4), dtype=np.uint64)
+        eng.check(eng.lib.p2hot_batch_digests(h, d2.ctypes.data))
+        assert (d2[:nd] == o["digests"]).all(), tag
+        c2 = np.zeros((W, n), dtype=np.uint64)
+        eng.check(eng.lib.p2hot_batch_coeffs(h, 0, W, c2.ctypes.data))
+        assert (c2 == coeffs).all(), tag
+        v = C.c_void_p()
+        rc = eng.lib.p2hot_batch_values(h, C.byref(v))
+        if keep and is_values:
+            assert rc == _lib.OK
+            back = np.zeros((W, n), dtype=np.uint64)
+            eng.check(eng.lib.p2hot_cols_download(v, 0, W, back.ctypes.data))
+            assert (back == cols).all(), tag          # the values as uploaded (any representative)
+            eng.lib.p2hot_cols_free(v)
+        else:
+            assert rc == _lib.EINVAL
+        eng.lib.p2hot_batch_free(h)
