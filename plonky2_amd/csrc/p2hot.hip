@@ -1234,7 +1234,9 @@ static int pow_search_dev(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned
     // continued by pow_continue_host, which checks after every chunk
     const int lg = std::min((int)pow_bits + extra, 34);
     const u64 limit = (u64)1 << (lg < 0 ? 0 : lg);
-    u64 chunk = (u64)1 << 14, start = 0;
+    // the first chunk holds a witness with probability 1 - e^-4 (4x the expected number of trials) but never more than one
+    // chip-wide wave of lanes (2^18): a permutation per lane takes ~25 us whether 2^14 or 2^18 lanes run it
+    u64 chunk = (u64)1 << std::min(18u, std::max(14u, pow_bits + 2)), start = 0;
     while (start < limit) {
         const u64 count = std::min(limit - start, chunk);
         P2HOT_LAUNCH(fri::pow_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, challenger->d, pow_bits, start, count, d_best);
