@@ -209,6 +209,47 @@ def other_configs(eng, torch, reps=3):
 
     path_line("per_proof_path_k20", 20, [4, 4, 4, 4])
     path_line("per_proof_path_k12", 12, [4, 4])
+
+    # C4: the starky per-proof path (StarkConfig::standard_fast_config: rate 1/2, cap 4, 84 queries, PoW 16 bits):
+    # trace commit (from_values, W=2) + quotient commit (from_coeffs, W = quotient_degree_factor * 2 = 2) + the
+    # StarkOpeningSet evaluations (trace + quotient at zeta, trace at g * zeta, starky/src/stark.rs:101-156) + prove_openings
+    def starky_line(name, log_n):
+        n, rb, cap, nq, arity = 1 << log_n, 1, 4, 84, [4, 4, 4, 4]
+        trace = eng.dev(fibonacci_trace(log_n))
+        quo = splitmix_columns_torch(torch, dev, 3000, 2, n)
+
+        def path():
+            stage = {}
+            t = [time.perf_counter()]
+
+            def lap(label):
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                stage[label] = (now - t[0]) * 1e3
+                t[0] = now
+            b_t = PolynomialBatch.from_values(trace, rb, False, cap, engine=eng)
+            lap("trace commit (W=2, from_values)")
+            b_q = PolynomialBatch.from_coeffs(quo, rb, False, cap, engine=eng)
+            lap("quotient commit (W=2, from_coeffs)")
+            ch = Challenger(eng)
+            ch.observe_elements(np.arange(8, dtype=np.uint64))
+            zeta = ch.get_extension_challenge()
+            gz = [(zeta[0] * 7) % P, zeta[1]]
+            eval_openings([b_t, b_q], [zeta, gz], eng)
+            lap("StarkOpeningSet (4 polynomials at 2 points)")
+            prove_openings([FriBatchInfo(zeta, [(0, 0), (0, 1), (1, 0), (1, 1)]), FriBatchInfo(gz, [(0, 0), (0, 1)])], [b_t, b_q], ch,
+                           rb, cap, arity, 16, nq, engine=eng)
+            lap("prove_openings (final_poly, FRI commit, PoW 16 bits, 84 queries)")
+            return stage
+
+        path()
+        stages = [path() for _ in range(reps)]
+        mean = {k: sum(s_[k] for s_ in stages) / reps for k in stages[0]}
+        out[name] = {"workload": "C4: every section-8 stage of one starky proof of a 2-column, 2^%d-row trace (Fibonacci), rate 1/2, back to "
+                                 "back (constraint evaluation excluded: out of scope)" % log_n,
+                     "ms": sum(mean.values()), "stage_ms": {k: round(v, 3) for k, v in mean.items()}}
+
+    starky_line("per_proof_path_starky_k22", 22)
     return out
 
 
