@@ -65,6 +65,10 @@ int p2hot_tune_overlap(p2hot_ctx *ctx, int on);
 /* leaf-hash / tree-level launches with at most max_perms permutations run the quad-cooperative kernels (4 lanes per
  * permutation, ~3x lower latency, 1.3x the work); default 2^15, 0 = never.  Results are identical. */
 int p2hot_tune_quad(p2hot_ctx *ctx, size_t max_perms);
+/* ... and launches with at most max_perms permutations the word-per-lane kernels (16 lanes per permutation, one state word
+ * and one MDS row per lane through DPP row broadcasts: ~3x lower latency than the quad kernels, ~3.6x the work); default 2^13, 0 = never.
+ * The Fiat-Shamir sponge always runs this mapping.  Results are identical. */
+int p2hot_tune_row(p2hot_ctx *ctx, size_t max_perms);
 const char *p2hot_profile_json(p2hot_ctx *ctx, int reset);
 
 /* sizes: number of digests (4 words each) in MerkleTree::digests for n_leaves = 2^log_leaves

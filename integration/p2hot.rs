@@ -158,6 +158,7 @@ extern "C" {
     pub fn p2hot_tune_ntt(ctx: *mut P2hotCtx, radix_bits: c_int) -> c_int;
     pub fn p2hot_tune_overlap(ctx: *mut P2hotCtx, on: c_int) -> c_int;
     pub fn p2hot_tune_quad(ctx: *mut P2hotCtx, max_perms: usize) -> c_int;
+    pub fn p2hot_tune_row(ctx: *mut P2hotCtx, max_perms: usize) -> c_int;
     pub fn p2hot_profile_json(ctx: *mut P2hotCtx, reset: c_int) -> *const c_char;
     pub fn p2hot_num_digests(log_leaves: c_uint, cap_height: c_uint) -> usize;
     // ---- primitives (device pointers)

@@ -65,6 +65,7 @@ SIGNATURES = {
     "p2hot_tune_ntt": (i, [vp, i]),
     "p2hot_tune_overlap": (i, [vp, i]),
     "p2hot_tune_quad": (i, [vp, sz]),
+    "p2hot_tune_row": (i, [vp, sz]),
     "p2hot_profile_json": (C.c_char_p, [vp, i]),
     "p2hot_num_digests": (sz, [u, u]),
     "p2hot_fft_dev": (i, [vp, vp, sz, sz, u]),

@@ -14,6 +14,7 @@
 #pragma once
 #include "poseidon.hpp"
 #include "poseidon4.hpp"
+#include "poseidon16.hpp"
 
 namespace fri {
 using gl::u32;
@@ -27,55 +28,48 @@ struct Challenger {  // mirrors challenger.rs:16-24
 };
 
 // observe n_obs elements, then squeeze n_get challenges (popped from the back, challenger.rs:82-92).
-// Launch with exactly one 64-thread block.  The sponge state lives in the first quad of the wave (3 words per
-// lane, poseidon4.hpp); the other lanes run the same instruction stream on zeros and store nothing.
+// Launch with exactly one 64-thread block.  The sponge state lives in the first 16-lane row of the wave, one word per
+// lane (poseidon16.hpp: the lowest-latency mapping -- a proof is a chain of dependent permutations here); the other
+// lanes run the same instruction stream on zeros and store nothing.
 __global__ void __launch_bounds__(64) challenger_kernel(Challenger *ch, const u64 *obs, size_t n_obs, u64 *out,
                                                        size_t n_get) {
     __shared__ u64 inbuf[8];
     __shared__ u64 outbuf[8];
-    const unsigned lane = threadIdx.x, q = lane & 3;
-    const bool owner = lane < 4;
+    const unsigned lane = threadIdx.x, r = lane & 15;
+    const bool owner = lane < 12;
     u32 n_in = ch->n_in, n_out = ch->n_out;
-    u64 w[3];
-#pragma unroll
-    for (unsigned u = 0; u < 3; ++u) w[u] = owner ? ch->state[3 * q + u] : 0;
+    u64 w = owner ? ch->state[lane] : 0;
     if (lane < 8) {
         inbuf[lane] = ch->in[lane];
         outbuf[lane] = ch->out[lane];
     }
     __syncthreads();
+    const poseidon16::RowConsts k = poseidon16::row_consts(r);
     // duplexing (challenger.rs:129-144): overwrite the first n_in words with the buffered inputs, permute,
     // refill the output buffer with the rate portion
     auto duplex = [&]() {
-#pragma unroll
-        for (unsigned u = 0; u < 3; ++u)
-            if (owner && 3 * q + u < n_in) w[u] = inbuf[3 * q + u];
-        poseidon4::permute_quad(w, q);
-#pragma unroll
-        for (unsigned u = 0; u < 3; ++u) {
-            w[u] = gl::canon(w[u]);
-            if (owner && 3 * q + u < 8) outbuf[3 * q + u] = w[u];
-        }
+        if (owner && lane < n_in) w = inbuf[lane];
+        poseidon16::permute_row(w, r, k);
+        w = gl::canon(w);
+        if (lane < 8) outbuf[lane] = w;
         n_in = 0;
         n_out = 8;
         __syncthreads();
     };
-    for (size_t k = 0; k < n_obs; ++k) {
+    for (size_t i = 0; i < n_obs; ++i) {
         n_out = 0;
-        if (lane == 0) inbuf[n_in] = gl::canon(obs[k]);
+        if (lane == 0) inbuf[n_in] = gl::canon(obs[i]);
         ++n_in;
         __syncthreads();
         if (n_in == 8) duplex();
     }
-    for (size_t k = 0; k < n_get; ++k) {
+    for (size_t i = 0; i < n_get; ++i) {
         if (n_in != 0 || n_out == 0) duplex();
         --n_out;
-        if (lane == 0) out[k] = outbuf[n_out];
+        if (lane == 0) out[i] = outbuf[n_out];
     }
     __syncthreads();
-#pragma unroll
-    for (unsigned u = 0; u < 3; ++u)
-        if (owner) ch->state[3 * q + u] = w[u];
+    if (owner) ch->state[lane] = w;
     if (lane < 8) {
         ch->in[lane] = inbuf[lane];
         ch->out[lane] = outbuf[lane];

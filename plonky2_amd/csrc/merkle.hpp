@@ -13,6 +13,7 @@
 #pragma once
 #include "poseidon.hpp"
 #include "poseidon4.hpp"
+#include "poseidon16.hpp"
 
 namespace merkle {
 using gl::u32;
@@ -149,6 +150,51 @@ __global__ void __launch_bounds__(256) merkle_level_quad_kernel(u64 *digests, u6
             dst[3] = gl::canon(w[0]);
         }
     }
+}
+
+// ---- word-per-lane variants (16 lanes per leaf / node, poseidon16.hpp): the lowest latency per permutation, used for
+// launches with at most a few thousand permutations.  Every thread stays alive to the end (the row broadcasts need the lanes).
+template <class Reader>
+__global__ void __launch_bounds__(256) hash_leaves_row_kernel(Reader rd, unsigned W, size_t leaf_offset, size_t leaf_count,
+                                                             unsigned h, u64 *digests, u64 *cap) {
+    const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const unsigned r = threadIdx.x & 15;
+    const bool live = t < leaf_count;
+    const size_t L = leaf_offset + (live ? t : 0);
+    u64 w = 0;  // state word r
+    if (W <= 4) {  // hash_or_noop: copy (plonk/config.rs:63-74)
+        if (live && r < W) w = rd(L, r);
+    } else {
+        const poseidon16::RowConsts k = poseidon16::row_consts(r);
+        for (unsigned off = 0; off < W; off += 8) {
+            const unsigned cnt = W - off < 8 ? W - off : 8;
+            if (live && r < cnt) w = rd(L, off + r);  // overwrite-mode absorb: word r of the rate portion <- input off + r
+            poseidon16::permute_row(w, r, k);
+        }
+    }
+    if (live && r < 4) node_slot(digests, cap, h, 0, L)[r] = gl::canon(w);
+}
+
+__global__ void __launch_bounds__(256) merkle_level_row_kernel(u64 *digests, u64 *cap, unsigned h, unsigned level, size_t n_nodes) {
+    const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const unsigned r = threadIdx.x & 15;
+    const bool live = j < n_nodes;
+    const u64 *ch = node_slot(digests, cap, h, level - 1, 2 * (live ? j : 0));  // 8 contiguous words [left, right]
+    u64 w = (live && r < 8) ? ch[r] : 0;                                        // words 8..11 = 0
+    const poseidon16::RowConsts k = poseidon16::row_consts(r);
+    poseidon16::permute_row(w, r, k);
+    if (live && r < 4) node_slot(digests, cap, h, level, j)[r] = gl::canon(w);
+}
+
+// raw permutations through the row mapping (parity primitive): states [count][12]
+__global__ void __launch_bounds__(256) permute_batch_row_kernel(u64 *states, size_t count) {
+    const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const unsigned r = threadIdx.x & 15;
+    const bool live = t < count && r < 12;
+    u64 w = live ? states[12 * t + r] : 0;
+    const poseidon16::RowConsts k = poseidon16::row_consts(r);
+    poseidon16::permute_row(w, r, k);
+    if (live) states[12 * t + r] = gl::canon(w);
 }
 
 // batch of raw permutations, states [count][12] (parity primitive for the reference KATs,

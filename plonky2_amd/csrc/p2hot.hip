@@ -37,6 +37,7 @@ struct p2hot_ctx {
     hipEvent_t join_event = nullptr;
     bool overlap = false;
     size_t quad_threshold = (size_t)1 << 15;  // launches with at most this many permutations use the quad kernels
+    size_t row_threshold = (size_t)1 << 13;   // ... and with at most this many the word-per-lane kernels (16 lanes per permutation)
     unsigned ntt_radix_bits = 3;  // 3: radix-8 rounds / 512 threads, 4: radix-16 / 256 threads
     struct Scratch {
         void *p = nullptr;
@@ -279,6 +280,13 @@ extern "C" const char *p2hot_last_error(const p2hot_ctx *ctx) { return ctx ? ctx
 extern "C" int p2hot_tune_quad(p2hot_ctx *ctx, size_t max_perms) {
     if (!ctx) return P2HOT_EINVAL;
     ctx->quad_threshold = max_perms;
+    return P2HOT_OK;
+}
+
+// tuning knob: launches with at most `max_perms` permutations use the word-per-lane Poseidon kernels (0 = never)
+extern "C" int p2hot_tune_row(p2hot_ctx *ctx, size_t max_perms) {
+    if (!ctx) return P2HOT_EINVAL;
+    ctx->row_threshold = max_perms;
     return P2HOT_OK;
 }
 
@@ -606,7 +614,10 @@ extern "C" int p2hot_poseidon_permute_dev(p2hot_ctx *ctx, uint64_t *d_states, si
     if (!ctx) return P2HOT_EINVAL;
     if (count == 0) return P2HOT_OK;
     if (!d_states) P2_FAIL(ctx, P2HOT_EINVAL, "poseidon_permute: null states");
-    P2HOT_LAUNCH(merkle::permute_batch_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, d_states, count);
+    if (count <= ctx->row_threshold)  // the word-per-lane mapping (also what the challenger runs); larger batches: one permutation per lane
+        P2HOT_LAUNCH(merkle::permute_batch_row_kernel, dim3(cdiv(16 * count, 256)), dim3(256), 0, ctx->stream, d_states, count);
+    else
+        P2HOT_LAUNCH(merkle::permute_batch_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, d_states, count);
     P2_LAUNCH_CHECK(ctx);
     return P2HOT_OK;
 }
@@ -663,7 +674,10 @@ static int hash_leaves_range(p2hot_ctx *ctx, hipStream_t stream, Reader rd, size
                              size_t leaf_offset, size_t count) {
     if (count == 0) return P2HOT_OK;
     ProfScope ps(ctx, "hash_leaves", stream, true);
-    if (count <= ctx->quad_threshold) {  // too few permutations to fill the chip: 4 lanes per leaf, ~3x lower latency
+    if (count <= ctx->row_threshold) {  // a few thousand leaves at most: 16 lanes per leaf, the lowest latency per permutation
+        P2HOT_LAUNCH((merkle::hash_leaves_row_kernel<Reader>), dim3(cdiv(16 * count, 256)), dim3(256), 0, stream, rd, (unsigned)W,
+                     leaf_offset, count, g.h, g.dig, g.cap);
+    } else if (count <= ctx->quad_threshold) {  // too few permutations to fill the chip: 4 lanes per leaf, ~3x lower latency
         P2HOT_LAUNCH((merkle::hash_leaves_quad_kernel<Reader>), dim3(cdiv(4 * count, 256)), dim3(256), 0, stream, rd,
                      (unsigned)W, leaf_offset, count, g.h, g.dig, g.cap);
     } else {
@@ -678,7 +692,10 @@ static int merkle_levels(p2hot_ctx *ctx, const ForestGeom &g, size_t leaf_count)
     ProfScope ps(ctx, "merkle_levels");
     for (unsigned level = 1; level <= g.h; ++level) {
         size_t nodes = leaf_count >> level;
-        if (nodes <= ctx->quad_threshold)
+        if (nodes <= ctx->row_threshold)
+            P2HOT_LAUNCH(merkle::merkle_level_row_kernel, dim3(cdiv(16 * nodes, 256)), dim3(256), 0, ctx->stream, g.dig, g.cap, g.h, level,
+                         nodes);
+        else if (nodes <= ctx->quad_threshold)
             P2HOT_LAUNCH(merkle::merkle_level_quad_kernel, dim3(cdiv(4 * nodes, 256)), dim3(256), 0, ctx->stream, g.dig,
                          g.cap, g.h, level, nodes);
         else

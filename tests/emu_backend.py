@@ -71,4 +71,7 @@ def emu_engine():
     # both Poseidon mappings get exercised by the CPU tier: launches of up to 20 permutations take the quad-cooperative
     # kernels (their emulated cross-lane exchanges are slow), larger ones the one-permutation-per-lane kernels
     eng.check(eng.lib.p2hot_tune_quad(eng.ctx, 20))
+    # ... and launches of up to 6 permutations the word-per-lane kernels (16 emulated lanes and 24 emulated row broadcasts
+    # per round: the slowest to emulate); the challenger always runs that mapping
+    eng.check(eng.lib.p2hot_tune_row(eng.ctx, 6))
     return eng

@@ -441,8 +441,9 @@ def test_fri_transcript_padding_options(eng, ora):
 
 
 def test_quad_and_lane_poseidon_kernels_agree(eng, ora):
-    """p2hot_tune_quad: the quad-cooperative kernels (4 lanes per permutation, DPP quad rotations) and the
-    one-permutation-per-lane kernels produce the same trees; both equal the oracle"""
+    """p2hot_tune_quad / p2hot_tune_row: the word-per-lane kernels (16 lanes per permutation, DPP row broadcasts), the
+    quad-cooperative kernels (4 lanes, DPP quad rotations) and the one-permutation-per-lane kernels produce the same
+    trees; all equal the oracle"""
     from plonky2_amd.hash.merkle_tree import MerkleTree
     rng = np.random.default_rng(91)
     gpu = is_gpu(eng)
@@ -451,13 +452,37 @@ def test_quad_and_lane_poseidon_kernels_agree(eng, ora):
         for (n, w, cap) in cases:
             leaves = rand_field(rng, n, w, noncanonical=True)
             digests, capv = ora.merkle_tree(leaves, cap)
-            for thr in (0, 1 << 20):
-                eng.check(eng.lib.p2hot_tune_quad(eng.ctx, thr))
+            for (quad, row) in ((0, 0), (1 << 20, 0), (0, 1 << 20) if (gpu or n * w <= 64 * 9) else (0, 8)):
+                eng.check(eng.lib.p2hot_tune_quad(eng.ctx, quad))
+                eng.check(eng.lib.p2hot_tune_row(eng.ctx, row))
                 t = MerkleTree.new(leaves, cap, engine=eng)
-                assert (t.cap.entries == capv).all(), (n, w, cap, thr)
-                assert (np.asarray(t.digests).reshape(-1, 4) == digests).all(), (n, w, cap, thr)
+                assert (t.cap.entries == capv).all(), (n, w, cap, quad, row)
+                assert (np.asarray(t.digests).reshape(-1, 4) == digests).all(), (n, w, cap, quad, row)
     finally:
         eng.check(eng.lib.p2hot_tune_quad(eng.ctx, 20 if not gpu else 1 << 15))
+        eng.check(eng.lib.p2hot_tune_row(eng.ctx, 6 if not gpu else 1 << 13))
+
+
+def test_row_poseidon_kats_and_edges(eng, ora, kats):
+    """the word-per-lane permutation (what the challenger and the smallest launches run) on the reference's four KATs
+    (poseidon_goldilocks.rs:455-490), boundary-word states and random states, vs the oracle; batch sizes that are not a
+    multiple of the four states a wave holds"""
+    rng = np.random.default_rng(1234)
+    gpu = is_gpu(eng)
+    edge = np.array([0, 1, P - 1, P, P + 1, 2**64 - 1, 2**32 - 1, 2**32, 2**63, 0xFFFFFFFF00000000], dtype=np.uint64)
+    states = [np.array(k["input"], dtype=np.uint64) for k in kats["poseidon12"]]
+    states += [edge[rng.integers(0, len(edge), size=12)] for _ in range(5 if not gpu else 200)]
+    states += [rng.integers(0, 2**64 - 1, size=12, dtype=np.uint64) for _ in range(4 if not gpu else 300)]
+    st = np.stack(states)
+    try:
+        eng.check(eng.lib.p2hot_tune_row(eng.ctx, 1 << 20))
+        for m in (1, 3, len(st)):
+            got = eng.host(eng.poseidon_permute(eng.dev(st[:m].copy())))
+            assert (got == np.stack([ora.poseidon(s) for s in st[:m]])).all(), m
+        for k, g in zip(kats["poseidon12"], got[:4]):
+            assert [int(x) for x in g] == k["output"]
+    finally:
+        eng.check(eng.lib.p2hot_tune_row(eng.ctx, 6 if not gpu else 1 << 13))
 
 
 def test_host_pointer_commit_random_shapes(eng, ora):
