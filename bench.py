@@ -275,13 +275,21 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    # P2HOT_BENCH_BACKEND=gloo (tooling): the ranks may share a GPU and exchange through the host -- the whole multi-process
+    # flow, cap check included, on a one-GPU box; the numbers of such a run are not scaling numbers
+    backend = os.environ.get("P2HOT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -328,16 +336,18 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_results(reset=True)
     eng.profile(False)
-    # what was timed is checked: the cap of the last timed step against the faithful oracle's golden cap of the same
-    # synthetic columns (tests/golden/commit_caps.json; only the headline single-GPU shape has one)
-    g = golden("c3_wires") if (world, W, log_n, rb, cap) == (1, 135, 20, 3, 4) else None
+    # what was timed is checked: the cap of the last timed step against the oracle's golden cap of the same synthetic
+    # columns (tests/golden/commit_caps.json: the headline shape and the 2 / 4 / 8-GPU weak-scaling shapes, C5 at 8)
+    gname = {(135, 16, 3, 4): "c2_wires", (135, 20, 3, 4): "c3_wires", (135, 21, 3, 4): "scale2_wires", (135, 22, 3, 4): "scale4_wires",
+             (135, 23, 3, 4): "c5_wires"}.get((W, log_n, rb, cap))
+    g = golden(gname) if gname else None
     cap_checked = None
     if g is not None:
         cap_checked = eng.host(job.cap).tolist() == g["cap"]
         if not cap_checked:
             raise SystemExit("bench: the Merkle cap of the timed commit differs from the oracle's golden cap")
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=eng.mem.device)
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.mem.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -363,6 +373,9 @@ def main():
             "config": {"workload": "PolynomialBatch::from_values, W=%d, 2^%d rows, rate 1/%d (N=2^%d), cap_height %d, "
                                    "PoseidonGoldilocksConfig (C3 wires commit at --gpus 1; +1 bit of rows per doubling of GPUs)"
                                    % (W, log_n, 1 << rb, log_n + rb, cap),
+                       "transport": None if world == 1 else {"rccl": "RCCL inside libp2hot (ncclBroadcast groups on the library's communication stream)",
+                                                                    "torch": "torch.distributed all_gather on device buffers (fallback: librccl could not be bound)",
+                                                                    "gloo": "gloo through host staging (ranks sharing a GPU: a functional run, not a scaling number)"}.get(job.comm.transport, job.comm.transport),
                        "sharding": "none" if world == 1 else "LDE cosets over %d ranks; iNTT column-sharded, coefficients all-gathered in "
                                    "async column chunks overlapped with the NTTs; RCCL all-gather of %s" % (world, "digests + cap" if gather_digests else "the cap (digests stay with the row owner)")},
             "roofline": {"kernel": "hash_leaves_kernel<ColMajorReader> (Poseidon leaf sponge)", "bound": "hbm",

@@ -84,16 +84,77 @@ def _gloo_transport(dist, rank):
     return _lib.ALLGATHER_FN(fn)
 
 
+class _DevBytes:
+    """a raw device range as a __cuda_array_interface__ object (torch.as_tensor wraps it without a copy)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _torch_transport(dist, rank):
+    """p2hot_allgather_fn over torch.distributed with DEVICE buffers (backend "nccl" = torch's own RCCL communicator): the
+    fallback when the library cannot bind RCCL itself.  Synchronous: waits for the library's communication stream, runs
+    the all-gather on torch's, waits for it -- correct, but without the overlap of the in-library path."""
+    import torch
+
+    def fn(_user, d_base, offsets, world, nbytes, stream):
+        try:
+            if stream:
+                torch.cuda.ExternalStream(stream).synchronize()
+            else:
+                torch.cuda.synchronize()
+            slots = [torch.as_tensor(_DevBytes(d_base + offsets[r], nbytes), device="cuda") for r in range(world)]
+            dist.all_gather(slots, slots[rank].clone())
+            torch.cuda.synchronize()
+            return 0
+        except Exception as e:  # an exception must not unwind through the C frames
+            print("p2hot transport callback failed:", repr(e), flush=True)
+            return 1
+    return _lib.ALLGATHER_FN(fn)
+
+
+def _gloo_device_transport(dist, rank):
+    """p2hot_allgather_fn over a gloo process group with DEVICE buffers staged through the host: lets several ranks share
+    one GPU (RCCL refuses a repeated device), which is how the multi-process bench flow is exercised on a one-GPU box."""
+    import torch
+
+    def fn(_user, d_base, offsets, world, nbytes, stream):
+        try:
+            torch.cuda.synchronize()
+            slots = [torch.as_tensor(_DevBytes(d_base + offsets[r], nbytes), device="cuda") for r in range(world)]
+            outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(outs, slots[rank].cpu())
+            for r in range(world):
+                if r != rank:
+                    slots[r].copy_(outs[r])
+            torch.cuda.synchronize()
+            return 0
+        except Exception as e:  # an exception must not unwind through the C frames
+            print("p2hot transport callback failed:", repr(e), flush=True)
+            return 1
+    return _lib.ALLGATHER_FN(fn)
+
+
 class Communicator:
     """p2hot_comm: this rank's end of the library's exchange.  transport: "rccl" (inside libp2hot, one process per GPU),
-    "gloo" (caller-supplied hook over torch.distributed, host buffers) or None = pick by the process group's backend."""
+    "torch" / "gloo" (caller-supplied hook over torch.distributed with device / host buffers) or None = pick by the process
+    group's backend (P2HOT_TRANSPORT overrides): "rccl" under "nccl" when every rank can bind librccl, else "torch"."""
 
     def __init__(self, engine, rank, world, dist=None, transport=None):
         self.engine, self.rank, self.world = engine, rank, world
         self._cb = None
         h = C.c_void_p()
         if transport is None:
+            transport = os.environ.get("P2HOT_TRANSPORT") or None
+        if transport is None:
             transport = "none" if world == 1 or dist is None else ("rccl" if dist.get_backend() == "nccl" else "gloo")
+            if transport == "rccl":  # can every rank bind RCCL inside the library?  (agreed on, so nobody waits alone)
+                import torch
+                probe = np.zeros(128, dtype=np.uint8)
+                ok = torch.tensor([1 if engine.lib.p2hot_comm_unique_id(probe.ctypes.data) == 0 else 0], device=engine.mem.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    transport = "torch"
         self.transport = transport
         if transport == "rccl":
             import torch
@@ -107,7 +168,9 @@ class Communicator:
                 uid = t.cpu().numpy()
             engine.check(engine.lib.p2hot_comm_create_rccl(engine.ctx, rank, world, uid.ctypes.data, C.byref(h)))
         else:
-            self._cb = _gloo_transport(dist, rank) if transport == "gloo" else _lib.ALLGATHER_FN(lambda *a: 1)
+            on_gpu = getattr(getattr(engine.mem, "device", None), "type", None) == "cuda"
+            self._cb = ((_gloo_device_transport if on_gpu else _gloo_transport)(dist, rank) if transport == "gloo"
+                        else _torch_transport(dist, rank) if transport == "torch" else _lib.ALLGATHER_FN(lambda *a: 1))
             engine.check(engine.lib.p2hot_comm_create_callback(engine.ctx, rank, world, self._cb, None, C.byref(h)))
         self._h = h
 

@@ -75,6 +75,83 @@ def test_baseline_commits_bit_exact_vs_oracle_goldens(gpu, name):
     torch.cuda.empty_cache()
 
 
+def _golden(name):
+    import json
+    import os
+    from tests.conftest import ROOT
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "commit_caps.json"))).get(name)
+
+
+@pytest.mark.parametrize("name,lde_blocks", [("scale2_wires", (0, 7)), ("scale4_wires", (3,)), ("c5_wires", (5,))])
+def test_weak_scaling_shapes_bit_exact_on_one_gpu(gpu, name, lde_blocks):
+    """The shapes bench.py commits at --gpus 2 / 4 / 8 (W = 135 at 2^21 / 2^22 / 2^23 rows; the last is BASELINE C5:
+    72.5 GB of LDE values, which one MI355X holds) as ONE context's commit: cap, SHA-256 of the coefficient matrix and of the
+    whole digest array, and of sampled leaf blocks of the LDE matrix, against the oracle's golden bytes
+    (tools/gen_golden_caps.py --streamed)."""
+    import hashlib
+    import torch
+    from plonky2_amd.util.synthetic import splitmix_columns_torch
+    g = _golden(name)
+    if g is None:
+        pytest.skip("no golden for " + name)
+    W, log_n, rb, cap = g["W"], g["log_n"], g["rate_bits"], g["cap_height"]
+    n = 1 << log_n
+    cols = splitmix_columns_torch(torch, gpu.mem.device, 0, W, n)
+    r = gpu.commit(cols, log_n, rb, cap, True)
+    del cols
+    assert gpu.host(r["cap"]).tolist() == g["cap"], "Merkle cap differs from the oracle"
+    h = hashlib.sha256()
+    nd = r["digests"].shape[0]
+    for lo in range(0, nd, 1 << 24):     # 512 MB at a time
+        h.update(gpu.host(r["digests"][lo:lo + (1 << 24)]).tobytes())
+    assert h.hexdigest() == g["sha256_digests"], "digest array differs"
+    h = hashlib.sha256()
+    for c in range(W):
+        co = gpu.host(r["coeffs"][c])
+        h.update(np.where(co >= np.uint64(P), co - np.uint64(P), co).tobytes())
+    assert h.hexdigest() == g["sha256_coeffs"]
+    for b in lde_blocks:                 # leaf block b = LDE coset bitrev(b): rows [b n, (b + 1) n) of every column
+        h = hashlib.sha256()
+        for c in range(W):
+            h.update(gpu.host(r["lde"][c, b * n:(b + 1) * n]).tobytes())
+        assert h.hexdigest() == g["sha256_lde_blocks"][b], ("LDE block", b)
+    del r
+    torch.cuda.empty_cache()
+    gpu.check(gpu.lib.p2hot_ctx_trim(gpu.ctx))
+
+
+@pytest.mark.parametrize("name,world,by_columns", [("scale2_wires", 2, False), ("c5_wires", 8, False), ("scale2_wires", 4, True)])
+def test_weak_scaling_shapes_as_rank_groups_on_one_gpu(gpu, name, world, by_columns):
+    """The same shapes the way the scaling runs shard them -- `world` ranks (all on device 0: the box has one GPU; C5 as
+    its 8 ranks), coset-sharded (and once column-sharded), host pointers in, through p2hot_group_commit: the assembled cap,
+    digest array and coefficients equal the oracle's golden bytes, and an owner serves rows + Merkle paths that verify"""
+    import hashlib
+    import torch
+    from oracle import p2oracle as ora
+    from plonky2_amd.distributed import GroupCommit
+    from plonky2_amd.util.synthetic import splitmix_columns_numpy
+    g = _golden(name)
+    if g is None:
+        pytest.skip("no golden for " + name)
+    W, log_n, rb, cap = g["W"], g["log_n"], g["rate_bits"], g["cap_height"]
+    torch.cuda.empty_cache()
+    gpu.check(gpu.lib.p2hot_ctx_trim(gpu.ctx))
+    cols = splitmix_columns_numpy(0, W, 1 << log_n)
+    grp = GroupCommit(gpu.lib, world, [0] * world)
+    r = grp.commit(cols, rb, cap, True, want_leaves=False, want_digests=True, by_columns=by_columns)
+    del cols
+    assert r["cap"].tolist() == g["cap"]
+    assert hashlib.sha256(r["digests"].tobytes()).hexdigest() == g["sha256_digests"]
+    assert hashlib.sha256(r["coeffs"].tobytes()).hexdigest() == g["sha256_coeffs"]
+    N = 1 << (log_n + rb)
+    xs = [0, N - 1, N // world, N // world - 1, N // 2 + 12345]
+    rows, paths = r["open"](xs)
+    for x, row, path in zip(xs, rows, paths):
+        assert ora.merkle_verify(row, x, r["cap"], path), x
+    r["free"]()
+    grp.close()
+
+
 def test_c3_wires_host_pointer_commit_equals_golden(gpu):
     """the same C3 wires commit through the host-pointer entry point the Rust shim calls (p2hot_commit, pipelined
     PCIe copies): cap and digest array equal the oracle's golden bytes"""

@@ -13,6 +13,15 @@ so the GPU tests (tests/test_gpu_fullsize.py) and bench.py can compare the devic
 inputs with the oracle's bytes WITHOUT running 1.5e8 CPU permutations on the GPU box, and independently of the
 tuned CPU code (oracle/p2fast.c), which this script also cross-checks against the same bytes.
 Inputs come from plonky2_amd/util/synthetic.py (the bench's splitmix columns, the C4 Fibonacci trace).
+
+    python tools/gen_golden_caps.py --streamed [--only NAME]      (~1 hour)
+
+The shapes of the weak-scaling bench lines (W=135 at 2^21 / 2^22 / 2^23 rows = BASELINE C5 on 2 / 4 / 8 GPUs) do not fit
+the whole-matrix oracle in this container's RAM (C5: 72.5 GB of LDE values).  `--streamed` computes them one LDE coset at
+a time from the SAME oracle primitives (ora_ifft, ora_coset_fft with shift g * w_N^j, ora_reverse_index_bits,
+ora_merkle_tree): coset j of the rate-1/B LDE is leaf block bitrev(j), i.e. cap subtrees
+[bitrev(j) * 2^cap / B, ...), so caps and digest arrays concatenate block by block.  The composition is first checked
+against the whole-matrix goldens above (c2_wires and c3_wires must reproduce byte for byte) before anything is written.
 """
 import argparse
 import hashlib
@@ -55,10 +64,113 @@ def sha_colmajor_from_rows(leaves):
     return h.hexdigest()
 
 
+# weak-scaling bench shapes (bench.py --gpus 2 / 4 / 8): name -> (W, log_n, rate_bits, cap_height, is_values)
+STREAMED = {
+    "scale2_wires": (135, 21, 3, 4, True),
+    "scale4_wires": (135, 22, 3, 4, True),
+    "c5_wires": (135, 23, 3, 4, True),
+}
+
+
+def bitrev(x, bits):
+    return int(format(x, "0%db" % bits)[::-1], 2) if bits else 0
+
+
+def streamed_commit(ora, cols, rb, cap, is_values, threads, fast=None):
+    """one coset at a time; returns cap, sha256 of coeffs / digests, and the per-block LDE hashes.
+    fast: hash the leaf rows with the tuned AVX-512 sponge (oracle/p2fast.c: 20x the faithful one's speed), spot-checked on
+    4096 random rows per block against the faithful ora_hash_no_pad; the tree levels above stay with ora_merkle_tree
+    (4-word leaves are their own digests, plonk/config.rs:63-74).  None: the faithful sponge for every leaf."""
+    from concurrent.futures import ThreadPoolExecutor
+    W, n = cols.shape
+    log_n = n.bit_length() - 1
+    B = 1 << rb
+    assert cap >= rb
+    w_N = ora.root_of_unity(log_n + rb)
+    pool = ThreadPoolExecutor(threads)
+    if is_values:
+        coeffs = np.empty_like(cols)
+
+        def inv(c):
+            coeffs[c] = ora.ifft(cols[c])
+        list(pool.map(inv, range(W)))
+    else:
+        coeffs = cols
+    sha_coeffs = hashlib.sha256()
+    for c in range(W):
+        sha_coeffs.update((coeffs[c] % np.uint64(ora.P)).tobytes())
+    sha_dig = hashlib.sha256()
+    caps, lde_blocks = [], []
+    block = np.empty((W, n), dtype=np.uint64)
+    for b in range(B):                       # leaf blocks in committed order
+        j = bitrev(b, rb)                    # ... = LDE coset j: the points g * w_N^(B q + j)
+        shift = ora.gl_mul(ora.COSET_SHIFT, ora.gl_pow(w_N, j))
+
+        def lde(c):
+            block[c] = ora.reverse_index_bits(ora.coset_fft(coeffs[c], shift))
+        list(pool.map(lde, range(W)))
+        h = hashlib.sha256()
+        for c in range(W):
+            h.update(block[c].tobytes())
+        lde_blocks.append(h.hexdigest())
+        rows = np.ascontiguousarray(block.T)
+        if fast is not None and W > 4:
+            leaf_digests = fast.hash_rows(rows)
+            for i in np.random.default_rng(b).integers(0, n, size=4096):
+                assert (ora.hash_no_pad(rows[i]) == leaf_digests[i]).all(), (b, i)
+            digests, capb = ora.merkle_tree(leaf_digests, cap - rb)
+        else:
+            digests, capb = ora.merkle_tree(rows, cap - rb)
+        del rows
+        sha_dig.update(digests.tobytes())
+        caps.append(capb)
+        print("   block %d/%d" % (b + 1, B), flush=True)
+    return dict(cap=np.concatenate(caps), sha256_coeffs=sha_coeffs.hexdigest(), sha256_digests=sha_dig.hexdigest(),
+                sha256_lde_blocks=lde_blocks)
+
+
+def main_streamed(args):
+    from oracle import p2fast
+    from oracle import p2oracle as ora
+    threads = ora.usable_cores()
+    ora.set_num_threads(threads)
+    p2fast.set_num_threads(threads)
+    fast = None if args.faithful_leaves else p2fast
+    out = json.load(open(OUT))
+    for name in ("c2_wires", "c3_wires"):   # the composition must reproduce the whole-matrix oracle's bytes first
+        W, log_n, rb, cap, is_values, _ = SHAPES[name]
+        t0 = time.time()
+        r = streamed_commit(ora, splitmix_columns_numpy(0, W, 1 << log_n), rb, cap, is_values, threads, fast)
+        g = out[name]
+        assert r["cap"].tolist() == g["cap"] and r["sha256_digests"] == g["sha256_digests"] \
+            and r["sha256_coeffs"] == g["sha256_coeffs"], name
+        print("streamed == whole-matrix oracle on %s (%.0f s)" % (name, time.time() - t0), flush=True)
+    for name, (W, log_n, rb, cap, is_values) in STREAMED.items():
+        if args.only and name != args.only:
+            continue
+        t0 = time.time()
+        r = streamed_commit(ora, splitmix_columns_numpy(0, W, 1 << log_n), rb, cap, is_values, threads, fast)
+        if name in out:   # a second method (e.g. --faithful-leaves after the default) must agree with what is there
+            assert out[name]["cap"] == r["cap"].tolist() and out[name]["sha256_digests"] == r["sha256_digests"], name
+        out[name] = {"W": W, "log_n": log_n, "rate_bits": rb, "cap_height": cap, "is_values": is_values, "input": "splitmix",
+                     "method": "coset-streamed composition of the oracle primitives (checked against c2_wires / c3_wires); leaf sponge: "
+                               + ("oracle/p2oracle.c" if fast is None else "oracle/p2fast.c, 4096 rows per block re-hashed by oracle/p2oracle.c"),
+                     "cap": [[int(x) for x in row] for row in r["cap"]], "sha256_coeffs": r["sha256_coeffs"],
+                     "sha256_digests": r["sha256_digests"], "sha256_lde_blocks": r["sha256_lde_blocks"]}
+        print("%s: %.0f s, cap[0] = %s" % (name, time.time() - t0, out[name]["cap"][0]), flush=True)
+        with open(OUT, "w") as fh:
+            json.dump(out, fh, indent=1)
+    print("wrote", OUT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--streamed", action="store_true")
+    ap.add_argument("--faithful-leaves", action="store_true", help="--streamed: every leaf through the faithful sponge (20x slower)")
     args = ap.parse_args()
+    if args.streamed:
+        return main_streamed(args)
     from oracle import p2fast as fast
     from oracle import p2oracle as ora
     ora.set_num_threads(ora.usable_cores())
