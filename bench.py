@@ -130,7 +130,7 @@ def other_configs(eng, torch, reps=3):
     dev = eng.mem.device
     out = {}
 
-    def timed(fn):
+    def timed(fn, reps=reps):
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -139,8 +139,8 @@ def other_configs(eng, torch, reps=3):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3
 
-    def commit_line(name, W, log_n, rb, cap, is_values, cols, what):
-        ms = timed(lambda: eng.commit(cols, log_n, rb, cap, is_values))
+    def commit_line(name, W, log_n, rb, cap, is_values, cols, what, reps=reps):
+        ms = timed(lambda: eng.commit(cols, log_n, rb, cap, is_values), reps)
         g = golden(name)
         rec = {"workload": what, "ms": ms, "GFE/s": W * (1 << (log_n + rb)) / ms / 1e6}
         if g is not None:
@@ -250,6 +250,13 @@ def other_configs(eng, torch, reps=3):
                      "ms": sum(mean.values()), "stage_ms": {k: round(v, 3) for k, v in mean.items()}}
 
     starky_line("per_proof_path_starky_k22", 22)
+
+    # C5 (2^23 rows, W = 135: the 8-GPU configuration, 72.5 GB of LDE values) as ONE MI355X's commit: HBM holds it whole
+    torch.cuda.empty_cache()
+    if torch.cuda.mem_get_info()[0] > 130 * (1 << 30):
+        commit_line("c5_wires", 135, 23, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 135, 1 << 23),
+                    "C5 on one GPU: from_values W=135, 2^23 rows, rate 1/8, cap 4 (the shape bench.py --gpus 8 shards over 8 ranks)", reps=2)
+        torch.cuda.empty_cache()
     return out
 
 

@@ -300,6 +300,30 @@ def test_rccl_communicator_one_rank(gpu, ora, chunks, gather):
     job.comm.close()
 
 
+def test_device_buffer_transport_hooks(gpu):
+    """The two caller-side p2hot_allgather_fn hooks that take DEVICE buffers -- over torch.distributed's own RCCL communicator
+    (the fallback when the library cannot bind librccl) and over gloo with host staging (ranks sharing a GPU) -- wrap raw
+    device ranges without copies and leave a one-rank buffer intact; the multi-rank flow through the second one is what
+    tools/gpu_multiproc.sh runs on this box"""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from plonky2_amd import distributed as D
+    buf = torch.arange(1 << 12, dtype=torch.int64, device=gpu.mem.device)
+    want = buf.clone()
+    offs = (C.c_size_t * 1)(0)
+    for backend, make, port in (("nccl", D._torch_transport, 29561), ("gloo", D._gloo_device_transport, 29562)):
+        kw = {"device_id": gpu.mem.device} if backend == "nccl" else {}
+        dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, **kw)
+        try:
+            cb = make(dist, 0)
+            assert cb(None, buf.data_ptr() + 64, offs, 1, buf.numel() * 8 - 64, None) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(buf, want)
+        finally:
+            dist.destroy_process_group()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("is_values,want_leaves", [(True, False), (False, True)])
 def test_host_pointer_commit_pipelined_path(gpu, ora, is_values, want_leaves):
