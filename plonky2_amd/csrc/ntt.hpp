@@ -244,6 +244,8 @@ struct RegPassArgs {
     int inverse;
     const u64 *twid;         // inter-pass twiddles of this (strided) pass as a table laid out like one block of the data,
                              // twid[(i << log_stride) + col] = w_{n'}^(col * bitrev(i)); null = build them from the root tables
+    unsigned xcd_remap;      // > 0 (= log2 of gridDim.x): workgroup b works on tile (b % 8) * gridDim.x / 8 + b / 8, so the
+                             // workgroups one XCD runs together are neighbouring column groups (they share 128-byte lines)
     unsigned zloop;          // > 0: this workgroup produces z = 0..zloop-1 itself (coset LDE first pass: the
                              // coefficient tile is fetched from HBM once and re-read from L2 for the other cosets)
 };
@@ -334,7 +336,7 @@ __global__ void __launch_bounds__(NT, MINW) ntt_regpass_kernel(RegPassArgs ra) {
     const unsigned logC = CONTIG ? 0u : a.log_c, C = 1u << logC;
     const unsigned log_stride = CONTIG ? 0u : a.log_nblk - a.log_r;
     const unsigned tiles_per_blk_log = log_stride - logC;
-    const size_t tau = blockIdx.x;
+    const size_t tau = (!CONTIG && ra.xcd_remap) ? (((size_t)(blockIdx.x & 7u) << (ra.xcd_remap - 3)) | (blockIdx.x >> 3)) : blockIdx.x;
     const size_t blk = tau >> tiles_per_blk_log;
     const size_t base0 = (tau & (((size_t)1 << tiles_per_blk_log) - 1)) << logC;
     const unsigned elems = 1u << (a.log_r + logC);

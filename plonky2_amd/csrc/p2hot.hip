@@ -39,6 +39,8 @@ struct p2hot_ctx {
     size_t quad_threshold = (size_t)1 << 15;  // launches with at most this many permutations use the quad kernels
     size_t row_threshold = (size_t)1 << 13;   // ... and with at most this many the word-per-lane kernels (16 lanes per permutation)
     unsigned ntt_radix_bits = 3;  // 3: radix-8 rounds / 512 threads, 4: radix-16 / 256 threads
+    unsigned ntt_strided_bits = 10;  // most bits a strided pass takes (tile = 2^b rows x 2^(12-b) columns)
+    bool ntt_xcd_remap = true;       // strided passes: neighbouring column groups (same 128-byte lines) on the same XCD
     struct Scratch {
         void *p = nullptr;
         size_t cap = 0;
@@ -189,6 +191,11 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     if (!out) return P2HOT_EINVAL;
     p2hot_ctx *ctx = new p2hot_ctx();
     ctx->device = device;
+    if (const char *e = getenv("P2HOT_NTT_STRIDED_BITS")) {  // pass-planning experiments (tools/tune_ntt.py)
+        const int b = atoi(e);
+        if (b >= 6 && b <= 11) ctx->ntt_strided_bits = (unsigned)b;
+    }
+    if (const char *e = getenv("P2HOT_NTT_XCD_REMAP")) ctx->ntt_xcd_remap = atoi(e) != 0;
     *out = ctx;  // returned even on failure so the caller can read last_error, then destroy
     P2_HIP(ctx, hipSetDevice(device));
     ctx->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream
@@ -349,17 +356,21 @@ struct Pass {
     unsigned log_r, log_c;
 };
 
-static std::vector<Pass> plan_passes(unsigned log_n) {
+static std::vector<Pass> plan_passes(unsigned log_n, unsigned maxb) {
     std::vector<Pass> p;
     if (log_n <= ntt::TILE_LOG) {
         p.push_back({log_n, 0});
         return p;
     }
-    // strided passes take up to 9 bits each: a tile is then 512 rows x 8 columns, i.e. 64-byte row segments -- half
-    // the 128-byte segments of an 8-bit pass, but 2^21 (the per-GPU transform of a 2-GPU C3 job) needs two passes
-    // instead of three, and the passes are ALU-bound, not HBM-bound
+    // strided passes take up to 10 bits each: a tile is then 1024 rows x 4 columns, i.e. 32-byte row segments.  Narrow
+    // segments cost HBM efficiency (an 11-bit pass with 16-byte segments measured 1.6x slower than two passes), but the
+    // passes are ALU-bound and the workgroups that share a 128-byte line run on the same XCD (xcd_remap), so 2^21 and 2^22
+    // -- the per-GPU transforms of 2- and 4-GPU C3 jobs -- take two passes instead of three (2^22: 20.1 ms instead of
+    // 2 x 11.6 per strided step; without the remap 28.0: profiles/r02_e_tune_strided.txt).  2^23 stays at three passes: a
+    // 2^13-element contiguous tile (64 KiB of LDS, five radix rounds, half the waves per CU) was built and measured -- its
+    // pass costs 35.4 ms instead of 29.2 and the single 10-bit strided pass 40.2 instead of 2 x 23.8: 559 ms either way.
     unsigned rem = log_n - ntt::TILE_LOG;
-    unsigned k = (rem + 8) / 9;
+    unsigned k = (rem + maxb - 1) / maxb;
     for (unsigned i = 0; i < k; ++i) {
         unsigned part = rem / (k - i);
         if (rem % (k - i)) ++part;
@@ -378,7 +389,7 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
                    u64 scale_const, const u64 *srow, const u64 *scol, bool canon_last) {
     if (batch == 0 || zcount == 0) return P2HOT_OK;
     if (batch > 65535 || zcount > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "batch %zu / z %zu exceed the grid limit", batch, zcount);
-    std::vector<Pass> passes = plan_passes(log_n);
+    std::vector<Pass> passes = plan_passes(log_n, ctx->ntt_strided_bits);
     unsigned log_nblk = log_n;
     for (size_t i = 0; i < passes.size(); ++i) {
         ntt::PassArgs a{};
@@ -425,6 +436,7 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
             }
             ra.local = inverse ? ctx->local_inv : ctx->local_fwd;
             ra.inverse = inverse;
+            ra.xcd_remap = (ctx->ntt_xcd_remap && a.log_c && tiles_log >= 3) ? tiles_log : 0;
             // rounds of radix <= 2^maxp, remainder split as evenly as possible.  Radix 8 with 512 threads
             // (8 points per lane, <= 64 VGPRs, 8 waves/SIMD) measured faster than radix 16 with 256 threads:
             // the pass is mostly VALU issue, and the extra waves cover the global / LDS / barrier waits.
@@ -468,7 +480,7 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
     return P2HOT_OK;
 }
 
-static unsigned first_pass_log_r(unsigned log_n) { return plan_passes(log_n)[0].log_r; }
+static unsigned first_pass_log_r(const p2hot_ctx *ctx, unsigned log_n) { return plan_passes(log_n, ctx->ntt_strided_bits)[0].log_r; }
 
 static size_t bitrev_sz(size_t x, unsigned bits) {
     size_t r = 0;
@@ -544,7 +556,7 @@ extern "C" int p2hot_coset_ifft_dev(p2hot_ctx *ctx, uint64_t *d_data, size_t bat
 // srow[z][i] = s_b^(i * stride), scol[z][base] = s_b^base
 static int coset_scale_tables(p2hot_ctx *ctx, unsigned log_n, unsigned rate_bits, u64 shift, size_t b0, size_t zc,
                               const u64 **srow, const u64 **scol) {
-    const unsigned log_r = first_pass_log_r(log_n);
+    const unsigned log_r = first_pass_log_r(ctx, log_n);
     auto key = std::make_tuple(log_n, rate_bits, shift, b0, zc, log_r);
     const size_t R = (size_t)1 << log_r, stride = (size_t)1 << (log_n - log_r);
     auto it = ctx->scale_cache.find(key);

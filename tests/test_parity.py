@@ -149,13 +149,14 @@ def test_fft_boundary_words_vs_oracle(eng, ora, log_n):
 
 
 def test_fft_three_pass_sizes(eng, ora):
-    """log_n = 21 is the largest two-pass size (a 9-bit strided pass); log_n >= 22 takes three passes"""
+    """log_n = 22 is the largest two-pass size (a 10-bit strided pass: 1024 x 4 tiles, the workgroups sharing a 128-byte
+    line placed on one XCD); log_n >= 23 takes three passes"""
     from plonky2_amd.field.fft import ifft
     from plonky2_amd.field.fft import fft
     if not is_gpu(eng):
         pytest.skip("2^21 points: GPU tier")
     rng = np.random.default_rng(5)
-    for log_n in (21, 22, 23):  # pass plans (9,12), (5,5,12) and (6,5,12); 2^23 is the per-rank transform of config C5
+    for log_n in (21, 22, 23):  # pass plans (9,12), (10,12) and (6,5,12); 2^23 is the per-rank transform of config C5
         a = rand_field(rng, 1, 1 << log_n)
         f = fft(a, eng)
         assert (f[0] == ora.fft(a[0].copy())).all(), log_n
