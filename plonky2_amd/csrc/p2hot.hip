@@ -196,6 +196,10 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
         if (b >= 6 && b <= 11) ctx->ntt_strided_bits = (unsigned)b;
     }
     if (const char *e = getenv("P2HOT_NTT_XCD_REMAP")) ctx->ntt_xcd_remap = atoi(e) != 0;
+    // start values of p2hot_tune_quad / p2hot_tune_row for every context of the process, the ones p2hot_group_create makes
+    // included (the kernel emulator's test tier lowers them: emulated cross-lane exchanges are slow)
+    if (const char *e = getenv("P2HOT_TUNE_QUAD")) ctx->quad_threshold = (size_t)strtoull(e, nullptr, 10);
+    if (const char *e = getenv("P2HOT_TUNE_ROW")) ctx->row_threshold = (size_t)strtoull(e, nullptr, 10);
     *out = ctx;  // returned even on failure so the caller can read last_error, then destroy
     P2_HIP(ctx, hipSetDevice(device));
     ctx->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream

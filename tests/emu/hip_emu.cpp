@@ -1,34 +1,107 @@
 // hip_emu.cpp -- TEST INFRASTRUCTURE ONLY (see hip_emu.h).
 #include "hip_emu.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace emu {
 emu_uint3 threadIdx_, blockIdx_;
 dim3 blockDim_, gridDim_;
 unsigned char *dyn_shared = nullptr;
 
 namespace {
+// Context switches: on x86-64 a hand-written callee-saved-register swap (glibc's swapcontext makes two sigprocmask system
+// calls per switch, which dominated the CPU test tier); elsewhere, or with -DEMU_UCONTEXT (the ASAN build), ucontext.
+#if defined(__x86_64__) && !defined(EMU_UCONTEXT)
+#define EMU_ASM_SWITCH 1
+extern "C" void emu_switch(void **save_sp, void *load_sp);
+asm(".text\n"
+    ".globl emu_switch\n"
+    ".type emu_switch,@function\n"
+    "emu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size emu_switch,.-emu_switch\n");
+#endif
+
 struct Fiber {
+#ifdef EMU_ASM_SWITCH
+    void *sp = nullptr;
+#else
     ucontext_t ctx;
+#endif
     std::vector<unsigned char> stack;
     bool done = false;
     bool started = false;
     emu_uint3 tid;
 };
+#ifdef EMU_ASM_SWITCH
+void *sched_sp = nullptr;
+#else
 ucontext_t sched_ctx;
+#endif
 Fiber *current = nullptr;
 const std::function<void()> *current_body = nullptr;
 std::vector<uint64_t> shfl_slots;
 
+void to_scheduler() {
+#ifdef EMU_ASM_SWITCH
+    emu_switch(&current->sp, sched_sp);
+#else
+    swapcontext(&current->ctx, &sched_ctx);
+#endif
+}
+
 void trampoline() {
     (*current_body)();
     current->done = true;
-    swapcontext(&current->ctx, &sched_ctx);
+    to_scheduler();
+    abort();  // a finished fiber is never resumed
+}
+
+void start_or_resume(Fiber &f) {
+#ifdef EMU_ASM_SWITCH
+    if (!f.started) {
+        f.started = true;
+        // initial frame: six callee-saved registers, then the return address emu_switch's `ret` jumps to; after the pops and
+        // the ret the stack pointer is 8 mod 16, as at any function entry
+        uintptr_t top = ((uintptr_t)f.stack.data() + f.stack.size()) & ~(uintptr_t)15;
+        void **sp = (void **)(top - 8 * 8);
+        for (int i = 0; i < 6; ++i) sp[i] = nullptr;
+        sp[6] = (void *)trampoline;
+        sp[7] = nullptr;
+        f.sp = sp;
+    }
+    emu_switch(&sched_sp, f.sp);
+#else
+    if (!f.started) {
+        f.started = true;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack.data();
+        f.ctx.uc_stack.ss_size = f.stack.size();
+        f.ctx.uc_link = &sched_ctx;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    swapcontext(&sched_ctx, &f.ctx);
+#endif
 }
 }  // namespace
 
+bool direct_mode = false;     // the running thread is a plain call on the scheduler's stack (no fiber to yield from)
+bool fiber_yielded = false;   // the fiber that is running has reached a barrier at least once
+
 void barrier() {
+    if (direct_mode) {  // thread 0 of this block finished without a barrier, another thread reached one: not expressible here
+        fprintf(stderr, "hip_emu: __syncthreads / shuffle reached by thread (%u,%u,%u) of block (%u,%u,%u) but not by thread 0\n",
+                threadIdx_.x, threadIdx_.y, threadIdx_.z, blockIdx_.x, blockIdx_.y, blockIdx_.z);
+        abort();
+    }
+    fiber_yielded = true;
     // yield to the scheduler; it resumes us once every live fiber of the block has yielded
-    swapcontext(&current->ctx, &sched_ctx);
+    to_scheduler();
 }
 
 uint64_t shfl_exchange(uint64_t v, int src_lane) {
@@ -45,8 +118,12 @@ uint64_t shfl_exchange(uint64_t v, int src_lane) {
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body) {
     const size_t nthreads = (size_t)block.x * block.y * block.z;
     const size_t stack_bytes = 96 * 1024;
-    std::vector<Fiber> fibers(nthreads);
-    for (auto &f : fibers) f.stack.resize(stack_bytes);
+    static std::vector<Fiber> fibers;  // stacks are kept between launches (one host thread drives the emulator)
+    if (fibers.size() < nthreads) {
+        const size_t have = fibers.size();
+        fibers.resize(nthreads);
+        for (size_t i = have; i < nthreads; ++i) fibers[i].stack.resize(stack_bytes);
+    }
     std::vector<unsigned char> dyn(shmem + 16);
     shfl_slots.assign(nthreads, 0);
     dyn_shared = dyn.data();
@@ -67,22 +144,31 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &bo
                             f.tid = {tx, ty, tz};
                         }
                 size_t live = nthreads;
+                bool first_pass = true;
                 while (live) {
-                    for (auto &f : fibers) {
+                    for (size_t i = 0; i < nthreads; ++i) {
+                        Fiber &f = fibers[i];
                         if (f.done) continue;
                         current = &f;
                         threadIdx_ = f.tid;
-                        if (!f.started) {
-                            f.started = true;
-                            getcontext(&f.ctx);
-                            f.ctx.uc_stack.ss_sp = f.stack.data();
-                            f.ctx.uc_stack.ss_size = f.stack.size();
-                            f.ctx.uc_link = &sched_ctx;
-                            makecontext(&f.ctx, (void (*)())trampoline, 0);
-                        }
-                        swapcontext(&sched_ctx, &f.ctx);
+                        if (first_pass && i == 0) fiber_yielded = false;
+                        start_or_resume(f);
                         if (f.done) --live;
+                        if (first_pass && i == 0 && f.done && !fiber_yielded) {
+                            // thread 0 ran to completion without a barrier: the block is barrier-free (a barrier that only
+                            // other threads reach aborts loudly), so its other threads run as plain calls -- no context switches
+                            direct_mode = true;
+                            for (size_t j = 1; j < nthreads; ++j) {
+                                threadIdx_ = fibers[j].tid;
+                                body();
+                                fibers[j].done = true;
+                            }
+                            direct_mode = false;
+                            live = 0;
+                            break;
+                        }
                     }
+                    first_pass = false;
                 }
             }
     dyn_shared = nullptr;

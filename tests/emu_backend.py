@@ -59,6 +59,10 @@ _lib_cache = None
 
 def emu_lib():
     global _lib_cache
+    # every emulated context of the process (those p2hot_group_create makes too) starts from the emulator's thresholds:
+    # all three Poseidon mappings run, the slow-to-emulate cooperative ones only on the smallest launches
+    os.environ.setdefault("P2HOT_TUNE_QUAD", "20")
+    os.environ.setdefault("P2HOT_TUNE_ROW", "6")
     if _lib_cache is None:
         subprocess.check_call(["make", "-C", _DIR, "-s"])
         _lib_cache = _lib.load(_SO)

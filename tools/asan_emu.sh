@@ -3,7 +3,7 @@
 # malloc'ed there, so any out-of-bounds index in a kernel shows up as an ASAN report (tooling, test infrastructure).
 set -e
 cd "$(dirname "$0")/.."
-g++ -O1 -g -fsanitize=address -fno-omit-frame-pointer -std=c++17 -fPIC -DP2HOT_EMU -Itests/emu -Iplonky2_amd/csrc \
+g++ -O1 -g -fsanitize=address -fno-omit-frame-pointer -std=c++17 -fPIC -DP2HOT_EMU -DEMU_UCONTEXT -Itests/emu -Iplonky2_amd/csrc \
     -shared -o /tmp/libp2hot_asan.so tests/emu/hip_emu.cpp -x c++ plonky2_amd/csrc/p2hot.hip
 cat > /tmp/asan_run.py <<'P'
 import sys
