@@ -170,7 +170,9 @@ class Communicator:
         else:
             on_gpu = getattr(getattr(engine.mem, "device", None), "type", None) == "cuda"
             self._cb = ((_gloo_device_transport if on_gpu else _gloo_transport)(dist, rank) if transport == "gloo"
-                        else _torch_transport(dist, rank) if transport == "torch" else _lib.ALLGATHER_FN(lambda *a: 1))
+                        else _torch_transport(dist, rank) if transport == "torch"
+                        else _lib.ALLGATHER_FN(lambda *a: 0) if transport == "null"   # tools/rank_work.py: nothing is exchanged
+                        else _lib.ALLGATHER_FN(lambda *a: 1))
             engine.check(engine.lib.p2hot_comm_create_callback(engine.ctx, rank, world, self._cb, None, C.byref(h)))
         self._h = h
 
