@@ -191,7 +191,7 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     if (!out) return P2HOT_EINVAL;
     p2hot_ctx *ctx = new p2hot_ctx();
     ctx->device = device;
-    if (const char *e = getenv("P2HOT_NTT_STRIDED_BITS")) {  // pass-planning experiments (tools/tune_ntt.py)
+    if (const char *e = getenv("P2HOT_NTT_STRIDED_BITS")) {  // pass-planning experiments (tools/tune_strided.sh)
         const int b = atoi(e);
         if (b >= 6 && b <= 11) ctx->ntt_strided_bits = (unsigned)b;
     }
