@@ -55,14 +55,17 @@ class HostMemory:
 
 
 _lib_cache = None
+# launches of up to this many permutations run the quad-cooperative / word-per-lane Poseidon kernels under the emulator
+# (the product's defaults are 2^15 / 2^13; emulated cross-lane exchanges cost two context switches per lane)
+EMU_TUNE_QUAD, EMU_TUNE_ROW = 512, 128
 
 
 def emu_lib():
     global _lib_cache
     # every emulated context of the process (those p2hot_group_create makes too) starts from the emulator's thresholds:
     # all three Poseidon mappings run, the slow-to-emulate cooperative ones only on the smallest launches
-    os.environ.setdefault("P2HOT_TUNE_QUAD", "20")
-    os.environ.setdefault("P2HOT_TUNE_ROW", "6")
+    os.environ.setdefault("P2HOT_TUNE_QUAD", str(EMU_TUNE_QUAD))
+    os.environ.setdefault("P2HOT_TUNE_ROW", str(EMU_TUNE_ROW))
     if _lib_cache is None:
         subprocess.check_call(["make", "-C", _DIR, "-s"])
         _lib_cache = _lib.load(_SO)
@@ -71,11 +74,4 @@ def emu_lib():
 
 
 def emu_engine():
-    eng = Engine(0, lib=emu_lib(), memory=HostMemory())
-    # both Poseidon mappings get exercised by the CPU tier: launches of up to 20 permutations take the quad-cooperative
-    # kernels (their emulated cross-lane exchanges are slow), larger ones the one-permutation-per-lane kernels
-    eng.check(eng.lib.p2hot_tune_quad(eng.ctx, 20))
-    # ... and launches of up to 6 permutations the word-per-lane kernels (16 emulated lanes and 24 emulated row broadcasts
-    # per round: the slowest to emulate); the challenger always runs that mapping
-    eng.check(eng.lib.p2hot_tune_row(eng.ctx, 6))
-    return eng
+    return Engine(0, lib=emu_lib(), memory=HostMemory())

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from tests.conftest import P, rand_field
+from tests.emu_backend import EMU_TUNE_QUAD, EMU_TUNE_ROW
 
 
 def is_gpu(eng):
@@ -153,10 +154,9 @@ def test_fft_three_pass_sizes(eng, ora):
     line placed on one XCD); log_n >= 23 takes three passes"""
     from plonky2_amd.field.fft import ifft
     from plonky2_amd.field.fft import fft
-    if not is_gpu(eng):
-        pytest.skip("2^21 points: GPU tier")
     rng = np.random.default_rng(5)
-    for log_n in (21, 22, 23):  # pass plans (9,12), (10,12) and (6,5,12); 2^23 is the per-rank transform of config C5
+    # pass plans (9,12), (10,12) and (6,5,12); 2^23 is the per-rank transform of config C5.  The CPU tier runs 2^22 only
+    for log_n in ((21, 22, 23) if is_gpu(eng) else (22,)):
         a = rand_field(rng, 1, 1 << log_n)
         f = fft(a, eng)
         assert (f[0] == ora.fft(a[0].copy())).all(), log_n
@@ -460,8 +460,8 @@ def test_quad_and_lane_poseidon_kernels_agree(eng, ora):
                 assert (t.cap.entries == capv).all(), (n, w, cap, quad, row)
                 assert (np.asarray(t.digests).reshape(-1, 4) == digests).all(), (n, w, cap, quad, row)
     finally:
-        eng.check(eng.lib.p2hot_tune_quad(eng.ctx, 20 if not gpu else 1 << 15))
-        eng.check(eng.lib.p2hot_tune_row(eng.ctx, 6 if not gpu else 1 << 13))
+        eng.check(eng.lib.p2hot_tune_quad(eng.ctx, EMU_TUNE_QUAD if not gpu else 1 << 15))
+        eng.check(eng.lib.p2hot_tune_row(eng.ctx, EMU_TUNE_ROW if not gpu else 1 << 13))
 
 
 def test_row_poseidon_kats_and_edges(eng, ora, kats):
@@ -483,7 +483,7 @@ def test_row_poseidon_kats_and_edges(eng, ora, kats):
         for k, g in zip(kats["poseidon12"], got[:4]):
             assert [int(x) for x in g] == k["output"]
     finally:
-        eng.check(eng.lib.p2hot_tune_row(eng.ctx, 6 if not gpu else 1 << 13))
+        eng.check(eng.lib.p2hot_tune_row(eng.ctx, EMU_TUNE_ROW if not gpu else 1 << 13))
 
 
 def test_host_pointer_commit_random_shapes(eng, ora):
