@@ -486,6 +486,25 @@ def test_row_poseidon_kats_and_edges(eng, ora, kats):
         eng.check(eng.lib.p2hot_tune_row(eng.ctx, EMU_TUNE_ROW if not gpu else 1 << 13))
 
 
+def test_c2_wires_golden_through_the_emulated_kernels(eng):
+    """BASELINE config C2 (W = 135, 2^16 rows, rate 1/8, cap 4) at full size in the CPU tier: the kernel sources, compiled for
+    the emulator, reproduce the faithful oracle's golden cap and digest-array hash (tests/golden/commit_caps.json).  The
+    GPU tier checks the same golden, and the larger ones, in tests/test_gpu_fullsize.py."""
+    import hashlib
+    import json
+    import os
+    from plonky2_amd.util.synthetic import splitmix_columns_numpy
+    from tests.conftest import ROOT
+    if is_gpu(eng):
+        pytest.skip("covered by tests/test_gpu_fullsize.py on the GPU")
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "commit_caps.json")))["c2_wires"]
+    r = eng.commit(eng.dev(splitmix_columns_numpy(0, g["W"], 1 << g["log_n"])), g["log_n"], g["rate_bits"], g["cap_height"], True)
+    assert eng.host(r["cap"]).tolist() == g["cap"]
+    assert hashlib.sha256(eng.host(r["digests"]).tobytes()).hexdigest() == g["sha256_digests"]
+    co = eng.host(r["coeffs"])
+    assert hashlib.sha256(np.where(co >= np.uint64(P), co - np.uint64(P), co).tobytes()).hexdigest() == g["sha256_coeffs"]
+
+
 def test_host_pointer_commit_random_shapes(eng, ora):
     """p2hot_commit (host pointers, what the Rust shim calls) over random shapes incl. single-row polynomials, rate 1,
     all-cap trees, widths around the sponge rate and the no-hash widths, with and without kept values / leaves /
