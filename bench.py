@@ -72,7 +72,7 @@ def pmc_valu(W, log_n, rb, cap, world):
 
 
 def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=45.0, golden_cap=None):
-    """The tuned CPU implementation of the same step (oracle/p2fast.c, "port-tuned": branch-free reduce128, the
+    """The tuned CPU implementation of the same step (oracle/p2fast.c, kind "port", tuned: branch-free reduce128, the
     reference's fast-partial Poseidon, eight rows per AVX-512 instruction stream in the leaf sponge / tree levels / NTT
     layers when the CPU has AVX-512, cached root tables, coset-by-coset LDE, OpenMP over the host cores this job may
     use), bit-exact against the faithful oracle (tests/test_fast_oracle.py).
@@ -96,7 +96,7 @@ def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=45.0, golden_cap=None
     dt = time.perf_counter() - t0
     fe = W * (1 << (kk + rate_bits))
     whole = kk == log_n
-    out = {"value": fe / dt / 1e9, "unit": "GFE/s", "cores": cores, "kind": "port-tuned", "seconds": dt,
+    out = {"value": fe / dt / 1e9, "unit": "GFE/s", "cores": cores, "kind": "port", "variant": "tuned (AVX-512 + OpenMP; oracle/p2fast.c)", "seconds": dt,
            "sample": ("the whole step" if whole else "1/%d of the GPU step's rows" % (1 << (log_n - kk)))
                      + ": from_values W=%d, 2^%d rows, rate 1/%d, cap %d, %.2f s on %d cores; oracle/p2fast.c (tuned C + OpenMP + AVX-512 "
                        "restatement of the reference algorithm), not the Rust prover (no cargo in the image)" % (W, kk, 1 << rate_bits, cap_height, dt, cores),

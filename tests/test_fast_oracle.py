@@ -1,4 +1,4 @@
-"""The tuned CPU implementation (oracle/p2fast.c: bench.py's "port-tuned" cpu_baseline and the fast checker of the
+"""The tuned CPU implementation (oracle/p2fast.c: bench.py's tuned "port" cpu_baseline and the fast checker of the
 full-size GPU tests) is pinned bit-for-bit to the faithful restatement (oracle/p2oracle.c) and to the reference's
 own Poseidon vectors.  CPU tier."""
 import json
