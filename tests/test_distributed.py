@@ -173,6 +173,7 @@ def test_group_and_comm_argument_errors():
     with pytest.raises(_lib.P2HotError):
         GroupCommit(lib, 3, [0, 0, 0])                      # not a power of two
     g = GroupCommit(lib, 4, [0] * 4)
+    assert lib.p2hot_group_size(g._h) == 4 and lib.p2hot_group_size(None) == 0
     cols = np.ones((2, 16), dtype=np.uint64)
     with pytest.raises(_lib.P2HotError, match="LDE cosets"):
         g.commit(cols, 1, 4)                                # starky rate 1/2: only two cosets
@@ -182,6 +183,11 @@ def test_group_and_comm_argument_errors():
     eng = emu_engine()
     h = C.c_void_p()
     assert lib.p2hot_comm_create_rccl(eng.ctx, 0, 1, np.zeros(128, dtype=np.uint8).ctypes.data, C.byref(h)) == _lib.ECOMM  # no RCCL in the emulator
+    cb = _lib.ALLGATHER_FN(lambda *a: 0)
+    assert lib.p2hot_comm_create_callback(eng.ctx, 3, 8, cb, None, C.byref(h)) == 0
+    assert (lib.p2hot_comm_rank(h), lib.p2hot_comm_world(h)) == (3, 8)
+    lib.p2hot_comm_destroy(h)
+    assert lib.p2hot_comm_create_callback(eng.ctx, 8, 8, cb, None, C.byref(h)) != 0   # rank outside the world
     first, count = C.c_size_t(), C.c_size_t()
     from plonky2_amd.distributed import ShardPlan
     for (W, world) in ((135, 8), (20, 4), (3, 8), (0, 2)):

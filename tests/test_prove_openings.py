@@ -135,6 +135,41 @@ def test_eval_openings_vs_horner(eng):
                 assert [int(got[pi][j][0]), int(got[pi][j][1])] == acc, (log_n, pi, j)
 
 
+def test_remaining_device_and_accessor_entry_points(eng, ora):
+    """Entry points nothing else calls directly: p2hot_eval_polys_dev (the device-pointer building block of OpeningSet::new,
+    plonk/proof.rs:314-327) against a Horner evaluation in F^2; the batch accessors; p2hot_tune_overlap (leaf sponge of coset
+    block b beside the LDE of block b+1 on a second stream -- identical commitment)."""
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    from tests import pyref
+    rng = np.random.default_rng(31)
+    log_n, n_polys = 6, 5
+    polys = rand_field(rng, n_polys, 1 << log_n, noncanonical=True)
+    dev = eng.dev(polys)
+    table = eng.dev(np.array([eng.mem.ptr(dev) + j * (8 << log_n) for j in range(n_polys)], dtype=np.uint64))
+    pts = np.array([[3, 5], [P - 1, 7], [2**63, 0]], dtype=np.uint64)
+    out = eng.mem.zeros(len(pts) * n_polys, 2)
+    eng.check(eng.lib.p2hot_eval_polys_dev(eng.ctx, eng.ptr(table), n_polys, log_n, pts.ctypes.data, len(pts), eng.ptr(out)))
+    got = eng.host(out).reshape(len(pts), n_polys, 2)
+    for pi, pt in enumerate(pts):
+        x = (int(pt[0]) % P, int(pt[1]) % P)
+        for j in range(n_polys):
+            want = pyref.ext_eval([(int(c) % P, 0) for c in polys[j]], x)
+            assert tuple(int(v) for v in got[pi, j]) == tuple(want), (pi, j)
+    # accessors of a commitment handle
+    cols = rand_field(rng, 3, 1 << 4)
+    b = PolynomialBatch.from_values(cols, 2, False, 1, engine=eng)
+    assert eng.lib.p2hot_batch_width(b._owner.h) == 3 and eng.lib.p2hot_batch_degree_log(b._owner.h) == 4
+    # the two-stream overlap knob changes nothing in the result
+    o = ora.commit(cols, 2, 1, True)
+    try:
+        eng.check(eng.lib.p2hot_tune_overlap(eng.ctx, 1))
+        r = eng.commit(eng.dev(cols), 4, 2, 1, True)
+        assert (eng.host(r["cap"]) == o["cap"]).all() and (eng.host(r["digests"]) == o["digests"]).all()
+    finally:
+        eng.check(eng.lib.p2hot_tune_overlap(eng.ctx, 0))
+    assert eng.lib.p2hot_tune_overlap(None, 1) != 0
+
+
 def test_polynomial_batch_wire_format(eng):
     """write_polynomial_batch / write_merkle_tree byte layout (util/serialization/mod.rs:1417-1431, :1744-1763)"""
     import struct
