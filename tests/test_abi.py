@@ -21,6 +21,17 @@ def test_header_and_binding_agree():
     assert _declared() == sorted(_lib.SIGNATURES), "include/p2hot.h and plonky2_amd/_lib.py disagree"
 
 
+def test_every_entry_point_is_exercised():
+    """each function of include/p2hot.h is called by a test, or by the host-side mirror the parity tests drive"""
+    import glob
+    text = ""
+    for f in glob.glob(os.path.join(ROOT, "tests", "*.py")) + glob.glob(os.path.join(ROOT, "plonky2_amd", "**", "*.py"), recursive=True):
+        if not f.endswith("_lib.py"):
+            text += open(f).read()
+    missing = [s for s in _declared() if not re.search(r"\b%s\b" % s, text) and s != "p2hot_version"]
+    assert not missing, missing
+
+
 def test_product_library_builds_and_exports_every_symbol():
     import __graft_entry__ as ge
     so = ge.build_product()
