@@ -269,6 +269,7 @@ def main():
     ap.add_argument("--width", type=int, default=135)
     ap.add_argument("--rate-bits", type=int, default=3)
     ap.add_argument("--cap-height", type=int, default=4)
+    ap.add_argument("--strong", action="store_true", help="strong scaling: 2^log_n rows in TOTAL (the C3 commit split over the GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra driver-timed lines of the other BASELINE shapes")
     args = ap.parse_args()
@@ -311,7 +312,7 @@ def main():
     log_g = (world - 1).bit_length()
     if world != 1 << log_g:
         raise SystemExit("--gpus must be a power of two")
-    log_n = args.log_n + log_g
+    log_n = args.log_n + (0 if args.strong else log_g)
     n, N = 1 << log_n, 1 << (log_n + rb)
 
     # digests stay with the rank that owns the rows (its Merkle paths never leave its cap subtrees); only the cap is
@@ -375,11 +376,12 @@ def main():
         out = {
             "metric": "LDE+Poseidon-commit GFE/s", "value": fe / (dt / args.steps) / 1e9, "unit": "GFE/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks)",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks)",
             "data": "synthetic (splitmix64 columns generated on device)",
             "config": {"workload": "PolynomialBatch::from_values, W=%d, 2^%d rows, rate 1/%d (N=2^%d), cap_height %d, "
-                                   "PoseidonGoldilocksConfig (C3 wires commit at --gpus 1; +1 bit of rows per doubling of GPUs)"
-                                   % (W, log_n, 1 << rb, log_n + rb, cap),
+                                   "PoseidonGoldilocksConfig (%s)"
+                                   % (W, log_n, 1 << rb, log_n + rb, cap, "--strong: the same total size at every --gpus" if args.strong else
+                                      "C3 wires commit at --gpus 1; +1 bit of rows per doubling of GPUs"),
                        "transport": None if world == 1 else {"rccl": "RCCL inside libp2hot (ncclBroadcast groups on the library's communication stream)",
                                                                     "torch": "torch.distributed all_gather on device buffers (fallback: librccl could not be bound)",
                                                                     "gloo": "gloo through host staging (ranks sharing a GPU: a functional run, not a scaling number)"}.get(job.comm.transport, job.comm.transport),
