@@ -115,6 +115,38 @@ __global__ void __launch_bounds__(256) reduce_polys_base_kernel(const u64 *const
     o1[t] = a1;
 }
 
+// The same sum for short polynomials (recursion-size proofs: n = 2^12, ~170 polynomials): with one lane per coefficient the
+// launch is 16 workgroups walking a chain of n_polys dependent multiply-adds.  Here a workgroup is 64 coefficients x 16
+// polynomial groups (lane (t, g) sums the polynomials j = g mod 16) and the groups are folded through LDS in a fixed order,
+// so the chain is n_polys / 16 long on 16x the lanes.  Field addition is exact: any order gives the same canonical value.
+__global__ void __launch_bounds__(1024) reduce_polys_base_small_kernel(const u64 *const *polys, size_t n_polys, const u64 *apow,
+                                                                      size_t n, u64 *o0, u64 *o1) {
+    __shared__ u64 s0[16][64], s1[16][64];
+    const unsigned lane = threadIdx.x & 63u, g = threadIdx.x >> 6;
+    const size_t t = (size_t)blockIdx.x * 64 + lane;
+    u64 a0 = 0, a1 = 0;
+    if (t < n)
+        for (size_t j = g; j < n_polys; j += 16) {
+            u64 p = polys[j][t];
+            a0 = gl::add(a0, gl::mul(apow[2 * j], p));
+            a1 = gl::add(a1, gl::mul(apow[2 * j + 1], p));
+        }
+    s0[g][lane] = a0;
+    s1[g][lane] = a1;
+    __syncthreads();
+    for (unsigned d = 8; d; d >>= 1) {
+        if (g < d) {
+            s0[g][lane] = gl::add(s0[g][lane], s0[g + d][lane]);
+            s1[g][lane] = gl::add(s1[g][lane], s1[g + d][lane]);
+        }
+        __syncthreads();
+    }
+    if (g == 0 && t < n) {
+        o0[t] = s0[0][lane];
+        o1[t] = s1[0][lane];
+    }
+}
+
 // divide_by_linear (field/src/polynomial/division.rs:79-92) is the Horner suffix scan
 //   b_k = b_{k+1} * z + c_k,  quotient[k-1] = b_k (k >= 1), padded with a zero.
 // Three steps over chunks of 2^chunk_log coefficients: (1) chunk totals, (2) chunk carries by a

@@ -453,7 +453,10 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
                 rem -= part;
             }
             size_t shm = (size_t)8 * ntt::TILE_WORDS_PADDED;
-            if (first && zcount > 1 && a.in_z_stride == 0) {  // every z slice reads the same input tile
+            // every z slice (coset) reads the same input tile: one workgroup produces them all from one fetch -- when the
+            // launch has workgroups to spare.  A small launch keeps the cosets in grid.z instead: at 2^12 rows the loop made
+            // the LDE a chain of 8 tile transforms on 2..135 workgroups (95 us whatever the width; 5 such launches per proof)
+            if (first && zcount > 1 && a.in_z_stride == 0 && ((size_t)1 << tiles_log) * batch >= 2048) {
                 ra.zloop = (unsigned)zcount;
                 grid.z = 1;
             }
@@ -706,6 +709,9 @@ static int hash_leaves_range(p2hot_ctx *ctx, hipStream_t stream, Reader rd, size
 
 static int merkle_levels(p2hot_ctx *ctx, const ForestGeom &g, size_t leaf_count) {
     ProfScope ps(ctx, "merkle_levels");
+    // One launch per level.  Walking the top levels of every cap subtree in one launch (a 1024-thread workgroup per subtree,
+    // a barrier per level, word-per-lane permutations) was built and measured at recursion size: 146 us per tree against
+    // 7 x 12.4 -- a level's nodes then share one CU (four waves per SIMD) instead of spreading over the chip
     for (unsigned level = 1; level <= g.h; ++level) {
         size_t nodes = leaf_count >> level;
         if (nodes <= ctx->row_threshold)
@@ -1092,7 +1098,9 @@ static int final_poly_core(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, 
     if (!batch_offsets || !points || (!alpha_host && !d_alpha) || !d_final || (n_batches && !d_poly_table))
         P2_FAIL(ctx, P2HOT_EINVAL, "fri_final_poly: null argument");
     const size_t n = (size_t)1 << log_n;
-    const unsigned chunk_log = log_n < 6 ? log_n : 6;
+    // Horner chunks of 64 coefficients for long polynomials; short ones (recursion size) get about 1024 chunks instead, so
+    // the serial walks inside a chunk are 4 long at 2^12 (three launches of dependent 64-step walks cost 100 us there)
+    const unsigned chunk_log = log_n < 2 ? log_n : std::min(6u, std::max(2u, log_n > 10 ? log_n - 10 : 0u));
     const size_t n_chunks = n >> chunk_log, per = (n_chunks + 1023) / 1024;
     size_t max_j = 1;
     for (size_t i = 0; i < n_batches; ++i) {
@@ -1119,8 +1127,12 @@ static int final_poly_core(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, 
         const size_t J = batch_offsets[i + 1] - batch_offsets[i];
         {
             ProfScope ps(ctx, "reduce_polys_base");
-            P2HOT_LAUNCH(fri::reduce_polys_base_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream,
-                         d_poly_table + batch_offsets[i], J, (const u64 *)d_apow, n, c0, c1);
+            if (log_n <= 16)
+                P2HOT_LAUNCH(fri::reduce_polys_base_small_kernel, dim3(cdiv(n, 64)), dim3(1024), 0, ctx->stream,
+                             d_poly_table + batch_offsets[i], J, (const u64 *)d_apow, n, c0, c1);
+            else
+                P2HOT_LAUNCH(fri::reduce_polys_base_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream,
+                             d_poly_table + batch_offsets[i], J, (const u64 *)d_apow, n, c0, c1);
             P2_LAUNCH_CHECK(ctx);
         }
         ProfScope ps(ctx, "divide_by_linear");
@@ -1267,9 +1279,10 @@ static int pow_search_dev(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned
     // continued by pow_continue_host, which checks after every chunk
     const int lg = std::min((int)pow_bits + extra, 34);
     const u64 limit = (u64)1 << (lg < 0 ? 0 : lg);
-    // the first chunk holds a witness with probability 1 - e^-4 (4x the expected number of trials) but never more than one
-    // chip-wide wave of lanes (2^18): a permutation per lane takes ~25 us whether 2^14 or 2^18 lanes run it
-    u64 chunk = (u64)1 << std::min(18u, std::max(14u, pow_bits + 2)), start = 0;
+    // the first chunk is the expected number of trials (a witness with probability 1 - 1/e), the following ones double and
+    // retire at once when an earlier one found a witness.  2^16 lanes are one wave per SIMD (a lone wave's latency), 2^18 fill
+    // every SIMD with four and take 2.5x as long (107 us measured) -- 4x the expected trials up front cost more than they saved
+    u64 chunk = (u64)1 << std::min(18u, std::max(14u, pow_bits)), start = 0;
     while (start < limit) {
         const u64 count = std::min(limit - start, chunk);
         P2HOT_LAUNCH(fri::pow_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, challenger->d, pow_bits, start, count, d_best);
