@@ -41,6 +41,7 @@ struct p2hot_ctx {
     unsigned ntt_radix_bits = 3;  // 3: radix-8 rounds / 512 threads, 4: radix-16 / 256 threads
     unsigned ntt_strided_bits = 10;  // most bits a strided pass takes (tile = 2^b rows x 2^(12-b) columns)
     bool ntt_xcd_remap = true;       // strided passes: neighbouring column groups (same 128-byte lines) on the same XCD
+    size_t zloop_min_groups = 2048;  // first LDE pass: one workgroup loops over the cosets when the launch has this many without
     struct Scratch {
         void *p = nullptr;
         size_t cap = 0;
@@ -196,6 +197,7 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
         if (b >= 6 && b <= 11) ctx->ntt_strided_bits = (unsigned)b;
     }
     if (const char *e = getenv("P2HOT_NTT_XCD_REMAP")) ctx->ntt_xcd_remap = atoi(e) != 0;
+    if (const char *e = getenv("P2HOT_NTT_ZLOOP_MIN")) ctx->zloop_min_groups = (size_t)strtoull(e, nullptr, 10);
     // start values of p2hot_tune_quad / p2hot_tune_row for every context of the process, the ones p2hot_group_create makes
     // included (the kernel emulator's test tier lowers them: emulated cross-lane exchanges are slow)
     if (const char *e = getenv("P2HOT_TUNE_QUAD")) ctx->quad_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -456,7 +458,7 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
             // every z slice (coset) reads the same input tile: one workgroup produces them all from one fetch -- when the
             // launch has workgroups to spare.  A small launch keeps the cosets in grid.z instead: at 2^12 rows the loop made
             // the LDE a chain of 8 tile transforms on 2..135 workgroups (95 us whatever the width; 5 such launches per proof)
-            if (first && zcount > 1 && a.in_z_stride == 0 && ((size_t)1 << tiles_log) * batch >= 2048) {
+            if (first && zcount > 1 && a.in_z_stride == 0 && ((size_t)1 << tiles_log) * batch >= ctx->zloop_min_groups) {
                 ra.zloop = (unsigned)zcount;
                 grid.z = 1;
             }
