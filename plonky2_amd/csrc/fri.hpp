@@ -234,6 +234,28 @@ __global__ void horner_emit_kernel(const u64 *c0, const u64 *c1, unsigned chunk_
     }
 }
 
+// [n_points][total][2] (how the evaluation kernels write) -> per oracle [n_points][W_o][2], oracles back to back (how the
+// caller's OpeningSet buffers are laid out), so the results go back in one copy.  Up to 8 oracles, described by value.
+struct OpeningLayout {
+    unsigned n_oracles;
+    unsigned width[8];   // W_o
+    unsigned first[8];   // index of the oracle's first polynomial among the `total`
+};
+__global__ void reorder_openings_kernel(const u64 *res, size_t total, size_t n_points, OpeningLayout lay, u64 *out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one (point, polynomial) pair of the device layout
+    if (t >= n_points * total) return;
+    const size_t p = t / total, j = t % total;
+    size_t out_off = 0;
+    unsigned o = 0;
+    while (o + 1 < lay.n_oracles && j >= lay.first[o] + lay.width[o]) {
+        out_off += 2 * n_points * lay.width[o];
+        ++o;
+    }
+    const size_t dst = out_off + 2 * (p * lay.width[o] + (j - lay.first[o]));
+    out[dst] = res[2 * t];
+    out[dst + 1] = res[2 * t + 1];
+}
+
 // OpeningSet::new (plonky2/src/plonk/proof.rs:314-327): out[j] = polys[j](z) for an extension point z.
 // Stage 1 (eval_polys_dot_kernel): workgroup (j, s) evaluates segment s (seg = 2^seg_log coefficients) of polynomial
 //   j at z as a dot product with the table z^u, u < seg -> part[j][s].

@@ -213,7 +213,7 @@ static int gather_start(std::vector<p2hot_comm *> &cs, std::vector<u64 *> &base,
     if (bytes == 0 || (world == 1 && c0->kind != p2hot_comm::RCCL)) return P2HOT_OK;
     if (c0->kind == p2hot_comm::CALLBACK) {  // the host application's collective: synchronous, after the slice is complete
         p2hot_ctx *ctx = c0->ctx;
-        P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        P2_HIP(ctx, stream_sync(ctx));
         int rc = c0->fn(c0->user, base[0], offsets.data(), world, bytes, (void *)ctx->stream);
         if (rc != 0) P2_FAIL(ctx, P2HOT_ECOMM, "the caller-supplied all-gather failed (%d)", rc);
         return P2HOT_OK;
@@ -607,7 +607,7 @@ extern "C" void p2hot_sharded_batch_free(p2hot_sharded_batch *b) {
     for (size_t s = 0; s < b->g->ctx.size(); ++s) {
         p2hot_ctx *ctx = b->g->ctx[s];
         (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)stream_sync(ctx);
         pool_release(ctx, b->coeffs_all[s]);
         pool_release(ctx, b->lde[s]);
         pool_release(ctx, b->digests[s]);
@@ -704,7 +704,7 @@ extern "C" int p2hot_group_commit(p2hot_group *g, const uint64_t *const *cols, s
     for (size_t s = 0; s < L; ++s) {  // every rank's work is complete (and its pool blocks reusable) on return
         p2hot_ctx *ctx = g->ctx[s];
         (void)hipSetDevice(ctx->device);
-        hipError_t e = hipStreamSynchronize(ctx->stream);
+        hipError_t e = stream_sync(ctx);
 #ifndef P2HOT_EMU
         if (g->comm[s]->comm_stream) (void)hipStreamSynchronize(g->comm[s]->comm_stream);
 #endif
@@ -771,7 +771,7 @@ static int sharded_open(p2hot_sharded_batch *b, const u64 *leaf_idx, size_t m, u
             return P2HOT_OK;
         };
         rc = body();
-        hipError_t e = hipStreamSynchronize(ctx->stream);  // the local vectors and pool blocks are released below
+        hipError_t e = stream_sync(ctx);  // the local vectors and pool blocks are released below
         if (rc != P2HOT_OK) {
             if (ctx != ctx0) ctx0->err = ctx->err;
             return rc;

@@ -20,9 +20,14 @@ struct CallGuard {
     bool ok;
     explicit CallGuard(p2hot_ctx *c) : ctx(c), ok(false) {
         if (ctx) ok = !ctx->busy.exchange(true, std::memory_order_acquire);
+        if (ok) ctx->in_host_call = true;
     }
     ~CallGuard() {
-        if (ok) ctx->busy.store(false, std::memory_order_release);
+        if (!ok) return;
+        ctx->in_host_call = false;
+        ctx->deferred.clear();  // a call that failed before its synchronisation delivers nothing
+        ctx->pinned_used = 0;
+        ctx->busy.store(false, std::memory_order_release);
     }
 };
 #define P2_ENTER(ctx)                                                                                                  \
@@ -31,7 +36,7 @@ struct CallGuard {
     if (!guard_.ok) return P2HOT_EBUSY /* the context's error text belongs to the call that is running */
 
 static int sync_checked(p2hot_ctx *ctx, int rc, const char *what) {
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = stream_sync(ctx);
     if (rc == P2HOT_OK && e != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "%s: %s", what, hipGetErrorString(e));
     return rc;
 }
@@ -178,7 +183,7 @@ extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t 
             }
         if (leaves_out && W) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, W * N * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (digests_out && nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
-        if (cap_out) P2_HIP(ctx, hipMemcpyAsync(cap_out, d_cap.p, cap_words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (cap_out) P2_TRY(d2h(ctx, cap_out, d_cap.p, cap_words * 8));
         return P2HOT_OK;
     };
     int rc = body();
@@ -242,7 +247,7 @@ extern "C" int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate
         if (coeffs_out && W) P2_HIP(ctx, hipMemcpyAsync(coeffs_out, co, W * n * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (leaves_out && W) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, W * N * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (digests_out && nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
-        if (cap_out) P2_HIP(ctx, hipMemcpyAsync(cap_out, d_cap.p, cap_words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (cap_out) P2_TRY(d2h(ctx, cap_out, d_cap.p, cap_words * 8));
         return P2HOT_OK;
     };
     int rc = sync_checked(ctx, body(), "commit_cols");
@@ -328,7 +333,7 @@ extern "C" int p2hot_batch_rows(p2hot_batch *b, const uint64_t *row_idx, size_t 
     auto body = [&]() -> int {
         P2_HIP(ctx, hipMemcpyAsync(d_idx.p, row_idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
         P2_TRY(p2hot_gather_rows_dev(ctx, b->d_lde, b->N, b->N, b->W, d_idx.u(), m, d_out.u()));
-        P2_HIP(ctx, hipMemcpyAsync(out, d_out.p, m * b->W * 8, hipMemcpyDeviceToHost, ctx->stream));
+        P2_TRY(d2h(ctx, out, d_out.p, m * b->W * 8));
         return P2HOT_OK;
     };
     return sync_checked(ctx, body(), "batch_rows");
@@ -349,7 +354,7 @@ extern "C" int p2hot_batch_paths(p2hot_batch *b, const uint64_t *leaf_idx, size_
     auto body = [&]() -> int {
         P2_HIP(ctx, hipMemcpyAsync(d_idx.p, leaf_idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
         P2_TRY(p2hot_merkle_paths_dev(ctx, b->d_dig, b->log_N, b->cap_height, d_idx.u(), m, d_out.u()));
-        P2_HIP(ctx, hipMemcpyAsync(out, d_out.p, m * layers * 32, hipMemcpyDeviceToHost, ctx->stream));
+        P2_TRY(d2h(ctx, out, d_out.p, m * layers * 32));
         return P2HOT_OK;
     };
     return sync_checked(ctx, body(), "batch_paths");
@@ -370,7 +375,7 @@ extern "C" void p2hot_batch_free(p2hot_batch *b) {
 // returns the cached free blocks of the host-pointer entry points to the driver (the cache is grow-only otherwise)
 extern "C" int p2hot_ctx_trim(p2hot_ctx *ctx) {
     P2_ENTER(ctx);
-    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P2_HIP(ctx, stream_sync(ctx));
     for (auto &blk : ctx->pool_free) (void)hipFree(blk.first);
     ctx->pool_free.clear();
     return P2HOT_OK;
@@ -415,13 +420,30 @@ static int eval_openings_core(p2hot_ctx *ctx, const std::vector<OracleView> &vie
         for (size_t j = 0; j < v.W; ++j) ptrs.push_back(v.d_coef + (j << log_n));
     const size_t total = ptrs.size();
     if (total == 0) return P2HOT_OK;
-    PoolBuf d_table(ctx), d_res(ctx);
+    PoolBuf d_table(ctx), d_res(ctx), d_out(ctx);
     P2_TRY(pool_alloc(ctx, total * sizeof(u64 *), &d_table.p));
     P2_TRY(pool_alloc(ctx, n_points * total * 16, &d_res.p));
+    const bool one_copy = views.size() <= 8 && total <= 0xFFFFFFFFull;
+    if (one_copy) P2_TRY(pool_alloc(ctx, n_points * total * 16, &d_out.p));
     auto body = [&]() -> int {
         P2_HIP(ctx, hipMemcpyAsync(d_table.p, ptrs.data(), total * sizeof(u64 *), hipMemcpyHostToDevice, ctx->stream));
         // device layout [n_points][total][2]; the caller's layout is per oracle [n_points][W_o][2]
         P2_TRY(p2hot_eval_polys_dev(ctx, (const uint64_t *const *)d_table.p, total, log_n, points, n_points, d_res.u()));
+        if (one_copy) {  // reordered on the device, one copy back (each copy into pageable memory costs ~20 us of host time)
+            fri::OpeningLayout lay{};
+            lay.n_oracles = (unsigned)views.size();
+            size_t first = 0;
+            for (size_t o = 0; o < views.size(); ++o) {
+                lay.width[o] = (unsigned)views[o].W;
+                lay.first[o] = (unsigned)first;
+                first += views[o].W;
+            }
+            P2HOT_LAUNCH(fri::reorder_openings_kernel, dim3(cdiv(n_points * total, 256)), dim3(256), 0, ctx->stream, (const u64 *)d_res.u(),
+                         total, n_points, lay, d_out.u());
+            P2_LAUNCH_CHECK(ctx);
+            P2_TRY(d2h(ctx, out, d_out.p, n_points * total * 16));
+            return P2HOT_OK;
+        }
         size_t off = 0, out_off = 0;
         for (auto &v : views) {
             for (size_t p = 0; p < n_points && v.W; ++p)
@@ -604,17 +626,17 @@ static int prove_openings_core(p2hot_ctx *ctx, const p2hot_fri_batch_info *batch
     auto tail = [&]() -> int {
         // prover.rs:197-198: observe the witness, draw the response
         P2_TRY(challenger_step_dev(challenger, d_best, 1, d_resp, 1));
-        P2_HIP(ctx, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+        P2_TRY(d2h(ctx, &best, d_best, 8));
         if (Q == 0) return P2HOT_OK;
         // fri/prover.rs:215-220: x_index = rand % n for num_query_rounds challenges; per round x_index >>= arity_bits (:243-253)
         P2_TRY(challenger_step_dev(challenger, nullptr, 0, d_rand, Q));
         P2HOT_LAUNCH(fri::query_indices_kernel, dim3(cdiv(Q, 256)), dim3(256), 0, ctx->stream, (const u64 *)d_rand, Q, log_N, ab, n_rounds,
                      d_idx);
         P2_LAUNCH_CHECK(ctx);
-        if (proof->query_indices) P2_HIP(ctx, hipMemcpyAsync(proof->query_indices, d_idx, Q * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (proof->query_indices) P2_TRY(d2h(ctx, proof->query_indices, d_idx, Q * 8));
         if (open_initial) {  // the owners of the rows need the indices on the host
             idx_for_owners.resize(Q);
-            P2_HIP(ctx, hipMemcpyAsync(idx_for_owners.data(), d_idx, Q * 8, hipMemcpyDeviceToHost, ctx->stream));
+            P2_TRY(d2h(ctx, idx_for_owners.data(), d_idx, Q * 8));
         }
         // prover.rs:238-241: initial_trees_proof = for every oracle (tree.get(x), tree.prove(x)), all queries per launch.
         // Device staging is oracle-major ([oracle][q][...]); the host layout is query-major (see p2hot.h), fixed by the D2H copies.
@@ -653,20 +675,16 @@ static int prove_openings_core(p2hot_ctx *ctx, const p2hot_fri_batch_info *batch
         for (size_t o = 0; o < n_oracles && !open_initial; ++o) {
             const size_t Wb = oracles[o].W;
             if (Wb)
-                P2_HIP(ctx, hipMemcpy2DAsync(proof->initial_leaves + w_off, w_sum * 8, d_il + Q * w_off, Wb * 8, Wb * 8, Q,
-                                             hipMemcpyDeviceToHost, ctx->stream));
+                P2_TRY(d2h_2d(ctx, proof->initial_leaves + w_off, w_sum * 8, d_il + Q * w_off, Wb * 8, Wb * 8, Q));
             if (layers0)
-                P2_HIP(ctx, hipMemcpy2DAsync(proof->initial_paths + o * 4 * layers0, n_oracles * 4 * layers0 * 8,
-                                             d_ip + o * Q * 4 * layers0, 4 * layers0 * 8, 4 * layers0 * 8, Q, hipMemcpyDeviceToHost,
-                                             ctx->stream));
+                P2_TRY(d2h_2d(ctx, proof->initial_paths + o * 4 * layers0, n_oracles * 4 * layers0 * 8, d_ip + o * Q * 4 * layers0,
+                              4 * layers0 * 8, 4 * layers0 * 8, Q));
             w_off += Wb;
         }
         for (unsigned r = 0; r < n_rounds; ++r) {
-            P2_HIP(ctx, hipMemcpy2DAsync(proof->step_evals + ev_offs[r], ev_off * 8, d_se + Q * ev_offs[r], ev_w[r] * 8, ev_w[r] * 8, Q,
-                                         hipMemcpyDeviceToHost, ctx->stream));
+            P2_TRY(d2h_2d(ctx, proof->step_evals + ev_offs[r], ev_off * 8, d_se + Q * ev_offs[r], ev_w[r] * 8, ev_w[r] * 8, Q));
             if (pa_w[r])
-                P2_HIP(ctx, hipMemcpy2DAsync(proof->step_paths + pa_offs[r], pa_off * 8, d_sp + Q * pa_offs[r], pa_w[r] * 8, pa_w[r] * 8, Q,
-                                             hipMemcpyDeviceToHost, ctx->stream));
+                P2_TRY(d2h_2d(ctx, proof->step_paths + pa_offs[r], pa_off * 8, d_sp + Q * pa_offs[r], pa_w[r] * 8, pa_w[r] * 8, Q));
         }
         return P2HOT_OK;
     };

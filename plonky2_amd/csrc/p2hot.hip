@@ -41,6 +41,17 @@ struct p2hot_ctx {
     unsigned ntt_radix_bits = 3;  // 3: radix-8 rounds / 512 threads, 4: radix-16 / 256 threads
     unsigned ntt_strided_bits = 10;  // most bits a strided pass takes (tile = 2^b rows x 2^(12-b) columns)
     bool ntt_xcd_remap = true;       // strided passes: neighbouring column groups (same 128-byte lines) on the same XCD
+    // small device-to-host results of a host-pointer call land in a pinned arena (a truly asynchronous copy) and are moved
+    // to the caller's pageable buffers when the call synchronises: a copy into pageable memory blocks the host ~20 us
+    struct DeferredCopy {
+        void *dst;
+        const unsigned char *src;
+        size_t width, height, dpitch;
+    };
+    unsigned char *pinned = nullptr;
+    size_t pinned_cap = 0, pinned_used = 0;
+    std::vector<DeferredCopy> deferred;
+    bool in_host_call = false;       // set by the host-pointer entry points (they end in stream_sync)
     size_t zloop_min_groups = 2048;  // first LDE pass: one workgroup loops over the cosets when the launch has this many without
     struct Scratch {
         void *p = nullptr;
@@ -113,11 +124,58 @@ struct ProfScope {
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// ---- small device-to-host results (see p2hot_ctx::deferred)
+static void flush_deferred(p2hot_ctx *ctx) {
+    for (auto &d : ctx->deferred)
+        for (size_t r = 0; r < d.height; ++r) std::copy(d.src + r * d.width, d.src + (r + 1) * d.width, (unsigned char *)d.dst + r * d.dpitch);
+    ctx->deferred.clear();
+    ctx->pinned_used = 0;
+}
+
+// hipStreamSynchronize of the context's stream + delivery of the deferred results; every synchronisation of the context goes
+// through here
+static hipError_t stream_sync(p2hot_ctx *ctx) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) {
+        flush_deferred(ctx);
+    } else {
+        ctx->deferred.clear();
+        ctx->pinned_used = 0;
+    }
+    return e;
+}
+
+// `height` rows of `width` bytes, device pitch `spitch`, host pitch `dpitch`
+static int d2h_2d(p2hot_ctx *ctx, void *dst, size_t dpitch, const void *d_src, size_t spitch, size_t width, size_t height) {
+    const size_t bytes = width * height, kArena = (size_t)4 << 20;
+    if (bytes == 0) return P2HOT_OK;
+    if (ctx->in_host_call && bytes <= ((size_t)256 << 10)) {
+        if (!ctx->pinned && hipHostMalloc((void **)&ctx->pinned, kArena, hipHostMallocDefault) == hipSuccess) ctx->pinned_cap = kArena;
+        const size_t at = (ctx->pinned_used + 63) & ~(size_t)63;
+        if (ctx->pinned && at + bytes <= ctx->pinned_cap) {
+            unsigned char *slot = ctx->pinned + at;
+            if (height == 1 || spitch == width)
+                P2_HIP(ctx, hipMemcpyAsync(slot, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            else
+                P2_HIP(ctx, hipMemcpy2DAsync(slot, width, d_src, spitch, width, height, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->pinned_used = at + bytes;
+            ctx->deferred.push_back({dst, slot, width, height, dpitch});
+            return P2HOT_OK;
+        }
+    }
+    if (height == 1 || (spitch == width && dpitch == width))
+        P2_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    else
+        P2_HIP(ctx, hipMemcpy2DAsync(dst, dpitch, d_src, spitch, width, height, hipMemcpyDeviceToHost, ctx->stream));
+    return P2HOT_OK;
+}
+static int d2h(p2hot_ctx *ctx, void *dst, const void *d_src, size_t bytes) { return d2h_2d(ctx, dst, bytes, d_src, bytes, bytes, 1); }
+
 static int scratch_get(p2hot_ctx *ctx, int slot, size_t bytes, void **out) {
     auto &s = ctx->scratch[slot];
     if (s.cap < bytes) {
         if (s.p) {
-            P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            P2_HIP(ctx, stream_sync(ctx));
             P2_HIP(ctx, hipFree(s.p));
             s.p = nullptr;
             s.cap = 0;
@@ -235,14 +293,14 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
                      (u64)1, (u64)0);
     }
     P2_LAUNCH_CHECK(ctx);
-    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P2_HIP(ctx, stream_sync(ctx));
     return P2HOT_OK;
 }
 
 extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)stream_sync(ctx);
 #ifndef P2HOT_EMU
     if (ctx->side) {
         (void)hipStreamSynchronize(ctx->side);
@@ -258,12 +316,13 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
     for (auto &s : ctx->scratch)
         if (s.p) (void)hipFree(s.p);
     if (ctx->tables) (void)hipFree(ctx->tables);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
 }
 
 extern "C" int p2hot_ctx_set_stream(p2hot_ctx *ctx, void *hip_stream) {
     if (!ctx) return P2HOT_EINVAL;
-    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P2_HIP(ctx, stream_sync(ctx));
     ctx->stream = (hipStream_t)hip_stream;
     return P2HOT_OK;
 }
@@ -272,7 +331,7 @@ extern "C" int p2hot_ctx_set_stream(p2hot_ctx *ctx, void *hip_stream) {
 static int check_oob(p2hot_ctx *ctx) {
     unsigned f = 0;
     P2_HIP(ctx, hipMemcpyAsync(&f, ctx->d_oob, 4, hipMemcpyDeviceToHost, ctx->stream));
-    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P2_HIP(ctx, stream_sync(ctx));
     if (f) {
         P2_HIP(ctx, hipMemsetAsync(ctx->d_oob, 0, 4, ctx->stream));
         P2_FAIL(ctx, P2HOT_EINVAL, "an earlier %s was given an index out of range (the reference panics on the slice index); its output rows are zero",
@@ -283,7 +342,7 @@ static int check_oob(p2hot_ctx *ctx) {
 
 extern "C" int p2hot_ctx_sync(p2hot_ctx *ctx) {
     if (!ctx) return P2HOT_EINVAL;
-    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P2_HIP(ctx, stream_sync(ctx));
     return check_oob(ctx);
 }
 
@@ -329,7 +388,7 @@ extern "C" int p2hot_profile_enable(p2hot_ctx *ctx, int on) {
 extern "C" const char *p2hot_profile_json(p2hot_ctx *ctx, int reset) {
     if (!ctx) return "{}";
 #ifndef P2HOT_EMU
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)stream_sync(ctx);
     for (auto &r : ctx->prof) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
@@ -836,7 +895,7 @@ static int challenger_io(p2hot_challenger *ch, size_t words, u64 **out) {
     p2hot_ctx *ctx = ch->ctx;
     if (ch->io_cap < words) {
         if (ch->d_io) {
-            P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            P2_HIP(ctx, stream_sync(ctx));
             P2_HIP(ctx, hipFree(ch->d_io));
             ch->d_io = nullptr;
             ch->io_cap = 0;
@@ -882,7 +941,7 @@ extern "C" int p2hot_challenger_load(p2hot_challenger *ch, const p2hot_challenge
     p2hot_ctx *ctx = ch->ctx;
     if (st->input_len >= 8 || st->output_len > 8) P2_FAIL(ctx, P2HOT_EINVAL, "challenger: buffer lengths out of range");
     P2_HIP(ctx, hipMemcpyAsync(ch->d, st, sizeof *st, hipMemcpyHostToDevice, ctx->stream));
-    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P2_HIP(ctx, stream_sync(ctx));
     return P2HOT_OK;
 }
 
@@ -890,7 +949,7 @@ extern "C" int p2hot_challenger_store(p2hot_challenger *ch, p2hot_challenger_sta
     if (!ch || !st) return P2HOT_EINVAL;
     p2hot_ctx *ctx = ch->ctx;
     P2_HIP(ctx, hipMemcpyAsync(st, ch->d, sizeof *st, hipMemcpyDeviceToHost, ctx->stream));
-    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P2_HIP(ctx, stream_sync(ctx));
     return P2HOT_OK;
 }
 
@@ -914,7 +973,7 @@ extern "C" int p2hot_challenger_step(p2hot_challenger *ch, const uint64_t *obser
     P2_TRY(challenger_step_dev(ch, io, n_observe, io + n_observe, n_challenges));
     if (n_challenges)
         P2_HIP(ctx, hipMemcpyAsync(challenges, io + n_observe, n_challenges * 8, hipMemcpyDeviceToHost, ctx->stream));
-    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P2_HIP(ctx, stream_sync(ctx));
     return P2HOT_OK;
 }
 
@@ -1005,13 +1064,13 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
                 digests_out += 4 * nd;
             }
             if (caps_out) {
-                P2_HIP(ctx, hipMemcpyAsync(caps_out, cap.p, cap_words * 8, hipMemcpyDeviceToHost, ctx->stream));
+                P2_TRY(d2h(ctx, caps_out, cap.p, cap_words * 8));
                 caps_out += cap_words;
             }
             // prover.rs:106-109: observe_cap, beta = get_extension_challenge (stays on the device)
             P2_TRY(challenger_step_dev(challenger, cap.u(), cap_words, beta.u(), 2));
             if (betas_out) {
-                P2_HIP(ctx, hipMemcpyAsync(betas_out, beta.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+                P2_TRY(d2h(ctx, betas_out, beta.p, 16));
                 betas_out += 2;
             }
             // prover.rs:111-118: fold the coefficients, shift <- shift^arity
@@ -1039,7 +1098,7 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
                      stage.u());
         P2_LAUNCH_CHECK(ctx);
         P2_TRY(challenger_step_dev(challenger, stage.u(), 2 * cur_n, nullptr, 0));
-        if (final_out) P2_HIP(ctx, hipMemcpyAsync(final_out, stage.p, cur_n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (final_out) P2_TRY(d2h(ctx, final_out, stage.p, cur_n * 16));
         // prover.rs:140-147: observe zeros up to the padded final polynomial length
         if (final_poly_coeff_len > cur_n) {
             const size_t extra = 2 * (final_poly_coeff_len - cur_n);  // extension elements -> words
@@ -1054,7 +1113,7 @@ static int fri_commit_core(p2hot_ctx *ctx, const uint64_t *coeffs, const uint64_
     };
     rc = body();
     if (defer_sync) return rc;  // the caller synchronises once, after everything it enqueues behind this (p2hot_prove_openings)
-    hipError_t e = hipStreamSynchronize(ctx->stream);  // host outputs are complete on return
+    hipError_t e = stream_sync(ctx);  // host outputs are complete on return
     if (rc == P2HOT_OK && e != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "fri_commit: %s", hipGetErrorString(e));
     return rc;
 }
@@ -1250,7 +1309,7 @@ extern "C" int p2hot_partial_products_dev(p2hot_ctx *ctx, const uint64_t *d_wire
     }
     unsigned zero = 0;
     P2_HIP(ctx, hipMemcpyAsync(&zero, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P2_HIP(ctx, stream_sync(ctx));
     if (zero) P2_FAIL(ctx, P2HOT_EINVAL, "partial_products: tried to invert zero (a denominator wire + beta*sigma + gamma vanished)");
     return P2HOT_OK;
 }
@@ -1307,7 +1366,7 @@ static int pow_continue_host(p2hot_ctx *ctx, p2hot_challenger *challenger, unsig
         P2HOT_LAUNCH(fri::pow_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, challenger->d, pow_bits, start, count, d_best);
         P2_LAUNCH_CHECK(ctx);
         P2_HIP(ctx, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
-        P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        P2_HIP(ctx, stream_sync(ctx));
         if (best != ~0ull) break;
         start += count;
     }
@@ -1325,7 +1384,7 @@ extern "C" int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsig
     u64 next = 0;
     P2_TRY(pow_search_dev(ctx, challenger, pow_bits, (unsigned long long *)io, &next));
     P2_HIP(ctx, hipMemcpyAsync(&best, io, 8, hipMemcpyDeviceToHost, ctx->stream));
-    P2_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    P2_HIP(ctx, stream_sync(ctx));
     if (best == ~0ull) P2_TRY(pow_continue_host(ctx, challenger, pow_bits, (unsigned long long *)io, next, &best));
     *witness_out = best;
     u64 w = best, resp;

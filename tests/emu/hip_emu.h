@@ -96,6 +96,9 @@ static inline hipError_t hipFree(void *p) {
     free(p);
     return hipSuccess;
 }
+enum { hipHostMallocDefault = 0 };
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) {
     memmove(d, s, n);
     return hipSuccess;
