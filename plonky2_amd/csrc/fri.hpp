@@ -209,6 +209,26 @@ __global__ void __launch_bounds__(1024) horner_carries_kernel(const u64 *p0, con
     }
 }
 
+// The chunk carries of a long polynomial in two levels (2^22 coefficients = 65536 chunks: one block walking 64 chunks per
+// thread took 319 us): groups of 2^group_log chunks get their totals from horner_chunk_totals_kernel (ratio zL), the group
+// carries T come from horner_carries_kernel over the groups, and this kernel walks each group down from its carry:
+//   t[last chunk of g] = T[g],  t[m] = t[m + 1] * zL + P[m + 1].
+__global__ void horner_group_walk_kernel(const u64 *p0, const u64 *p1, unsigned group_log, size_t n_groups, gl::ext2 zL, const u64 *T0,
+                                         const u64 *T1, u64 *t0, u64 *t1) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    gl::ext2 carry{T0[g], T1[g]};
+    const size_t base = g << group_log;
+    for (size_t i = (size_t)1 << group_log; i-- > 0;) {
+        const size_t m = base + i;
+        t0[m] = carry.a0;
+        t1[m] = carry.a1;
+        carry = gl::ext_mul(carry, zL);
+        carry.a0 = gl::add(carry.a0, p0[m]);
+        carry.a1 = gl::add(carry.a1, p1[m]);
+    }
+}
+
 __global__ void horner_emit_kernel(const u64 *c0, const u64 *c1, unsigned chunk_log, size_t n_chunks, gl::ext2 z,
                                    const u64 *t0, const u64 *t1, const u64 *shift_ptr, int accumulate, u64 *a0, u64 *a1) {
     size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -52,6 +52,7 @@ struct p2hot_ctx {
     size_t pinned_cap = 0, pinned_used = 0;
     std::vector<DeferredCopy> deferred;
     bool in_host_call = false;       // set by the host-pointer entry points (they end in stream_sync)
+    size_t horner_two_level_min = 4096;  // divide_by_linear: more chunks than this -> carries in two levels (P2HOT_HORNER_2L_MIN)
     size_t zloop_min_groups = 2048;  // first LDE pass: one workgroup loops over the cosets when the launch has this many without
     struct Scratch {
         void *p = nullptr;
@@ -256,6 +257,7 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     }
     if (const char *e = getenv("P2HOT_NTT_XCD_REMAP")) ctx->ntt_xcd_remap = atoi(e) != 0;
     if (const char *e = getenv("P2HOT_NTT_ZLOOP_MIN")) ctx->zloop_min_groups = (size_t)strtoull(e, nullptr, 10);
+    if (const char *e = getenv("P2HOT_HORNER_2L_MIN")) ctx->horner_two_level_min = (size_t)strtoull(e, nullptr, 10);
     // start values of p2hot_tune_quad / p2hot_tune_row for every context of the process, the ones p2hot_group_create makes
     // included (the kernel emulator's test tier lowers them: emulated cross-lane exchanges are slow)
     if (const char *e = getenv("P2HOT_TUNE_QUAD")) ctx->quad_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -1168,11 +1170,17 @@ static int final_poly_core(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, 
         if (batch_offsets[i + 1] < batch_offsets[i]) P2_FAIL(ctx, P2HOT_EINVAL, "fri_final_poly: offsets must ascend");
         max_j = std::max(max_j, batch_offsets[i + 1] - batch_offsets[i]);
     }
-    // scratch: composition planes [2][n], chunk totals [2][n_chunks], carries [2][n_chunks], alpha powers [max_j + 1][2], alpha [2]
+    // more than 4096 chunks: the carries in two levels (groups of 64 chunks), see horner_group_walk_kernel
+    const unsigned group_log = 6;
+    const bool two_level = n_chunks > ctx->horner_two_level_min && n_chunks >= ((size_t)1 << group_log);
+    const size_t n_groups = two_level ? n_chunks >> group_log : 0, gper = (n_groups + 1023) / 1024;
+    // scratch: composition planes [2][n], chunk totals [2][n_chunks], carries [2][n_chunks], group totals and carries
+    // [4][n_groups], alpha powers [max_j + 1][2], alpha [2]
     u64 *sc = nullptr;
-    P2_TRY(scratch_get(ctx, 1, (2 * n + 4 * n_chunks + 2 * (max_j + 1) + 2) * 8, (void **)&sc));
+    P2_TRY(scratch_get(ctx, 1, (2 * n + 4 * n_chunks + 4 * n_groups + 2 * (max_j + 1) + 2) * 8, (void **)&sc));
     u64 *c0 = sc, *c1 = sc + n, *p0 = sc + 2 * n, *p1 = p0 + n_chunks, *t0 = p1 + n_chunks, *t1 = t0 + n_chunks;
-    u64 *d_apow = t1 + n_chunks, *d_a = d_apow + 2 * (max_j + 1);
+    u64 *g0 = t1 + n_chunks, *g1 = g0 + n_groups, *T0 = g1 + n_groups, *T1 = T0 + n_groups;
+    u64 *d_apow = T1 + n_groups, *d_a = d_apow + 2 * (max_j + 1);
     if (alpha_host) {
         ctx->alpha_stage[0] = gl::canon(alpha_host[0]);
         ctx->alpha_stage[1] = gl::canon(alpha_host[1]);
@@ -1201,8 +1209,18 @@ static int final_poly_core(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, 
         const gl::ext2 zL = ext_pow(z, (u64)1 << chunk_log);
         P2HOT_LAUNCH(fri::horner_chunk_totals_kernel, dim3(cdiv(n_chunks, 256)), dim3(256), 0, ctx->stream, (const u64 *)c0,
                      (const u64 *)c1, chunk_log, n_chunks, z, p0, p1);
-        P2HOT_LAUNCH(fri::horner_carries_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u64 *)p0, (const u64 *)p1,
-                     n_chunks, per, zL, t0, t1);
+        if (two_level) {
+            const gl::ext2 zG = ext_pow(zL, (u64)1 << group_log);
+            P2HOT_LAUNCH(fri::horner_chunk_totals_kernel, dim3(cdiv(n_groups, 256)), dim3(256), 0, ctx->stream, (const u64 *)p0,
+                         (const u64 *)p1, group_log, n_groups, zL, g0, g1);
+            P2HOT_LAUNCH(fri::horner_carries_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u64 *)g0, (const u64 *)g1, n_groups, gper,
+                         zG, T0, T1);
+            P2HOT_LAUNCH(fri::horner_group_walk_kernel, dim3(cdiv(n_groups, 256)), dim3(256), 0, ctx->stream, (const u64 *)p0,
+                         (const u64 *)p1, group_log, n_groups, zL, (const u64 *)T0, (const u64 *)T1, t0, t1);
+        } else {
+            P2HOT_LAUNCH(fri::horner_carries_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u64 *)p0, (const u64 *)p1,
+                         n_chunks, per, zL, t0, t1);
+        }
         P2HOT_LAUNCH(fri::horner_emit_kernel, dim3(cdiv(n_chunks, 256)), dim3(256), 0, ctx->stream, (const u64 *)c0,
                      (const u64 *)c1, chunk_log, n_chunks, z, (const u64 *)t0, (const u64 *)t1, (const u64 *)(d_apow + 2 * J),
                      i > 0 ? 1 : 0, d_final, d_final + n);

@@ -7,6 +7,10 @@ import pytest
 from tests.conftest import P, rand_field
 
 
+def is_gpu(eng):
+    return not bool(eng.lib.p2hot_is_emulated())
+
+
 def _ext_mul(a, b):
     return [(a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P]
 
@@ -96,6 +100,39 @@ def test_final_poly_and_prove_openings_vs_oracle(eng, ora, log_n, widths, rb, ca
             assert (sib == ora.merkle_prove(x >> ab, nl, cap, o["digests"][i])).all()
             x >>= ab
     assert c.get_n_challenges(2) == oc.get_n_challenges(2)
+
+
+def test_final_poly_long_polynomials_two_level_carries(eng, ora):
+    """divide_by_linear (division.rs:79-92) on polynomials long enough for the two-level carry scan (more than 4096 chunks:
+    2^19 coefficients and up; the starky trace of C4 has 2^22): final_poly against the oracle's reduce_polys_base +
+    divide_by_linear.  The CPU tier lowers the switch-over (P2HOT_HORNER_2L_MIN) on a context of its own to reach the same code."""
+    import os
+    from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, final_poly_device
+    rng = np.random.default_rng(19)
+    if is_gpu(eng):
+        e, sizes = eng, (19, 20)
+    else:
+        from tests.emu_backend import emu_engine
+        old = os.environ.get("P2HOT_HORNER_2L_MIN")
+        os.environ["P2HOT_HORNER_2L_MIN"] = "16"
+        try:
+            e = emu_engine()
+        finally:
+            if old is None:
+                os.environ.pop("P2HOT_HORNER_2L_MIN")
+            else:
+                os.environ["P2HOT_HORNER_2L_MIN"] = old
+        sizes = (9, 12, 14)      # 128 / 1024 / 1024 chunks -> 2 / 16 / 16 groups
+    for log_n in sizes:
+        widths = [2, 1]
+        cols = [rand_field(rng, w, 1 << log_n) for w in widths]
+        oracles = [PolynomialBatch.from_coeffs(e.dev(c), 1, False, 0, engine=e) for c in cols]
+        all_polys = [(oi, pi) for oi, w in enumerate(widths) for pi in range(w)]
+        z0, z1, alpha = rand_field(rng, 2), rand_field(rng, 2), rand_field(rng, 2)
+        batches = [FriBatchInfo(z0, all_polys), FriBatchInfo(z1, [(0, 0), (0, 1)])]
+        got = e.host(final_poly_device(batches, oracles, alpha, e))
+        exp = _oracle_final_poly(ora, [(z0, all_polys), (z1, [(0, 0), (0, 1)])], cols, alpha)
+        assert (got.T == exp).all(), log_n
 
 
 def test_merkle_paths_device(eng, ora):
