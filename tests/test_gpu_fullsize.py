@@ -96,6 +96,10 @@ def test_weak_scaling_shapes_bit_exact_on_one_gpu(gpu, name, lde_blocks):
         pytest.skip("no golden for " + name)
     W, log_n, rb, cap = g["W"], g["log_n"], g["rate_bits"], g["cap_height"]
     n = 1 << log_n
+    need = (2 * W * n + W * (n << rb) + 8 * (n << rb)) * 8 * 1.15      # columns, coefficients, LDE, digests + slack
+    torch.cuda.empty_cache()
+    if torch.cuda.mem_get_info()[0] < need:
+        pytest.skip("needs %.0f GB of free HBM" % (need / 2**30))
     cols = splitmix_columns_torch(torch, gpu.mem.device, 0, W, n)
     r = gpu.commit(cols, log_n, rb, cap, True)
     del cols
@@ -136,6 +140,11 @@ def test_weak_scaling_shapes_as_rank_groups_on_one_gpu(gpu, name, world, by_colu
     W, log_n, rb, cap = g["W"], g["log_n"], g["rate_bits"], g["cap_height"]
     torch.cuda.empty_cache()
     gpu.check(gpu.lib.p2hot_ctx_trim(gpu.ctx))
+    n = 1 << log_n
+    # every rank holds all coefficients and its row block of the LDE (column mode: its columns' whole LDE and the row block)
+    need = (world * 2 * W * n + (2 if by_columns else 1) * W * (n << rb) + 8 * (n << rb)) * 8 * 1.1
+    if torch.cuda.mem_get_info()[0] < need:
+        pytest.skip("needs %.0f GB of free HBM" % (need / 2**30))
     cols = splitmix_columns_numpy(0, W, 1 << log_n)
     grp = GroupCommit(gpu.lib, world, [0] * world)
     r = grp.commit(cols, rb, cap, True, want_leaves=False, want_digests=True, by_columns=by_columns)
