@@ -51,10 +51,9 @@ extern "C" int p2hot_cols_upload(p2hot_ctx *ctx, const uint64_t *const *cols, si
     const size_t n = (size_t)1 << log_n;
     PoolBuf d(ctx);
     P2_TRY(pool_alloc(ctx, (W ? W : 1) * n * 8, &d.p));
-    for (size_t c = 0; c < W; ++c) {
+    for (size_t c = 0; c < W; ++c)
         if (!cols[c]) P2_FAIL(ctx, P2HOT_EINVAL, "cols_upload: column %zu is null", c);
-        P2_HIP(ctx, hipMemcpyAsync(d.u() + c * n, cols[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
-    }
+    P2_TRY(h2d_columns(ctx, d.u(), cols, W, n * 8, 0, W * n * 8, ctx->stream));
     P2_TRY(sync_checked(ctx, P2HOT_OK, "cols_upload"));
     *out = new p2hot_cols{ctx, d.u(), W, log_n, true};
     d.p = nullptr;
@@ -149,8 +148,7 @@ extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t 
             const size_t c0 = b * kBlockCols, cnt = (c0 + kBlockCols <= W ? kBlockCols : W - c0);
             u64 *blk = d_work.u() + c0 * n;
             u64 *land = keep_vals ? d_vals.u() + c0 * n : blk;  // where the upload lands
-            for (size_t c = c0; c < c0 + cnt; ++c)
-                P2_HIP(ctx, hipMemcpyAsync(land + (c - c0) * n, cols[c], n * 8, hipMemcpyHostToDevice, copy_stream));
+            P2_TRY(h2d_columns(ctx, land, cols + c0, cnt, n * 8, c0 * n * 8, W * n * 8, copy_stream));
 #ifndef P2HOT_EMU
             if (two_streams) {
                 P2_HIP(ctx, hipEventRecord(up[b], ctx->side));

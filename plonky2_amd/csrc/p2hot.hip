@@ -50,6 +50,8 @@ struct p2hot_ctx {
     };
     unsigned char *pinned = nullptr;
     size_t pinned_cap = 0, pinned_used = 0;
+    unsigned char *pinned_up = nullptr;  // upload staging: many short host columns -> one contiguous pinned block -> one copy
+    size_t pinned_up_cap = 0;
     std::vector<DeferredCopy> deferred;
     bool in_host_call = false;       // set by the host-pointer entry points (they end in stream_sync)
     size_t horner_two_level_min = 4096;  // divide_by_linear: more chunks than this -> carries in two levels (P2HOT_HORNER_2L_MIN)
@@ -171,6 +173,34 @@ static int d2h_2d(p2hot_ctx *ctx, void *dst, size_t dpitch, const void *d_src, s
     return P2HOT_OK;
 }
 static int d2h(p2hot_ctx *ctx, void *dst, const void *d_src, size_t bytes) { return d2h_2d(ctx, dst, bytes, d_src, bytes, bytes, 1); }
+
+// `count` host columns of `bytes` each -> d_dst (contiguous, column after column).  Short columns are gathered into the pinned
+// upload block at byte offset `stage_off` and go up in one asynchronous copy (a copy from pageable memory costs ~15 us of host
+// time whatever its size: 135 columns of a recursion-size trace were 1.5 ms); long ones are copied one by one as before.
+// The staging block is only reused after the call's synchronisation, so distinct blocks of one call use distinct offsets.
+static int h2d_columns(p2hot_ctx *ctx, void *d_dst, const uint64_t *const *cols, size_t count, size_t bytes, size_t stage_off,
+                       size_t stage_total, hipStream_t stream) {
+    const size_t kMaxStage = (size_t)64 << 20;
+    if (ctx->in_host_call && count > 1 && bytes <= ((size_t)1 << 20) && stage_total <= kMaxStage) {
+        if (ctx->pinned_up_cap < stage_total) {
+            if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);  // idle: the previous call synchronised before returning
+            ctx->pinned_up = nullptr;
+            ctx->pinned_up_cap = 0;
+            const size_t want = std::max(stage_total, (size_t)8 << 20);
+            if (hipHostMalloc((void **)&ctx->pinned_up, want, hipHostMallocDefault) == hipSuccess) ctx->pinned_up_cap = want;
+        }
+        if (ctx->pinned_up && stage_off + count * bytes <= ctx->pinned_up_cap) {
+            unsigned char *slot = ctx->pinned_up + stage_off;
+            for (size_t c = 0; c < count; ++c)
+                std::copy((const unsigned char *)cols[c], (const unsigned char *)cols[c] + bytes, slot + c * bytes);
+            P2_HIP(ctx, hipMemcpyAsync(d_dst, slot, count * bytes, hipMemcpyHostToDevice, stream));
+            return P2HOT_OK;
+        }
+    }
+    for (size_t c = 0; c < count; ++c)
+        P2_HIP(ctx, hipMemcpyAsync((unsigned char *)d_dst + c * bytes, cols[c], bytes, hipMemcpyHostToDevice, stream));
+    return P2HOT_OK;
+}
 
 static int scratch_get(p2hot_ctx *ctx, int slot, size_t bytes, void **out) {
     auto &s = ctx->scratch[slot];
@@ -319,6 +349,7 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
         if (s.p) (void)hipFree(s.p);
     if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);
     delete ctx;
 }
 
