@@ -50,6 +50,9 @@ from plonky2_amd.util.synthetic import splitmix_columns_torch  # noqa: E402
 
 eng = Engine(0)
 dev = torch.device("cuda:0")
+host = "--host" in sys.argv   # inputs as host arrays: every stage through the host-pointer entry points the Rust shim calls
+if host:
+    sys.argv.remove("--host")
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 n, rb, cap = 1 << log_n, 3, 4
 arity = [4] * ((log_n - 4) // 4)
@@ -57,6 +60,8 @@ wires = splitmix_columns_torch(torch, dev, 0, 135, n)
 sig = splitmix_columns_torch(torch, dev, 1000, 80, n)
 quo = splitmix_columns_torch(torch, dev, 2000, 16, n)
 k_is = [pow(14293326489335486720, j, P) for j in range(80)]
+if host:
+    wires, sig, quo = (eng.host(x) for x in (wires, sig, quo))
 for rep in range(5):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -74,4 +79,4 @@ for rep in range(5):
     nxt = [(oi, pi) for oi, W in enumerate((135, 20)) for pi in range(W)]
     prove_openings([FriBatchInfo(zeta, allp), FriBatchInfo(gz, nxt)], oracles, ch, rb, cap, arity, 16, 28, engine=eng)
     torch.cuda.synchronize()
-    print("path 2^%d: %.3f ms" % (log_n, (time.perf_counter() - t0) * 1e3))
+    print("path 2^%d%s: %.3f ms" % (log_n, " (host pointers)" if host else "", (time.perf_counter() - t0) * 1e3))
