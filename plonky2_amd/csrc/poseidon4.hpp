@@ -87,24 +87,129 @@ __device__ __forceinline__ void mds_quad(u64 w[3], unsigned q, const u64 rc3[3],
     w[2] = y[2];
 }
 
+// value of lane 0 of this quad
+__device__ __forceinline__ u64 quad_bcast0(u64 v) {
+#ifdef P2HOT_EMU
+    const int lane = (int)(threadIdx.x & 63);
+    return emu::shfl_exchange(v, lane & ~3);
+#else
+    const u32 lo = (u32)__builtin_amdgcn_mov_dpp((int)(u32)v, 0, 0xF, 0xF, true);
+    const u32 hi = (u32)__builtin_amdgcn_mov_dpp((int)(u32)(v >> 32), 0, 0xF, 0xF, true);
+    return ((u64)hi << 32) | lo;
+#endif
+}
+
+// The constants of the batched partial rounds as THIS lane needs them: its three rows of M^3 in the rotated word order its
+// quad rotations deliver (z'[i] = x_{(i + 3q) % 12}; M^3 is not circulant, so unlike the MDS immediates they differ per lane)
+// and its rows' entries of the columns M^2 e0 and M e0.  Selected from literals once per permutation.
+struct QuadM3 {
+    u32 m[36], c2[3], c1[3];
+};
+__device__ __forceinline__ u32 sel4(unsigned q, u32 a0, u32 a1, u32 a2, u32 a3) { return q == 0 ? a0 : q == 1 ? a1 : q == 2 ? a2 : a3; }
+__device__ __forceinline__ QuadM3 quad_m3(unsigned q) {
+    QuadM3 k;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            k.m[12 * t + i] = sel4(q, P2_POSEIDON_M3[12 * (0 + t) + (i + 0) % 12], P2_POSEIDON_M3[12 * (3 + t) + (i + 3) % 12],
+                                   P2_POSEIDON_M3[12 * (6 + t) + (i + 6) % 12], P2_POSEIDON_M3[12 * (9 + t) + (i + 9) % 12]);
+        k.c2[t] = sel4(q, P2_POSEIDON_MCOL0[12 + t], P2_POSEIDON_MCOL0[15 + t], P2_POSEIDON_MCOL0[18 + t], P2_POSEIDON_MCOL0[21 + t]);
+        k.c1[t] = sel4(q, P2_POSEIDON_MCOL0[t], P2_POSEIDON_MCOL0[3 + t], P2_POSEIDON_MCOL0[6 + t], P2_POSEIDON_MCOL0[9 + t]);
+    }
+    return k;
+}
+
+// Three partial rounds in one dense pass on the quad-distributed state: poseidon::partial_rounds3 (see there for the algebra)
+// with the word-0 chain -- S-box, the row-0 products (M z)[0] and (M^2 z)[0], the two deltas -- run by every lane on its own
+// rotated view (lane 0's view is the true order, the others' results are discarded), the deltas broadcast from lane 0, and
+// each lane finishing its own three rows of M^3 z + d1 M^2 e0 + d2 M e0.  ~130 instructions per round instead of the ~190 of
+// a round-by-round MDS (the quad kernels spend two thirds of a permutation in the partial rounds).
+__device__ __forceinline__ void partial_rounds3_quad(u64 w[3], unsigned q, u64 c0, u64 c1, u64 c2, const QuadM3 &k) {
+    const u64 s0 = poseidon::sbox7_asm(gl::add_canon(w[0], c0));
+    w[0] = q == 0 ? s0 : w[0];
+    u64 z[12];  // z[i] = x_{(i + 3q) % 12}
+    dpp_guard(w);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        z[u] = w[u];
+        z[3 + u] = quad_rot<1>(w[u]);
+        z[6 + u] = quad_rot<2>(w[u]);
+        z[9 + u] = quad_rot<3>(w[u]);
+    }
+    u32 zl[12], zh[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        zl[i] = (u32)z[i];
+        zh[i] = (u32)(z[i] >> 32);
+    }
+    u64 al = 0, ah = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        al += (u64)zl[i] * P2_POSEIDON_M1_ROW0[i];
+        ah += (u64)zh[i] * P2_POSEIDON_M1_ROW0[i];
+    }
+    const u64 y1 = gl::fold1(al, ah);
+    u64 d1 = gl::sub(poseidon::sbox7_asm(gl::add_canon(y1, c1)), y1);
+    al = (u64)(u32)d1 * P2_POSEIDON_MCOL0[0];
+    ah = (u64)(u32)(d1 >> 32) * P2_POSEIDON_MCOL0[0];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        al += (u64)zl[i] * P2_POSEIDON_M2_ROW0[i];
+        ah += (u64)zh[i] * P2_POSEIDON_M2_ROW0[i];
+    }
+    const u64 y2 = gl::fold1(al, ah);
+    u64 d2 = gl::sub(poseidon::sbox7_asm(gl::add_canon(y2, c2)), y2);
+#ifndef P2HOT_EMU
+    asm volatile("s_nop 1" : "+v"(d1), "+v"(d2));  // VALU write -> DPP read (see dpp_guard)
+#endif
+    d1 = quad_bcast0(d1);
+    d2 = quad_bcast0(d2);
+    const u32 d1l = (u32)d1, d1h = (u32)(d1 >> 32), d2l = (u32)d2, d2h = (u32)(d2 >> 32);
+    u64 bl[3], bh[3], y[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        bl[t] = (u64)d1l * k.c2[t] + (u64)d2l * k.c1[t];
+        bh[t] = (u64)d1h * k.c2[t] + (u64)d2h * k.c1[t];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            bl[t] += (u64)zl[i] * k.m[12 * t + i];
+            bh[t] += (u64)zh[i] * k.m[12 * t + i];
+        }
+    }
+    gl::fold3(bl, bh, y);
+    w[0] = y[0];
+    w[1] = y[1];
+    w[2] = y[2];
+}
+
 // the permutation on a quad-distributed state; q = lane & 3 holds words 3q..3q+2.  All four lanes must call it.
 __device__ inline void permute_quad(u64 w[3], unsigned q) {
     const u64 *rc = P2_POSEIDON_PUSHED_ROUND_CONSTANTS + 3 * q;  // pushed form: partial rounds add to word 0 only
+    const QuadM3 k = quad_m3(q);
 #pragma unroll
     for (int t = 0; t < 3; ++t) w[t] = gl::add_canon(w[t], rc[t]);
     int round = 0;
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k, ++round) {  // rounds 0..3 (the constants after round 3 are scalar: zeros elsewhere)
+    for (int j = 0; j < 3; ++j, ++round) {  // rounds 0..2
         poseidon::sbox7_x3(w[0], w[1], w[2]);
         mds_quad(w, q, rc + 12 * (round + 1), true);
     }
+    poseidon::sbox7_x3(w[0], w[1], w[2]);  // round 3: the batched partial rounds add their scalar constants themselves
+    mds_quad(w, q, rc, false);
+    ++round;
 #pragma unroll 1
-    for (int k = 0; k < 22; ++k, ++round) {  // rounds 4..25
-        w[0] = q == 0 ? poseidon::sbox7_asm(w[0]) : w[0];
+    for (int j = 0; j < 7; ++j, round += 3)  // rounds 4..24 in seven batches of three
+        partial_rounds3_quad(w, q, P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * round], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 1)],
+                             P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 2)], k);
+    {  // round 25, then the full constant vector of round 26 (which absorbed the pushed remainder)
+        const u64 s0 = poseidon::sbox7_asm(gl::add_canon(w[0], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * round]));
+        w[0] = q == 0 ? s0 : w[0];
         mds_quad(w, q, rc + 12 * (round + 1), true);
+        ++round;
     }
 #pragma unroll 1
-    for (int k = 0; k < 3; ++k, ++round) {  // rounds 26..28
+    for (int j = 0; j < 3; ++j, ++round) {  // rounds 26..28
         poseidon::sbox7_x3(w[0], w[1], w[2]);
         mds_quad(w, q, rc + 12 * (round + 1), true);
     }
