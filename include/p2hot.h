@@ -57,7 +57,8 @@ int p2hot_is_emulated(void);
  * {"kernel": {"ms": total, "launches": count}, ...} (valid until the next call); reset != 0 clears
  * the totals.  This is the TimingTree analogue (plonky2/src/util/timing.rs) for the GPU stages. */
 int p2hot_profile_enable(p2hot_ctx *ctx, int on);
-/* tuning knob for the NTT pass kernels (0 = LDS radix-2 layers, 3 = register radix 8 [default], 4 = radix 16);
+/* tuning knob for the NTT pass kernels (0 = LDS radix-2 layers, 3 = register radix 8 on carry-free 24-bit limbs
+ * [default; 4096-element tiles, other tiles as 8], 8 = register radix 8 on 64-bit words, 4 = radix 16);
  * results are identical, only the speed differs */
 int p2hot_tune_ntt(p2hot_ctx *ctx, int radix_bits);
 /* overlap the Poseidon leaf sponge of coset block b with the LDE of block b+1 on a second HIP stream (default 0: measured neutral on MI355X) */

@@ -15,6 +15,7 @@
 #include "plonk.hpp"
 #include "merkle.hpp"
 #include "ntt.hpp"
+#include "nttl.hpp"
 
 using gl::u32;
 using gl::u64;
@@ -31,6 +32,13 @@ struct p2hot_ctx {
     ntt::RootTable fwd{}, inv{};
     u64 *local_fwd = nullptr, *local_inv = nullptr;  // [2^m + e] = w_{2^m}^(+-e), m <= TILE_LOG
     bool use_regpass = true;
+    bool use_limb = true;  // 4096-element tiles run the carry-free limb passes (nttl.hpp); P2HOT_NTT_LIMB=0 selects the round-2 kernels
+    struct LimbTables {
+        nttl::W2 *tw_all = nullptr;
+        u64 *ufac[4] = {nullptr, nullptr, nullptr, nullptr};
+    };
+    std::map<std::pair<int, unsigned>, LimbTables> limb_tw_cache;  // (inverse, log_r) -> the round tables of a 2^log_r-row tile
+    unsigned limb_tiles_log = 2;  // contiguous limb passes: a workgroup stages its tables once for 2^this tiles (P2HOT_LIMB_TILES_LOG)
     // second stream: the VALU-bound leaf sponge of coset block b runs beside the wait-bound NTT of block b+1
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> fork_events;
@@ -286,6 +294,8 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
         if (b >= 6 && b <= 11) ctx->ntt_strided_bits = (unsigned)b;
     }
     if (const char *e = getenv("P2HOT_NTT_XCD_REMAP")) ctx->ntt_xcd_remap = atoi(e) != 0;
+    if (const char *e = getenv("P2HOT_NTT_LIMB")) ctx->use_limb = atoi(e) != 0;
+    if (const char *e = getenv("P2HOT_LIMB_TILES_LOG")) ctx->limb_tiles_log = (unsigned)atoi(e);
     if (const char *e = getenv("P2HOT_NTT_ZLOOP_MIN")) ctx->zloop_min_groups = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HORNER_2L_MIN")) ctx->horner_two_level_min = (size_t)strtoull(e, nullptr, 10);
     // start values of p2hot_tune_quad / p2hot_tune_row for every context of the process, the ones p2hot_group_create makes
@@ -343,6 +353,11 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
 #endif
     for (auto &kv : ctx->scale_cache) (void)hipFree(kv.second);
     for (auto &kv : ctx->twid_cache) (void)hipFree(kv.second);
+    for (auto &kv : ctx->limb_tw_cache) {
+        (void)hipFree(kv.second.tw_all);
+        for (u64 *u : kv.second.ufac)
+            if (u) (void)hipFree(u);
+    }
     for (auto &b : ctx->pool_free) (void)hipFree(b.first);
     for (auto &kv : ctx->pool_live) (void)hipFree(kv.first);
     for (auto &s : ctx->scratch)
@@ -404,9 +419,10 @@ extern "C" int p2hot_tune_overlap(p2hot_ctx *ctx, int on) {
 
 // tuning knob (not part of the drop-in surface): 0 = LDS radix-2 layers, 3 = register radix 8, 4 = radix 16
 extern "C" int p2hot_tune_ntt(p2hot_ctx *ctx, int radix_bits) {
-    if (!ctx || (radix_bits != 0 && radix_bits != 3 && radix_bits != 4)) return P2HOT_EINVAL;
+    if (!ctx || (radix_bits != 0 && radix_bits != 3 && radix_bits != 4 && radix_bits != 8)) return P2HOT_EINVAL;
     ctx->use_regpass = radix_bits != 0;
-    if (radix_bits) ctx->ntt_radix_bits = (unsigned)radix_bits;
+    ctx->use_limb = radix_bits == 3;  // 8: radix 8 on 64-bit words (the round-2 kernels), 3: radix 8 on 24-bit limbs
+    if (radix_bits) ctx->ntt_radix_bits = radix_bits == 8 ? 3u : (unsigned)radix_bits;
     return P2HOT_OK;
 }
 
@@ -479,6 +495,100 @@ static std::vector<Pass> plan_passes(unsigned log_n, unsigned maxb) {
     return p;
 }
 
+
+// ------------------------------------------------------------------ limb passes (nttl.hpp)
+// the round tables of a 2^log_r-row tile, concatenated in the layout the kernel copies to LDS (nttl::round_table_off)
+static int limb_tables(p2hot_ctx *ctx, bool inverse, unsigned log_r, p2hot_ctx::LimbTables *out) {
+    auto key = std::make_pair((int)inverse, log_r);
+    auto it = ctx->limb_tw_cache.find(key);
+    if (it == ctx->limb_tw_cache.end()) {
+        p2hot_ctx::LimbTables lt;
+        const size_t total = (size_t)nttl::limb_tables_w2((int)log_r);
+        P2_HIP(ctx, hipMalloc((void **)&lt.tw_all, (total ? total : 1) * sizeof(nttl::W2)));
+        for (int r = 0; r < nttl::n_rounds((int)log_r); ++r) {
+            const unsigned p = (unsigned)nttl::round_bits((int)log_r, r), log_rb = (unsigned)nttl::round_log_rb((int)log_r, r);
+            if (log_rb <= p) continue;  // the last round of a tile has no table twiddles
+            const unsigned s_log = log_rb - p, s_eff = (unsigned)nttl::round_s_eff((int)log_r, r);
+            size_t count = ((((size_t)1 << p) - 1) << s_eff);
+            if (s_log > s_eff) {
+                P2_HIP(ctx, hipMalloc((void **)&lt.ufac[r], (size_t)8 * 8 << (s_log - s_eff)));
+                count = std::max(count, (size_t)8 << (s_log - s_eff));
+            }
+            P2HOT_LAUNCH(nttl::limb_twiddle_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream,
+                         lt.tw_all + nttl::round_table_off((int)log_r, r), lt.ufac[r], log_rb, p, inverse ? ctx->inv : ctx->fwd);
+            P2_LAUNCH_CHECK(ctx);
+        }
+        it = ctx->limb_tw_cache.emplace(key, lt).first;
+    }
+    *out = it->second;
+    return P2HOT_OK;
+}
+
+static bool limb_supported(unsigned log_r, unsigned log_c) {
+    if (log_r + log_c != (unsigned)nttl::TILE_LOG) return false;
+    return log_r == 12 || (log_r >= 4 && log_r <= 10);
+}
+
+// launches one limb pass; `last_const` != 1 multiplies every output of this (last) pass by it (the 1/n of the inverse transform)
+static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse, const u64 *twid, unsigned xcd_remap,
+                            unsigned zloop, dim3 grid, u64 last_const) {
+    nttl::LimbPassArgs ra{};
+    ra.a = a;
+    ra.twid = twid;
+    ra.xcd_remap = xcd_remap;
+    ra.zloop = zloop;
+    p2hot_ctx::LimbTables lt;
+    P2_TRY(limb_tables(ctx, inverse, a.log_r, &lt));
+    ra.tw_all = lt.tw_all;
+    for (int r = 0; r < 4; ++r) ra.ufac[r] = lt.ufac[r];
+    // a workgroup of the contiguous pass keeps its staged tables for several tiles
+    ra.tiles_log = 0;
+    if (a.log_c == 0)
+        while (ra.tiles_log < ctx->limb_tiles_log && (grid.x >> (ra.tiles_log + 1)) >= 1 &&
+               (size_t)(grid.x >> (ra.tiles_log + 1)) * grid.y * grid.z >= 4096)
+            ++ra.tiles_log;
+    grid.x >>= ra.tiles_log;
+    if (ra.xcd_remap) ra.xcd_remap -= ra.tiles_log;
+    const bool wlast = gl::canon(last_const) != 1;
+    ra.wlast[0] = gl::canon(last_const);
+    ra.wlast[1] = gl::canon(gl::mul(last_const, nttl::B1));
+    ra.wlast[2] = gl::canon(gl::mul(last_const, nttl::B2));
+    ra.wlast[3] = gl::canon(gl::mul(last_const, nttl::B3));
+    const size_t shm = nttl::limb_shmem_bytes((int)a.log_r);
+    if (wlast && !(a.log_r == 12 && a.scale_mode == ntt::SCALE_NONE)) P2_FAIL(ctx, P2HOT_EINVAL, "limb pass: a final constant needs the contiguous pass");
+#define P2_LIMB(INVF, LR, MODE) \
+    P2HOT_LAUNCH((nttl::ntt_limbpass_kernel<INVF, LR, 12 - LR, MODE>), grid, dim3(nttl::NT), shm, ctx->stream, ra)
+#define P2_LIMB_DIR(LR, MODE) do { if (inverse) P2_LIMB(true, LR, MODE); else P2_LIMB(false, LR, MODE); } while (0)
+#define P2_LIMB_MODE(LR)                                                              \
+    do {                                                                              \
+        if (a.scale_mode == ntt::SCALE_TABLE) P2_LIMB_DIR(LR, ntt::SCALE_TABLE);      \
+        else if (a.scale_mode == ntt::SCALE_CONST) P2_LIMB_DIR(LR, ntt::SCALE_CONST); \
+        else P2_LIMB_DIR(LR, ntt::SCALE_NONE);                                        \
+    } while (0)
+    if (wlast) {
+        if (inverse)
+            P2HOT_LAUNCH((nttl::ntt_limbpass_kernel<true, 12, 0, ntt::SCALE_NONE, true>), grid, dim3(nttl::NT), shm, ctx->stream, ra);
+        else
+            P2HOT_LAUNCH((nttl::ntt_limbpass_kernel<false, 12, 0, ntt::SCALE_NONE, true>), grid, dim3(nttl::NT), shm, ctx->stream, ra);
+        return P2HOT_OK;
+    }
+    switch (a.log_r) {
+        case 12: P2_LIMB_MODE(12); break;
+        case 10: P2_LIMB_MODE(10); break;
+        case 9: P2_LIMB_MODE(9); break;
+        case 8: P2_LIMB_MODE(8); break;
+        case 7: P2_LIMB_MODE(7); break;
+        case 6: P2_LIMB_MODE(6); break;
+        case 5: P2_LIMB_MODE(5); break;
+        case 4: P2_LIMB_MODE(4); break;
+        default: P2_FAIL(ctx, P2HOT_EINVAL, "limb pass: unsupported tile 2^%u x 2^%u", a.log_r, a.log_c);
+    }
+#undef P2_LIMB_MODE
+#undef P2_LIMB_DIR
+#undef P2_LIMB
+    return P2HOT_OK;
+}
+
 // Runs the DIF chain: natural-order input -> bit-reversed output (per polynomial, per z slice).
 // The first pass reads `in` (no z offset: every z slice reads the same polynomials) and writes
 // `out`; later passes run in place on `out`.
@@ -489,6 +599,9 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
     if (batch > 65535 || zcount > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "batch %zu / z %zu exceed the grid limit", batch, zcount);
     std::vector<Pass> passes = plan_passes(log_n, ctx->ntt_strided_bits);
     unsigned log_nblk = log_n;
+    bool limb_all = ctx->use_limb && ctx->use_regpass && ctx->ntt_radix_bits == 3;  // every pass of this chain is a limb pass
+    for (const Pass &ps : passes) limb_all = limb_all && limb_supported(ps.log_r, ps.log_c);
+    limb_all = limb_all && log_n <= 24;  // strided limb passes take their inter-pass twiddles from the table (blocks <= 2^24)
     for (size_t i = 0; i < passes.size(); ++i) {
         ntt::PassArgs a{};
         const bool first = i == 0;
@@ -553,6 +666,19 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
             if (first && zcount > 1 && a.in_z_stride == 0 && ((size_t)1 << tiles_log) * batch >= ctx->zloop_min_groups) {
                 ra.zloop = (unsigned)zcount;
                 grid.z = 1;
+            }
+            if (ctx->use_limb && maxp == 3 && limb_supported(a.log_r, a.log_c) && (a.log_c == 0 || ra.twid)) {
+                // the constant scale of an inverse transform moves from the first pass to the last conversion of the last
+                // pass (every output of a tile's last round is converted by a constant 4-form anyway: it becomes c * B^i)
+                u64 last_const = 1;
+                if (limb_all && scale_mode == ntt::SCALE_CONST) {
+                    ra.a.scale_mode = ntt::SCALE_NONE;
+                    if (i + 1 == passes.size()) last_const = scale_const;
+                }
+                P2_TRY(launch_limb_pass(ctx, ra.a, inverse, ra.twid, ra.xcd_remap, ra.zloop, grid, last_const));
+                P2_LAUNCH_CHECK(ctx);
+                log_nblk -= a.log_r;
+                continue;
             }
             if (maxp == 3) {  // one kernel per (direction, scale mode): the per-point mode tests are compiled out
 #define P2_NTT512C(INVF, MODE, CT) P2HOT_LAUNCH((ntt::ntt_regpass_kernel<INVF, 512, (CT) ? 8 : 6, MODE, CT>), grid, dim3(512), shm, ctx->stream, ra)

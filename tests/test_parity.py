@@ -178,13 +178,14 @@ def test_coset_ifft_vs_oracle(eng, ora):
 
 
 def test_ntt_kernel_variants_agree(eng, ora):
-    """p2hot_tune_ntt: LDS radix-2 layers (0), register radix 8 (3, default) and radix 16 (4) are the same function"""
+    """p2hot_tune_ntt: LDS radix-2 layers (0), register radix 8 on 64-bit words (8), on 24-bit limbs (3, default) and
+    radix 16 (4) are the same function"""
     from plonky2_amd.field.fft import fft, ifft
     rng = np.random.default_rng(21)
     a = rand_field(rng, 2, 1 << 13)
     exp = np.stack([ora.fft(x.copy()) for x in a])
     try:
-        for mode in (0, 4, 3):
+        for mode in (0, 4, 8, 3):
             eng.check(eng.lib.p2hot_tune_ntt(eng.ctx, mode))
             assert (fft(a, eng) == exp).all(), mode
             assert (ifft(exp, eng) == a).all(), mode

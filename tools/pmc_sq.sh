@@ -13,9 +13,9 @@ acc=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collect
 for f in glob.glob(R+'/gpurun_out/pmc_sq/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name']
-        for key in ('hash_leaves','merkle_level','regpass','bitrev'):
+        for key in ('hash_leaves','merkle_level','regpass','limbpass','bitrev'):
             if key in k:
-                if key=='regpass': key += '_g%s_lds%s' % (r['Grid_Size'], r['LDS_Block_Size'])
+                if key in ('regpass','limbpass'): key += k[k.index('<'):k.index('>')+1].replace(' ','') + '_g%s' % r['Grid_Size']
                 acc[key][r['Counter_Name']]+=float(r['Counter_Value'])
                 if r['Dispatch_Id'] not in seen:
                     seen.add(r['Dispatch_Id']); cnt[key]+=1; dur[key]+=int(r['End_Timestamp'])-int(r['Start_Timestamp'])

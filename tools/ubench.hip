@@ -16,8 +16,8 @@
 #define OPS                                                                                         \
     : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), \
       "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])  \
-    : "v"(c), "v"(d)                                                                                 \
-    : "vcc"
+    : "v"(c), "v"(d), "v"(e)                                                                         \
+    : "vcc", "s20", "s21"
 
 #define I_ADD(i) "v_add_u32 %" #i ", %" #i ", %16"
 #define I_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %16"
@@ -45,6 +45,41 @@
 #define I_LSHLADD64(i) "v_lshl_add_u64 %" #i ", %" #i ", 3, %" #i
 #define I_CMP64(i) "v_cmp_lt_u64 vcc, %" #i ", %" #i
 
+
+// ---- round-3 additions: the instructions a carry-free limb NTT and the Poseidon alternatives are built from ----
+#define I_SUB(i) "v_sub_u32 %" #i ", %" #i ", %16"
+#define I_AND(i) "v_and_b32 %" #i ", %" #i ", %16"
+#define I_LSHR(i) "v_lshrrev_b32 %" #i ", 8, %" #i
+#define I_LSHL(i) "v_lshlrev_b32 %" #i ", 3, %" #i
+#define I_SUBCO(i) "v_sub_co_u32 %" #i ", vcc, %" #i ", %16"
+#define I_SUBB(i) "v_subb_co_u32 %" #i ", vcc, %" #i ", %16, vcc"
+#define I_ADDCE64(i) "v_addc_co_u32_e64 %" #i ", s[20:21], %" #i ", %16, s[20:21]"
+#define I_FMA32(i) "v_fma_f32 %" #i ", %" #i ", %16, %17"
+#define I_ADDF32(i) "v_add_f32 %" #i ", %" #i ", %16"
+#define I_PKADD16(i) "v_pk_add_u16 %" #i ", %" #i ", %16"
+#define I_LSHLADD32(i) "v_lshl_add_u32 %" #i ", %" #i ", 3, %16"
+#define I_MAD64S(i) "v_mad_u64_u32 %" #i ", vcc, %16, s20, %" #i
+#define I_MAD64I(i) "v_mad_u64_u32 %" #i ", vcc, %16, 41, %" #i
+#define I_MADI64(i) "v_mad_i64_i32 %" #i ", vcc, %16, %17, %" #i
+#define I_MAD64E(i) "v_mad_u64_u32 %" #i ", s[20:21], %16, %17, %" #i
+#define I_ADDF64(i) "v_add_f64 %" #i ", %" #i ", %18"
+#define I_MULF64(i) "v_mul_f64 %" #i ", %" #i ", %18"
+#define I_FMAF64(i) "v_fma_f64 %" #i ", %" #i ", %18, %18"
+#define I_PKFMA32(i) "v_pk_fma_f32 %" #i ", %" #i ", %18, %18"
+#define I_CVTF64U(i) "v_cvt_f64_u32 %" #i ", %16"
+#define I_LSHR64(i) "v_lshrrev_b64 %" #i ", 8, %" #i
+// 4 cheap 32-bit ops + 4 multiply-adds per iteration: do the rates add or overlap?
+#define MIX_ADD_MAD                                                                                   \
+    "v_add_u32 %0, %0, %16\n\tv_mad_u64_u32 %8, vcc, %16, %17, %8\n\tv_add_u32 %1, %1, %16\n\t"       \
+    "v_mad_u64_u32 %9, vcc, %16, %17, %9\n\tv_add_u32 %2, %2, %16\n\tv_mad_u64_u32 %10, vcc, %16, %17, %10\n\t" \
+    "v_add_u32 %3, %3, %16\n\tv_mad_u64_u32 %11, vcc, %16, %17, %11"
+// a dependent chain of one accumulator (latency, 8 waves/SIMD hide it or not)
+#define CHAIN_ADD "v_add_u32 %0, %0, %16\n\tv_add_u32 %0, %0, %17\n\tv_add_u32 %0, %0, %16\n\tv_add_u32 %0, %0, %17\n\t" \
+                  "v_add_u32 %0, %0, %16\n\tv_add_u32 %0, %0, %17\n\tv_add_u32 %0, %0, %16\n\tv_add_u32 %0, %0, %17"
+#define CHAIN_MAD "v_mad_u64_u32 %8, vcc, %16, %17, %8\n\tv_mad_u64_u32 %8, vcc, %17, %16, %8\n\tv_mad_u64_u32 %8, vcc, %16, %17, %8\n\t" \
+                  "v_mad_u64_u32 %8, vcc, %17, %16, %8\n\tv_mad_u64_u32 %8, vcc, %16, %17, %8\n\tv_mad_u64_u32 %8, vcc, %17, %16, %8\n\t" \
+                  "v_mad_u64_u32 %8, vcc, %16, %17, %8\n\tv_mad_u64_u32 %8, vcc, %17, %16, %8"
+
 #define R8B(INS) INS(8) "\n\t" INS(9) "\n\t" INS(10) "\n\t" INS(11) "\n\t" INS(12) "\n\t" INS(13) "\n\t" INS(14) "\n\t" INS(15)
 
 template <int OP>
@@ -53,6 +88,7 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t 
     uint64_t a[8];
     uint32_t b[8];
     uint32_t c = t * 2654435761u + seed, d = (t ^ seed) * 40503u + 1;
+    uint64_t e = 0x3FF0000000000001ull + t;  // a double near 1.0 (f64 probes)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         a[i] = (uint64_t)t * 0x9E3779B97F4A7C15ull + i + seed;
@@ -84,6 +120,30 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t 
         if (OP == 20) asm volatile(R8(I_XOR) OPS);
         if (OP == 21) asm volatile(R8(I_ADDE64) OPS, "s20", "s21");
         if (OP == 22) asm volatile(R8B(I_LSHL64) OPS);
+        if (OP == 23) asm volatile(R8(I_SUB) OPS);
+        if (OP == 24) asm volatile(R8(I_AND) OPS);
+        if (OP == 25) asm volatile(R8(I_LSHR) OPS);
+        if (OP == 26) asm volatile(R8(I_LSHL) OPS);
+        if (OP == 27) asm volatile(R8(I_SUBCO) OPS);
+        if (OP == 28) asm volatile(R8(I_SUBB) OPS);
+        if (OP == 29) asm volatile(R8(I_ADDCE64) OPS);
+        if (OP == 30) asm volatile(R8(I_FMA32) OPS);
+        if (OP == 31) asm volatile(R8(I_ADDF32) OPS);
+        if (OP == 32) asm volatile(R8(I_PKADD16) OPS);
+        if (OP == 33) asm volatile(R8(I_LSHLADD32) OPS);
+        if (OP == 34) asm volatile(R8B(I_MAD64S) OPS);
+        if (OP == 36) asm volatile(R8B(I_MAD64I) OPS);
+        if (OP == 37) asm volatile(R8B(I_MADI64) OPS);
+        if (OP == 38) asm volatile(R8B(I_MAD64E) OPS);
+        if (OP == 39) asm volatile(R8B(I_ADDF64) OPS);
+        if (OP == 40) asm volatile(R8B(I_MULF64) OPS);
+        if (OP == 41) asm volatile(R8B(I_FMAF64) OPS);
+        if (OP == 42) asm volatile(R8B(I_PKFMA32) OPS);
+        if (OP == 43) asm volatile(R8B(I_CVTF64U) OPS);
+        if (OP == 44) asm volatile(R8B(I_LSHR64) OPS);
+        if (OP == 45) asm volatile(MIX_ADD_MAD OPS);
+        if (OP == 46) asm volatile(CHAIN_ADD OPS);
+        if (OP == 47) asm volatile(CHAIN_MAD OPS);
     }
     uint64_t t1 = __builtin_readcyclecounter();
     uint64_t s = 0;
@@ -157,5 +217,29 @@ int main() {
     run<15>("v_and_or_b32");
     run<17>("v_lshl_add_u64");
     run<18>("v_cmp_lt_u64");
+    run<23>("v_sub_u32");
+    run<24>("v_and_b32");
+    run<25>("v_lshrrev_b32");
+    run<26>("v_lshlrev_b32");
+    run<33>("v_lshl_add_u32");
+    run<27>("v_sub_co_u32");
+    run<28>("v_subb_co_u32");
+    run<29>("v_addc_co_u32_e64");
+    run<30>("v_fma_f32");
+    run<31>("v_add_f32");
+    run<42>("v_pk_fma_f32");
+    run<32>("v_pk_add_u16");
+    run<34>("v_mad_u64_u32 sgpr");
+    run<36>("v_mad_u64_u32 inl");
+    run<38>("v_mad_u64_u32 sdst");
+    run<37>("v_mad_i64_i32");
+    run<39>("v_add_f64");
+    run<40>("v_mul_f64");
+    run<41>("v_fma_f64");
+    run<43>("v_cvt_f64_u32");
+    run<44>("v_lshrrev_b64");
+    run<45>("mix 4add+4mad");
+    run<46>("chain v_add_u32");
+    run<47>("chain v_mad_u64");
     return 0;
 }
