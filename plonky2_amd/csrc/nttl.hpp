@@ -160,7 +160,9 @@ __device__ __forceinline__ u64 conv_unit(const L4 &v) {
 struct LimbPassArgs {
     ntt::PassArgs a;
     const W2 *tw_all;    // the round tables of this tile shape, concatenated in their LDS layout (limb_tables_w2 entries)
-    const u64 *ufac[4];  // rounds whose sub-block has more than 64 twiddle columns: ufac[r][a * 8 + k] = w_{Rb}^(64 * a * k)
+    const u64 *ufac;     // tiles whose first round borrows the second round's table: ufac[a * 8 + k] = w_{2^LOG_R}^(a * k)
+    const u64 *srow2;    // strided LDE first pass: srow2[z * 4096 + e] = s_z^((e >> LOG_C) * stride + (e & (C-1))), tile-shaped
+    const W2 *sbase;     // ... and sbase[(z * tiles + tile) * 2 + h] = 4-form of s_z^(tile * C): the last conversion's constant
     u64 wlast[4];        // WLAST kernels: the forms the round without table twiddles multiplies by, c * B^i (c = 1/n for the iNTT)
     const u64 *twid;     // inter-pass twiddles as in ntt::RegPassArgs
     unsigned xcd_remap;  // > 0 (= log2 of gridDim.x): workgroup b takes slot (b % 8) * gridDim.x / 8 + b / 8 (see ntt::RegPassArgs)
@@ -183,17 +185,16 @@ constexpr int round_log_rb(int log_r, int r) {
     for (int q = 0; q < r; ++q) rb -= round_bits(log_r, q);
     return rb;
 }
-// Round tables live in LDS.  A table holds the 4-forms of w_{Rb}^(b * k) for b < 2^min(s_log, 6), k = 1..2^p - 1, as
-// t[((k-1)*2 + h) << s_eff | b] = {W_{2h}, W_{2h+1}}; a round with more twiddle columns (lo = 64 a + b: the first round of the
-// contiguous pass) multiplies by the wave-uniform w_{Rb}^(64 a k) afterwards -- 3584 distinct twiddles from 448 + 56.
+// Round tables live in LDS: the 4-forms of w_{Rb}^(lo * k) for lo < S = Rb / 2^p, k = 1..2^p - 1, as
+// t[((k-1)*2 + h) << s_log | lo] = {W_{2h}, W_{2h+1}}.  A round with more than 64 twiddle columns (the first round of the
+// contiguous pass: 512) has no table of its own: with lo = a + 2^p b its twiddle is w_{Rb}^(a k) * w_{Rb/2^p}^(b k), i.e. the
+// NEXT round's table entry (same radix) times one of 2^p (2^p - 1) small factors u[a * 8 + k] = w_{Rb}^(a * k), also in LDS:
+// 3584 distinct twiddles from 448 + 56 table entries, and 51 KB of LDS per workgroup (three workgroups per CU).
 constexpr int TW_S_MAX_LOG = 6;
-constexpr int round_s_eff(int log_r, int r) {
+constexpr bool round_borrows(int log_r, int r) { return round_log_rb(log_r, r) - round_bits(log_r, r) > TW_S_MAX_LOG; }
+constexpr int round_table_w2(int log_r, int r) {  // W2 entries of round r's own table
     const int s = round_log_rb(log_r, r) - round_bits(log_r, r);
-    return s > TW_S_MAX_LOG ? TW_S_MAX_LOG : s;
-}
-constexpr int round_table_w2(int log_r, int r) {  // W2 entries of round r's table
-    const int s = round_log_rb(log_r, r) - round_bits(log_r, r);
-    return s == 0 ? 0 : (((1 << round_bits(log_r, r)) - 1) * 2) << round_s_eff(log_r, r);
+    return (s == 0 || round_borrows(log_r, r)) ? 0 : (((1 << round_bits(log_r, r)) - 1) * 2) << s;
 }
 constexpr int round_table_off(int log_r, int r) {
     int o = 0;
@@ -201,7 +202,10 @@ constexpr int round_table_off(int log_r, int r) {
     return o;
 }
 constexpr int limb_tables_w2(int log_r) { return round_table_off(log_r, n_rounds(log_r)); }
-constexpr size_t limb_shmem_bytes(int log_r) { return (size_t)8 * ntt::TILE_WORDS_PADDED + (size_t)16 * limb_tables_w2(log_r); }
+constexpr int UFAC_WORDS = 64;  // u[a * 8 + k], a < 8, k < 8 (only round 0 ever borrows)
+constexpr size_t limb_shmem_bytes(int log_r) {
+    return (size_t)8 * ntt::TILE_WORDS_PADDED + (size_t)16 * limb_tables_w2(log_r) + (round_borrows(log_r, 0) ? 8 * UFAC_WORDS : 0);
+}
 
 __device__ __forceinline__ u64 limb_mul(u64 a, u64 b) { return gl::mul1(a, b); }
 __device__ __forceinline__ unsigned wave_uniform(unsigned v) {
@@ -212,30 +216,75 @@ __device__ __forceinline__ unsigned wave_uniform(unsigned v) {
 #endif
 }
 
-template <bool INV, int LOG_R, int LOG_C, int SCALE, bool WLAST, int RI>
-__device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, const W2 *ltw, const u64 *gin, unsigned log_stride,
-                                           size_t z, size_t base0) {
+// the workgroup barrier, or -- after a round whose sub-blocks a wave owns entirely -- nothing but program order
+// (the LDS executes one wave's accesses in order; the emulator's lanes are fibers, so there it stays a barrier)
+template <bool WAVE_PRIVATE>
+__device__ __forceinline__ void round_sync() {
+#ifdef P2HOT_EMU
+    __syncthreads();
+#else
+    if constexpr (WAVE_PRIVATE)
+        __builtin_amdgcn_wave_barrier();
+    else
+        __syncthreads();
+#endif
+}
+
+// how the tile's last round (no table twiddles) converts: by 1, by ra.wlast (a constant: the 1/n of the inverse transform),
+// or by the tile's entry of ra.sbase (the column part of the coset scale, see below)
+enum { LAST_UNIT = 0, LAST_CONST = 1, LAST_TILE = 2 };
+
+// the eight inputs of a thread's first-round units: element q of unit uu is raw[uu * 2^P + q]
+template <int LOG_R, int LOG_C>
+__device__ __forceinline__ void load_inputs(const u64 *gin, unsigned log_stride, u64 (&raw)[8]) {
+    constexpr int P = round_bits(LOG_R, 0);
+    constexpr int S_LOG = LOG_R - P;
+    constexpr unsigned C = 1u << LOG_C;
+    constexpr int UPT = 8 >> P;
+    constexpr unsigned UW = 512u >> P;
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int uu = 0; uu < UPT; ++uu) {
+        const unsigned u = wave * UW + lane + 64u * (unsigned)uu;
+        const unsigned c = u & (C - 1), lo = u >> LOG_C;  // first round: hi = 0
+        // one 32-bit per-thread byte offset, wave-uniform row steps (a block of a strided limb pass is <= 2^24 elements)
+        const u32 off0 = ((lo << log_stride) + c) * 8u;
+#pragma unroll
+        for (int q = 0; q < (1 << P); ++q)
+            raw[(uu << P) + q] =
+                *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(gin + ((size_t)q << (S_LOG + log_stride))) + off0);
+    }
+}
+
+// Round RI of the tile.  FIRST round: the inputs are `raw` (already loaded); once they are split, the inputs of the next tile
+// are fetched from `next_gin` (if not null) so that their latency hides behind the rest of this tile.
+template <bool INV, int LOG_R, int LOG_C, int SCALE, int LAST, int RI>
+__device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, const W2 *ltw, const u64 *lu, u64 (&raw)[8],
+                                           const u64 *next_gin, unsigned log_stride, size_t z, size_t base0) {
     constexpr int P = round_bits(LOG_R, RI);
     constexpr int LOG_RB = round_log_rb(LOG_R, RI);
     constexpr int S_LOG = LOG_RB - P;
-    constexpr int S_EFF = round_s_eff(LOG_R, RI);
+    constexpr bool BORROW = round_borrows(LOG_R, RI);
+    static_assert(!BORROW || (RI == 0 && round_bits(LOG_R, 1) == P && S_LOG - P <= TW_S_MAX_LOG), "borrowed table shape");
+    constexpr int T_LOG = BORROW ? S_LOG - P : S_LOG;  // log2 of the table's columns
+    constexpr int T_OFF = round_table_off(LOG_R, BORROW ? RI + 1 : RI);
     constexpr bool FIRST = RI == 0;
     constexpr unsigned C = 1u << LOG_C;
     constexpr int UPT = (1 << (TILE_LOG - P)) / NT;  // units per thread
+    constexpr unsigned UW = 512u >> P;               // units per wave: a wave's units cover 512 consecutive tile elements
+    constexpr int UNROLL = FIRST ? UPT : 1;          // `raw` is indexed by uu: registers only when unrolled
     const ntt::PassArgs &a = ra.a;
-#pragma unroll 1
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll UNROLL
     for (int uu = 0; uu < UPT; ++uu) {
-        const unsigned u = threadIdx.x + (unsigned)uu * NT;
+        const unsigned u = wave * UW + lane + 64u * (unsigned)uu;
         const unsigned c = u & (C - 1), rest = u >> LOG_C;
         const unsigned lo = rest & ((1u << S_LOG) - 1), hi = rest >> S_LOG;
         const unsigned i0 = (hi << LOG_RB) + lo;
         u64 v[1 << P];
         if constexpr (FIRST) {
-            // one 32-bit per-thread offset, wave-uniform row steps (a block of one pass is < 2^32 elements)
-            const u32 off0 = ((i0 << log_stride) + c) * 8u;  // bytes
 #pragma unroll
-            for (int q = 0; q < (1 << P); ++q)
-                v[q] = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(gin + ((size_t)q << (S_LOG + log_stride))) + off0);
+            for (int q = 0; q < (1 << P); ++q) v[q] = raw[(uu << P) + q];
         } else {
 #pragma unroll
             for (int q = 0; q < (1 << P); ++q) v[q] = tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)];
@@ -243,57 +292,64 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
         if constexpr (FIRST && SCALE == ntt::SCALE_CONST) {
 #pragma unroll
             for (int q = 0; q < (1 << P); ++q) v[q] = limb_mul(v[q], a.scale_const);
-        } else if constexpr (FIRST && SCALE == ntt::SCALE_TABLE) {
-            const u64 scol = log_stride ? a.scol[(z << log_stride) + base0 + c] : 1;
+        } else if constexpr (FIRST && SCALE == ntt::SCALE_TABLE && LOG_C > 0) {
+            // coset scale s_z^t, t = i * stride + base0 + c: the (i, c) part from a tile-shaped table, the base0 part (uniform)
+            // in the last round's conversion (LAST_TILE)
+            const u64 *sr = ra.srow2 + (z << TILE_LOG) + (i0 << LOG_C) + c;
 #pragma unroll
-            for (int q = 0; q < (1 << P); ++q) {
-                u64 sc = a.srow[z * (1u << LOG_R) + i0 + ((unsigned)q << S_LOG)];
-                if (log_stride) sc = limb_mul(sc, scol);
-                v[q] = limb_mul(v[q], sc);
-            }
+            for (int q = 0; q < (1 << P); ++q) v[q] = limb_mul(v[q], sr[(size_t)q << (S_LOG + LOG_C)]);
+        } else if constexpr (FIRST && SCALE == ntt::SCALE_TABLE) {  // single-pass transform: the row table is everything
+#pragma unroll
+            for (int q = 0; q < (1 << P); ++q) v[q] = limb_mul(v[q], a.srow[z * (1u << LOG_R) + i0 + ((unsigned)q << S_LOG)]);
         }
         L4 x[1 << P];
 #pragma unroll
         for (int q = 0; q < (1 << P); ++q) x[q] = split(v[q]);
+        if constexpr (FIRST)
+            if (uu == UPT - 1 && next_gin) load_inputs<LOG_R, LOG_C>(next_gin, log_stride, raw);
         x[0].l[0] += O0;
         x[0].l[1] += O1;
         x[0].l[2] += O2;
         x[0].l[3] += O3;
         dft_limbs<P, INV>(x);
         if constexpr (S_LOG > 0) {
-            const W2 *tw = ltw + round_table_off(LOG_R, RI) + (lo & ((1u << S_EFF) - 1));
-            const u64 *uf = nullptr;
-            if constexpr (S_LOG > S_EFF) uf = ra.ufac[RI] + wave_uniform(lo >> S_EFF) * 8;  // lanes of a wave share u >> 6
+            const W2 *tw = ltw + T_OFF + (BORROW ? lo >> P : lo);
+            const u64 *uf = lu + (lo & ((1u << P) - 1)) * 8;
             tile[ntt::pad_idx((i0 << LOG_C) + c)] = conv_unit(x[0]);
 #pragma unroll
             for (int q = 1; q < (1 << P); ++q) {
                 const unsigned k = (unsigned)(__brev((unsigned)q) >> (32 - P));
-                const W2 wa = tw[((k - 1) * 2) << S_EFF], wb = tw[((k - 1) * 2 + 1) << S_EFF];
+                const W2 wa = tw[((k - 1) * 2) << T_LOG], wb = tw[((k - 1) * 2 + 1) << T_LOG];
                 u64 y = convmul(x[q], wa.a, wa.b, wb.a, wb.b);
-                if constexpr (S_LOG > S_EFF) y = limb_mul(y, uf[k]);
+                if constexpr (BORROW) y = limb_mul(y, uf[k]);
                 tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = y;
             }
+        } else if constexpr (LAST == LAST_UNIT) {
+#pragma unroll
+            for (int q = 0; q < (1 << P); ++q) tile[ntt::pad_idx(((i0 + (unsigned)q) << LOG_C) + c)] = conv_unit(x[q]);
         } else {
-            if constexpr (WLAST) {
-#pragma unroll
-                for (int q = 0; q < (1 << P); ++q)
-                    tile[ntt::pad_idx(((i0 + (unsigned)q) << LOG_C) + c)] =
-                        convmul(x[q], ra.wlast[0], ra.wlast[1], ra.wlast[2], ra.wlast[3]);
-            } else {
-#pragma unroll
-                for (int q = 0; q < (1 << P); ++q) tile[ntt::pad_idx(((i0 + (unsigned)q) << LOG_C) + c)] = conv_unit(x[q]);
+            u64 w0, w1, w2, w3;
+            if constexpr (LAST == LAST_CONST) {
+                w0 = ra.wlast[0], w1 = ra.wlast[1], w2 = ra.wlast[2], w3 = ra.wlast[3];
+            } else {  // wave-uniform: scalar loads
+                const W2 *sb = ra.sbase + (((z << (log_stride - LOG_C)) + (base0 >> LOG_C)) << 1);
+                w0 = sb[0].a, w1 = sb[0].b, w2 = sb[1].a, w3 = sb[1].b;
             }
+#pragma unroll
+            for (int q = 0; q < (1 << P); ++q)
+                tile[ntt::pad_idx(((i0 + (unsigned)q) << LOG_C) + c)] = convmul(x[q], w0, w1, w2, w3);
         }
     }
-    __syncthreads();
+    // the next round (and the store phase) reads what this one wrote: a wave's own 512 elements once the sub-blocks are that small
+    round_sync<(LOG_RB + LOG_C <= 9)>();
     if constexpr (RI + 1 < n_rounds(LOG_R))
-        limb_round<INV, LOG_R, LOG_C, SCALE, WLAST, RI + 1>(ra, tile, ltw, gin, log_stride, z, base0);
+        limb_round<INV, LOG_R, LOG_C, SCALE, LAST, RI + 1>(ra, tile, ltw, lu, raw, next_gin, log_stride, z, base0);
 }
 
 // One pass over 2^LOG_R x 2^LOG_C tiles (LOG_R + LOG_C = 12); LOG_C = 0 is the contiguous (last) pass.
 // grid = (tiles per polynomial >> tiles_log, polynomials, z), 512 threads, limb_shmem_bytes(LOG_R) of dynamic LDS.
-// WLAST: the conversions of the tile's last round multiply by ra.wlast (the 1/n of an inverse transform) instead of 1.
-template <bool INV, int LOG_R, int LOG_C, int SCALE, bool WLAST = false>
+// Workgroup barriers: one after the first round and one per tile; the later rounds and the store phase are wave-private.
+template <bool INV, int LOG_R, int LOG_C, int SCALE, int LAST = LAST_UNIT>
 __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPassArgs ra) {
     static_assert(LOG_R + LOG_C == TILE_LOG, "a tile is 4096 elements");
     P2HOT_DYN_SHARED(u64, tile);
@@ -301,60 +357,98 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
     const unsigned tid = threadIdx.x;
     constexpr unsigned C = 1u << LOG_C;
     W2 *ltw = reinterpret_cast<W2 *>(tile + ntt::TILE_WORDS_PADDED);
+    u64 *lu = reinterpret_cast<u64 *>(ltw + limb_tables_w2(LOG_R));
     for (unsigned e = tid; e < (unsigned)limb_tables_w2(LOG_R); e += NT) ltw[e] = ra.tw_all[e];
+    if constexpr (round_borrows(LOG_R, 0))
+        if (tid < (unsigned)UFAC_WORDS) lu[tid] = ra.ufac[tid];
     __syncthreads();
     const unsigned log_stride = LOG_C ? a.log_nblk - LOG_R : 0u;  // the contiguous pass is the last one: blocks of one tile
     const unsigned tiles_per_blk_log = log_stride - LOG_C;
     const size_t wg = (LOG_C && ra.xcd_remap) ? (((size_t)(blockIdx.x & 7u) << (ra.xcd_remap - 3)) | (blockIdx.x >> 3)) : blockIdx.x;
     const size_t z_begin = ra.zloop ? 0 : blockIdx.z, z_end = ra.zloop ? ra.zloop : blockIdx.z + 1;
+    const bool same_input = a.in_z_stride == 0;  // every z slice transforms the same polynomials (coset LDE): fetch them once
+    const unsigned e0 = (tid >> 6) * 512u + (tid & 63u);  // store phase: wave w moves tile elements [512 w, 512 w + 512)
+    const size_t n_tiles = (size_t)1 << ra.tiles_log;
+    auto tile_in = [&](size_t t, size_t z) {
+        const size_t tau = (wg << ra.tiles_log) + t;
+        const size_t blk = tau >> tiles_per_blk_log;
+        const size_t base0 = (tau & (((size_t)1 << tiles_per_blk_log) - 1)) << LOG_C;
+        return a.in + (size_t)blockIdx.y * a.in_poly_stride + z * a.in_z_stride + (blk << a.log_nblk) + base0;
+    };
+    u64 raw[8];
+    load_inputs<LOG_R, LOG_C>(tile_in(0, z_begin), log_stride, raw);
 #pragma unroll 1
-    for (size_t t = 0; t < ((size_t)1 << ra.tiles_log); ++t) {
+    for (size_t t = 0; t < n_tiles; ++t) {
         const size_t tau = (wg << ra.tiles_log) + t;
         const size_t blk = tau >> tiles_per_blk_log;
         const size_t base0 = (tau & (((size_t)1 << tiles_per_blk_log) - 1)) << LOG_C;
 #pragma unroll 1
         for (size_t z = z_begin; z < z_end; ++z) {
-            const u64 *in = a.in + (size_t)blockIdx.y * a.in_poly_stride + z * a.in_z_stride + (blk << a.log_nblk) + base0;
             u64 *out = a.out + (size_t)blockIdx.y * a.out_poly_stride + z * a.out_z_stride + (blk << a.log_nblk) + base0;
-            limb_round<INV, LOG_R, LOG_C, SCALE, WLAST, 0>(ra, tile, ltw, in, log_stride, z, base0);
-            // inter-pass twiddle w_{n'}^(base * k1) from the per-pass table (laid out like a block), then the coalesced store
+            // what to fetch while this tile is transformed: the same tile's next z slice (unless it is the same data), else the
+            // next tile's first slice
+            const u64 *next = nullptr;
+            if (z + 1 < z_end) {
+                if (!same_input) next = tile_in(t, z + 1);
+            } else if (t + 1 < n_tiles) {
+                next = tile_in(t + 1, z_begin);
+            }
+            limb_round<INV, LOG_R, LOG_C, SCALE, LAST, 0>(ra, tile, ltw, lu, raw, next, log_stride, z, base0);
             if constexpr (LOG_C == 0) {
 #pragma unroll
-                for (unsigned e = tid; e < (1u << TILE_LOG); e += NT) {
-                    const u64 v = tile[ntt::pad_idx(e)];
-                    out[e] = a.canon_out ? gl::canon(v) : v;
+                for (unsigned j = 0; j < 8; ++j) {
+                    const u64 v = tile[ntt::pad_idx(e0 + 64 * j)];
+                    out[e0 + 64 * j] = a.canon_out ? gl::canon(v) : v;
                 }
-            } else {  // strided pass: the host always supplies the inter-pass table (blocks of <= 2^24 elements)
-                const u32 off0 = (((tid >> LOG_C) << log_stride) + (tid & (C - 1))) * 8u;  // bytes, per thread; row steps are uniform
+            } else {
+                // inter-pass twiddle w_{n'}^(base * k1) from the per-pass table (laid out like a block; the host always supplies
+                // it: blocks of <= 2^24 elements), then the store in runs of C elements.
+                // element e = U + lane with U = 512 w + 64 j wave-uniform: row (U >> LOG_C) + (lane >> LOG_C), column (U + lane) mod C
+                const unsigned lane = tid & 63u;
+                const u32 off0 = (((lane >> LOG_C) << log_stride) + (lane & (C - 1))) * 8u;  // bytes, per lane
+                const unsigned U0 = wave_uniform(tid >> 6) * 512u;
 #pragma unroll 2
-                for (unsigned j = 0; j < (1u << TILE_LOG) / NT; ++j) {
-                    const size_t step = (size_t)(j * (NT >> LOG_C)) << log_stride;
+                for (unsigned j = 0; j < 8; ++j) {
+                    const unsigned U = U0 + 64 * j;
+                    const size_t step = ((size_t)(U >> LOG_C) << log_stride) + (U & (C - 1));
                     const u64 w = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ra.twid + base0 + step) + off0);
-                    u64 v = limb_mul(tile[ntt::pad_idx(tid + j * NT)], w);
+                    u64 v = limb_mul(tile[ntt::pad_idx(e0 + 64 * j)], w);
                     *reinterpret_cast<u64 *>(reinterpret_cast<char *>(out + step) + off0) = a.canon_out ? gl::canon(v) : v;
                 }
             }
-            __syncthreads();  // the tile is reused by the next coset / tile
+            __syncthreads();  // the next tile's first round overwrites what other waves may still be reading
         }
     }
 }
 
-// Fills one round's table in its LDS layout (see round_s_eff) and, for a round with more than 64 twiddle columns, its
-// wave-uniform factors: t[((k-1)*2 + h) << s_eff | b] = 4-form of w_{2^log_rb}^(b*k); u[a*8 + k] = w_{2^log_rb}^(64*a*k)
-__global__ void limb_twiddle_kernel(W2 *t, u64 *u, unsigned log_rb, unsigned p, ntt::RootTable roots) {
+// Fills one round's table in its LDS layout: t[((k-1)*2 + h) << s_log | lo] = 4-form of w_{2^log_rb}^(lo*k), s_log = log_rb - p
+__global__ void limb_twiddle_kernel(W2 *t, unsigned log_rb, unsigned p, ntt::RootTable roots) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned s_log = log_rb - p, s_eff = s_log > (unsigned)TW_S_MAX_LOG ? (unsigned)TW_S_MAX_LOG : s_log;
-    const size_t S = (size_t)1 << s_eff;
-    if (idx < (((size_t)1 << p) - 1) * S) {
-        const u32 b = (u32)(idx & (S - 1)), k = (u32)(idx >> s_eff) + 1;
-        const u64 w = ntt::root_pow(roots, (u32)(((u64)b * k) << (32 - log_rb)));
-        W2 *o = t + ((size_t)(k - 1) * 2 << s_eff) + b;
-        o[0] = W2{gl::canon(w), gl::canon(gl::mul(w, B1))};
-        o[S] = W2{gl::canon(gl::mul(w, B2)), gl::canon(gl::mul(w, B3))};
-    }
-    if (u && idx < ((size_t)8 << (s_log - s_eff))) {
-        const u32 a = (u32)(idx >> 3), k = (u32)(idx & 7);
-        u[idx] = gl::canon(ntt::root_pow(roots, (u32)((((u64)a << s_eff) * k) << (32 - log_rb))));
+    const unsigned s_log = log_rb - p;
+    const size_t S = (size_t)1 << s_log;
+    if (idx >= (((size_t)1 << p) - 1) * S) return;
+    const u32 lo = (u32)(idx & (S - 1)), k = (u32)(idx >> s_log) + 1;
+    const u64 w = ntt::root_pow(roots, (u32)(((u64)lo * k) << (32 - log_rb)));
+    W2 *o = t + ((size_t)(k - 1) * 2 << s_log) + lo;
+    o[0] = W2{gl::canon(w), gl::canon(gl::mul(w, B1))};
+    o[S] = W2{gl::canon(gl::mul(w, B2)), gl::canon(gl::mul(w, B3))};
+}
+// u[a * 8 + k] = w_{2^log_rb}^(a * k), a < 8, k < 8
+__global__ void limb_ufac_kernel(u64 *u, unsigned log_rb, ntt::RootTable roots) {
+    const unsigned idx = threadIdx.x;
+    if (idx >= (unsigned)UFAC_WORDS) return;
+    u[idx] = gl::canon(ntt::root_pow(roots, (u32)((u64)((idx >> 3) * (idx & 7)) << (32 - log_rb))));
+}
+// the coset scale of a strided first pass, tile-shaped: srow2[e] = s^((e >> log_c) << log_stride | (e & (C-1))), e < 4096, and
+// sbase[tile * 2 + h] = 4-form of s^(tile << log_c), tile < 2^(log_stride - log_c)   (one launch per coset)
+__global__ void limb_scale_kernel(u64 *srow2, W2 *sbase, unsigned log_c, unsigned log_stride, u64 s) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < ((size_t)1 << TILE_LOG))
+        srow2[idx] = gl::canon(gl::pow(s, ((idx >> log_c) << log_stride) + (idx & (((size_t)1 << log_c) - 1))));
+    if (idx < ((size_t)1 << (log_stride - log_c))) {
+        const u64 w = gl::pow(s, idx << log_c);
+        sbase[idx * 2] = W2{gl::canon(w), gl::canon(gl::mul(w, B1))};
+        sbase[idx * 2 + 1] = W2{gl::canon(gl::mul(w, B2)), gl::canon(gl::mul(w, B3))};
     }
 }
 

@@ -35,10 +35,10 @@ struct p2hot_ctx {
     bool use_limb = true;  // 4096-element tiles run the carry-free limb passes (nttl.hpp); P2HOT_NTT_LIMB=0 selects the round-2 kernels
     struct LimbTables {
         nttl::W2 *tw_all = nullptr;
-        u64 *ufac[4] = {nullptr, nullptr, nullptr, nullptr};
+        u64 *ufac = nullptr;
     };
     std::map<std::pair<int, unsigned>, LimbTables> limb_tw_cache;  // (inverse, log_r) -> the round tables of a 2^log_r-row tile
-    unsigned limb_tiles_log = 2;  // contiguous limb passes: a workgroup stages its tables once for 2^this tiles (P2HOT_LIMB_TILES_LOG)
+    unsigned limb_tiles_log = 4;  // contiguous limb passes: a workgroup stages its tables once for 2^this tiles (P2HOT_LIMB_TILES_LOG)
     // second stream: the VALU-bound leaf sponge of coset block b runs beside the wait-bound NTT of block b+1
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> fork_events;
@@ -355,8 +355,7 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
     for (auto &kv : ctx->twid_cache) (void)hipFree(kv.second);
     for (auto &kv : ctx->limb_tw_cache) {
         (void)hipFree(kv.second.tw_all);
-        for (u64 *u : kv.second.ufac)
-            if (u) (void)hipFree(u);
+        if (kv.second.ufac) (void)hipFree(kv.second.ufac);
     }
     for (auto &b : ctx->pool_free) (void)hipFree(b.first);
     for (auto &kv : ctx->pool_live) (void)hipFree(kv.first);
@@ -507,15 +506,15 @@ static int limb_tables(p2hot_ctx *ctx, bool inverse, unsigned log_r, p2hot_ctx::
         P2_HIP(ctx, hipMalloc((void **)&lt.tw_all, (total ? total : 1) * sizeof(nttl::W2)));
         for (int r = 0; r < nttl::n_rounds((int)log_r); ++r) {
             const unsigned p = (unsigned)nttl::round_bits((int)log_r, r), log_rb = (unsigned)nttl::round_log_rb((int)log_r, r);
-            if (log_rb <= p) continue;  // the last round of a tile has no table twiddles
-            const unsigned s_log = log_rb - p, s_eff = (unsigned)nttl::round_s_eff((int)log_r, r);
-            size_t count = ((((size_t)1 << p) - 1) << s_eff);
-            if (s_log > s_eff) {
-                P2_HIP(ctx, hipMalloc((void **)&lt.ufac[r], (size_t)8 * 8 << (s_log - s_eff)));
-                count = std::max(count, (size_t)8 << (s_log - s_eff));
-            }
+            if (nttl::round_table_w2((int)log_r, r) == 0) continue;  // no table twiddles (last round) or a borrowed table
+            const size_t count = ((((size_t)1 << p) - 1) << (log_rb - p));
             P2HOT_LAUNCH(nttl::limb_twiddle_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream,
-                         lt.tw_all + nttl::round_table_off((int)log_r, r), lt.ufac[r], log_rb, p, inverse ? ctx->inv : ctx->fwd);
+                         lt.tw_all + nttl::round_table_off((int)log_r, r), log_rb, p, inverse ? ctx->inv : ctx->fwd);
+            P2_LAUNCH_CHECK(ctx);
+        }
+        if (nttl::round_borrows((int)log_r, 0)) {
+            P2_HIP(ctx, hipMalloc((void **)&lt.ufac, (size_t)8 * nttl::UFAC_WORDS));
+            P2HOT_LAUNCH(nttl::limb_ufac_kernel, dim3(1), dim3(64), 0, ctx->stream, lt.ufac, log_r, inverse ? ctx->inv : ctx->fwd);
             P2_LAUNCH_CHECK(ctx);
         }
         it = ctx->limb_tw_cache.emplace(key, lt).first;
@@ -531,7 +530,7 @@ static bool limb_supported(unsigned log_r, unsigned log_c) {
 
 // launches one limb pass; `last_const` != 1 multiplies every output of this (last) pass by it (the 1/n of the inverse transform)
 static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse, const u64 *twid, unsigned xcd_remap,
-                            unsigned zloop, dim3 grid, u64 last_const) {
+                            unsigned zloop, dim3 grid, u64 last_const, const u64 *srow2, const nttl::W2 *sbase) {
     nttl::LimbPassArgs ra{};
     ra.a = a;
     ra.twid = twid;
@@ -540,7 +539,7 @@ static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse
     p2hot_ctx::LimbTables lt;
     P2_TRY(limb_tables(ctx, inverse, a.log_r, &lt));
     ra.tw_all = lt.tw_all;
-    for (int r = 0; r < 4; ++r) ra.ufac[r] = lt.ufac[r];
+    ra.ufac = lt.ufac;
     // a workgroup of the contiguous pass keeps its staged tables for several tiles
     ra.tiles_log = 0;
     if (a.log_c == 0)
@@ -556,20 +555,27 @@ static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse
     ra.wlast[3] = gl::canon(gl::mul(last_const, nttl::B3));
     const size_t shm = nttl::limb_shmem_bytes((int)a.log_r);
     if (wlast && !(a.log_r == 12 && a.scale_mode == ntt::SCALE_NONE)) P2_FAIL(ctx, P2HOT_EINVAL, "limb pass: a final constant needs the contiguous pass");
-#define P2_LIMB(INVF, LR, MODE) \
-    P2HOT_LAUNCH((nttl::ntt_limbpass_kernel<INVF, LR, 12 - LR, MODE>), grid, dim3(nttl::NT), shm, ctx->stream, ra)
-#define P2_LIMB_DIR(LR, MODE) do { if (inverse) P2_LIMB(true, LR, MODE); else P2_LIMB(false, LR, MODE); } while (0)
-#define P2_LIMB_MODE(LR)                                                              \
-    do {                                                                              \
-        if (a.scale_mode == ntt::SCALE_TABLE) P2_LIMB_DIR(LR, ntt::SCALE_TABLE);      \
-        else if (a.scale_mode == ntt::SCALE_CONST) P2_LIMB_DIR(LR, ntt::SCALE_CONST); \
-        else P2_LIMB_DIR(LR, ntt::SCALE_NONE);                                        \
+    ra.srow2 = srow2;
+    ra.sbase = sbase;
+    // the last conversion multiplies by 1 (LAST_UNIT), by a constant (LAST_CONST: the inverse transform's 1/n) or -- the
+    // strided first pass of a coset LDE -- by the tile's share of the coset scale (LAST_TILE)
+#define P2_LIMB(INVF, LR, MODE, LASTM) \
+    P2HOT_LAUNCH((nttl::ntt_limbpass_kernel<INVF, LR, 12 - LR, MODE, LASTM>), grid, dim3(nttl::NT), shm, ctx->stream, ra)
+#define P2_LIMB_DIR(LR, MODE, LASTM) do { if (inverse) P2_LIMB(true, LR, MODE, LASTM); else P2_LIMB(false, LR, MODE, LASTM); } while (0)
+#define P2_LIMB_MODE(LR)                                                                                          \
+    do {                                                                                                          \
+        if (a.scale_mode == ntt::SCALE_TABLE) {                                                                   \
+            if (LR == 12) P2_LIMB_DIR(LR, ntt::SCALE_TABLE, nttl::LAST_UNIT);                                     \
+            else P2_LIMB_DIR(LR, ntt::SCALE_TABLE, nttl::LAST_TILE);                                              \
+        } else if (a.scale_mode == ntt::SCALE_CONST) P2_LIMB_DIR(LR, ntt::SCALE_CONST, nttl::LAST_UNIT);          \
+        else P2_LIMB_DIR(LR, ntt::SCALE_NONE, nttl::LAST_UNIT);                                                   \
     } while (0)
+    if (a.scale_mode == ntt::SCALE_TABLE && a.log_r != 12 && (!srow2 || !sbase)) P2_FAIL(ctx, P2HOT_EINVAL, "limb pass: missing coset scale tables");
     if (wlast) {
         if (inverse)
-            P2HOT_LAUNCH((nttl::ntt_limbpass_kernel<true, 12, 0, ntt::SCALE_NONE, true>), grid, dim3(nttl::NT), shm, ctx->stream, ra);
+            P2HOT_LAUNCH((nttl::ntt_limbpass_kernel<true, 12, 0, ntt::SCALE_NONE, nttl::LAST_CONST>), grid, dim3(nttl::NT), shm, ctx->stream, ra);
         else
-            P2HOT_LAUNCH((nttl::ntt_limbpass_kernel<false, 12, 0, ntt::SCALE_NONE, true>), grid, dim3(nttl::NT), shm, ctx->stream, ra);
+            P2HOT_LAUNCH((nttl::ntt_limbpass_kernel<false, 12, 0, ntt::SCALE_NONE, nttl::LAST_CONST>), grid, dim3(nttl::NT), shm, ctx->stream, ra);
         return P2HOT_OK;
     }
     switch (a.log_r) {
@@ -594,7 +600,8 @@ static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse
 // `out`; later passes run in place on `out`.
 static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, size_t out_stride, size_t out_z_stride,
                    size_t batch, size_t zcount, unsigned log_n, const ntt::RootTable &roots, int scale_mode,
-                   u64 scale_const, const u64 *srow, const u64 *scol, bool canon_last) {
+                   u64 scale_const, const u64 *srow, const u64 *scol, bool canon_last, const u64 *srow2 = nullptr,
+                   const nttl::W2 *sbase = nullptr) {
     if (batch == 0 || zcount == 0) return P2HOT_OK;
     if (batch > 65535 || zcount > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "batch %zu / z %zu exceed the grid limit", batch, zcount);
     std::vector<Pass> passes = plan_passes(log_n, ctx->ntt_strided_bits);
@@ -667,7 +674,8 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
                 ra.zloop = (unsigned)zcount;
                 grid.z = 1;
             }
-            if (ctx->use_limb && maxp == 3 && limb_supported(a.log_r, a.log_c) && (a.log_c == 0 || ra.twid)) {
+            if (ctx->use_limb && maxp == 3 && limb_supported(a.log_r, a.log_c) && (a.log_c == 0 || ra.twid) &&
+                !(a.scale_mode == ntt::SCALE_TABLE && a.log_c && !srow2)) {
                 // the constant scale of an inverse transform moves from the first pass to the last conversion of the last
                 // pass (every output of a tile's last round is converted by a constant 4-form anyway: it becomes c * B^i)
                 u64 last_const = 1;
@@ -675,7 +683,7 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
                     ra.a.scale_mode = ntt::SCALE_NONE;
                     if (i + 1 == passes.size()) last_const = scale_const;
                 }
-                P2_TRY(launch_limb_pass(ctx, ra.a, inverse, ra.twid, ra.xcd_remap, ra.zloop, grid, last_const));
+                P2_TRY(launch_limb_pass(ctx, ra.a, inverse, ra.twid, ra.xcd_remap, ra.zloop, grid, last_const, srow2, sbase));
                 P2_LAUNCH_CHECK(ctx);
                 log_nblk -= a.log_r;
                 continue;
@@ -782,16 +790,21 @@ extern "C" int p2hot_coset_ifft_dev(p2hot_ctx *ctx, uint64_t *d_data, size_t bat
 // scale tables for row blocks [b0, b0 + zc): block b is coset j = bitrev_rb(b), s_b = shift * w_N^j;
 // srow[z][i] = s_b^(i * stride), scol[z][base] = s_b^base
 static int coset_scale_tables(p2hot_ctx *ctx, unsigned log_n, unsigned rate_bits, u64 shift, size_t b0, size_t zc,
-                              const u64 **srow, const u64 **scol) {
-    const unsigned log_r = first_pass_log_r(ctx, log_n);
+                              const u64 **srow, const u64 **scol, const u64 **srow2, const nttl::W2 **sbase) {
+    const Pass first = plan_passes(log_n, ctx->ntt_strided_bits)[0];
+    const unsigned log_r = first.log_r;
     auto key = std::make_tuple(log_n, rate_bits, shift, b0, zc, log_r);
     const size_t R = (size_t)1 << log_r, stride = (size_t)1 << (log_n - log_r);
+    // a strided limb first pass takes the scale as a tile-shaped (row, column-in-tile) table plus one 4-form per tile
+    const bool limb = first.log_c > 0 && limb_supported(first.log_r, first.log_c);
+    const size_t tiles = limb ? stride >> first.log_c : 0;
+    const size_t words = zc * (R + stride) + (limb ? zc * ((size_t)4096 + tiles * 4) : 0);
     auto it = ctx->scale_cache.find(key);
     u64 *t;
     if (it != ctx->scale_cache.end()) {
         t = it->second;
     } else {
-        P2_HIP(ctx, hipMalloc((void **)&t, zc * (R + stride) * 8));
+        P2_HIP(ctx, hipMalloc((void **)&t, words * 8));
         const u64 wN = gl::root_of_unity(log_n + rate_bits);
         for (size_t z = 0; z < zc; ++z) {
             u64 s = gl::mul(shift, gl::pow(wN, bitrev_sz(b0 + z, rate_bits)));
@@ -799,12 +812,20 @@ static int coset_scale_tables(p2hot_ctx *ctx, unsigned log_n, unsigned rate_bits
                          (u64)stride, (u64)0);
             P2HOT_LAUNCH(ntt::pow_table_kernel, dim3(cdiv(stride, 256)), dim3(256), 0, ctx->stream,
                          t + zc * R + z * stride, stride, s, (u64)1, (u64)0);
+            if (limb) {
+                u64 *s2 = t + zc * (R + stride) + z * 4096;
+                nttl::W2 *sb = reinterpret_cast<nttl::W2 *>(t + zc * (R + stride) + zc * 4096) + z * tiles * 2;
+                P2HOT_LAUNCH(nttl::limb_scale_kernel, dim3(cdiv(std::max((size_t)4096, tiles), 256)), dim3(256), 0, ctx->stream, s2,
+                             sb, first.log_c, log_n - log_r, s);
+            }
         }
         P2_LAUNCH_CHECK(ctx);
         ctx->scale_cache[key] = t;
     }
     *srow = t;
     *scol = t + zc * R;
+    *srow2 = limb ? t + zc * (R + stride) : nullptr;
+    *sbase = limb ? reinterpret_cast<const nttl::W2 *>(t + zc * (R + stride) + zc * 4096) : nullptr;
     return P2HOT_OK;
 }
 
@@ -820,10 +841,11 @@ extern "C" int p2hot_coset_lde_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, siz
     if (row_begin % n || row_count % n || row_begin + row_count > N)
         P2_FAIL(ctx, P2HOT_EINVAL, "coset_lde: rows [%zu,+%zu) are not whole coset blocks of %zu", row_begin, row_count, n);
     const size_t b0 = row_begin >> log_n, zc = row_count >> log_n;
-    const u64 *srow, *scol;
-    P2_TRY(coset_scale_tables(ctx, log_n, rate_bits, shift, b0, zc, &srow, &scol));
+    const u64 *srow, *scol, *srow2;
+    const nttl::W2 *sbase;
+    P2_TRY(coset_scale_tables(ctx, log_n, rate_bits, shift, b0, zc, &srow, &scol, &srow2, &sbase));
     return run_dif(ctx, d_coeffs, coeff_stride, d_lde, lde_stride, n, W, zc, log_n, ctx->fwd, ntt::SCALE_TABLE, 0, srow,
-                   scol, true);
+                   scol, true, srow2, sbase);
 }
 
 extern "C" int p2hot_transpose_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W,
