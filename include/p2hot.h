@@ -33,7 +33,7 @@ extern "C" {
 #define P2HOT_EINVAL 1       /* bad shape / argument (the reference would panic!, e.g. fft.rs:171, merkle_tree.rs:195) */
 #define P2HOT_ENOMEM 2       /* device allocation failed */
 #define P2HOT_EHIP 3         /* HIP runtime error */
-#define P2HOT_EUNSUPPORTED 4 /* valid in the reference but not on this path (e.g. blinding = true: salts come from OsRng, oracle.rs:136) */
+#define P2HOT_EUNSUPPORTED 4 /* valid in the reference but not on this path */
 
 #define P2HOT_P 0xFFFFFFFF00000001ULL
 #define P2HOT_COSET_SHIFT 14293326489335486720ULL /* F::coset_shift(), field/src/goldilocks_field.rs:80 */
@@ -254,6 +254,17 @@ typedef struct p2hot_cols p2hot_cols;
 int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
                  unsigned cap_height, int is_values, unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out,
                  uint64_t *digests_out, uint64_t *cap_out, p2hot_batch **handle_out);
+/* the same with blinding = true (fri/oracle.rs:123-137; standard_recursion_zk_config, circuit_data.rs:135-137): the
+ * reference appends SALT_SIZE = 4 random LDE-value vectors of length N to the leaves.  The random numbers stay the
+ * caller's (Rust draws them with F::rand_vec / OsRng and hands them over): salt_cols = n_salt host pointers to N words
+ * each, in the order F::rand_vec produced them (natural index, like the LDE values before transpose +
+ * reverse_index_bits, oracle.rs:97-98).  Leaves are W + n_salt wide: leaves_out [N][W + n_salt], p2hot_batch_rows and
+ * the opened rows of p2hot_prove_openings carry the salts (MerkleTree::get does; get_lde_values strips them, :146);
+ * p2hot_batch_width stays W (the polynomials), p2hot_batch_leaf_width is W + n_salt.  n_salt = 0 is p2hot_commit. */
+int p2hot_commit_salted(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
+                        unsigned cap_height, int is_values, unsigned flags, const uint64_t *const *salt_cols, size_t n_salt,
+                        uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out,
+                        p2hot_batch **handle_out);
 /* the same on a device-resident column set (the output of p2hot_partial_products / p2hot_quotient_chunks, or an upload).
  * CONSUMES `cols`, on success and on failure: its block becomes the batch's coefficients or kept values, or is released. */
 int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate_bits, unsigned cap_height, int is_values,
@@ -263,11 +274,12 @@ int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate_bits, unsi
  * frees only the handle.  d_coeffs [W][n] stride n, d_lde [W][N] stride N, d_digests the full tree's array. */
 int p2hot_batch_wrap_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, const uint64_t *d_lde, const uint64_t *d_digests, size_t W,
                          unsigned log_n, unsigned rate_bits, unsigned cap_height, p2hot_batch **out);
-size_t p2hot_batch_width(const p2hot_batch *batch);
+size_t p2hot_batch_width(const p2hot_batch *batch);      /* polynomials */
+size_t p2hot_batch_leaf_width(const p2hot_batch *batch); /* words per leaf: polynomials + salt columns */
 unsigned p2hot_batch_degree_log(const p2hot_batch *batch);
 /* `polynomials[first .. first + count)` (fri/oracle.rs:32), canonical: out [count][n] */
 int p2hot_batch_coeffs(p2hot_batch *batch, size_t first, size_t count, uint64_t *out);
-/* MerkleTree::get for m leaf indices (merkle_tree.rs:227): out [m][W] */
+/* MerkleTree::get for m leaf indices (merkle_tree.rs:227): out [m][p2hot_batch_leaf_width] */
 int p2hot_batch_rows(p2hot_batch *batch, const uint64_t *row_idx, size_t m, uint64_t *out);
 /* merkle_tree_prove (merkle_tree.rs:151-190) for m leaf indices from the batch's device-resident digests:
  * out [m][log2(N) - cap_height][4].  With it the caller may pass digests_out = NULL to p2hot_commit and never copy
@@ -308,7 +320,7 @@ typedef struct {
     unsigned rate_bits, cap_height, proof_of_work_bits, num_query_rounds;
     const unsigned *reduction_arity_bits;
     unsigned n_reduction_rounds;
-    int hiding;                     /* FriParams::hiding: must be 0 (blinded leaves are not on this path) */
+    int hiding;                     /* FriParams::hiding: carried for the caller's transcript (fri/mod.rs:148); the prover's FRI path does not depend on it */
     unsigned max_num_query_steps;   /* fri/prover.rs:90 */
     size_t final_poly_coeff_len;    /* fri/prover.rs:89 */
 } p2hot_fri_params;
@@ -319,7 +331,7 @@ typedef struct {
  *   pow_witness
  *   query_indices            [Q] x_index of every query round (optional, may be NULL; the verifier re-derives them)
  *   query_round_proofs[q].initial_trees_proof.evals_proofs[o] = (leaf, path):
- *     initial_leaves         [Q][sum_o W_o]   the opened row of every oracle, oracles in order
+ *     initial_leaves         [Q][sum_o leaf_width_o]   the opened row (salts included) of every oracle, oracles in order
  *     initial_paths          [Q][n_oracles][log2(N) - cap_height][4]
  *   query_round_proofs[q].steps[r] = (evals, merkle_proof):
  *     step_evals             [Q][sum_r 2 * 2^arity_bits[r]]       evals of round r = 2^arity_bits[r] extension elements

@@ -2,8 +2,8 @@
 //! PolynomialBatch LDE + Poseidon-Merkle commit pipeline, the FRI commit phase and `prove_openings`.
 //!
 //! This file is added to the crate as `plonky2/src/p2hot.rs` by `integration/plonky2_p2hot.patch`
-//! (feature `p2hot`).  With the feature on and `F = GoldilocksField`, `C::Hasher = PoseidonHash`, `D = 2`,
-//! `blinding = false`, the bodies of
+//! (feature `p2hot`).  With the feature on and `F = GoldilocksField`, `C::Hasher = PoseidonHash`, `D = 2`
+//! (blinded commitments included: the salts are drawn here with `F::rand_vec` and handed to the library), the bodies of
 //!   `PolynomialBatch::from_values` / `from_coeffs`   (fri/oracle.rs:57-112)
 //!   `PolynomialBatch::prove_openings`                 (fri/oracle.rs:176-237)
 //!   `fri_committed_trees`                             (fri/prover.rs:84-150)
@@ -20,12 +20,23 @@
 //!                   formats) works unchanged; "device": `leaves` stays empty, rows and Merkle paths are fetched from
 //!                   the GPU on demand (`MerkleTree::get` / `::prove`) -- 9 GB less PCIe traffic per wires commit.
 //!
-//! This image has no Rust toolchain: the file is checked against include/p2hot.h symbol by symbol
-//! (tests/test_integration_files.py) but has not been compiled here.
+//!   P2HOT_DISABLE   "1": every call takes the unchanged CPU body (the same switch as `set_enabled(false)`)
+//!
+//! Bit-exact harness: `#[cfg(test)] mod tests` at the end of this file runs every replaced body twice in one process --
+//! CPU (`set_enabled(false)`) and GPU -- on the same inputs and `assert_eq!`s polynomials, trees, FRI caps, final_poly
+//! and `proof.to_bytes()`:
+//!     P2HOT_LIB_DIR=/path/to/plonky2_amd cargo test --release --features p2hot p2hot:: -- --test-threads=1
+//! `examples/p2hot_dump_goldens.rs` (added by the same patch) writes the CPU prover's commitments of the synthetic
+//! inputs in the schema of tests/golden/commit_caps.json, so the oracle of the GPU repository can be pinned against
+//! the real reference on any box with cargo (no GPU needed for that step).
+//!
+//! The build image of the GPU repository has no Rust toolchain: this file is checked against include/p2hot.h symbol by
+//! symbol (tests/test_integration_files.py) but has not been compiled there.
 #![allow(non_camel_case_types, clippy::missing_safety_doc, clippy::too_many_arguments)]
 
 use core::any::type_name;
 use core::ffi::{c_char, c_int, c_uint, c_void};
+use core::sync::atomic::{AtomicBool, Ordering};
 use std::collections::HashMap;
 use std::sync::{Mutex, OnceLock};
 
@@ -33,7 +44,7 @@ use crate::field::extension::{Extendable, FieldExtension};
 use crate::field::goldilocks_field::GoldilocksField;
 use crate::field::polynomial::{PolynomialCoeffs, PolynomialValues};
 use crate::field::types::{Field, PrimeField64};
-use crate::fri::oracle::PolynomialBatch;
+use crate::fri::oracle::{PolynomialBatch, SALT_SIZE};
 use crate::fri::proof::{FriInitialTreeProof, FriProof, FriQueryRound, FriQueryStep};
 use crate::fri::structure::FriInstanceInfo;
 use crate::fri::FriParams;
@@ -223,6 +234,11 @@ extern "C" {
         ctx: *mut P2hotCtx, cols: *const *const u64, W: usize, log_n: c_uint, rate_bits: c_uint, cap_height: c_uint, is_values: c_int,
         flags: c_uint, coeffs_out: *mut u64, leaves_out: *mut u64, digests_out: *mut u64, cap_out: *mut u64, handle_out: *mut *mut P2hotBatch,
     ) -> c_int;
+    pub fn p2hot_commit_salted(
+        ctx: *mut P2hotCtx, cols: *const *const u64, W: usize, log_n: c_uint, rate_bits: c_uint, cap_height: c_uint, is_values: c_int,
+        flags: c_uint, salt_cols: *const *const u64, n_salt: usize, coeffs_out: *mut u64, leaves_out: *mut u64, digests_out: *mut u64,
+        cap_out: *mut u64, handle_out: *mut *mut P2hotBatch,
+    ) -> c_int;
     pub fn p2hot_commit_cols(
         ctx: *mut P2hotCtx, cols: *mut P2hotCols, rate_bits: c_uint, cap_height: c_uint, is_values: c_int, flags: c_uint, coeffs_out: *mut u64,
         leaves_out: *mut u64, digests_out: *mut u64, cap_out: *mut u64, handle_out: *mut *mut P2hotBatch,
@@ -232,6 +248,7 @@ extern "C" {
         cap_height: c_uint, out: *mut *mut P2hotBatch,
     ) -> c_int;
     pub fn p2hot_batch_width(batch: *const P2hotBatch) -> usize;
+    pub fn p2hot_batch_leaf_width(batch: *const P2hotBatch) -> usize;
     pub fn p2hot_batch_degree_log(batch: *const P2hotBatch) -> c_uint;
     pub fn p2hot_batch_coeffs(batch: *mut P2hotBatch, first: usize, count: usize, out: *mut u64) -> c_int;
     pub fn p2hot_batch_rows(batch: *mut P2hotBatch, row_idx: *const u64, m: usize, out: *mut u64) -> c_int;
@@ -357,10 +374,24 @@ fn leaves_on_device() -> bool {
     matches!(std::env::var("P2HOT_LEAVES").as_deref(), Ok("device"))
 }
 
+static ENABLED: AtomicBool = AtomicBool::new(true);
+
+/// `false` sends every call down the unchanged CPU bodies (the bit-exact harness proves the same circuit both ways in
+/// one process); `P2HOT_DISABLE=1` does the same from the environment.
+pub fn set_enabled(on: bool) {
+    ENABLED.store(on, Ordering::SeqCst);
+}
+
+pub fn enabled() -> bool {
+    static ENV_OFF: OnceLock<bool> = OnceLock::new();
+    ENABLED.load(Ordering::SeqCst) && !*ENV_OFF.get_or_init(|| matches!(std::env::var("P2HOT_DISABLE").as_deref(), Ok("1")))
+}
+
 /// Does the GPU path apply to this instantiation?  (type / size checks instead of a plugin trait;
 /// `type_name` rather than `TypeId` because the config's associated types carry no `'static` bound.)
-pub fn applies<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(blinding: bool) -> bool {
-    !blinding
+/// `blinding` no longer matters: a blinded commitment takes the same path with its salt columns (`commit`).
+pub fn applies<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(_blinding: bool) -> bool {
+    enabled()
         && D == 2
         && type_name::<F>() == type_name::<GoldilocksField>()
         && type_name::<C::Hasher>() == type_name::<PoseidonHash>()
@@ -464,37 +495,61 @@ pub fn commit<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D:
     rate_bits: usize,
     cap_height: usize,
     is_values: bool,
+    blinding: bool,
+) -> PolynomialBatch<F, C, D> {
+    // "If blinding, salt with two random elements to each leaf vector" (oracle.rs:122-123, :133-137): the random numbers
+    // are drawn HERE, by the reference's own generator, in the reference's order; the library only places and hashes them
+    let salts: Vec<Vec<F>> = if blinding {
+        let big_n = cols[0].len() << rate_bits;
+        (0..SALT_SIZE).map(|_| F::rand_vec(big_n)).collect()
+    } else {
+        Vec::new()
+    };
+    commit_with_salts::<F, C, D>(cols, rate_bits, cap_height, is_values, &salts)
+}
+
+/// `commit` with the salt vectors given (each of length N = n << rate_bits, in LDE-value order: oracle.rs:133-137 appends
+/// them to the LDE vectors BEFORE transpose + reverse_index_bits); empty = an unblinded commitment.
+pub(crate) fn commit_with_salts<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(
+    cols: &[&[F]],
+    rate_bits: usize,
+    cap_height: usize,
+    is_values: bool,
+    salts: &[Vec<F>],
 ) -> PolynomialBatch<F, C, D> {
     let w = cols.len();
+    let lw = w + salts.len(); // words per leaf
     let n = cols[0].len(); // polynomials[0].len(), oracle.rs:90
     let log_n = log2_strict(n);
     assert!(cols.iter().all(|c| c.len() == n));
     let big_n = n << rate_bits;
     let num_digests = 2 * (big_n - (1usize << cap_height));
     let ptrs: Vec<*const u64> = cols.iter().map(|c| words(c)).collect();
+    assert!(salts.iter().all(|v| v.len() == big_n));
+    let salt_ptrs: Vec<*const u64> = salts.iter().map(|v| words(v)).collect();
     let on_device = leaves_on_device();
     let mut handle: *mut P2hotBatch = core::ptr::null_mut();
     // `polynomials` always comes back (W * n words): the quotient evaluation and the openings read it on the host
     let mut coeffs = Out::<F>::new(w * n, true);
     let mut cap = Out::<<C::Hasher as Hasher<F>>::Hash>::new(1 << cap_height, true);
     let mut digests = Out::<<C::Hasher as Hasher<F>>::Hash>::new(num_digests, !on_device);
-    let mut flat_leaves = Out::<F>::new(big_n * w, !on_device);
+    let mut flat_leaves = Out::<F>::new(big_n * lw, !on_device);
     with_ctx(|ctx| {
         let rc = unsafe {
-            p2hot_commit(
-                ctx, ptrs.as_ptr(), w, log_n as c_uint, rate_bits as c_uint, cap_height as c_uint, is_values as c_int, 0, coeffs.ptr(),
-                flat_leaves.ptr(), digests.ptr(), cap.ptr(), &mut handle,
+            p2hot_commit_salted(
+                ctx, ptrs.as_ptr(), w, log_n as c_uint, rate_bits as c_uint, cap_height as c_uint, is_values as c_int, 0,
+                salt_ptrs.as_ptr(), salt_ptrs.len(), coeffs.ptr(), flat_leaves.ptr(), digests.ptr(), cap.ptr(), &mut handle,
             )
         };
-        check(ctx, rc, "p2hot_commit");
+        check(ctx, rc, "p2hot_commit_salted");
     });
     let (coeffs, cap, digests, flat_leaves) = unsafe { (coeffs.finish(), cap.finish(), digests.finish(), flat_leaves.finish()) };
     let polynomials = coeffs.chunks_exact(n.max(1)).map(|c| PolynomialCoeffs::new(c.to_vec())).collect();
     // merkle_tree.leaves: N rows of W (oracle.rs:97-98); empty when the matrix stays on the GPU
-    let leaves: Vec<Vec<F>> = if on_device { Vec::new() } else { flat_leaves.chunks_exact(w.max(1)).map(|r| r.to_vec()).collect() };
+    let leaves: Vec<Vec<F>> = if on_device { Vec::new() } else { flat_leaves.chunks_exact(lw.max(1)).map(|r| r.to_vec()).collect() };
     let device = std::sync::Arc::new(DeviceTree {
         batch: handle,
-        width: w,
+        width: lw, // MerkleTree::get returns the whole leaf; get_lde_values strips the salt (oracle.rs:146)
         num_layers: log_n + rate_bits - cap_height,
         rows: Mutex::new(HashMap::new()),
     });
@@ -503,7 +558,7 @@ pub fn commit<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D:
         merkle_tree: MerkleTree { leaves, digests, cap: MerkleCap(cap), device: Some(device) },
         degree_log: log_n,
         rate_bits,
-        blinding: false,
+        blinding: !salts.is_empty(),
     }
 }
 
@@ -635,7 +690,9 @@ pub fn prove_openings<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, 
     final_poly_coeff_len: Option<usize>,
     max_num_query_steps: Option<usize>,
 ) -> Option<FriProof<F, C::Hasher, D>> {
-    if fri_params.hiding || !applies::<F, C, D>(false) {
+    // FriParams::hiding does not reach the prover's FRI path (it is observed into the transcript by the caller and tells the
+    // VERIFIER to strip the salts, fri/verifier.rs:149-151): blinded oracles simply have wider leaves
+    if !applies::<F, C, D>(false) {
         return None;
     }
     let handles: Option<Vec<*const P2hotBatch>> = oracles.iter().map(|o| o.merkle_tree.device.as_ref().map(|d| d.raw())).collect();
@@ -694,7 +751,8 @@ pub fn prove_openings<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, 
     });
     let degree_bits = oracles[0].degree_log;
     let layers0 = degree_bits + fri_params.config.rate_bits - fri_params.config.cap_height;
-    let widths: Vec<usize> = oracles.iter().map(|o| o.polynomials.len()).collect();
+    // the opened leaf of a blinded oracle carries its SALT_SIZE salt words behind the polynomial values (fri/proof.rs:45-52)
+    let widths: Vec<usize> = oracles.iter().map(|o| o.polynomials.len() + if o.blinding { SALT_SIZE } else { 0 }).collect();
     let wsum: usize = widths.iter().sum();
     let mut ev_w = Vec::new();
     let mut pa_w = Vec::new();
@@ -763,3 +821,246 @@ impl<F: RichField> PartialEq for DeviceTree<F> {
     }
 }
 impl<F: RichField> Eq for DeviceTree<F> {}
+
+// ------------------------------------------------------------------------------------------------
+// Bit-exact harness (SURVEY 8c "Parity status" / "Bit-exact vs CPU prover protocol"): every replaced body, CPU vs GPU, in one
+// process on the same inputs.  Needs an MI355X and libp2hot.so:
+//     P2HOT_LIB_DIR=/path/to/plonky2_amd cargo test --release --features p2hot p2hot:: -- --test-threads=1
+// (`--test-threads=1`: `set_enabled` is process-wide.)  The 2^16 / 2^20 circuits are `#[ignore]`d: add `--ignored`.
+// ------------------------------------------------------------------------------------------------
+#[cfg(test)]
+mod tests {
+    use anyhow::Result;
+
+    use super::*;
+    use crate::field::types::Sample;
+    use crate::fri::reduction_strategies::FriReductionStrategy;
+    use crate::fri::FriConfig;
+    use crate::gates::noop::NoopGate;
+    use crate::iop::witness::{PartialWitness, WitnessWrite};
+    use crate::plonk::circuit_builder::CircuitBuilder;
+    use crate::plonk::circuit_data::{CircuitConfig, CircuitData, CommonCircuitData, VerifierOnlyCircuitData};
+    use crate::plonk::config::PoseidonGoldilocksConfig;
+    use crate::plonk::proof::ProofWithPublicInputs;
+    use crate::plonk::prover::prove;
+    use crate::util::serialization::Write;
+    use crate::util::timing::TimingTree;
+    use crate::util::{reverse_index_bits_in_place, transpose};
+
+    const D: usize = 2;
+    type C = PoseidonGoldilocksConfig;
+    type F = <C as GenericConfig<D>>::F;
+    type H = <C as GenericConfig<D>>::Hasher;
+    type Batch = PolynomialBatch<F, C, D>;
+
+    /// the unchanged reference bodies
+    fn on_cpu<R>(f: impl FnOnce() -> R) -> R {
+        set_enabled(false);
+        let r = f();
+        set_enabled(true);
+        r
+    }
+
+    fn assert_same_batch(cpu: &Batch, gpu: &Batch) {
+        assert_eq!(cpu.polynomials, gpu.polynomials, "polynomials (oracle.rs:32)");
+        assert_eq!(cpu.merkle_tree.cap, gpu.merkle_tree.cap, "merkle_tree.cap");
+        assert_eq!(cpu.merkle_tree.digests, gpu.merkle_tree.digests, "merkle_tree.digests (reference layout, merkle_tree.rs:50-57)");
+        assert_eq!(cpu.merkle_tree.leaves, gpu.merkle_tree.leaves, "merkle_tree.leaves (LDE values, transposed, bit-reversed)");
+        assert_eq!((cpu.degree_log, cpu.rate_bits, cpu.blinding), (gpu.degree_log, gpu.rate_bits, gpu.blinding));
+        assert_eq!(cpu, gpu); // the derived PartialEq (oracle.rs:29) over all of the above
+        // 8f-4 wire formats: the reference serializer over the shim-built structs (util/serialization/mod.rs:1417-1431, :1744-1763)
+        let (mut a, mut b) = (Vec::<u8>::new(), Vec::<u8>::new());
+        a.write_polynomial_batch(cpu).unwrap();
+        b.write_polynomial_batch(gpu).unwrap();
+        assert_eq!(a, b, "write_polynomial_batch bytes");
+        let (mut a, mut b) = (Vec::<u8>::new(), Vec::<u8>::new());
+        a.write_merkle_tree(&cpu.merkle_tree).unwrap();
+        b.write_merkle_tree(&gpu.merkle_tree).unwrap();
+        assert_eq!(a, b, "write_merkle_tree bytes");
+    }
+
+    /// from_values and from_coeffs at the widths of a proof's four commitments (constants_sigmas ~84, wires 135, Zs 20, quotient 16)
+    #[test]
+    fn commit_matches_the_cpu_prover() {
+        assert!(leaves_on_device() == false, "run the harness with P2HOT_LEAVES unset: it compares merkle_tree.leaves");
+        for &(w, log_n, rate_bits, cap_height) in &[(3usize, 5usize, 3usize, 4usize), (135, 12, 3, 4), (84, 12, 3, 4), (20, 12, 3, 4), (16, 13, 3, 4), (2, 10, 1, 0), (1, 0, 3, 0)] {
+            let values: Vec<PolynomialValues<F>> = (0..w).map(|_| PolynomialValues::new(F::rand_vec(1 << log_n))).collect();
+            let cpu = on_cpu(|| Batch::from_values(values.clone(), rate_bits, false, cap_height, &mut TimingTree::default(), None));
+            let gpu = Batch::from_values(values.clone(), rate_bits, false, cap_height, &mut TimingTree::default(), None);
+            assert!(gpu.merkle_tree.device.is_some(), "the p2hot body did not run");
+            assert_same_batch(&cpu, &gpu);
+            let polys: Vec<PolynomialCoeffs<F>> = values.into_iter().map(|v| PolynomialCoeffs::new(v.values)).collect();
+            let cpu = on_cpu(|| Batch::from_coeffs(polys.clone(), rate_bits, false, cap_height, &mut TimingTree::default(), None));
+            let gpu = Batch::from_coeffs(polys, rate_bits, false, cap_height, &mut TimingTree::default(), None);
+            assert_same_batch(&cpu, &gpu);
+            // MerkleTree::get / ::prove through the device handle
+            let dev = gpu.merkle_tree.device.as_ref().unwrap();
+            for i in [0usize, 1, (1 << (log_n + rate_bits)) - 1] {
+                assert_eq!(dev.row(i), cpu.merkle_tree.get(i));
+                assert_eq!(dev.path::<H>(i), cpu.merkle_tree.prove(i).siblings);
+            }
+        }
+    }
+
+    /// blinding = true with the SAME salts on both sides: the CPU tree is assembled exactly as from_coeffs does it
+    /// (lde_values + salts -> transpose -> reverse_index_bits -> MerkleTree::new, oracle.rs:91-103, :114-139)
+    #[test]
+    fn salted_commit_matches_the_cpu_prover() {
+        for &(w, log_n, rate_bits, cap_height) in &[(5usize, 6usize, 3usize, 4usize), (135, 10, 3, 4), (2, 4, 1, 1)] {
+            let polys: Vec<PolynomialCoeffs<F>> = (0..w).map(|_| PolynomialCoeffs::new(F::rand_vec(1 << log_n))).collect();
+            let salts: Vec<Vec<F>> = (0..SALT_SIZE).map(|_| F::rand_vec(1 << (log_n + rate_bits))).collect();
+            let mut lde_values = on_cpu(|| Batch::lde_values(&polys, rate_bits, false, None));
+            lde_values.extend(salts.iter().cloned());
+            let mut leaves = transpose(&lde_values);
+            reverse_index_bits_in_place(&mut leaves);
+            let cpu_tree = MerkleTree::<F, H>::new(leaves, cap_height);
+            let gpu = commit_with_salts::<F, C, D>(&coeff_slices(&polys), rate_bits, cap_height, false, &salts);
+            assert!(gpu.blinding);
+            assert_eq!(gpu.polynomials, polys);
+            assert_eq!(cpu_tree.cap, gpu.merkle_tree.cap);
+            assert_eq!(cpu_tree.digests, gpu.merkle_tree.digests);
+            assert_eq!(cpu_tree.leaves, gpu.merkle_tree.leaves);
+            // get_lde_values strips the salt (oracle.rs:142-147)
+            assert_eq!(gpu.get_lde_values(3, 1).len(), w);
+        }
+    }
+
+    /// fri_committed_trees (fri/prover.rs:84-150), the starky entry: trees, final_poly and the transcript afterwards
+    #[test]
+    fn fri_commit_phase_matches_the_cpu_prover() {
+        for &(log_n, rate_bits, cap_height, ref arity) in &[(8usize, 3usize, 4usize, vec![4usize]), (10, 1, 2, vec![1, 2, 1]), (6, 3, 0, vec![])] {
+            let n = 1usize << log_n;
+            let mut coeffs = <F as Extendable<D>>::Extension::rand_vec(n);
+            coeffs.resize(n << rate_bits, <F as Extendable<D>>::Extension::ZERO); // "only the first 1/rate coefficients are non-zero"
+            let coeffs = PolynomialCoeffs::new(coeffs);
+            let fri_params = FriParams {
+                config: FriConfig { rate_bits, cap_height, proof_of_work_bits: 4, reduction_strategy: FriReductionStrategy::Fixed(arity.clone()), num_query_rounds: 5 },
+                hiding: false,
+                degree_bits: log_n,
+                reduction_arity_bits: arity.clone(),
+            };
+            let seed = F::rand_vec(7);
+            let run = || {
+                let mut challenger = Challenger::<F, H>::new();
+                challenger.observe_elements(&seed);
+                let out = crate::fri::prover::p2hot_fri_committed_trees_for_tests::<F, C, D>(&coeffs, &mut challenger, &fri_params);
+                (out, challenger.get_n_challenges(4))
+            };
+            let ((cpu_trees, cpu_final), cpu_next) = on_cpu(run);
+            let ((gpu_trees, gpu_final), gpu_next) = run();
+            assert_eq!(cpu_trees, gpu_trees, "round trees (leaves, digests, caps)");
+            assert_eq!(cpu_final, gpu_final, "final_poly");
+            assert_eq!(cpu_next, gpu_next, "the transcript after the commit phase");
+        }
+    }
+
+    fn dummy_circuit(config: &CircuitConfig, log2_size: usize) -> CircuitData<F, C, D> {
+        // examples/bench_recursion.rs:78-105 (dummy_proof)
+        let num_dummy_gates = match log2_size {
+            0 | 1 => 0,
+            2 => 1,
+            n => (1 << (n - 1)) + 1,
+        };
+        let mut builder = CircuitBuilder::<F, D>::new(config.clone());
+        for _ in 0..num_dummy_gates {
+            builder.add_gate(NoopGate, vec![]);
+        }
+        builder.build::<C>()
+    }
+
+    type ProofTuple = (ProofWithPublicInputs<F, C, D>, VerifierOnlyCircuitData<C, D>, CommonCircuitData<F, D>);
+
+    /// builds the circuit and proves it on both paths; everything the prover commits to and the proof bytes must agree
+    /// (the CPU grind takes the smallest witness under the `p2hot` feature: fri/prover.rs, `find_first`)
+    fn prove_both_ways(build: &dyn Fn() -> (CircuitData<F, C, D>, PartialWitness<F>)) -> Result<ProofTuple> {
+        let (cpu_data, cpu_pw) = on_cpu(build);
+        let (gpu_data, gpu_pw) = build();
+        // CircuitBuilder::build commits constants + sigmas (circuit_builder.rs:1182-1191)
+        assert_eq!(cpu_data.verifier_only.constants_sigmas_cap, gpu_data.verifier_only.constants_sigmas_cap);
+        assert_eq!(cpu_data.verifier_only.circuit_digest, gpu_data.verifier_only.circuit_digest);
+        assert_same_batch(&cpu_data.prover_only.constants_sigmas_commitment, &gpu_data.prover_only.constants_sigmas_commitment);
+        let cpu_proof = on_cpu(|| prove::<F, C, D>(&cpu_data.prover_only, &cpu_data.common, cpu_pw, &mut TimingTree::default()))?;
+        let gpu_proof = prove::<F, C, D>(&gpu_data.prover_only, &gpu_data.common, gpu_pw, &mut TimingTree::default())?;
+        let (c, g) = (&cpu_proof.proof, &gpu_proof.proof);
+        assert_eq!(c.wires_cap, g.wires_cap, "wires_cap");
+        assert_eq!(c.plonk_zs_partial_products_cap, g.plonk_zs_partial_products_cap, "plonk_zs_partial_products_cap");
+        assert_eq!(c.quotient_polys_cap, g.quotient_polys_cap, "quotient_polys_cap");
+        assert_eq!(c.openings, g.openings, "OpeningSet");
+        assert_eq!(c.opening_proof.commit_phase_merkle_caps, g.opening_proof.commit_phase_merkle_caps, "FRI commit_phase_merkle_caps");
+        assert_eq!(c.opening_proof.final_poly, g.opening_proof.final_poly, "FRI final_poly");
+        assert_eq!(c.opening_proof.pow_witness, g.opening_proof.pow_witness, "pow_witness (smallest on both sides)");
+        assert_eq!(c.opening_proof.query_round_proofs, g.opening_proof.query_round_proofs, "FRI query rounds");
+        assert_eq!(cpu_proof.to_bytes(), gpu_proof.to_bytes(), "proof.to_bytes()");
+        gpu_data.verify(gpu_proof.clone())?;
+        cpu_data.verify(gpu_proof.clone())?;
+        Ok((gpu_proof, gpu_data.verifier_only, gpu_data.common))
+    }
+
+    fn dummy_both_ways(log2_size: usize) -> Result<ProofTuple> {
+        let config = CircuitConfig::standard_recursion_config();
+        prove_both_ways(&|| (dummy_circuit(&config, log2_size), PartialWitness::new()))
+    }
+
+    /// one recursion layer over `inner` (examples/bench_recursion.rs:200-245), proved both ways
+    fn recursive_both_ways(inner: &ProofTuple, min_degree_bits: Option<usize>) -> Result<ProofTuple> {
+        let config = CircuitConfig::standard_recursion_config();
+        let (inner_proof, inner_vd, inner_cd) = inner;
+        prove_both_ways(&|| {
+            let mut builder = CircuitBuilder::<F, D>::new(config.clone());
+            let pt = builder.add_virtual_proof_with_pis(inner_cd);
+            let inner_data = builder.add_virtual_verifier_data(inner_cd.config.fri_config.cap_height);
+            builder.verify_proof::<C>(&pt, &inner_data, inner_cd);
+            if let Some(min_degree_bits) = min_degree_bits {
+                let min_gates = (1 << (min_degree_bits - 1)) + 1;
+                for _ in builder.num_gates()..min_gates {
+                    builder.add_gate(NoopGate, vec![]);
+                }
+            }
+            let data = builder.build::<C>();
+            let mut pw = PartialWitness::new();
+            pw.set_proof_with_pis_target(&pt, inner_proof).unwrap();
+            pw.set_verifier_data_target(&inner_data, inner_vd).unwrap();
+            (data, pw)
+        })
+    }
+
+    #[test]
+    fn prove_2_12_matches_the_cpu_prover() -> Result<()> {
+        dummy_both_ways(12).map(|_| ())
+    }
+
+    /// the 3-proof chain of bench_recursion (:317-345) at its recursion-threshold size: inner -> middle -> outer
+    #[test]
+    fn recursion_chain_matches_the_cpu_prover() -> Result<()> {
+        let inner = dummy_both_ways(12)?;
+        let middle = recursive_both_ways(&inner, None)?;
+        recursive_both_ways(&middle, None).map(|_| ())
+    }
+
+    #[test]
+    #[ignore = "BASELINE C2: a 2^16-gate circuit (about a minute on the CPU side)"]
+    fn prove_2_16_matches_the_cpu_prover() -> Result<()> {
+        dummy_both_ways(16).map(|_| ())
+    }
+
+    #[test]
+    #[ignore = "BASELINE C3: bench_recursion --size 20 (2^20 gates; the CPU side takes minutes and ~40 GB)"]
+    fn recursion_chain_2_20_matches_the_cpu_prover() -> Result<()> {
+        let inner = dummy_both_ways(20)?;
+        let middle = recursive_both_ways(&inner, None)?;
+        recursive_both_ways(&middle, None).map(|_| ())
+    }
+
+    /// zero-knowledge configuration: the salts (and the blinding gates' witness values) are fresh randomness on each run,
+    /// so the check is the reference's own acceptance test -- the GPU-built proof verifies -- plus the shapes
+    #[test]
+    fn zk_config_proof_verifies() -> Result<()> {
+        let config = CircuitConfig::standard_recursion_zk_config();
+        let data = dummy_circuit(&config, 12);
+        assert!(!data.prover_only.constants_sigmas_commitment.blinding); // PlonkOracle::CONSTANTS_SIGMAS
+        let proof = prove::<F, C, D>(&data.prover_only, &data.common, PartialWitness::new(), &mut TimingTree::default())?;
+        let q = &proof.proof.opening_proof.query_round_proofs[0].initial_trees_proof.evals_proofs;
+        assert_eq!(q[1].0.len(), config.num_wires + SALT_SIZE, "the opened wires leaf carries its salt");
+        data.verify(proof)
+    }
+}

@@ -205,6 +205,20 @@ def commit(cols, rate_bits, cap_height, is_values=True, timed=None):
     return dict(coeffs=coeffs, leaves=leaves, digests=digests, cap=cap)
 
 
+def commit_salted(cols, salts, rate_bits, cap_height, is_values=True):
+    """blinding = true (oracle.rs:114-139): the SALT_SIZE salt vectors (length N, in the order F::rand_vec produced them) are
+    appended to the LDE-value vectors BEFORE transpose + reverse_index_bits (:97-98), so leaf L ends in salt_j[reverse_bits(L)];
+    the tree is built over the widened leaves.  Returns dict(coeffs, leaves [N][W + S], digests, cap)."""
+    r = commit(cols, rate_bits, cap_height, is_values)
+    salts = arr(salts) % np.uint64(P)
+    N = r["leaves"].shape[0]
+    bits = N.bit_length() - 1
+    rev = np.array([int(format(i, "0%db" % bits)[::-1], 2) if bits else 0 for i in range(N)], dtype=np.int64)
+    leaves = np.ascontiguousarray(np.concatenate([r["leaves"], salts[:, rev].T], axis=1))
+    digests, cap = merkle_tree(leaves, cap_height)
+    return dict(coeffs=r["coeffs"], leaves=leaves, digests=digests, cap=cap)
+
+
 class ChallengerState(C.Structure):
     _fields_ = [("state", C.c_uint64 * 12), ("inb", C.c_uint64 * 8), ("n_in", C.c_uint32),
                 ("outb", C.c_uint64 * 8), ("n_out", C.c_uint32)]

@@ -92,9 +92,11 @@ SIGNATURES = {
     "p2hot_partial_products_dev": (i, [vp, vp, sz, vp, sz, vp, u, u, u, vp, vp, u, vp, sz]),
     "p2hot_fri_pow": (i, [vp, vp, u, C.POINTER(u64)]),
     "p2hot_commit": (i, [vp, C.POINTER(vp), sz, u, u, u, i, u, vp, vp, vp, vp, C.POINTER(vp)]),
+    "p2hot_commit_salted": (i, [vp, C.POINTER(vp), sz, u, u, u, i, u, C.POINTER(vp), sz, vp, vp, vp, vp, C.POINTER(vp)]),
     "p2hot_commit_cols": (i, [vp, vp, u, u, i, u, vp, vp, vp, vp, C.POINTER(vp)]),
     "p2hot_batch_wrap_dev": (i, [vp, vp, vp, vp, sz, u, u, u, C.POINTER(vp)]),
     "p2hot_batch_width": (sz, [vp]),
+    "p2hot_batch_leaf_width": (sz, [vp]),
     "p2hot_batch_degree_log": (u, [vp]),
     "p2hot_batch_coeffs": (i, [vp, sz, sz, vp]),
     "p2hot_batch_rows": (i, [vp, vp, sz, vp]),

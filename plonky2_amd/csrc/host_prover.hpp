@@ -86,8 +86,9 @@ extern "C" void p2hot_cols_free(p2hot_cols *c) {
 
 // ------------------------------------------------------------------ from_values / from_coeffs
 static p2hot_batch *make_batch(p2hot_ctx *ctx, PoolBuf &lde, PoolBuf &dig, PoolBuf &coef, PoolBuf *vals, size_t W, unsigned log_n,
-                               unsigned rate_bits, unsigned cap_height) {
+                               unsigned rate_bits, unsigned cap_height, size_t S = 0) {
     p2hot_batch *b = new p2hot_batch{ctx, lde.u(), W, ((size_t)1 << log_n) << rate_bits, dig.u(), log_n + rate_bits, cap_height};
+    b->S = S;
     b->d_coef = coef.u();
     b->d_vals = vals ? vals->u() : nullptr;
     b->log_n = log_n;
@@ -97,11 +98,16 @@ static p2hot_batch *make_batch(p2hot_ctx *ctx, PoolBuf &lde, PoolBuf &dig, PoolB
     return b;
 }
 
-extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
-                            unsigned cap_height, int is_values, unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out,
-                            uint64_t *digests_out, uint64_t *cap_out, p2hot_batch **handle_out) {
+// from_values / from_coeffs with host pointers; S salt columns (blinding = true: oracle.rs:123-137) or none
+static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
+                       unsigned cap_height, int is_values, unsigned flags, const uint64_t *const *salt_cols, size_t S,
+                       uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out,
+                       p2hot_batch **handle_out) {
     P2_ENTER(ctx);
     if (handle_out) *handle_out = nullptr;
+    if (S && !salt_cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit: null salt column table");
+    for (size_t j = 0; j < S; ++j)
+        if (!salt_cols[j]) P2_FAIL(ctx, P2HOT_EINVAL, "commit: salt column %zu is null", j);
     P2_TRY(check_log(ctx, log_n + rate_bits, "commit"));
     if (W > 0 && !cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit: null column table");
     if (flags & ~(unsigned)P2HOT_KEEP_VALUES) P2_FAIL(ctx, P2HOT_EINVAL, "commit: unknown flags %#x", flags);
@@ -113,11 +119,14 @@ extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t 
     const size_t nd = p2hot_num_digests(log_N, cap_height), cap_words = (size_t)4 << cap_height;
     const bool keep_vals = is_values && handle_out && (flags & P2HOT_KEEP_VALUES);
     PoolBuf d_work(ctx), d_vals(ctx), d_lde(ctx), d_leaves(ctx), d_dig(ctx), d_cap(ctx);
-    const size_t Wn = (W ? W : 1) * n * 8, WN = (W ? W : 1) * N * 8;
+    const size_t LW = W + S;  // leaf width
+    const size_t Wn = (W ? W : 1) * n * 8, WN = (LW ? LW : 1) * N * 8;
+    PoolBuf d_salt(ctx);
     P2_TRY(pool_alloc(ctx, Wn, &d_work.p));  // uploaded columns; becomes the coefficients in place
     if (keep_vals) P2_TRY(pool_alloc(ctx, Wn, &d_vals.p));
     P2_TRY(pool_alloc(ctx, WN, &d_lde.p));
     if (leaves_out) P2_TRY(pool_alloc(ctx, WN, &d_leaves.p));
+    if (S) P2_TRY(pool_alloc(ctx, S * N * 8, &d_salt.p));
     P2_TRY(pool_alloc(ctx, (nd ? nd : 1) * 32, &d_dig.p));
     P2_TRY(pool_alloc(ctx, cap_words * 8, &d_cap.p));
     // The PCIe copies run on the side stream beside the compute stream.  Column blocks are uploaded, transformed (iNTT)
@@ -167,8 +176,14 @@ extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t 
 #endif
             P2_TRY(p2hot_coset_lde_dev(ctx, blk, cnt, n, log_n, rate_bits, gl::COSET_SHIFT, 0, N, d_lde.u() + c0 * N, N));
         }
-        P2_TRY(p2hot_merkle_dev(ctx, d_lde.u(), 0, N, W, log_N, cap_height, 0, N, d_dig.u(), d_cap.u()));
-        if (leaves_out && W) P2_TRY(p2hot_transpose_dev(ctx, d_lde.u(), N, W, N, d_leaves.u()));
+        if (S) {
+            // the salt vectors are LDE-value columns in natural order (oracle.rs:133-137): like the LDE values they reach the
+            // leaves through transpose + reverse_index_bits (:97-98), i.e. column W + j of the committed matrix is salt_j[bitrev(r)]
+            P2_TRY(h2d_columns(ctx, d_salt.u(), salt_cols, S, N * 8, 0, S * N * 8, ctx->stream));
+            P2_TRY(launch_bitrev(ctx, d_salt.u(), d_lde.u() + W * N, S, N, N, log_N));
+        }
+        P2_TRY(p2hot_merkle_dev(ctx, d_lde.u(), 0, N, LW, log_N, cap_height, 0, N, d_dig.u(), d_cap.u()));
+        if (leaves_out && LW) P2_TRY(p2hot_transpose_dev(ctx, d_lde.u(), N, LW, N, d_leaves.u()));
         // coefficient blocks go back while the leaf sponge runs: queued behind the uploads on the copy stream, each
         // waiting for its block's transform only
         if (coeffs_out)
@@ -179,7 +194,7 @@ extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t 
 #endif
                 P2_HIP(ctx, hipMemcpyAsync(coeffs_out + c0 * n, d_work.u() + c0 * n, cnt * n * 8, hipMemcpyDeviceToHost, copy_stream));
             }
-        if (leaves_out && W) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, W * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (leaves_out && LW) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, LW * N * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (digests_out && nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
         if (cap_out) P2_TRY(d2h(ctx, cap_out, d_cap.p, cap_words * 8));
         return P2HOT_OK;
@@ -193,8 +208,23 @@ extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t 
 #endif
     rc = sync_checked(ctx, rc, "commit");
     if (rc == P2HOT_OK && e1 != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "commit: %s", hipGetErrorString(e1));
-    if (rc == P2HOT_OK && handle_out) *handle_out = make_batch(ctx, d_lde, d_dig, d_work, keep_vals ? &d_vals : nullptr, W, log_n, rate_bits, cap_height);
+    if (rc == P2HOT_OK && handle_out) *handle_out = make_batch(ctx, d_lde, d_dig, d_work, keep_vals ? &d_vals : nullptr, W, log_n, rate_bits, cap_height, S);
     return rc;
+}
+
+extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
+                            unsigned cap_height, int is_values, unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out,
+                            uint64_t *digests_out, uint64_t *cap_out, p2hot_batch **handle_out) {
+    return commit_host(ctx, cols, W, log_n, rate_bits, cap_height, is_values, flags, nullptr, 0, coeffs_out, leaves_out, digests_out,
+                       cap_out, handle_out);
+}
+
+extern "C" int p2hot_commit_salted(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
+                                   unsigned cap_height, int is_values, unsigned flags, const uint64_t *const *salt_cols,
+                                   size_t n_salt, uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out,
+                                   uint64_t *cap_out, p2hot_batch **handle_out) {
+    return commit_host(ctx, cols, W, log_n, rate_bits, cap_height, is_values, flags, salt_cols, n_salt, coeffs_out, leaves_out,
+                       digests_out, cap_out, handle_out);
 }
 
 // from_values / from_coeffs on a device-resident column set.  CONSUMES `cols` (on success and on failure): its block
@@ -277,6 +307,7 @@ extern "C" int p2hot_batch_wrap_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, co
 }
 
 extern "C" size_t p2hot_batch_width(const p2hot_batch *b) { return b ? b->W : 0; }
+extern "C" size_t p2hot_batch_leaf_width(const p2hot_batch *b) { return b ? b->W + b->S : 0; }
 extern "C" unsigned p2hot_batch_degree_log(const p2hot_batch *b) { return b ? b->log_n : 0; }
 
 // the kept input values of a from_values batch as a BORROWED column set (valid while the batch lives; free the view
@@ -321,17 +352,18 @@ extern "C" int p2hot_batch_rows(p2hot_batch *b, const uint64_t *row_idx, size_t 
     if (!b) return P2HOT_EINVAL;
     p2hot_ctx *ctx = b->ctx;
     P2_ENTER(ctx);
-    if (m == 0 || b->W == 0) return P2HOT_OK;
+    const size_t LW = b->W + b->S;  // MerkleTree::get returns the whole leaf, salt included (get_lde_values strips it, oracle.rs:146)
+    if (m == 0 || LW == 0) return P2HOT_OK;
     if (!row_idx || !out) P2_FAIL(ctx, P2HOT_EINVAL, "batch_rows: null buffer");
     for (size_t i = 0; i < m; ++i)
         if (row_idx[i] >= b->N) P2_FAIL(ctx, P2HOT_EINVAL, "batch_rows: index %llu out of range", (unsigned long long)row_idx[i]);
     PoolBuf d_idx(ctx), d_out(ctx);
     P2_TRY(pool_alloc(ctx, m * 8, &d_idx.p));
-    P2_TRY(pool_alloc(ctx, m * b->W * 8, &d_out.p));
+    P2_TRY(pool_alloc(ctx, m * LW * 8, &d_out.p));
     auto body = [&]() -> int {
         P2_HIP(ctx, hipMemcpyAsync(d_idx.p, row_idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
-        P2_TRY(p2hot_gather_rows_dev(ctx, b->d_lde, b->N, b->N, b->W, d_idx.u(), m, d_out.u()));
-        P2_TRY(d2h(ctx, out, d_out.p, m * b->W * 8));
+        P2_TRY(p2hot_gather_rows_dev(ctx, b->d_lde, b->N, b->N, LW, d_idx.u(), m, d_out.u()));
+        P2_TRY(d2h(ctx, out, d_out.p, m * LW * 8));
         return P2HOT_OK;
     };
     return sync_checked(ctx, body(), "batch_rows");
@@ -386,6 +418,8 @@ extern "C" int p2hot_ctx_trim(p2hot_ctx *ctx) {
 struct OracleView {
     const u64 *d_coef, *d_lde, *d_dig;
     size_t W, N;
+    size_t S = 0;  // salt columns behind the W polynomial columns of d_lde (blinded oracles): a leaf is W + S words
+    size_t leaf_width() const { return W + S; }
 };
 // fills proof->initial_leaves / initial_paths (query-major layout) for the Q host-resident query indices
 typedef std::function<int(const u64 *idx, size_t Q, u64 *leaves_out, u64 *paths_out)> InitialOpener;
@@ -406,7 +440,7 @@ extern "C" int p2hot_eval_openings(p2hot_ctx *ctx, const p2hot_batch *const *bat
         if (!B || B->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "oracle %zu is null or belongs to another context", b);
         if (B->log_n != batches[0]->log_n)
             P2_FAIL(ctx, P2HOT_EINVAL, "all oracles must have the same degree (oracle %zu: 2^%u vs 2^%u)", b, B->log_n, batches[0]->log_n);
-        views.push_back(OracleView{B->d_coef, B->d_lde, B->d_dig, B->W, B->N});
+        views.push_back(OracleView{B->d_coef, B->d_lde, B->d_dig, B->W, B->N, B->S});
     }
     return eval_openings_core(ctx, views, batches[0]->log_n, points, n_points, out);
 }
@@ -503,7 +537,7 @@ extern "C" int p2hot_fri_proof_sizes(const p2hot_batch *const *oracles, size_t n
     std::vector<size_t> widths;
     for (size_t o = 0; o < n_oracles; ++o) {
         if (!oracles[o]) return P2HOT_EINVAL;
-        widths.push_back(oracles[o]->W);
+        widths.push_back(oracles[o]->W + oracles[o]->S);  // evals_proofs carry whole leaves (fri/prover.rs:238-241)
     }
     return fri_proof_layout(widths.data(), n_oracles, oracles[0]->log_n, fp, out);
 }
@@ -522,7 +556,7 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
         if (!oracles[o] || oracles[o]->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: oracle %zu is null or belongs to another context", o);
         if (oracles[o]->log_n != oracles[0]->log_n || (fp && (oracles[o]->rate_bits != fp->rate_bits || oracles[o]->cap_height != fp->cap_height)))
             P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: oracle %zu was committed with another degree / rate / cap height", o);
-        views.push_back(OracleView{oracles[o]->d_coef, oracles[o]->d_lde, oracles[o]->d_dig, oracles[o]->W, oracles[o]->N});
+        views.push_back(OracleView{oracles[o]->d_coef, oracles[o]->d_lde, oracles[o]->d_dig, oracles[o]->W, oracles[o]->N, oracles[o]->S});
     }
     return prove_openings_core(ctx, batches, n_batches, views, oracles[0]->log_n, challenger, fp, proof, nullptr);
 }
@@ -533,14 +567,15 @@ static int prove_openings_core(p2hot_ctx *ctx, const p2hot_fri_batch_info *batch
     const size_t n_oracles = views.size();
     if (!challenger || challenger->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: the challenger belongs to another context");
     if (!proof || (n_batches && !batches)) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: null argument");
-    if (fp && fp->hiding) P2_FAIL(ctx, P2HOT_EUNSUPPORTED, "prove_openings: hiding = true needs the blinded (salted) leaves of oracle.rs:133-137");
+    // FriParams::hiding changes nothing on the prover's FRI path (it is observed into the transcript by the caller,
+    // fri/mod.rs:148, and tells the VERIFIER to strip the salts, fri/verifier.rs:149-151): blinded oracles carry their salt columns
     P2_TRY(fri_check_params(ctx, fp, log_n));
     const unsigned rate_bits = fp->rate_bits, cap_height = fp->cap_height, log_N = log_n + rate_bits, n_rounds = fp->n_reduction_rounds;
     const size_t n = (size_t)1 << log_n, N = n << rate_bits, Q = fp->num_query_rounds;
     p2hot_fri_proof_layout lay;
     {
         std::vector<size_t> widths;
-        for (auto &v : views) widths.push_back(v.W);
+        for (auto &v : views) widths.push_back(v.leaf_width());
         if (fri_proof_layout(widths.data(), n_oracles, log_n, fp, &lay) != P2HOT_OK) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: inconsistent parameters");
     }
     if ((lay.caps_words && !proof->commit_phase_merkle_caps) || !proof->final_poly ||
@@ -597,7 +632,7 @@ static int prove_openings_core(p2hot_ctx *ctx, const p2hot_fri_batch_info *batch
     if (fp->proof_of_work_bits > 64) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: proof_of_work_bits > 64");
     for (unsigned r = 0; r < n_rounds; ++r) ab.b[r] = (unsigned char)fp->reduction_arity_bits[r];
     size_t w_sum = 0;
-    for (size_t o = 0; o < n_oracles; ++o) w_sum += oracles[o].W;
+    for (size_t o = 0; o < n_oracles; ++o) w_sum += oracles[o].leaf_width();
     unsigned long long best = ~0ull;
     u64 pow_next = 0;
     std::vector<u64> idx_for_owners;
@@ -641,9 +676,9 @@ static int prove_openings_core(p2hot_ctx *ctx, const p2hot_fri_batch_info *batch
         size_t w_off = 0;
         for (size_t o = 0; o < n_oracles && !open_initial; ++o) {
             const OracleView &B = oracles[o];
-            P2_TRY(p2hot_gather_rows_dev(ctx, B.d_lde, B.N, B.N, B.W, d_idx, Q, d_il + Q * w_off));
+            P2_TRY(p2hot_gather_rows_dev(ctx, B.d_lde, B.N, B.N, B.leaf_width(), d_idx, Q, d_il + Q * w_off));
             P2_TRY(p2hot_merkle_paths_dev(ctx, B.d_dig, log_N, cap_height, d_idx, Q, d_ip + o * Q * 4 * layers0));
-            w_off += B.W;
+            w_off += B.leaf_width();
         }
         // prover.rs:242-253: per round (evals = unflatten(tree.get(x >> arity_bits)), tree.prove(x >> arity_bits))
         size_t ev_off = 0, pa_off = 0, lv = 0, dg = 0, m = N;
@@ -671,7 +706,7 @@ static int prove_openings_core(p2hot_ctx *ctx, const p2hot_fri_batch_info *batch
         // D2H: one strided copy per (oracle | round) turns the oracle-major staging into the query-major proof layout
         w_off = 0;
         for (size_t o = 0; o < n_oracles && !open_initial; ++o) {
-            const size_t Wb = oracles[o].W;
+            const size_t Wb = oracles[o].leaf_width();
             if (Wb)
                 P2_TRY(d2h_2d(ctx, proof->initial_leaves + w_off, w_sum * 8, d_il + Q * w_off, Wb * 8, Wb * 8, Q));
             if (layers0)

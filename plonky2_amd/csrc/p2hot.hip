@@ -1601,6 +1601,7 @@ struct p2hot_batch {
     u64 *d_vals = nullptr;  // [W][n] values on H_n, kept on request
     unsigned log_n = 0, rate_bits = 0;
     bool owned = true;      // false: a view over caller-owned device buffers (p2hot_batch_wrap_dev)
+    size_t S = 0;           // blinding (oracle.rs:123-137): salt columns W .. W+S-1 of d_lde; a leaf is W + S words wide
 };
 
 // A device-resident column set [W][n] (Vec<PolynomialValues> / Vec<PolynomialCoeffs> that never visits the host)

@@ -2,7 +2,7 @@
 
 from_values / from_coeffs keep the reference's signature (values, rate_bits, blinding, cap_height,
 timing, fft_root_table); `timing` and `fft_root_table` are accepted and ignored (the GPU path has
-its own twiddle tables), `blinding=True` raises (salts come from OsRng in the reference,
+its own twiddle tables), `blinding=True` takes the caller's salt vectors (they come from OsRng in the reference,
 oracle.rs:133-137).  Every batch is a `p2hot_batch` handle of the library: host arrays go through
 the host-pointer entry point (p2hot_commit -- what the Rust shim calls), device buffers through
 p2hot_commit_dev + p2hot_batch_wrap_dev.  The LDE matrix stays on the GPU in column-major form;
@@ -27,8 +27,8 @@ class _BatchHandle:
     each other: no reference cycle, so a dropped batch returns its 9 GB LDE block immediately (refcount, not the
     cycle collector) -- a cycle cost a fresh hipMalloc of the LDE matrix per commit (310 ms instead of 67)."""
 
-    def __init__(self, engine, handle, W, degree_log, rate_bits, cap_height, keepalive=()):
-        self.engine, self.h, self.W = engine, handle, W
+    def __init__(self, engine, handle, W, degree_log, rate_bits, cap_height, keepalive=(), salt=0):
+        self.engine, self.h, self.W = engine, handle, W + salt  # leaf width
         self.degree_log, self.rate_bits, self.cap_height = degree_log, rate_bits, cap_height
         self.keepalive = keepalive  # device buffers a wrapped (borrowing) handle points into
 
@@ -66,9 +66,10 @@ class _BatchHandle:
 
 class PolynomialBatch:
     def __init__(self, engine, handle, W, degree_log, rate_bits, cap_height, cap, digests=None, coeffs=None, lde=None,
-                 blinding=False):
+                 blinding=False, salt=0):
         self.engine = engine
-        self._owner = _BatchHandle(engine, handle, W, degree_log, rate_bits, cap_height, keepalive=(coeffs, lde, digests))
+        self._owner = _BatchHandle(engine, handle, W, degree_log, rate_bits, cap_height, keepalive=(coeffs, lde, digests), salt=salt)
+        self.salt_size = salt
         self._W = W
         self._coeffs = coeffs      # device [W][n] when the batch was built from device buffers, else None
         self.lde = lde             # device [W][N] (same condition)
@@ -97,22 +98,26 @@ class PolynomialBatch:
 
     @classmethod
     def from_values(cls, values, rate_bits, blinding, cap_height, timing=None, fft_root_table=None, engine=None,
-                    keep_values=False):
+                    keep_values=False, salts=None):
         """oracle.rs:57-79.  values: [W][n] (host ndarray or device buffer), values on H_n.
-        keep_values: keep the values on the device for plonk.prover (P2HOT_KEEP_VALUES)."""
-        return cls._build(values, rate_bits, blinding, cap_height, True, engine, keep_values)
+        keep_values: keep the values on the device for plonk.prover (P2HOT_KEEP_VALUES).
+        blinding=True: `salts` = the SALT_SIZE random vectors [4][N] the reference draws with F::rand_vec (oracle.rs:133-137);
+        the caller owns the randomness."""
+        return cls._build(values, rate_bits, blinding, cap_height, True, engine, keep_values, salts)
 
     @classmethod
-    def from_coeffs(cls, polynomials, rate_bits, blinding, cap_height, timing=None, fft_root_table=None, engine=None):
+    def from_coeffs(cls, polynomials, rate_bits, blinding, cap_height, timing=None, fft_root_table=None, engine=None, salts=None):
         """oracle.rs:82-112.  polynomials: [W][n] coefficients."""
-        return cls._build(polynomials, rate_bits, blinding, cap_height, False, engine, False)
+        return cls._build(polynomials, rate_bits, blinding, cap_height, False, engine, False, salts)
 
     @classmethod
-    def _build(cls, cols, rate_bits, blinding, cap_height, is_values, engine, keep_values):
+    def _build(cls, cols, rate_bits, blinding, cap_height, is_values, engine, keep_values, salts=None):
         eng = engine or default_engine()
         if blinding:
-            raise NotImplementedError("blinding=True draws salts from OsRng in the reference (oracle.rs:133-137); "
-                                      "use the CPU prover for zero-knowledge configs")
+            if salts is None:
+                raise ValueError("blinding=True needs the caller's salt vectors (the reference draws them from OsRng, "
+                                 "oracle.rs:133-137): pass salts=[SALT_SIZE][N]")
+            return cls._build_salted(cols, rate_bits, cap_height, is_values, eng, keep_values, salts)
         if isinstance(cols, DeviceColumns):
             return cls._from_device_columns(cols, rate_bits, cap_height, is_values, eng, keep_values)
         if not eng.mem.is_buffer(cols):
@@ -141,6 +146,29 @@ class PolynomialBatch:
         return cls(eng, h, W, log_n, rate_bits, cap_height, cap)
 
     @classmethod
+    def _build_salted(cls, cols, rate_bits, cap_height, is_values, eng, keep_values, salts):
+        """p2hot_commit_salted: host columns + host salt vectors (what the Rust shim passes for a zk config)"""
+        cols = np.ascontiguousarray(np.asarray(cols, dtype=np.uint64))
+        salts = np.ascontiguousarray(np.asarray(salts, dtype=np.uint64))
+        if cols.ndim != 2 or salts.ndim != 2:
+            raise ValueError("expected [W][n] columns and [SALT_SIZE][N] salts")
+        W, n = cols.shape
+        log_n = int(n).bit_length() - 1
+        if n != 1 << log_n:
+            raise ValueError("polynomial length must be a power of two")
+        S = salts.shape[0]
+        if salts.shape[1] != n << rate_bits:
+            raise ValueError("salt vectors have length N = n << rate_bits (oracle.rs:136)")
+        ptrs = (C.c_void_p * max(W, 1))(*[cols[c].ctypes.data for c in range(W)])
+        sptrs = (C.c_void_p * max(S, 1))(*[salts[j].ctypes.data for j in range(S)])
+        cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+        h = C.c_void_p()
+        eng.check(eng.lib.p2hot_commit_salted(eng.ctx, ptrs, W, log_n, rate_bits, cap_height, 1 if is_values else 0,
+                                              _lib.KEEP_VALUES if (keep_values and is_values) else 0, sptrs, S, None, None, None,
+                                              cap.ctypes.data, C.byref(h)))
+        return cls(eng, h, W, log_n, rate_bits, cap_height, cap, blinding=True, salt=S)
+
+    @classmethod
     def _from_device_columns(cls, dc, rate_bits, cap_height, is_values, eng, keep_values):
         W, log_n = dc.width, dc.degree_log
         cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
@@ -162,7 +190,8 @@ class PolynomialBatch:
         bits = self.degree_log + self.rate_bits
         i = index * step
         rev = int(format(i, "0%db" % bits)[::-1], 2) if bits else 0
-        return self.merkle_tree.get(rev)
+        row = self.merkle_tree.get(rev)
+        return row[..., :row.shape[-1] - self.salt_size] if self.salt_size else row  # oracle.rs:146
 
 
 class DeviceColumns:
@@ -301,7 +330,7 @@ def prove_openings(batches, oracles, challenger, rate_bits, cap_height, reductio
     # reshape the flat buffers (layout: include/p2hot.h, p2hot_fri_proof)
     ncap = 1 << cap_height
     log_N = oracles[0].degree_log + rate_bits
-    widths = [o._W for o in oracles]
+    widths = [o._W + getattr(o, "salt_size", 0) for o in oracles]  # evals_proofs carry whole leaves, salts included
     wsum = sum(widths)
     il = bufs["initial_leaves"][:Q * wsum].reshape(Q, wsum) if wsum else np.zeros((Q, 0), dtype=np.uint64)
     layers0 = log_N - cap_height

@@ -83,10 +83,12 @@ def test_shape_errors_match_reference_panics(emu):
     co = np.zeros((1, 8), dtype=np.uint64)
     with pytest.raises(_lib.P2HotError, match="coset blocks"):
         emu.coset_lde(co, 3, 1, row_begin=4, row_count=8)
-    # blinding is refused, not silently ignored
+    # blinding needs the caller's salts (the library draws no random numbers), of the right shape
     from plonky2_amd.fri.oracle import PolynomialBatch
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="salt"):
         PolynomialBatch.from_values(co, 1, True, 0, engine=emu)
+    with pytest.raises(ValueError, match="salt"):
+        PolynomialBatch.from_values(co, 1, True, 0, engine=emu, salts=np.zeros((4, 8), dtype=np.uint64))
     with pytest.raises(ValueError):
         PolynomialBatch.from_values(np.zeros((1, 6), dtype=np.uint64), 1, False, 0, engine=emu)
 

@@ -16,6 +16,7 @@ from tests.conftest import ROOT
 HDR = os.path.join(ROOT, "include", "p2hot.h")
 RS = os.path.join(ROOT, "integration", "p2hot.rs")
 PATCH = os.path.join(ROOT, "integration", "plonky2_p2hot.patch")
+DUMPER = os.path.join(ROOT, "integration", "p2hot_dump_goldens.rs")
 
 SCALAR = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8",
           "char": "c_char", "void": "c_void"}
@@ -135,6 +136,12 @@ def test_patch_carries_the_module_verbatim():
     body = body[:end + 1] if end >= 0 else body
     added = "".join(line[1:] + "\n" for line in body.splitlines() if line.startswith("+"))
     assert added == open(RS).read()
+    # ... and the golden dumper as plonky2/examples/p2hot_dump_goldens.rs
+    start = p.index("+++ b/plonky2/examples/p2hot_dump_goldens.rs\n")
+    body = p[start:].split("\n", 2)[2]
+    end = body.find("\ndiff -ruN ")
+    body = body[:end + 1] if end >= 0 else body
+    assert "".join(line[1:] + "\n" for line in body.splitlines() if line.startswith("+")) == open(DUMPER).read()
     for f in ("plonky2/Cargo.toml", "plonky2/build.rs", "plonky2/src/fri/oracle.rs", "plonky2/src/fri/prover.rs",
               "plonky2/src/hash/merkle_tree.rs", "plonky2/src/iop/challenger.rs", "plonky2/src/lib.rs"):
         assert "+++ b/%s\n" % f in p, f
@@ -150,3 +157,96 @@ def test_patch_applies_to_the_reference_tree():
     before = open(PATCH).read()
     subprocess.check_call(["python", os.path.join(ROOT, "tools", "make_rust_patch.py")], stdout=subprocess.DEVNULL)
     assert open(PATCH).read() == before, "integration/plonky2_p2hot.patch is stale: run tools/make_rust_patch.py"
+
+
+def _strip_rust(src):
+    """comments, string and char literals removed (enough for bracket counting)"""
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r'"(?:\\.|[^"\\])*"', '""', src, flags=re.S)
+    src = re.sub(r"'(?:\\.|[^'\\])'", "''", src)
+    return src
+
+
+@pytest.mark.parametrize("path", [RS, DUMPER])
+def test_rust_sources_are_bracket_balanced(path):
+    """no Rust toolchain here: at least every bracket the files open is closed, in order"""
+    src = _strip_rust(open(path).read())
+    stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+    for i, ch in enumerate(src):
+        if ch in "([{":
+            stack.append(ch)
+        elif ch in ")]}":
+            assert stack and stack[-1] == pairs[ch], "unbalanced %r near: %s" % (ch, src[max(0, i - 60):i + 20])
+            stack.pop()
+    assert not stack
+
+
+def test_bit_exact_harness_is_part_of_the_shim():
+    """same process, same witness, CPU body vs p2hot body, assert_eq! on polynomials, trees, FRI caps, final_poly,
+    the smallest PoW witness and proof.to_bytes() -- as a #[cfg(test)] module of the file the patch installs"""
+    s = open(RS).read()
+    assert "pub fn set_enabled(on: bool)" in s and re.search(r"pub fn applies<.*?\{\s*enabled\(\)", s, flags=re.S)
+    m = re.search(r"#\[cfg\(test\)\]\nmod tests \{(.*)\n\}\n\Z", s, flags=re.S)
+    assert m, "the harness must be the last item of integration/p2hot.rs"
+    t = m.group(1)
+    tests = re.findall(r"#\[test\](?:\s*#\[ignore[^\]]*\])?\s*fn (\w+)", t)
+    for name in ("commit_matches_the_cpu_prover", "salted_commit_matches_the_cpu_prover", "fri_commit_phase_matches_the_cpu_prover",
+                 "prove_2_12_matches_the_cpu_prover", "recursion_chain_matches_the_cpu_prover", "prove_2_16_matches_the_cpu_prover",
+                 "recursion_chain_2_20_matches_the_cpu_prover", "zk_config_proof_verifies"):
+        assert name in tests, name
+    for needle in ("assert_eq!(cpu.polynomials, gpu.polynomials", "cpu.merkle_tree.digests, gpu.merkle_tree.digests",
+                   "cpu.merkle_tree.leaves, gpu.merkle_tree.leaves", "commit_phase_merkle_caps, g.opening_proof.commit_phase_merkle_caps",
+                   "c.opening_proof.final_poly, g.opening_proof.final_poly", "c.opening_proof.pow_witness, g.opening_proof.pow_witness",
+                   "cpu_proof.to_bytes(), gpu_proof.to_bytes()", "write_polynomial_batch", "write_merkle_tree", "set_enabled(false)"):
+        assert needle in t, needle
+    p = open(PATCH).read()
+    assert "find_first(pow_check)" in p and "p2hot_fri_committed_trees_for_tests" in p
+    # every crate-internal item the harness reaches exists in the reference tree with that name
+    ref = os.environ.get("P2_REFERENCE", "/root/reference")
+    if os.path.isdir(os.path.join(ref, "plonky2", "src")):
+        src = lambda f: open(os.path.join(ref, "plonky2", "src", f)).read()
+        assert "pub(crate) fn lde_values(" in src("fri/oracle.rs") and "pub const SALT_SIZE" in src("fri/oracle.rs")
+        assert "fn write_polynomial_batch<" in src("util/serialization/mod.rs") and "fn write_merkle_tree<" in src("util/serialization/mod.rs")
+        assert "pub fn standard_recursion_zk_config()" in src("plonk/circuit_data.rs")
+        assert "pub fn set_proof_with_pis_target" in src("iop/witness.rs") or "fn set_proof_with_pis_target" in src("iop/witness.rs")
+        assert "pub constants_sigmas_commitment" in src("plonk/circuit_data.rs")
+
+
+def test_golden_dumper_matches_the_python_side():
+    """examples/p2hot_dump_goldens.rs must hash the same inputs in the same layout as tools/gen_golden_caps.py /
+    tools/reference_run.py: splitmix constants, the shape table, the SHA-256 round constants, the record fields"""
+    import hashlib
+    from plonky2_amd.util import synthetic
+    from tools import reference_run as rr
+    s = open(DUMPER).read()
+    assert "0x%016X" % synthetic.SEED == "0x" + re.search(r"const SEED: u64 = 0x([0-9A-Fa-f_]+);", s).group(1).replace("_", "").upper()
+    for c in (0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB):
+        assert ("%016X" % c) in s.replace("_", "").upper()
+    # the shape table
+    rows = re.findall(r'\("(\w+)", (\d+), (\d+), (\d+), (\d+), (true|false), "(\w+)"\)', s)
+    table = {r[0]: (int(r[1]), int(r[2]), int(r[3]), int(r[4]), r[5] == "true", r[6]) for r in rows}
+    assert table == rr.DUMP_SHAPES
+    fri = re.findall(r'\("(fri_\w+)", (\d+)(?:usize)?, (\d+)(?:usize)?, (\d+)(?:usize)?, vec!\[([^\]]*)\], (\d+)(?:u32)?\)', s)
+    assert {f[0]: (int(f[1]), int(f[2]), int(f[3]), [int(x.replace("usize", "")) for x in f[4].split(",")], int(f[5])) for f in fri} == rr.DUMP_FRI
+    for name, sh in rr.DUMP_SHAPES.items():  # shared names carry the shapes of the oracle goldens
+        from tools.gen_golden_caps import SHAPES
+        if name in SHAPES:
+            assert SHAPES[name] == sh, name
+    # SHA-256 constants: first 32 bits of the fractional parts of the cube roots of the first 64 primes
+    ks = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{8})\b", s[s.index("const K: [u32; 64]"):s.index("impl Sha256")])]
+    primes = [p for p in range(2, 312) if all(p % q for q in range(2, int(p ** 0.5) + 1))][:64]
+
+    def frac_cuberoot_bits(p):
+        lo, hi = 0, 1 << 40  # floor(cbrt(p) * 2^32) by bisection on integers
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            if mid ** 3 <= p << 96:
+                lo = mid
+            else:
+                hi = mid - 1
+        return lo & 0xFFFFFFFF
+    assert ks == [frac_cuberoot_bits(p) for p in primes]
+    for f in rr.COMMIT_FIELDS:
+        assert '\\"%s\\"' % f in s, f
+    assert hashlib.sha256(b"abc").hexdigest().startswith("ba7816bf")  # the layout both sides hash: u64 little endian

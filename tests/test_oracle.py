@@ -325,3 +325,43 @@ def test_reduce_and_divide(ora):
     lhs = ((px[0] - pz[0]) % P, (px[1] - pz[1]) % P)
     rhs = pyref.ext_mul(pyref.ext_eval(q, x), ((x[0] - z[0]) % P, (x[1] - z[1]) % P))
     assert lhs == rhs
+
+
+# ---------------------------------------------------------------- the reference-run pin
+def test_reference_run_comparer_on_the_oracles_own_dump(ora, tmp_path):
+    """tools/reference_run.py: the comparison a `reference_run.json` from the Rust dumper goes through, exercised on a dump
+    in the same schema written by the oracle itself (must pass) and on tampered copies (must name the field)"""
+    import copy
+    import json
+    from tools import reference_run as rr
+    p = tmp_path / "run.json"
+    run = rr.emit(str(p), ["small_values", "small_coeffs", "small_fibonacci", "fri_small", "fri_starky_like"])
+    done = dict(rr.check(str(p)))
+    assert set(done) == {"small_values", "small_coeffs", "small_fibonacci", "fri_small", "fri_starky_like"}
+    for name, field, mutate in (("small_values", "cap", lambda v: [[v[0][0] ^ 1] + v[0][1:]] + v[1:]),
+                                ("small_coeffs", "sha256_lde", lambda v: v[:-1] + ("0" if v[-1] != "0" else "1")),
+                                ("fri_small", "final_poly", lambda v: [[(v[0][0] + 1) % P, v[0][1]]] + v[1:]),
+                                ("fri_starky_like", "pow_witness", lambda v: v + 1)):
+        bad = copy.deepcopy(run)
+        bad[name][field] = mutate(bad[name][field])
+        q = tmp_path / "bad.json"
+        json.dump(bad, open(q, "w"))
+        with pytest.raises(AssertionError, match=name):
+            rr.check(str(q))
+    # a record of a golden shape is compared with tests/golden/commit_caps.json without recomputation
+    g = json.load(open(rr.GOLDEN))
+    json.dump({"c3_wires": {k: g["c3_wires"][k] for k in rr.COMMIT_FIELDS}}, open(p, "w"))
+    assert rr.check(str(p)) == [("c3_wires", "tests/golden/commit_caps.json")]
+
+
+def test_reference_run_pins_the_oracle_when_present(ora):
+    """`tests/golden/reference_run.json` = the output of `cargo run --release --example p2hot_dump_goldens` on a box with the
+    Rust toolchain (integration/plonky2_p2hot.patch).  When it is committed, the oracle -- and through
+    tests/golden/commit_caps.json every GPU result -- is pinned to the real reference's bytes."""
+    import os
+    from tools import reference_run as rr
+    path = os.path.join(os.path.dirname(__file__), "golden", "reference_run.json")
+    if not os.path.exists(path):
+        pytest.skip("no reference run has been recorded yet (no cargo in the build image): parity stays pinned by KAT + property")
+    done = rr.check(path)
+    assert done, "empty reference run"

@@ -285,6 +285,49 @@ def test_commit_row_ranges_assemble_to_the_full_tree(eng, ora):
     assert (eng.host(capbuf) == o["cap"]).all()
 
 
+@pytest.mark.parametrize("shape", [(5, 4, 3, 2, True), (9, 6, 1, 3, False), (1, 3, 2, 0, True), (135, 5, 3, 4, True)])
+def test_salted_commit_vs_oracle(eng, ora, shape):
+    """blinding = true (fri/oracle.rs:114-139, standard_recursion_zk_config): SALT_SIZE = 4 caller-supplied random
+    vectors become leaf columns W..W+3 (through transpose + reverse_index_bits like the LDE values), are hashed by the
+    leaf sponge and come back from MerkleTree::get; get_lde_values strips them (:146)"""
+    import ctypes as C
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    W, log_n, rb, cap, is_values = shape
+    rng = np.random.default_rng(W * 31 + log_n)
+    n, N, S = 1 << log_n, 1 << (log_n + rb), 4
+    cols = [rand_field(rng, n) for _ in range(W)]
+    salts = rand_field(rng, S, N, noncanonical=True)
+    o = ora.commit_salted(np.stack(cols), salts, rb, cap, is_values)
+    ptrs = (C.c_void_p * W)(*[c.ctypes.data for c in cols])
+    sptrs = (C.c_void_p * S)(*[salts[j].ctypes.data for j in range(S)])
+    coeffs = np.zeros((W, n), dtype=np.uint64)
+    leaves = np.zeros((N, W + S), dtype=np.uint64)
+    digests = np.zeros((eng.num_digests(log_n + rb, cap), 4), dtype=np.uint64)
+    capv = np.zeros((1 << cap, 4), dtype=np.uint64)
+    handle = C.c_void_p()
+    eng.check(eng.lib.p2hot_commit_salted(eng.ctx, ptrs, W, log_n, rb, cap, 1 if is_values else 0, 0, sptrs, S, coeffs.ctypes.data,
+                                          leaves.ctypes.data, digests.ctypes.data, capv.ctypes.data, C.byref(handle)))
+    assert (coeffs == o["coeffs"]).all() and (leaves == o["leaves"]).all()
+    assert (digests == o["digests"]).all() and (capv == o["cap"]).all()
+    assert eng.lib.p2hot_batch_width(handle) == W and eng.lib.p2hot_batch_leaf_width(handle) == W + S
+    idx = np.array([0, N // 3, N - 1], dtype=np.uint64)
+    rows = np.zeros((3, W + S), dtype=np.uint64)
+    eng.check(eng.lib.p2hot_batch_rows(handle, idx.ctypes.data, 3, rows.ctypes.data))
+    assert (rows == o["leaves"][idx.astype(np.int64)]).all()
+    eng.lib.p2hot_batch_free(handle)
+    # the salts change the tree, not the polynomials; without salts the unblinded commitment comes back
+    plain = ora.commit(np.stack(cols), rb, cap, is_values)
+    assert (plain["coeffs"] == o["coeffs"]).all() and (plain["cap"] != o["cap"]).any()
+    # the mirror of the reference signature: from_values / from_coeffs(…, blinding = true) with the caller's salts
+    build = PolynomialBatch.from_values if is_values else PolynomialBatch.from_coeffs
+    b = build(np.stack(cols), rb, True, cap, engine=eng, salts=salts)
+    assert b.blinding and (np.asarray(b.merkle_tree.cap.entries) == o["cap"]).all()
+    L = 5 % N
+    rev = int(format(L, "0%db" % (log_n + rb))[::-1], 2) if log_n + rb else 0
+    assert (np.asarray(b.get_lde_values(L)).reshape(-1) == o["leaves"][rev][:W]).all()
+    assert (np.asarray(b.merkle_tree.get(rev)).reshape(-1) == o["leaves"][rev]).all()
+
+
 def test_host_pointer_commit_abi(eng, ora):
     """p2hot_commit / p2hot_batch_rows: the entry points the Rust shim binds (W separate host vectors)"""
     import ctypes as C

@@ -243,6 +243,17 @@ def test_polynomial_batch_wire_format(eng):
     (4, [3], 2, 0, [], 2, 3),             # no reduction rounds: the final polynomial is the whole codeword's polynomial
 ])
 def test_fri_proof_passes_the_reference_verifier(eng, ora, log_n, widths, rb, cap, arity, pow_bits, nq):
+    _fri_proof_verifies(eng, ora, log_n, widths, rb, cap, arity, pow_bits, nq, blinded=())
+
+
+def test_fri_proof_over_blinded_oracles_passes_the_reference_verifier(eng, ora):
+    """zero-knowledge configs (standard_recursion_zk_config): oracles 1 and 2 are salted (PlonkOracle::WIRES / ZS blinding,
+    plonk/plonk_common.rs), oracle 0 is not (CONSTANTS_SIGMAS).  The opened leaves carry the salts, the Merkle paths
+    authenticate the salted leaves, the verifier reads the polynomial evaluations in front of them (fri/proof.rs:45-52)"""
+    _fri_proof_verifies(eng, ora, 6, [4, 5, 3], 3, 2, [2, 1], 4, 5, blinded=(1, 2))
+
+
+def _fri_proof_verifies(eng, ora, log_n, widths, rb, cap, arity, pow_bits, nq, blinded):
     """The acceptance check of SURVEY 3.5: a proof produced on the device (commits, OpeningSet evaluations,
     prove_openings) verifies under a restatement of plonky2/src/fri/verifier.rs + challenges.rs that re-derives every
     challenge from the proof with the ORACLE's challenger; tampering with any part makes it fail."""
@@ -252,7 +263,10 @@ def test_fri_proof_passes_the_reference_verifier(eng, ora, log_n, widths, rb, ca
     from plonky2_amd.iop.challenger import Challenger
     rng = np.random.default_rng(log_n * 977 + len(widths))
     n = 1 << log_n
-    oracles = [PolynomialBatch.from_coeffs(rand_field(rng, w, n), rb, False, cap, engine=eng) for w in widths]
+    oracles = [PolynomialBatch.from_coeffs(rand_field(rng, w, n), rb, oi in blinded, cap, engine=eng,
+                                           salts=rand_field(rng, 4, n << rb) if oi in blinded else None)
+               for oi, w in enumerate(widths)]
+    leaf_widths = [w + (4 if oi in blinded else 0) for oi, w in enumerate(widths)]
     caps = [np.asarray(o.merkle_tree.cap.entries) for o in oracles]
     c, oc = Challenger(eng), ora.Challenger()
     for ch in (c, oc):
@@ -286,13 +300,13 @@ def test_fri_proof_passes_the_reference_verifier(eng, ora, log_n, widths, rb, ca
     blob = write_fri_proof(proof)
     ncap, N = 1 << cap, n << rb
     expect, m = 32 * ncap * len(arity), N
-    per_query = sum(8 * w + 1 + 32 * (log_n + rb - cap) for w in widths)
+    per_query = sum(8 * w + 1 + 32 * (log_n + rb - cap) for w in leaf_widths)
     for ab in arity:
         m >>= ab
         per_query += 16 * (1 << ab) + 1 + 32 * max(0, m.bit_length() - 1 - cap)
     expect += nq * per_query + 16 * (n >> sum(arity)) + 8
     assert len(blob) == expect
-    back = read_fri_proof(blob, widths, log_n, rb, cap, arity, nq)
+    back = read_fri_proof(blob, leaf_widths, log_n, rb, cap, arity, nq)
     assert write_fri_proof(back) == blob
     verify(back)
 

@@ -8,6 +8,8 @@ The patch is the Rust side of the drop-in boundary: Cargo feature `p
   hash/merkle_tree.rs  `device` handle on MerkleTree, get / prove
   iop/challenger.rs    accessor for the transcript state
   util/serialization   the one other MerkleTree struct literal
+  fri/prover.rs        also: the grind takes the smallest witness under the feature; a test hook for the harness
+plus plonky2/examples/p2hot_dump_goldens.rs (= integration/p2hot_dump_goldens.rs, verbatim): the golden dumper.
 It is built by anchored edits of a scratch copy, so this script holds only the NEW lines and short
 anchors -- no reference source is stored in the repository beyond the diff context of the patch itself.
 
@@ -38,11 +40,12 @@ def edit(path, pairs):
 
 GATE = '''        #[cfg(feature = "p2hot")]
         if crate::p2hot::applies::<F, C, D>(blinding) {
-            // MI355X path (include/p2hot.h): iNTT + coset LDE + Poseidon leaf sponge + Merkle levels in one call
+            // MI355X path (include/p2hot.h): iNTT + coset LDE + Poseidon leaf sponge + Merkle levels in one call; a blinded
+            // commitment draws its salts on this side (F::rand_vec, as lde_values does) and hands them over
             return timed!(
                 timing,
                 "p2hot commit",
-                crate::p2hot::commit::<F, C, D>(&crate::p2hot::%s(&%s), rate_bits, cap_height, %s)
+                crate::p2hot::commit::<F, C, D>(&crate::p2hot::%s(&%s), rate_bits, cap_height, %s, blinding)
             );
         }
 '''
@@ -76,6 +79,8 @@ fn main() {
     edit(os.path.join(b, "plonky2/src/lib.rs"), [
         ("pub mod iop;\n", "pub mod iop;\n#[cfg(feature = \"p2hot\")]\npub mod p2hot;\n")])
     shutil.copy(os.path.join(ROOT, "integration", "p2hot.rs"), os.path.join(b, "plonky2/src/p2hot.rs"))
+    os.makedirs(os.path.join(b, "plonky2/examples"), exist_ok=True)
+    shutil.copy(os.path.join(ROOT, "integration", "p2hot_dump_goldens.rs"), os.path.join(b, "plonky2/examples/p2hot_dump_goldens.rs"))
     # ---- PolynomialBatch
     edit(os.path.join(b, "plonky2/src/fri/oracle.rs"), [
         ('''        fft_root_table: Option<&FftRootTable<F>>,
@@ -127,7 +132,7 @@ fn main() {
 ''', '''    max_num_query_steps: Option<usize>,
 ) -> FriCommitedTrees<F, C, D> {
     #[cfg(feature = "p2hot")]
-    if !fri_params.hiding && crate::p2hot::applies::<F, C, D>(false) {
+    if crate::p2hot::applies::<F, C, D>(false) {
         // every round (tree, challenge, fold, coset NTT) on the GPU; `values` is recomputed there from `coeffs`
         return crate::p2hot::fri_committed_trees::<F, C, D>(
             &coeffs,
@@ -138,6 +143,50 @@ fn main() {
         );
     }
     let mut trees = Vec::with_capacity(fri_params.reduction_arity_bits.len());
+'''),
+        # the grind: the GPU search returns the SMALLEST witness, rayon's find_any returns any.  With the feature on the CPU
+        # body takes the smallest too, so that proofs are byte-identical whichever side ran (the bit-exact harness relies on it)
+        ('''    let pow_witness = (0..=F::NEG_ONE.to_canonical_u64())
+        .into_par_iter()
+        .find_any(|&candidate| {
+''', '''    let pow_candidates = (0..=F::NEG_ONE.to_canonical_u64()).into_par_iter();
+    let pow_check = |&candidate: &u64| {
+        {
+'''),
+        ('''            leading_zeros >= min_leading_zeros
+        })
+        .map(F::from_canonical_u64)
+        .expect("Proof of work failed. This is highly unlikely!");
+''', '''            leading_zeros >= min_leading_zeros
+        }
+    };
+    // (without `parallel` the iterator is sequential and find_any already is the first match, maybe_rayon/src/lib.rs:254)
+    #[cfg(all(feature = "p2hot", feature = "parallel"))]
+    let pow_found = pow_candidates.find_first(pow_check); // the smallest witness, as libp2hot's grind returns it
+    #[cfg(not(all(feature = "p2hot", feature = "parallel")))]
+    let pow_found = pow_candidates.find_any(pow_check);
+    let pow_witness = pow_found
+        .map(F::from_canonical_u64)
+        .expect("Proof of work failed. This is highly unlikely!");
+'''),
+        ('''fn fri_prover_query_rounds<
+''', '''/// Test hook of the `p2hot` bit-exact harness (`crate::p2hot::tests`): `fri_committed_trees` is private to this module.
+/// `lde_coeffs`: the zero-padded coefficients (length N); the values are recomputed as `fri_proof`'s caller does.
+#[cfg(all(test, feature = "p2hot"))]
+pub(crate) fn p2hot_fri_committed_trees_for_tests<
+    F: RichField + Extendable<D>,
+    C: GenericConfig<D, F = F>,
+    const D: usize,
+>(
+    lde_coeffs: &PolynomialCoeffs<F::Extension>,
+    challenger: &mut Challenger<F, C::Hasher>,
+    fri_params: &FriParams,
+) -> FriCommitedTrees<F, C, D> {
+    let lde_values = lde_coeffs.coset_fft(F::coset_shift().into());
+    fri_committed_trees::<F, C, D>(lde_coeffs.clone(), lde_values, challenger, fri_params, None, None)
+}
+
+fn fri_prover_query_rounds<
 ''')])
     # ---- MerkleTree
     edit(os.path.join(b, "plonky2/src/hash/merkle_tree.rs"), [
