@@ -46,29 +46,48 @@ def algorithmic_bytes(W, log_n, rate_bits, is_values=True):
     return b
 
 
-def pmc_traffic(W, log_n, rb, cap, world, kernel):
-    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), if they were
-    collected for exactly this workload; None otherwise.  Counters cannot be read inside this run."""
+def _pmc_file():
+    """profiles/pmc_traffic.json (tools/profile_all.sh + tools/prof_summarize.py): one entry per kernel instantiation, stamped with
+    the hash of plonky2_amd/csrc it was collected on.  Counters cannot be read inside this run."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        w = d["workload"]
-        if (w["W"], w["log_n"], w["rate_bits"], w["cap_height"], w["n_gpus"]) != (W, log_n, rb, cap, world):
-            return None
-        return d["kernels"][kernel]["hbm_bytes_per_launch"]
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
         return None
 
 
-def pmc_valu(W, log_n, rb, cap, world):
-    """SQ_INSTS_VALU of one hash_leaves launch from the committed PMC pass (same workload only)"""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        w = d["workload"]
-        if (w["W"], w["log_n"], w["rate_bits"], w["cap_height"], w["n_gpus"]) != (W, log_n, rb, cap, world):
-            return None
-        return d["kernels"]["hash_leaves_kernel"].get("sq_insts_valu_per_launch")
-    except Exception:
+def pmc_entry(W, log_n, rb, cap, world, *needles):
+    """the entry of the kernel instantiation whose key contains every needle (same workload only), else None"""
+    d = _pmc_file()
+    if not d:
         return None
+    w = d.get("workload", {})
+    if (w.get("W"), w.get("log_n"), w.get("rate_bits"), w.get("cap_height"), w.get("n_gpus")) != (W, log_n, rb, cap, world):
+        return None
+    hits = [v for k, v in d["kernels"].items() if all(n in k for n in needles)]
+    return hits[0] if len(hits) == 1 else None
+
+
+def pmc_stale():
+    """True when the committed counters were collected on other kernel sources than the ones being timed"""
+    d = _pmc_file()
+    if not d:
+        return None
+    from tools.csrc_hash import csrc_hash
+    return d.get("csrc_sha256_16") != csrc_hash()
+
+
+def ubench_cycles():
+    """{instruction: SIMD cycles per wave64 instruction at 2.4 GHz} from profiles/r03_ubench.txt (tools/ubench.hip on the
+    MI355X: 8 independent streams, 8 waves per SIMD, all 1024 SIMDs busy -- i.e. at the clock the chip sustains under that load)"""
+    out = {}
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r03_ubench.txt")):
+            m = __import__("re").match(r"(.+?)\s+[\d.]+ ms\s+([\d.]+) cyc/inst/SIMD by wall", line)
+            if m:
+                out[m.group(1).strip()] = float(m.group(2))
+    except Exception:
+        pass
+    return out
 
 
 def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=45.0, golden_cap=None):
@@ -119,6 +138,50 @@ def golden(name):
         return None
 
 
+def host_pointer_lines(eng, out, reps):
+    """SURVEY 8d's second and third figures, driver-timed: p2hot_commit with PAGEABLE host columns (what the Rust shim passes:
+    W separate Vec<F>), PCIe included -- (i) coefficients + digests + cap back, (ii) digests kept on the device (paths served
+    from the handle), (iii) the 9 GB row-major leaf matrix copied back too; and the recursion-size (2^12 rows) call."""
+    import ctypes as C
+    rb, cap = 3, 4
+
+    def run(name, W, log_n, what, want_coeffs, want_digests, want_leaves, gname, reps=reps):
+        n, N = 1 << log_n, 1 << (log_n + rb)
+        cols = [np.ascontiguousarray(c) for c in splitmix_columns_numpy(0, W, n)]
+        ptrs = (C.c_void_p * W)(*[c.ctypes.data for c in cols])
+        coeffs = np.zeros((W, n), dtype=np.uint64) if want_coeffs else None
+        digests = np.zeros((eng.num_digests(log_n + rb, cap), 4), dtype=np.uint64) if want_digests else None
+        leaves = np.zeros((N, W), dtype=np.uint64) if want_leaves else None   # touched here: page faults are not timed
+        capv = np.zeros((1 << cap, 4), dtype=np.uint64)
+
+        def ptr(a):
+            return a.ctypes.data if a is not None else None
+
+        def once():
+            h = C.c_void_p()
+            eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, 0, ptr(coeffs), ptr(leaves), ptr(digests), capv.ctypes.data,
+                                           C.byref(h)))
+            eng.lib.p2hot_batch_free(h)
+        once()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once()  # synchronous: the call returns when the caller's buffers are filled
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        g = golden(gname) if gname else None
+        out[name] = {"workload": what, "ms": ms, "GFE/s": W * N / ms / 1e6, "pcie_inclusive": True,
+                     **({"cap_checked": capv.tolist() == g["cap"]} if g else {})}
+
+    base = "p2hot_commit (host pointers, pageable memory) C3 wires: W=135, 2^20 rows, rate 1/8, cap 4; 1.1 GB of columns in, "
+    run("host_c3_wires_coeffs_digests", 135, 20, base + "1.1 GB of coefficients + 0.54 GB of digests + cap out (leaf matrix stays on the device)",
+        True, True, False, "c3_wires")
+    run("host_c3_wires_digests_on_device", 135, 20, base + "coefficients + cap out; digests and leaves stay behind the handle (p2hot_batch_paths / _rows)",
+        True, False, False, "c3_wires")
+    run("host_c3_wires_leaves_back", 135, 20, base + "coefficients + digests + cap + the 9.1 GB row-major leaf matrix out (P2HOT_LEAVES=host)",
+        True, True, True, "c3_wires", reps=2)
+    run("host_k12_wires", 135, 12, "p2hot_commit (host pointers) at recursion size: W=135, 2^12 rows, rate 1/8, cap 4; coefficients + digests + cap out",
+        True, True, False, None, reps=20)
+
+
 def other_configs(eng, torch, reps=3):
     """Driver-timed lines for the other BASELINE shapes (extra keys of the JSON line; the headline is unchanged):
     each is `reps` timed repetitions after one warm-up, inputs resident in HBM, synchronised wall time."""
@@ -149,12 +212,16 @@ def other_configs(eng, torch, reps=3):
 
     commit_line("c2_wires", 135, 16, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 135, 1 << 16),
                 "C2: from_values W=135, 2^16 rows, rate 1/8, cap 4")
+    commit_line("c3_constants_sigmas", 84, 20, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 84, 1 << 20),
+                "C3: from_values W=84 (constants + sigmas: the commitment CircuitBuilder::build makes, circuit_builder.rs:1182-1191), "
+                "2^20 rows, rate 1/8, cap 4")
     commit_line("c3_zs_partial_products", 20, 20, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 20, 1 << 20),
                 "C3: from_values W=20 (Zs + partial products), 2^20 rows, rate 1/8, cap 4")
     commit_line("c3_quotient_chunks", 16, 20, 3, 4, False, splitmix_columns_torch(torch, dev, 0, 16, 1 << 20),
                 "C3: from_coeffs W=16 (quotient chunks), 2^20 rows, rate 1/8, cap 4")
     commit_line("c4_fibonacci_trace", 2, 22, 1, 4, True, eng.dev(fibonacci_trace(22)),
                 "C4: from_values W=2 (Fibonacci trace), 2^22 rows, rate 1/2, cap 4 (hash_or_noop leaves)")
+    host_pointer_lines(eng, out, reps)
     for name, log_n, rb in (("c3_fri_commit_phase", 20, 3), ("c4_fri_commit_phase", 22, 1)):
         planes = splitmix_columns_torch(torch, dev, 500, 2, 1 << log_n)
         ch = Challenger(eng)
@@ -258,6 +325,54 @@ def other_configs(eng, torch, reps=3):
                     "C5 on one GPU: from_values W=135, 2^23 rows, rate 1/8, cap 4 (the shape bench.py --gpus 8 shards over 8 ranks)", reps=2)
         torch.cuda.empty_cache()
     return out
+
+
+def valu_line(e, launches_per_step, h):
+    """issue-rate view of the dominant kernel: SQ_INSTS_VALU (committed PMC pass) over the live launch time, priced against
+    the rate tools/ubench.hip measured for the instruction class the kernel is made of (profiles/r03_ubench.txt)"""
+    if not e or not e.get("sq_insts_valu_per_launch"):
+        return None
+    ub = ubench_cycles()
+    vop3 = ub.get("v_mad_u64_u32", 4.66)   # carry / 64-bit / multiply-add class: what the Poseidon kernels issue
+    vop2 = ub.get("v_add_u32", 3.16)       # plain 32-bit VOP2
+    n = e["sq_insts_valu_per_launch"] / launches_per_step
+    ach = n / (h["ms_per_launch"] * 1e-3) / 1e9
+    peak = 1024 * 2.4 / vop3
+    return {"kernel": "hash_leaves", "insts_per_launch": n, "unit": "Gwave-inst/s", "achieved": ach, "peak": peak, "frac": ach / peak,
+            "peak_vop2": 1024 * 2.4 / vop2, "clock_ghz_under_pmc": e.get("clock_ghz"),
+            "note": "peak = 1024 SIMDs x 2.4 GHz / %.2f cycles: the measured rate of a saturating stream of v_mad_u64_u32 "
+                    "(profiles/r03_ubench.txt; carry, 64-bit and VOP3 instructions measure the same, a plain 32-bit VOP2 %.2f); "
+                    "frac ~ 1 means the SIMDs cannot issue this instruction mix faster; SQ_INSTS_VALU from profiles/pmc_traffic.json" % (vop3, vop2)}
+
+
+def ntt_roofline(kern, W, n_local, rows_local, steps, entry):
+    """HBM view of the four NTT launches of a step (each reads and writes its elements once):
+    iNTT strided + contiguous 16*W*n each, LDE strided 8*W*n + 8*W*N, LDE contiguous 16*W*N"""
+    per = {"ntt_intt_strided": (16 * W * n_local, ("ntt_limbpass_kernel<true", ",4,")),
+           "ntt_intt_contig": (16 * W * n_local, ("ntt_limbpass_kernel<true,12,0",)),
+           "ntt_lde_strided": (8 * W * n_local + 8 * W * rows_local, ("ntt_limbpass_kernel<false", ",4,")),
+           "ntt_lde_contig": (16 * W * rows_local, ("ntt_limbpass_kernel<false,12,0",))}
+    passes, tot_b, tot_ms = {}, 0, 0.0
+    for k, (b, needles) in per.items():
+        if k not in kern:
+            continue
+        ms = kern[k]["ms_per_launch"]
+        e = entry(*needles)
+        passes[k] = {"ms": ms, "algorithmic_bytes": b, "achieved": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": e["hbm_bytes_per_launch"] if e else None,
+                     "valu_insts_per_element": (e["sq_insts_valu_per_launch"] * 64 / (b / 16)) if e and e.get("sq_insts_valu_per_launch") else None}
+        tot_b += b
+        tot_ms += ms * kern[k]["launches"] / steps
+    if not passes:
+        return None
+    big = passes.get("ntt_lde_contig") or max(passes.values(), key=lambda p: p["algorithmic_bytes"])
+    return {"kernel": "ntt_limbpass_kernel (24-bit-limb radix-8 passes, nttl.hpp): the contiguous pass of the coset LDE; `passes` has all four",
+            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": big["achieved"], "frac": big["frac"],
+            "family_ms_per_step": tot_ms, "family_achieved": tot_b / (tot_ms * 1e-3) / 1e9, "family_frac": tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "passes": passes,
+            "note": "HBM-bound by design; the passes retire ~%s VALU instructions per element (carry-free 24-bit limbs: half of them "
+                    "plain 32-bit adds) and run with VALU, LDS and HBM all busy (profiles/*_pmc_sq.txt)"
+                    % ("%.0f" % big["valu_insts_per_element"] if big.get("valu_insts_per_element") else "~30")}
 
 
 def main():
@@ -366,6 +481,11 @@ def main():
         rows_local = N // world
         ab = algorithmic_bytes(W, log_n, rb)
         kern = {k: {"ms_per_launch": v["ms"] / max(v["launches"], 1), "launches": v["launches"]} for k, v in prof.items()}
+        for agg in ("strided", "contig"):  # the aggregated keys of rounds 1-2: all passes of that kind in a step
+            parts = [v for k, v in kern.items() if k.startswith("ntt_") and k.endswith("_" + agg)]
+            if parts:
+                ln = sum(v["launches"] for v in parts)
+                kern["ntt_pass_" + agg] = {"ms_per_launch": sum(v["ms_per_launch"] * v["launches"] for v in parts) / ln, "launches": ln}
         h = kern.get("hash_leaves", {"ms_per_launch": float("nan"), "launches": args.steps})
         # the sponge runs once per coset block when it is overlapped with the next block's LDE
         launches_per_step = max(1, h["launches"] // args.steps)
@@ -389,32 +509,20 @@ def main():
                                    "async column chunks overlapped with the NTTs; RCCL all-gather of %s" % (world, "digests + cap" if gather_digests else "the cap (digests stay with the row owner)")},
             "roofline": {"kernel": "hash_leaves_kernel<ColMajorReader> (Poseidon leaf sponge)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (lambda t: t / launches_per_step if t else None)(pmc_traffic(W, log_n, rb, cap, world, "hash_leaves_kernel")),
+                         "traffic": (lambda e: e["hbm_bytes_per_launch"] / launches_per_step if e else None)(
+                             pmc_entry(W, log_n, rb, cap, world, "hash_leaves_kernel", "ColMajorReader")),
+                         "traffic_stale": pmc_stale(),
                          "launches_per_step": launches_per_step,
-                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                           "traffic_stale = the kernel sources changed since they were collected)",
                          **({"overlap": "launched on a second stream beside the next coset block's LDE; durations are wall "
                                         "time while sharing the GPU"} if launches_per_step > 1 else {}),
                          "note": "integer-VALU bound by nature (%.3g permutations per launch, %.1f Gperm/s); "
                                  "algorithmic bytes per launch = 8*W*rows + 32*rows = %d"
                                  % (perms, perms / (h["ms_per_launch"] * 1e-3) / 1e9, hash_bytes)},
-            "valu": (lambda n: None if not n else {
-                "kernel": "hash_leaves", "insts_per_launch": n / launches_per_step, "unit": "Gwave-inst/s",
-                "achieved": n / launches_per_step / (h["ms_per_launch"] * 1e-3) / 1e9,
-                "peak": 1024 * 2.4 / 2, "frac": n / launches_per_step / (h["ms_per_launch"] * 1e-3) / 1e9 / (1024 * 2.4 / 2),
-                "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VOP2; measured on this chip (tools/ubench) a "
-                        "wave64 VOP3 / carry / v_mad_u64_u32 instruction occupies ~4.5 cycles, so a VOP3-dominated "
-                        "integer kernel saturates its SIMDs near frac 0.5; SQ_INSTS_VALU from profiles/pmc_traffic.json"})(
-                pmc_valu(W, log_n, rb, cap, world)),
-            "roofline_ntt": (lambda k: None if not k else {
-                "kernel": "ntt_regpass_kernel, contiguous (last) passes of the iNTT and of the %d-coset LDE" % (1 << rb),
-                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                # per step the two contiguous passes read and write every iNTT / LDE element once
-                "achieved": (16 * W * (n // world if world > 1 else n) + 16 * W * rows_local)
-                            / (k["ms_per_launch"] * 1e-3 * k["launches"] / args.steps) / 1e9,
-                "frac": (16 * W * (n // world if world > 1 else n) + 16 * W * rows_local)
-                        / (k["ms_per_launch"] * 1e-3 * k["launches"] / args.steps) / 1e9 / HBM_PEAK_GBS,
-                "note": "HBM-bound by design, measured VALU-bound (about 210 VALU instructions per element-pass, profiles/*_pmc_sq.txt)"})(
-                kern.get("ntt_pass_contig")),
+            "valu": valu_line(pmc_entry(W, log_n, rb, cap, world, "hash_leaves_kernel", "ColMajorReader"), launches_per_step, h),
+            "roofline_ntt": ntt_roofline(kern, W, n if world == 1 else n // world, rows_local, args.steps,
+                                         lambda *needles: pmc_entry(W, log_n, rb, cap, world, *needles)),
             "cap_checked": cap_checked,
             "kernels": kern,
             "algorithmic_bytes_per_step": ab,

@@ -410,6 +410,7 @@ extern "C" int p2hot_commit_sharded_dev(p2hot_ctx *ctx, p2hot_comm *comm, const 
                                         unsigned log_n, unsigned rate_bits, unsigned cap_height, int is_values, int gather_digests,
                                         unsigned pipeline_chunks, uint64_t *d_coeffs_all, uint64_t *d_lde, size_t lde_stride,
                                         uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap) {
+    DeviceGuard restore_caller_device_(0);  // ranks' devices are visited below; the caller's comes back on return
     if (!ctx) return P2HOT_EINVAL;
     if (!comm || comm->ctx != ctx || comm->kind == p2hot_comm::GROUP) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: the communicator belongs to another context");
     ShardPlan p;
@@ -509,6 +510,7 @@ static int sharded_commit_columns_core(std::vector<p2hot_comm *> &cs, std::vecto
 
 // ------------------------------------------------------------------ single process, all GPUs of the node (the Rust prover's mode)
 extern "C" int p2hot_group_create(int n_gpus, const int *devices, p2hot_group **out) {
+    DeviceGuard restore_caller_device_(0);  // the loop below visits every rank's GPU
     if (!out || n_gpus < 1 || (n_gpus & (n_gpus - 1))) return P2HOT_EINVAL;
     *out = nullptr;
     std::unique_ptr<p2hot_group> g(new p2hot_group());
@@ -571,6 +573,7 @@ extern "C" int p2hot_group_create(int n_gpus, const int *devices, p2hot_group **
 }
 
 extern "C" void p2hot_group_destroy(p2hot_group *g) {
+    DeviceGuard restore_caller_device_(0);  // the loop below visits every rank's GPU
     if (!g) return;
     for (auto *c : g->comm) p2hot_comm_destroy(c);
     for (auto *c : g->ctx) p2hot_ctx_destroy(c);
@@ -603,6 +606,7 @@ struct p2hot_sharded_batch {
 };
 
 extern "C" void p2hot_sharded_batch_free(p2hot_sharded_batch *b) {
+    DeviceGuard restore_caller_device_(0);  // the loop below visits every rank's GPU
     if (!b) return;
     for (size_t s = 0; s < b->g->ctx.size(); ++s) {
         p2hot_ctx *ctx = b->g->ctx[s];
@@ -620,6 +624,7 @@ extern "C" void p2hot_sharded_batch_free(p2hot_sharded_batch *b) {
 extern "C" int p2hot_group_commit(p2hot_group *g, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
                                   unsigned cap_height, int is_values, int shard_mode, unsigned pipeline_chunks, uint64_t *coeffs_out,
                                   uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out, p2hot_sharded_batch **handle_out) {
+    DeviceGuard restore_caller_device_(0);  // ranks' devices are visited below; the caller's comes back on return
     if (!g) return P2HOT_EINVAL;
     p2hot_ctx *ctx0 = g->ctx[0];
     P2_ENTER(ctx0);
@@ -787,6 +792,7 @@ static int sharded_open(p2hot_sharded_batch *b, const u64 *leaf_idx, size_t m, u
 }
 
 extern "C" int p2hot_sharded_batch_open(p2hot_sharded_batch *b, const uint64_t *leaf_idx, size_t m, uint64_t *rows_out, uint64_t *paths_out) {
+    DeviceGuard restore_caller_device_(0);  // ranks' devices are visited below; the caller's comes back on return
     if (!b) return P2HOT_EINVAL;
     p2hot_ctx *ctx0 = b->g->ctx[0];
     P2_ENTER(ctx0);
@@ -817,6 +823,7 @@ static int sharded_views(p2hot_group *g, const p2hot_sharded_batch *const *oracl
 
 extern "C" int p2hot_group_eval_openings(p2hot_group *g, const p2hot_sharded_batch *const *oracles, size_t n_oracles, const uint64_t *points,
                                          size_t n_points, uint64_t *out) {
+    DeviceGuard restore_caller_device_(0);  // ranks' devices are visited below; the caller's comes back on return
     if (!g) return P2HOT_EINVAL;
     p2hot_ctx *ctx = g->ctx[0];
     P2_ENTER(ctx);
@@ -844,6 +851,7 @@ extern "C" int p2hot_group_fri_proof_sizes(const p2hot_sharded_batch *const *ora
 extern "C" int p2hot_group_prove_openings(p2hot_group *g, const p2hot_fri_batch_info *batches, size_t n_batches,
                                           const p2hot_sharded_batch *const *oracles, size_t n_oracles, p2hot_challenger *challenger,
                                           const p2hot_fri_params *fp, p2hot_fri_proof *proof) {
+    DeviceGuard restore_caller_device_(0);  // ranks' devices are visited below; the caller's comes back on return
     if (!g) return P2HOT_EINVAL;
     p2hot_ctx *ctx = g->ctx[0];
     std::vector<OracleView> views;

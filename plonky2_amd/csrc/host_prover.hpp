@@ -32,6 +32,7 @@ struct CallGuard {
 };
 #define P2_ENTER(ctx)                                                                                                  \
     CallGuard guard_(ctx);                                                                                             \
+    DeviceGuard dev_guard_(ctx);                                                                                       \
     if (!(ctx)) return P2HOT_EINVAL;                                                                                   \
     if (!guard_.ok) return P2HOT_EBUSY /* the context's error text belongs to the call that is running */
 

@@ -272,7 +272,7 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
     constexpr unsigned C = 1u << LOG_C;
     constexpr int UPT = (1 << (TILE_LOG - P)) / NT;  // units per thread
     constexpr unsigned UW = 512u >> P;               // units per wave: a wave's units cover 512 consecutive tile elements
-    constexpr int UNROLL = FIRST ? UPT : 1;          // `raw` is indexed by uu: registers only when unrolled
+    [[maybe_unused]] constexpr int UNROLL = FIRST ? UPT : 1;  // `raw` is indexed by uu: registers only when unrolled
     const ntt::PassArgs &a = ra.a;
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll UNROLL

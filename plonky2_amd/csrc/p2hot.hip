@@ -133,6 +133,26 @@ struct ProfScope {
 
 #define P2_LAUNCH_CHECK(ctx) P2_HIP(ctx, hipGetLastError())
 
+// Makes the context's GPU the calling thread's current device for the scope (allocations, pinned memory and launches follow the
+// current device) and restores the caller's on exit.  Every entry point that takes a context holds one: after a p2hot_group_*
+// call -- which walks over the ranks' devices -- a single-context call on p2hot_group_ctx(group, r) must not inherit the last
+// rank's device.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const p2hot_ctx *ctx) {
+        if (!ctx) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    explicit DeviceGuard(int keep_current) { (void)keep_current; if (hipGetDevice(&prev) == hipSuccess) switched = true; }  // restore only
+    ~DeviceGuard() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 // ---- small device-to-host results (see p2hot_ctx::deferred)
@@ -211,6 +231,7 @@ static int h2d_columns(p2hot_ctx *ctx, void *d_dst, const uint64_t *const *cols,
 }
 
 static int scratch_get(p2hot_ctx *ctx, int slot, size_t bytes, void **out) {
+    DeviceGuard dev_guard_(ctx);
     auto &s = ctx->scratch[slot];
     if (s.cap < bytes) {
         if (s.p) {
@@ -228,6 +249,7 @@ static int scratch_get(p2hot_ctx *ctx, int slot, size_t bytes, void **out) {
 
 // block cache of the host-pointer entry points (see p2hot_ctx::pool_free)
 static int pool_alloc(p2hot_ctx *ctx, size_t bytes, void **out) {
+    DeviceGuard dev_guard_(ctx);
     if (bytes == 0) bytes = 8;
     size_t best = ctx->pool_free.size();
     for (size_t k = 0; k < ctx->pool_free.size(); ++k) {
@@ -254,6 +276,7 @@ static int pool_alloc(p2hot_ctx *ctx, size_t bytes, void **out) {
     return P2HOT_OK;
 }
 static void pool_release(p2hot_ctx *ctx, void *p) {
+    DeviceGuard dev_guard_(ctx);
     if (!p) return;
     auto it = ctx->pool_live.find(p);
     if (it == ctx->pool_live.end()) return;
@@ -369,6 +392,7 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
 
 extern "C" int p2hot_ctx_set_stream(p2hot_ctx *ctx, void *hip_stream) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     P2_HIP(ctx, stream_sync(ctx));
     ctx->stream = (hipStream_t)hip_stream;
     return P2HOT_OK;
@@ -389,6 +413,7 @@ static int check_oob(p2hot_ctx *ctx) {
 
 extern "C" int p2hot_ctx_sync(p2hot_ctx *ctx) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     P2_HIP(ctx, stream_sync(ctx));
     return check_oob(ctx);
 }
@@ -398,6 +423,7 @@ extern "C" const char *p2hot_last_error(const p2hot_ctx *ctx) { return ctx ? ctx
 // tuning knob: launches with at most `max_perms` leaves / nodes use the quad-cooperative Poseidon kernels (0 = never)
 extern "C" int p2hot_tune_quad(p2hot_ctx *ctx, size_t max_perms) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     ctx->quad_threshold = max_perms;
     return P2HOT_OK;
 }
@@ -405,6 +431,7 @@ extern "C" int p2hot_tune_quad(p2hot_ctx *ctx, size_t max_perms) {
 // tuning knob: launches with at most `max_perms` permutations use the word-per-lane Poseidon kernels (0 = never)
 extern "C" int p2hot_tune_row(p2hot_ctx *ctx, size_t max_perms) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     ctx->row_threshold = max_perms;
     return P2HOT_OK;
 }
@@ -412,6 +439,7 @@ extern "C" int p2hot_tune_row(p2hot_ctx *ctx, size_t max_perms) {
 // tuning knob: overlap the leaf sponge of coset block b with the LDE of block b+1 on a second stream (default on)
 extern "C" int p2hot_tune_overlap(p2hot_ctx *ctx, int on) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     ctx->overlap = on != 0;
     return P2HOT_OK;
 }
@@ -427,6 +455,7 @@ extern "C" int p2hot_tune_ntt(p2hot_ctx *ctx, int radix_bits) {
 
 extern "C" int p2hot_profile_enable(p2hot_ctx *ctx, int on) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     ctx->profiling = on != 0;
     return P2HOT_OK;
 }
@@ -631,7 +660,10 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
         const unsigned tiles_log = log_n - a.log_r - a.log_c;
         dim3 grid(1u << tiles_log, (unsigned)batch, (unsigned)zcount);
         size_t shmem = ((size_t)8) << (a.log_r + a.log_c);
-        ProfScope ps(ctx, a.log_c ? "ntt_pass_strided" : "ntt_pass_contig");
+        // live timing per (transform, pass kind): the iNTT, the coset LDE (scale tables) and plain forward transforms apart
+        const bool inv_t = roots.lo == ctx->inv.lo, lde_t = scale_mode == ntt::SCALE_TABLE;
+        ProfScope ps(ctx, a.log_c ? (inv_t ? "ntt_intt_strided" : lde_t ? "ntt_lde_strided" : "ntt_fwd_strided")
+                                  : (inv_t ? "ntt_intt_contig" : lde_t ? "ntt_lde_contig" : "ntt_fwd_contig"));
         if (ctx->use_regpass) {
             ntt::RegPassArgs ra{};
             ra.a = a;
@@ -747,6 +779,7 @@ static int check_log(p2hot_ctx *ctx, unsigned log_n, const char *what) {
 
 static int ntt_natural(p2hot_ctx *ctx, u64 *d_data, size_t batch, size_t stride, unsigned log_n, bool inverse) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     P2_TRY(check_log(ctx, log_n, "ntt"));
     const size_t n = (size_t)1 << log_n;
     if (batch == 0) return P2HOT_OK;
@@ -833,6 +866,7 @@ extern "C" int p2hot_coset_lde_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, siz
                                    unsigned log_n, unsigned rate_bits, uint64_t shift, size_t row_begin,
                                    size_t row_count, uint64_t *d_lde, size_t lde_stride) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     P2_TRY(check_log(ctx, log_n + rate_bits, "coset_lde"));
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
     if (W == 0 || row_count == 0) return P2HOT_OK;
@@ -851,6 +885,7 @@ extern "C" int p2hot_coset_lde_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, siz
 extern "C" int p2hot_transpose_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W,
                                    size_t rows, uint64_t *d_rowmajor) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     if (W == 0 || rows == 0) return P2HOT_OK;
     if (!d_colmajor || !d_rowmajor || col_stride < rows) P2_FAIL(ctx, P2HOT_EINVAL, "transpose: bad arguments");
     if (cdiv(W, 32) > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "transpose: W too large");
@@ -864,6 +899,7 @@ extern "C" int p2hot_transpose_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, s
 extern "C" int p2hot_reverse_index_bits_dev(p2hot_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t batch,
                                             size_t poly_stride, unsigned log_n) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     if (batch == 0) return P2HOT_OK;
     const size_t n = (size_t)1 << log_n;
     if (!d_in || !d_out || d_in == d_out || poly_stride < n || batch > 65535)
@@ -873,6 +909,7 @@ extern "C" int p2hot_reverse_index_bits_dev(p2hot_ctx *ctx, const uint64_t *d_in
 
 extern "C" int p2hot_poseidon_permute_dev(p2hot_ctx *ctx, uint64_t *d_states, size_t count) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     if (count == 0) return P2HOT_OK;
     if (!d_states) P2_FAIL(ctx, P2HOT_EINVAL, "poseidon_permute: null states");
     if (count <= ctx->row_threshold)  // the word-per-lane mapping (also what the challenger runs); larger batches: one permutation per lane
@@ -886,6 +923,7 @@ extern "C" int p2hot_poseidon_permute_dev(p2hot_ctx *ctx, uint64_t *d_states, si
 extern "C" int p2hot_field_selftest_dev(p2hot_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t count,
                                         uint64_t *d_out) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     if (count == 0) return P2HOT_OK;
     if (!d_a || !d_b || !d_out) P2_FAIL(ctx, P2HOT_EINVAL, "field_selftest: null pointer");
     P2HOT_LAUNCH(merkle::field_selftest_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream, d_a, d_b, count, d_out);
@@ -896,6 +934,7 @@ extern "C" int p2hot_field_selftest_dev(p2hot_ctx *ctx, const uint64_t *d_a, con
 extern "C" int p2hot_gather_rows_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t rows, size_t W,
                                      const uint64_t *d_idx, size_t m, uint64_t *d_out) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     if (W == 0 || m == 0) return P2HOT_OK;
     if (!d_colmajor || !d_idx || !d_out) P2_FAIL(ctx, P2HOT_EINVAL, "gather_rows: null pointer");
     if (rows > col_stride) P2_FAIL(ctx, P2HOT_EINVAL, "gather_rows: rows > col_stride");
@@ -984,6 +1023,7 @@ extern "C" int p2hot_merkle_dev(p2hot_ctx *ctx, const uint64_t *d_leaves, int la
                                 unsigned log_leaves, unsigned cap_height, size_t leaf_begin, size_t leaf_count,
                                 uint64_t *d_digests, uint64_t *d_cap) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     if (W > 0 && !d_leaves) P2_FAIL(ctx, P2HOT_EINVAL, "merkle: null leaves");
     if (W > 0xFFFFFFFFull) P2_FAIL(ctx, P2HOT_EINVAL, "merkle: leaf too wide");
     if (layout == 0) {
@@ -1003,6 +1043,7 @@ extern "C" int p2hot_commit_dev(p2hot_ctx *ctx, const uint64_t *d_cols, size_t c
                                 size_t row_count, uint64_t *d_coeffs, size_t coeff_stride, uint64_t *d_lde,
                                 size_t lde_stride, uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     P2_TRY(check_log(ctx, log_n + rate_bits, "commit"));
     const size_t n = (size_t)1 << log_n;
     const unsigned log_N = log_n + rate_bits;
@@ -1091,6 +1132,7 @@ static int challenger_io(p2hot_challenger *ch, size_t words, u64 **out) {
 
 extern "C" int p2hot_challenger_create(p2hot_ctx *ctx, p2hot_challenger **out) {
     if (!ctx || !out) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     p2hot_challenger *ch = new p2hot_challenger{ctx, nullptr, nullptr, 0};
     hipError_t e = hipMalloc((void **)&ch->d, sizeof(fri::Challenger));
     if (e != hipSuccess) {
@@ -1109,6 +1151,7 @@ extern "C" int p2hot_challenger_create(p2hot_ctx *ctx, p2hot_challenger **out) {
 
 extern "C" void p2hot_challenger_destroy(p2hot_challenger *ch) {
     if (!ch) return;
+    DeviceGuard dev_guard_(ch->ctx);
     (void)hipStreamSynchronize(ch->ctx->stream);
     if (ch->d_io) (void)hipFree(ch->d_io);
     (void)hipFree(ch->d);
@@ -1120,6 +1163,7 @@ static_assert(sizeof(p2hot_challenger_state) == sizeof(fri::Challenger), "challe
 extern "C" int p2hot_challenger_load(p2hot_challenger *ch, const p2hot_challenger_state *st) {
     if (!ch || !st) return P2HOT_EINVAL;
     p2hot_ctx *ctx = ch->ctx;
+    DeviceGuard dev_guard_(ctx);
     if (st->input_len >= 8 || st->output_len > 8) P2_FAIL(ctx, P2HOT_EINVAL, "challenger: buffer lengths out of range");
     P2_HIP(ctx, hipMemcpyAsync(ch->d, st, sizeof *st, hipMemcpyHostToDevice, ctx->stream));
     P2_HIP(ctx, stream_sync(ctx));
@@ -1129,6 +1173,7 @@ extern "C" int p2hot_challenger_load(p2hot_challenger *ch, const p2hot_challenge
 extern "C" int p2hot_challenger_store(p2hot_challenger *ch, p2hot_challenger_state *st) {
     if (!ch || !st) return P2HOT_EINVAL;
     p2hot_ctx *ctx = ch->ctx;
+    DeviceGuard dev_guard_(ctx);
     P2_HIP(ctx, hipMemcpyAsync(st, ch->d, sizeof *st, hipMemcpyDeviceToHost, ctx->stream));
     P2_HIP(ctx, stream_sync(ctx));
     return P2HOT_OK;
@@ -1147,6 +1192,7 @@ extern "C" int p2hot_challenger_step(p2hot_challenger *ch, const uint64_t *obser
                                      uint64_t *challenges, size_t n_challenges) {
     if (!ch) return P2HOT_EINVAL;
     p2hot_ctx *ctx = ch->ctx;
+    DeviceGuard dev_guard_(ctx);
     if ((n_observe && !observe) || (n_challenges && !challenges)) P2_FAIL(ctx, P2HOT_EINVAL, "challenger: null buffer");
     u64 *io;
     P2_TRY(challenger_io(ch, n_observe + n_challenges, &io));
@@ -1412,6 +1458,7 @@ extern "C" int p2hot_fri_final_poly_dev(p2hot_ctx *ctx, const uint64_t *const *d
                                         size_t n_batches, const uint64_t *points, const uint64_t alpha[2], unsigned log_n,
                                         uint64_t *d_final) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     if (!alpha) P2_FAIL(ctx, P2HOT_EINVAL, "fri_final_poly: null argument");
     return final_poly_core(ctx, d_poly_table, batch_offsets, n_batches, points, alpha, nullptr, log_n, d_final);
 }
@@ -1419,6 +1466,7 @@ extern "C" int p2hot_fri_final_poly_dev(p2hot_ctx *ctx, const uint64_t *const *d
 extern "C" int p2hot_eval_polys_dev(p2hot_ctx *ctx, const uint64_t *const *d_poly_table, size_t n_polys, unsigned log_n,
                                     const uint64_t *points, size_t n_points, uint64_t *d_out) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     P2_TRY(check_log(ctx, log_n, "eval_polys"));
     if (n_polys == 0 || n_points == 0) return P2HOT_OK;
     if (!d_poly_table || !points || !d_out) P2_FAIL(ctx, P2HOT_EINVAL, "eval_polys: null argument");
@@ -1451,6 +1499,7 @@ extern "C" int p2hot_partial_products_dev(p2hot_ctx *ctx, const uint64_t *d_wire
                                           const uint64_t *gammas, unsigned num_challenges, uint64_t *d_out,
                                           size_t out_stride) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     P2_TRY(check_log(ctx, log_n, "partial_products"));
     if (num_challenges == 0) return P2HOT_OK;
     const size_t n = (size_t)1 << log_n;
@@ -1514,6 +1563,7 @@ extern "C" int p2hot_partial_products_dev(p2hot_ctx *ctx, const uint64_t *d_wire
 extern "C" int p2hot_merkle_paths_dev(p2hot_ctx *ctx, const uint64_t *d_digests, unsigned log_leaves,
                                       unsigned cap_height, const uint64_t *d_idx, size_t m, uint64_t *d_out) {
     if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     if (cap_height > log_leaves) P2_FAIL(ctx, P2HOT_EINVAL, "merkle_paths: cap_height > log2(leaves)");
     const unsigned layers = log_leaves - cap_height;
     if (m == 0 || layers == 0) return P2HOT_OK;

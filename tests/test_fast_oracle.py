@@ -66,7 +66,7 @@ def test_golden_caps_file_matches_the_oracle_on_the_small_config(ora):
     import hashlib
     from plonky2_amd.util.synthetic import splitmix_columns_numpy
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "commit_caps.json")))
-    for name in ("c2_wires", "c3_wires", "c3_zs_partial_products", "c3_quotient_chunks", "c4_fibonacci_trace"):
+    for name in ("c2_wires", "c3_wires", "c3_constants_sigmas", "c3_zs_partial_products", "c3_quotient_chunks", "c4_fibonacci_trace"):
         assert name in g and len(g[name]["cap"]) == 1 << g[name]["cap_height"]
     r = g["c2_wires"]
     cols = splitmix_columns_numpy(0, r["W"], 1 << 12)   # the recipe at a smaller row count: cheap regression of the generator

@@ -45,7 +45,7 @@ def _sha_device_matrix(gpu, mat):
     return h.hexdigest()
 
 
-@pytest.mark.parametrize("name", ["c2_wires", "c3_wires", "c3_zs_partial_products", "c3_quotient_chunks", "c4_fibonacci_trace"])
+@pytest.mark.parametrize("name", ["c2_wires", "c3_wires", "c3_constants_sigmas", "c3_zs_partial_products", "c3_quotient_chunks", "c4_fibonacci_trace"])
 def test_baseline_commits_bit_exact_vs_oracle_goldens(gpu, name):
     """Every full-size commit of BASELINE.json's configs -- C2, the three C3 commits (W = 135 / 20 from_values, 16
     from_coeffs; 2^20 rows, rate 1/8, cap 4: W = 135 is the bench workload) and the C4 trace commit (W = 2, 2^22 rows,

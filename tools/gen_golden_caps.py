@@ -43,6 +43,7 @@ OUT = os.path.join(ROOT, "tests", "golden", "commit_caps.json")
 SHAPES = {
     "c2_wires": (135, 16, 3, 4, True, "splitmix"),
     "c3_wires": (135, 20, 3, 4, True, "splitmix"),        # the bench workload
+    "c3_constants_sigmas": (84, 20, 3, 4, True, "splitmix"),  # CircuitBuilder::build's commitment (circuit_builder.rs:1182-1191)
     "c3_zs_partial_products": (20, 20, 3, 4, True, "splitmix"),
     "c3_quotient_chunks": (16, 20, 3, 4, False, "splitmix"),
     "c4_fibonacci_trace": (2, 22, 1, 4, True, "fibonacci"),
