@@ -270,6 +270,20 @@ int p2hot_commit_salted(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, u
 int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate_bits, unsigned cap_height, int is_values,
                       unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out,
                       p2hot_batch **handle_out);
+/* M commitments of ONE shape in one set of launches (recursion workloads: the 2^12-row proofs of bench_recursion's chain,
+ * examples/bench_recursion.rs:317-345, are latency-bound one at a time).  M is a power of two, W * M <= 65535.
+ * Results equal M separate p2hot_commit calls (fri/oracle.rs:57-112 per proof), bit for bit.
+ * cols[m * W + e]: column e of proof m (n words).  coeffs_out [M][W][n], digests_out [M][p2hot_num_digests][4],
+ * caps_out [M][2^cap_height][4], each optional.  handles_out [M] (optional): one p2hot_batch per proof (rows, paths,
+ * coefficients, p2hot_eval_openings, p2hot_prove_openings); the proofs share their device blocks, which return to the
+ * context's cache when the last of the M handles is freed. */
+int p2hot_commit_many(p2hot_ctx *ctx, const uint64_t *const *cols, size_t M, size_t W, unsigned log_n, unsigned rate_bits,
+                      unsigned cap_height, int is_values, uint64_t *coeffs_out, uint64_t *digests_out, uint64_t *caps_out,
+                      p2hot_batch **handles_out);
+/* the device-pointer form: d_cols [W][M][n] (column e of every proof, then column e + 1, ...; becomes the coefficients in
+ * place), d_lde [W][M][N] in the same interleaving, d_digests [M][num_digests][4], d_cap [M][2^cap_height][4]. */
+int p2hot_commit_many_dev(p2hot_ctx *ctx, uint64_t *d_cols, size_t M, size_t W, unsigned log_n, unsigned rate_bits,
+                          unsigned cap_height, int is_values, uint64_t *d_lde, uint64_t *d_digests, uint64_t *d_cap);
 /* a handle over device buffers the CALLER owns (the outputs of p2hot_commit_dev): nothing is copied, p2hot_batch_free
  * frees only the handle.  d_coeffs [W][n] stride n, d_lde [W][N] stride N, d_digests the full tree's array. */
 int p2hot_batch_wrap_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, const uint64_t *d_lde, const uint64_t *d_digests, size_t W,

@@ -243,6 +243,14 @@ extern "C" {
         ctx: *mut P2hotCtx, cols: *mut P2hotCols, rate_bits: c_uint, cap_height: c_uint, is_values: c_int, flags: c_uint, coeffs_out: *mut u64,
         leaves_out: *mut u64, digests_out: *mut u64, cap_out: *mut u64, handle_out: *mut *mut P2hotBatch,
     ) -> c_int;
+    pub fn p2hot_commit_many(
+        ctx: *mut P2hotCtx, cols: *const *const u64, M: usize, W: usize, log_n: c_uint, rate_bits: c_uint, cap_height: c_uint, is_values: c_int,
+        coeffs_out: *mut u64, digests_out: *mut u64, caps_out: *mut u64, handles_out: *mut *mut P2hotBatch,
+    ) -> c_int;
+    pub fn p2hot_commit_many_dev(
+        ctx: *mut P2hotCtx, d_cols: *mut u64, M: usize, W: usize, log_n: c_uint, rate_bits: c_uint, cap_height: c_uint, is_values: c_int,
+        d_lde: *mut u64, d_digests: *mut u64, d_cap: *mut u64,
+    ) -> c_int;
     pub fn p2hot_batch_wrap_dev(
         ctx: *mut P2hotCtx, d_coeffs: *const u64, d_lde: *const u64, d_digests: *const u64, W: usize, log_n: c_uint, rate_bits: c_uint,
         cap_height: c_uint, out: *mut *mut P2hotBatch,

@@ -94,6 +94,8 @@ SIGNATURES = {
     "p2hot_commit": (i, [vp, C.POINTER(vp), sz, u, u, u, i, u, vp, vp, vp, vp, C.POINTER(vp)]),
     "p2hot_commit_salted": (i, [vp, C.POINTER(vp), sz, u, u, u, i, u, C.POINTER(vp), sz, vp, vp, vp, vp, C.POINTER(vp)]),
     "p2hot_commit_cols": (i, [vp, vp, u, u, i, u, vp, vp, vp, vp, C.POINTER(vp)]),
+    "p2hot_commit_many": (i, [vp, C.POINTER(vp), sz, sz, u, u, u, i, vp, vp, vp, C.POINTER(vp)]),
+    "p2hot_commit_many_dev": (i, [vp, vp, sz, sz, u, u, u, i, vp, vp, vp]),
     "p2hot_batch_wrap_dev": (i, [vp, vp, vp, vp, sz, u, u, u, C.POINTER(vp)]),
     "p2hot_batch_width": (sz, [vp]),
     "p2hot_batch_leaf_width": (sz, [vp]),

@@ -158,7 +158,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             const size_t c0 = b * kBlockCols, cnt = (c0 + kBlockCols <= W ? kBlockCols : W - c0);
             u64 *blk = d_work.u() + c0 * n;
             u64 *land = keep_vals ? d_vals.u() + c0 * n : blk;  // where the upload lands
-            P2_TRY(h2d_columns(ctx, land, cols + c0, cnt, n * 8, c0 * n * 8, W * n * 8, copy_stream));
+            P2_TRY(h2d_columns(ctx, land, cols + c0, cnt, n * 8, c0 * n * 8, W * n * 8 + S * N * 8, copy_stream));
 #ifndef P2HOT_EMU
             if (two_streams) {
                 P2_HIP(ctx, hipEventRecord(up[b], ctx->side));
@@ -180,7 +180,8 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         if (S) {
             // the salt vectors are LDE-value columns in natural order (oracle.rs:133-137): like the LDE values they reach the
             // leaves through transpose + reverse_index_bits (:97-98), i.e. column W + j of the committed matrix is salt_j[bitrev(r)]
-            P2_TRY(h2d_columns(ctx, d_salt.u(), salt_cols, S, N * 8, 0, S * N * 8, ctx->stream));
+            // (the pinned staging block is shared with the column uploads still in flight: the salts take the slots behind them)
+            P2_TRY(h2d_columns(ctx, d_salt.u(), salt_cols, S, N * 8, W * n * 8, W * n * 8 + S * N * 8, ctx->stream));
             P2_TRY(launch_bitrev(ctx, d_salt.u(), d_lde.u() + W * N, S, N, N, log_N));
         }
         P2_TRY(p2hot_merkle_dev(ctx, d_lde.u(), 0, N, LW, log_N, cap_height, 0, N, d_dig.u(), d_cap.u()));
@@ -289,6 +290,96 @@ extern "C" int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate
     return rc;
 }
 
+// ------------------------------------------------------------------ M commitments of one shape in one set of launches
+// Recursion-size proofs (2^12 rows) are latency-bound: a tree level is one ~12 us permutation chain whatever its width.  M
+// proofs of the same shape therefore share every launch: their columns are interleaved as [W][M][n] (column e of all proofs,
+// then column e+1, ...), so the iNTT and the coset LDE see W*M polynomials, and the M leaf matrices form ONE forest of
+// M * 2^cap_height subtrees (leaf L = m*N + r of width W, column stride M*N): the digest array is the M trees' arrays back to back,
+// the cap array the M caps -- exactly what M separate p2hot_commit_dev calls produce (fri/oracle.rs:57-112 per proof).
+extern "C" int p2hot_commit_many_dev(p2hot_ctx *ctx, uint64_t *d_cols, size_t M, size_t W, unsigned log_n, unsigned rate_bits,
+                                     unsigned cap_height, int is_values, uint64_t *d_lde, uint64_t *d_digests, uint64_t *d_cap) {
+    if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
+    P2_TRY(check_log(ctx, log_n + rate_bits, "commit_many"));
+    if (M == 0 || W == 0) return P2HOT_OK;
+    if (M & (M - 1)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: the number of proofs (%zu) must be a power of two", M);
+    unsigned lm = 0;
+    while (((size_t)1 << lm) < M) ++lm;
+    const unsigned log_N = log_n + rate_bits;
+    if (cap_height > log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: cap_height %u > log2(N) %u (merkle_tree.rs:195-200)", cap_height, log_N);
+    if (!d_cols || !d_lde || !d_cap || (p2hot_num_digests(log_N, cap_height) && !d_digests)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: null buffer");
+    if (W * M > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: W * M = %zu polynomials exceed one launch (65535)", W * M);
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    if (is_values) {
+        P2_TRY(ntt_natural(ctx, d_cols, W * M, n, log_n, true));  // "IFFT": in place, the block becomes the coefficients
+    } else {
+        P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(W * M * n, 256)), dim3(256), 0, ctx->stream, d_cols, W * M * n);
+        P2_LAUNCH_CHECK(ctx);
+    }
+    P2_TRY(p2hot_coset_lde_dev(ctx, d_cols, W * M, n, log_n, rate_bits, gl::COSET_SHIFT, 0, N, d_lde, N));
+    // one forest: M * 2^cap_height subtrees of 2^(log_N - cap_height) leaves
+    return p2hot_merkle_dev(ctx, d_lde, 0, M * N, W, log_N + lm, cap_height + lm, 0, M * N, d_digests, d_cap);
+}
+
+// the host-pointer form: cols[m * W + e] = column e of proof m (n words each).  coeffs_out [M][W][n], digests_out [M][nd][4],
+// caps_out [M][2^cap_height][4] (any may be NULL); handles_out [M] (optional): one p2hot_batch per proof, for p2hot_batch_rows /
+// _paths / _coeffs, p2hot_eval_openings and p2hot_prove_openings -- they share the device blocks, freed with the last handle.
+extern "C" int p2hot_commit_many(p2hot_ctx *ctx, const uint64_t *const *cols, size_t M, size_t W, unsigned log_n, unsigned rate_bits,
+                                 unsigned cap_height, int is_values, uint64_t *coeffs_out, uint64_t *digests_out, uint64_t *caps_out,
+                                 p2hot_batch **handles_out) {
+    P2_ENTER(ctx);
+    if (handles_out)
+        for (size_t m = 0; m < M; ++m) handles_out[m] = nullptr;
+    P2_TRY(check_log(ctx, log_n + rate_bits, "commit_many"));
+    if (M == 0 || W == 0) return P2HOT_OK;
+    if (M & (M - 1)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: the number of proofs (%zu) must be a power of two", M);
+    if (!cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: null column table");
+    for (size_t i = 0; i < M * W; ++i)
+        if (!cols[i]) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: column %zu of proof %zu is null", i % W, i / W);
+    const unsigned log_N = log_n + rate_bits;
+    if (cap_height > log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: cap_height %u > log2(N) %u (merkle_tree.rs:195-200)", cap_height, log_N);
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits, nd = p2hot_num_digests(log_N, cap_height), cap_words = (size_t)4 << cap_height;
+    PoolBuf d_co(ctx), d_lde(ctx), d_dig(ctx), d_cap(ctx);
+    P2_TRY(pool_alloc(ctx, W * M * n * 8, &d_co.p));
+    P2_TRY(pool_alloc(ctx, W * M * N * 8, &d_lde.p));
+    P2_TRY(pool_alloc(ctx, (nd ? nd : 1) * M * 32, &d_dig.p));
+    P2_TRY(pool_alloc(ctx, cap_words * M * 8, &d_cap.p));
+    auto body = [&]() -> int {
+        // interleave on the way in: column e of proof m lands in slot e * M + m (one staged copy for short columns)
+        std::vector<const uint64_t *> order(W * M);
+        for (size_t e = 0; e < W; ++e)
+            for (size_t m = 0; m < M; ++m) order[e * M + m] = cols[m * W + e];
+        P2_TRY(h2d_columns(ctx, d_co.u(), order.data(), W * M, n * 8, 0, W * M * n * 8, ctx->stream));
+        P2_TRY(p2hot_commit_many_dev(ctx, d_co.u(), M, W, log_n, rate_bits, cap_height, is_values, d_lde.u(), d_dig.u(), d_cap.u()));
+        if (coeffs_out)  // [M][W][n] <- [W][M][n]: one strided copy per proof
+            for (size_t m = 0; m < M; ++m)
+                P2_TRY(d2h_2d(ctx, coeffs_out + m * W * n, n * 8, d_co.u() + m * n, M * n * 8, n * 8, W));
+        if (digests_out && nd) P2_TRY(d2h(ctx, digests_out, d_dig.p, nd * M * 32));
+        if (caps_out) P2_TRY(d2h(ctx, caps_out, d_cap.p, cap_words * M * 8));
+        return P2HOT_OK;
+    };
+    int rc = sync_checked(ctx, body(), "commit_many");
+    if (rc == P2HOT_OK && handles_out) {
+        SharedBlocks *sh = new SharedBlocks;
+        sh->refs = (int)M;
+        sh->lde = d_lde.p;
+        sh->dig = d_dig.p;
+        sh->coef = d_co.p;
+        for (size_t m = 0; m < M; ++m) {
+            p2hot_batch *b = new p2hot_batch{ctx, d_lde.u() + m * N, W, N, d_dig.u() + m * nd * 4, log_N, cap_height};
+            b->d_coef = d_co.u() + m * n;
+            b->log_n = log_n;
+            b->rate_bits = rate_bits;
+            b->lde_stride = M * N;
+            b->coef_stride = M * n;
+            b->shared = sh;
+            handles_out[m] = b;
+        }
+        d_lde.p = d_dig.p = d_co.p = nullptr;  // owned by the handles now
+    }
+    return rc;
+}
+
 // a handle over device buffers the caller owns (the *_dev flow: p2hot_commit_dev outputs); nothing is copied or freed
 extern "C" int p2hot_batch_wrap_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, const uint64_t *d_lde, const uint64_t *d_digests,
                                     size_t W, unsigned log_n, unsigned rate_bits, unsigned cap_height, p2hot_batch **out) {
@@ -331,7 +422,8 @@ extern "C" int p2hot_batch_coeffs(p2hot_batch *b, size_t first, size_t count, ui
     const size_t n = (size_t)1 << b->log_n;
     PoolBuf tmp(ctx);
     P2_TRY(pool_alloc(ctx, count * n * 8, &tmp.p));
-    P2_HIP(ctx, hipMemcpyAsync(tmp.p, b->d_coef + first * n, count * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    P2_HIP(ctx, hipMemcpy2DAsync(tmp.p, n * 8, b->d_coef + first * b->col_stride_coef(), b->col_stride_coef() * 8, n * 8, count,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
     P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(count * n, 256)), dim3(256), 0, ctx->stream, tmp.u(), count * n);
     P2_LAUNCH_CHECK(ctx);
     P2_HIP(ctx, hipMemcpyAsync(out, tmp.p, count * n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -363,7 +455,7 @@ extern "C" int p2hot_batch_rows(p2hot_batch *b, const uint64_t *row_idx, size_t 
     P2_TRY(pool_alloc(ctx, m * LW * 8, &d_out.p));
     auto body = [&]() -> int {
         P2_HIP(ctx, hipMemcpyAsync(d_idx.p, row_idx, m * 8, hipMemcpyHostToDevice, ctx->stream));
-        P2_TRY(p2hot_gather_rows_dev(ctx, b->d_lde, b->N, b->N, LW, d_idx.u(), m, d_out.u()));
+        P2_TRY(p2hot_gather_rows_dev(ctx, b->d_lde, b->col_stride_lde(), b->N, LW, d_idx.u(), m, d_out.u()));
         P2_TRY(d2h(ctx, out, d_out.p, m * LW * 8));
         return P2HOT_OK;
     };
@@ -393,7 +485,15 @@ extern "C" int p2hot_batch_paths(p2hot_batch *b, const uint64_t *leaf_idx, size_
 
 extern "C" void p2hot_batch_free(p2hot_batch *b) {
     if (!b) return;
-    if (b->owned) {
+    if (b->shared) {  // a member of a batched commitment: the last one returns the blocks
+        if (b->shared->refs.fetch_sub(1) == 1) {
+            (void)hipStreamSynchronize(b->ctx->stream);
+            pool_release(b->ctx, b->shared->lde);
+            pool_release(b->ctx, b->shared->dig);
+            pool_release(b->ctx, b->shared->coef);
+            delete b->shared;
+        }
+    } else if (b->owned) {
         (void)hipStreamSynchronize(b->ctx->stream);
         pool_release(b->ctx, b->d_lde);
         pool_release(b->ctx, b->d_dig);
@@ -420,7 +520,10 @@ struct OracleView {
     const u64 *d_coef, *d_lde, *d_dig;
     size_t W, N;
     size_t S = 0;  // salt columns behind the W polynomial columns of d_lde (blinded oracles): a leaf is W + S words
+    size_t lde_stride = 0, coef_stride = 0;  // elements between columns when they are interleaved with other proofs' (0: N / n)
     size_t leaf_width() const { return W + S; }
+    size_t col_lde() const { return lde_stride ? lde_stride : N; }
+    size_t col_coef(unsigned log_n) const { return coef_stride ? coef_stride : ((size_t)1 << log_n); }
 };
 // fills proof->initial_leaves / initial_paths (query-major layout) for the Q host-resident query indices
 typedef std::function<int(const u64 *idx, size_t Q, u64 *leaves_out, u64 *paths_out)> InitialOpener;
@@ -441,7 +544,7 @@ extern "C" int p2hot_eval_openings(p2hot_ctx *ctx, const p2hot_batch *const *bat
         if (!B || B->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "oracle %zu is null or belongs to another context", b);
         if (B->log_n != batches[0]->log_n)
             P2_FAIL(ctx, P2HOT_EINVAL, "all oracles must have the same degree (oracle %zu: 2^%u vs 2^%u)", b, B->log_n, batches[0]->log_n);
-        views.push_back(OracleView{B->d_coef, B->d_lde, B->d_dig, B->W, B->N, B->S});
+        views.push_back(OracleView{B->d_coef, B->d_lde, B->d_dig, B->W, B->N, B->S, B->lde_stride, B->coef_stride});
     }
     return eval_openings_core(ctx, views, batches[0]->log_n, points, n_points, out);
 }
@@ -450,7 +553,7 @@ static int eval_openings_core(p2hot_ctx *ctx, const std::vector<OracleView> &vie
                               uint64_t *out) {
     std::vector<const u64 *> ptrs;
     for (auto &v : views)
-        for (size_t j = 0; j < v.W; ++j) ptrs.push_back(v.d_coef + (j << log_n));
+        for (size_t j = 0; j < v.W; ++j) ptrs.push_back(v.d_coef + j * v.col_coef(log_n));
     const size_t total = ptrs.size();
     if (total == 0) return P2HOT_OK;
     PoolBuf d_table(ctx), d_res(ctx), d_out(ctx);
@@ -557,7 +660,8 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
         if (!oracles[o] || oracles[o]->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: oracle %zu is null or belongs to another context", o);
         if (oracles[o]->log_n != oracles[0]->log_n || (fp && (oracles[o]->rate_bits != fp->rate_bits || oracles[o]->cap_height != fp->cap_height)))
             P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: oracle %zu was committed with another degree / rate / cap height", o);
-        views.push_back(OracleView{oracles[o]->d_coef, oracles[o]->d_lde, oracles[o]->d_dig, oracles[o]->W, oracles[o]->N, oracles[o]->S});
+        views.push_back(OracleView{oracles[o]->d_coef, oracles[o]->d_lde, oracles[o]->d_dig, oracles[o]->W, oracles[o]->N, oracles[o]->S,
+                                   oracles[o]->lde_stride, oracles[o]->coef_stride});
     }
     return prove_openings_core(ctx, batches, n_batches, views, oracles[0]->log_n, challenger, fp, proof, nullptr);
 }
@@ -595,7 +699,7 @@ static int prove_openings_core(p2hot_ctx *ctx, const p2hot_fri_batch_info *batch
             const size_t oi = bi.oracle_index[j], pi = bi.poly_index[j];
             if (oi >= n_oracles || pi >= oracles[oi].W)
                 P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings: batch %zu opens polynomial (%zu, %zu) which does not exist", i, oi, pi);
-            ptrs.push_back(oracles[oi].d_coef + (pi << log_n));
+            ptrs.push_back(oracles[oi].d_coef + pi * oracles[oi].col_coef(log_n));
         }
         offsets.push_back(ptrs.size());
         points.push_back(bi.point[0]);
@@ -677,7 +781,7 @@ static int prove_openings_core(p2hot_ctx *ctx, const p2hot_fri_batch_info *batch
         size_t w_off = 0;
         for (size_t o = 0; o < n_oracles && !open_initial; ++o) {
             const OracleView &B = oracles[o];
-            P2_TRY(p2hot_gather_rows_dev(ctx, B.d_lde, B.N, B.N, B.leaf_width(), d_idx, Q, d_il + Q * w_off));
+            P2_TRY(p2hot_gather_rows_dev(ctx, B.d_lde, B.col_lde(), B.N, B.leaf_width(), d_idx, Q, d_il + Q * w_off));
             P2_TRY(p2hot_merkle_paths_dev(ctx, B.d_dig, log_N, cap_height, d_idx, Q, d_ip + o * Q * 4 * layers0));
             w_off += B.leaf_width();
         }

@@ -1652,6 +1652,16 @@ struct p2hot_batch {
     unsigned log_n = 0, rate_bits = 0;
     bool owned = true;      // false: a view over caller-owned device buffers (p2hot_batch_wrap_dev)
     size_t S = 0;           // blinding (oracle.rs:123-137): salt columns W .. W+S-1 of d_lde; a leaf is W + S words wide
+    // a member of a batched commitment (p2hot_commit_many): its columns are interleaved with the other proofs' ([W][M][N]), the
+    // blocks are shared and go back to the pool with the last member
+    size_t lde_stride = 0, coef_stride = 0;  // elements between consecutive columns; 0 = N / n
+    struct SharedBlocks *shared = nullptr;
+    size_t col_stride_lde() const { return lde_stride ? lde_stride : N; }
+    size_t col_stride_coef() const { return coef_stride ? coef_stride : ((size_t)1 << log_n); }
+};
+struct SharedBlocks {
+    std::atomic<int> refs{0};
+    void *lde = nullptr, *dig = nullptr, *coef = nullptr;
 };
 
 // A device-resident column set [W][n] (Vec<PolynomialValues> / Vec<PolynomialCoeffs> that never visits the host)

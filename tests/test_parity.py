@@ -328,6 +328,80 @@ def test_salted_commit_vs_oracle(eng, ora, shape):
     assert (np.asarray(b.merkle_tree.get(rev)).reshape(-1) == o["leaves"][rev]).all()
 
 
+@pytest.mark.parametrize("shape", [(4, 5, 6, 3, 2, True), (2, 135, 5, 3, 4, True), (8, 3, 4, 1, 0, False), (1, 7, 5, 2, 1, True)])
+def test_commit_many_equals_separate_commits(eng, ora, shape):
+    """p2hot_commit_many: M same-shape commitments sharing every launch (columns interleaved [W][M][n], one forest of
+    M * 2^cap subtrees) -- coefficients, digests and caps of each proof equal its own from_values / from_coeffs
+    (fri/oracle.rs:57-112), and each proof's handle serves rows, paths and openings like a separate commitment's"""
+    import ctypes as C
+    from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, prove_openings
+    from plonky2_amd.iop.challenger import Challenger
+    M, W, log_n, rb, cap, is_values = shape
+    rng = np.random.default_rng(M * 1000 + W)
+    n, N = 1 << log_n, 1 << (log_n + rb)
+    cols = [[rand_field(rng, n, noncanonical=True) for _ in range(W)] for _ in range(M)]
+    ptrs = (C.c_void_p * (M * W))(*[cols[m][e].ctypes.data for m in range(M) for e in range(W)])
+    nd = eng.num_digests(log_n + rb, cap)
+    coeffs = np.zeros((M, W, n), dtype=np.uint64)
+    digests = np.zeros((M, max(nd, 1), 4), dtype=np.uint64)
+    caps = np.zeros((M, 1 << cap, 4), dtype=np.uint64)
+    handles = (C.c_void_p * M)()
+    eng.check(eng.lib.p2hot_commit_many(eng.ctx, ptrs, M, W, log_n, rb, cap, 1 if is_values else 0, coeffs.ctypes.data,
+                                        digests.ctypes.data, caps.ctypes.data, handles))
+    idx = np.array([0, N // 2 + 1, N - 1], dtype=np.uint64)
+    for m in range(M):
+        o = ora.commit(np.stack(cols[m]), rb, cap, is_values)
+        o["coeffs"] = o["coeffs"] % np.uint64(P)  # from_coeffs hands the caller's representatives through; outputs here are canonical
+        assert (coeffs[m] == o["coeffs"]).all(), m
+        assert (caps[m] == o["cap"]).all(), m
+        if nd:
+            assert (digests[m][:nd] == o["digests"]).all(), m
+        rows = np.zeros((3, W), dtype=np.uint64)
+        eng.check(eng.lib.p2hot_batch_rows(handles[m], idx.ctypes.data, 3, rows.ctypes.data))
+        assert (rows == o["leaves"][idx.astype(np.int64)]).all(), m
+        layers = log_n + rb - cap
+        if layers:
+            paths = np.zeros((3, layers, 4), dtype=np.uint64)
+            eng.check(eng.lib.p2hot_batch_paths(handles[m], idx.ctypes.data, 3, paths.ctypes.data))
+            for q, i in enumerate(idx):
+                assert ora.merkle_verify(rows[q], int(i), o["cap"], paths[q])
+        back = np.zeros((W, n), dtype=np.uint64)
+        eng.check(eng.lib.p2hot_batch_coeffs(handles[m], 0, W, back.ctypes.data))
+        assert (back == o["coeffs"]).all()
+    # an opening proof over a member of the batch equals the one over a separate commitment of the same proof
+    if rb >= 1 and log_n >= 5 and cap <= log_n:
+        m = M - 1
+        sep = PolynomialBatch.from_values(np.stack(cols[m]), rb, False, cap, engine=eng) if is_values else \
+            PolynomialBatch.from_coeffs(np.stack(cols[m]), rb, False, cap, engine=eng)
+        mem = PolynomialBatch(eng, C.c_void_p(handles[m]), W, log_n, rb, cap, caps[m])
+        handles[m] = None  # owned by `mem` now
+        pfs = []
+        for b in (sep, mem):
+            ch = Challenger(eng)
+            ch.observe_cap(caps[m])
+            zeta = ch.get_extension_challenge()
+            pfs.append(prove_openings([FriBatchInfo(zeta, [(0, pi) for pi in range(W)])], [b], ch, rb, cap, [2, 1], 3, 4, engine=eng))
+        assert repr(pfs[0]) == repr(pfs[1])
+        del mem
+    for m in range(M):
+        if handles[m]:
+            eng.lib.p2hot_batch_free(handles[m])
+    assert eng.lib.p2hot_ctx_trim(eng.ctx) == 0
+    # shape errors
+    assert eng.lib.p2hot_commit_many(eng.ctx, ptrs, 3, W, log_n, rb, cap, 1, None, None, caps.ctypes.data, None) != 0 or M < 3
+    # the device-pointer form on the interleaved layout [W][M][n] -> LDE [W][M][N], digests [M][nd][4], caps [M][2^cap][4]
+    inter = np.stack([np.stack([cols[m][e] for m in range(M)]) for e in range(W)])          # [W][M][n]
+    d_cols = eng.dev(inter.reshape(W * M, n))
+    d_lde, d_dig, d_cap = eng.mem.empty(W * M, N), eng.mem.empty(M * max(nd, 1), 4), eng.mem.empty(M << cap, 4)
+    eng.check(eng.lib.p2hot_commit_many_dev(eng.ctx, eng.ptr(d_cols), M, W, log_n, rb, cap, 1 if is_values else 0, eng.ptr(d_lde),
+                                            eng.ptr(d_dig), eng.ptr(d_cap)))
+    assert (eng.host(d_cap).reshape(M, 1 << cap, 4) == caps).all()
+    lde = eng.host(d_lde).reshape(W, M, N)
+    o0 = ora.commit(np.stack(cols[0]), rb, cap, is_values)
+    assert (lde[:, 0, :].T == o0["leaves"]).all()
+    assert (eng.host(d_cols).reshape(W, M, n)[:, 0, :] % np.uint64(P) == o0["coeffs"] % np.uint64(P)).all()
+
+
 def test_host_pointer_commit_abi(eng, ora):
     """p2hot_commit / p2hot_batch_rows: the entry points the Rust shim binds (W separate host vectors)"""
     import ctypes as C

@@ -389,7 +389,16 @@ def test_host_session_handles_and_errors(eng, ora):
     pr = _lib.FriProof(bufs[0].ctypes.data, bufs[1].ctypes.data, 0, None, bufs[2].ctypes.data, bufs[3].ctypes.data,
                        bufs[4].ctypes.data, bufs[5].ctypes.data)
     info = (_lib.FriBatchInfo * 1)()
-    assert eng.lib.p2hot_prove_openings(eng.ctx, info, 0, h, 1, ch._h, C.byref(fp), C.byref(pr)) == _lib.EUNSUPPORTED
+    # FriParams::hiding is carried for the caller's transcript only (fri/mod.rs:148): the prover's FRI path does not depend on it
+    st = _lib.ChallengerState()
+    eng.check(eng.lib.p2hot_challenger_store(ch._h, C.byref(st)))
+    rc1 = eng.lib.p2hot_prove_openings(eng.ctx, info, 0, h, 1, ch._h, C.byref(fp), C.byref(pr))
+    assert rc1 != _lib.EUNSUPPORTED
+    first = [x.copy() for x in bufs]
+    eng.check(eng.lib.p2hot_challenger_load(ch._h, C.byref(st)))
+    fp.hiding = 0
+    assert eng.lib.p2hot_prove_openings(eng.ctx, info, 0, h, 1, ch._h, C.byref(fp), C.byref(pr)) == rc1
+    assert all((a == b_).all() for a, b_ in zip(first, bufs))
     assert eng.lib.p2hot_ctx_trim(eng.ctx) == _lib.OK
 
 
