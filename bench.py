@@ -182,6 +182,98 @@ def host_pointer_lines(eng, out, reps):
         True, True, False, None, reps=20)
 
 
+def recursion_lines(eng, torch, out):
+    """Recursion-size throughput (the two 2^12-row recursive proofs of bench_recursion's chain, examples/bench_recursion.rs:317-345):
+    one proof at a time is latency-bound, so (a) p2hot_commit_many commits M same-shape proofs in one set of launches and
+    (b) K host threads, each with its own context and stream, prove independent proofs concurrently."""
+    import threading
+    from plonky2_amd import Engine
+    from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, eval_openings, prove_openings
+    from plonky2_amd.iop.challenger import Challenger
+    dev = eng.mem.device
+    W, log_n, rb, cap = 135, 12, 3, 4
+    n, N = 1 << log_n, 1 << (log_n + rb)
+    nd = eng.num_digests(log_n + rb, cap)
+    ref_cap = None
+    rec = {"workload": "p2hot_commit_many_dev: M wires commitments (W=135, 2^12 rows, rate 1/8, cap 4) per call, device resident", "M": {}}
+    for M in (1, 8, 64):
+        inter = splitmix_columns_torch(torch, dev, 0, W, n).unsqueeze(1).repeat(1, M, 1).contiguous().reshape(W * M, n)  # [W][M][n]
+        d_lde, d_dig, d_cap = eng.mem.empty(W * M, N), eng.mem.empty(M * nd, 4), eng.mem.empty(M << cap, 4)
+
+        def run():
+            work = inter.clone()  # the call transforms its input in place
+            eng.check(eng.lib.p2hot_commit_many_dev(eng.ctx, eng.ptr(work), M, W, log_n, rb, cap, 1, eng.ptr(d_lde), eng.ptr(d_dig), eng.ptr(d_cap)))
+        run()
+        torch.cuda.synchronize()
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        caps = eng.host(d_cap).reshape(M, 1 << cap, 4)
+        if ref_cap is None:
+            ref_cap = eng.host(eng.commit(splitmix_columns_torch(torch, dev, 0, W, n), log_n, rb, cap, True)["cap"])
+        rec["M"][str(M)] = {"ms": ms, "commits_per_s": M / ms * 1e3, "caps_equal_single_commit": bool((caps == ref_cap[None]).all())}
+        del inter, d_lde, d_dig, d_cap
+    out["recursion_commit_many"] = rec
+
+    # (b) whole per-proof paths through the host-pointer entry points, K contexts side by side
+    cols = splitmix_columns_numpy(0, W, n)
+    zs = splitmix_columns_numpy(1000, 20, n)
+    quo = splitmix_columns_numpy(2000, 16, n)
+
+    def one_proof(e):
+        b_w = PolynomialBatch.from_values(cols, rb, False, cap, engine=e)
+        b_z = PolynomialBatch.from_values(zs, rb, False, cap, engine=e)
+        b_q = PolynomialBatch.from_coeffs(quo, rb, False, cap, engine=e)
+        ch = Challenger(e)
+        ch.observe_elements(np.arange(8, dtype=np.uint64))
+        zeta = ch.get_extension_challenge()
+        gz = [(zeta[0] * 7) % P, zeta[1]]
+        oracles = [b_w, b_z, b_q]
+        eval_openings(oracles, [zeta, gz], e)
+        allp = [(oi, pi) for oi, w in enumerate((135, 20, 16)) for pi in range(w)]
+        nxt = [(oi, pi) for oi, w in enumerate((135, 20)) for pi in range(w)]
+        return prove_openings([FriBatchInfo(zeta, allp), FriBatchInfo(gz, nxt)], oracles, ch, rb, cap, [4, 4], 16, 28, engine=e)["pow_witness"]
+
+    rec = {"workload": "K host threads x (3 commits from host columns + OpeningSet + prove_openings) at 2^12 rows, one context and stream per "
+                       "thread, host-pointer entry points (PCIe included)", "K": {}}
+    for K in (1, 4, 8):
+        per, results, errs = 12, [None] * K, []
+
+        def worker(k):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    e = Engine(eng.mem.device_index if hasattr(eng.mem, "device_index") else 0)
+                    one_proof(e)
+                    barrier.wait()
+                    for _ in range(per):
+                        results[k] = one_proof(e)
+                    e.sync()
+                    barrier.wait()
+                    e.close()
+            except Exception as ex:  # noqa: BLE001
+                errs.append(repr(ex))
+                barrier.abort()
+        barrier = threading.Barrier(K + 1)
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(K)]
+        for t in ths:
+            t.start()
+        try:
+            barrier.wait()
+            t0 = time.perf_counter()
+            barrier.wait()
+            dt = time.perf_counter() - t0
+        except threading.BrokenBarrierError:
+            dt = float("nan")
+        for t in ths:
+            t.join()
+        rec["K"][str(K)] = {"proofs_per_s": K * per / dt, "ms_per_proof_per_thread": dt / per * 1e3,
+                            "same_witness_on_every_thread": len(set(results)) == 1, **({"errors": errs[:2]} if errs else {})}
+    out["recursion_proofs_concurrent_contexts"] = rec
+
+
 def other_configs(eng, torch, reps=3):
     """Driver-timed lines for the other BASELINE shapes (extra keys of the JSON line; the headline is unchanged):
     each is `reps` timed repetitions after one warm-up, inputs resident in HBM, synchronised wall time."""
@@ -222,6 +314,7 @@ def other_configs(eng, torch, reps=3):
     commit_line("c4_fibonacci_trace", 2, 22, 1, 4, True, eng.dev(fibonacci_trace(22)),
                 "C4: from_values W=2 (Fibonacci trace), 2^22 rows, rate 1/2, cap 4 (hash_or_noop leaves)")
     host_pointer_lines(eng, out, reps)
+    recursion_lines(eng, torch, out)
     for name, log_n, rb in (("c3_fri_commit_phase", 20, 3), ("c4_fri_commit_phase", 22, 1)):
         planes = splitmix_columns_torch(torch, dev, 500, 2, 1 << log_n)
         ch = Challenger(eng)
