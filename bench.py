@@ -532,6 +532,24 @@ def main():
     c0, c1 = job.column_range
     cols = splitmix_columns_torch(torch, eng.mem.device, c0, c1 - c0, n)
 
+    # preflight (before anything is timed): peer access between the node's GPUs, the transport that was bound, and a 1 MB
+    # all-gather through the library's own exchange path checked on every rank -- a broken fabric fails here, by name
+    preflight = None
+    if world > 1:
+        preflight = {"transport": job.comm.transport}
+        try:
+            nd_ = torch.cuda.device_count()
+            preflight["peer_access"] = [bool(torch.cuda.can_device_access_peer(local_rank, j)) for j in range(nd_) if j != local_rank] if backend == "nccl" else None
+        except Exception as ex:  # noqa: BLE001
+            preflight["peer_access"] = "query failed: %r" % (ex,)
+        t_pf = time.perf_counter()
+        try:
+            job.comm.selftest(1 << 20)
+            preflight["selftest"] = "ok"
+        except Exception as ex:  # noqa: BLE001
+            raise SystemExit("bench preflight: the 1 MB all-gather through the %s transport failed on rank %d: %s" % (job.comm.transport, rank, ex))
+        preflight["selftest_ms"] = (time.perf_counter() - t_pf) * 1e3
+
     def step():
         job.run(cols)
 
@@ -562,10 +580,20 @@ def main():
         cap_checked = eng.host(job.cap).tolist() == g["cap"]
         if not cap_checked:
             raise SystemExit("bench: the Merkle cap of the timed commit differs from the oracle's golden cap")
+    rank_rows = None
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.mem.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt_local, dt = dt, float(t.item())
+        # one row per rank: its own wall time, the span of its exchanges on the communication stream, the sum of its compute
+        # kernels and the kernel table -- a slow curve is diagnosed from ONE driver run
+        ex_ms = prof.get("exchange", {"ms": 0.0})["ms"] / args.steps
+        comp_ms = sum(v["ms"] for k, v in prof.items() if k != "exchange") / args.steps
+        mine = {"rank": rank, "device": torch.cuda.get_device_name(local_rank), "transport": job.comm.transport, "ms_per_step": dt_local / args.steps * 1e3,
+                "exchange_ms": ex_ms, "compute_ms": comp_ms, "preflight": preflight,
+                "kernels": {k: round(v["ms"] / max(v["launches"], 1), 4) for k, v in prof.items()}}
+        rank_rows = [None] * world
+        dist.all_gather_object(rank_rows, mine)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -617,6 +645,7 @@ def main():
             "roofline_ntt": ntt_roofline(kern, W, n if world == 1 else n // world, rows_local, args.steps,
                                          lambda *needles: pmc_entry(W, log_n, rb, cap, world, *needles)),
             "cap_checked": cap_checked,
+            **({"ranks": rank_rows} if rank_rows else {}),
             "kernels": kern,
             "algorithmic_bytes_per_step": ab,
             "commit_hbm_frac": ab["total"] / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,

@@ -416,6 +416,9 @@ int p2hot_comm_create_callback(p2hot_ctx *ctx, int rank, int world, p2hot_allgat
 void p2hot_comm_destroy(p2hot_comm *comm);
 int p2hot_comm_rank(const p2hot_comm *comm);
 int p2hot_comm_world(const p2hot_comm *comm);
+/* preflight (collective: every rank calls it): a `bytes`-sized pattern slice per rank is all-gathered the way the commit
+ * exchanges coefficients and caps, and every rank checks every slice; P2HOT_ECOMM with a named cause on failure */
+int p2hot_comm_selftest(p2hot_comm *comm, size_t bytes);
 /* columns [first, first + count) of W are the ones rank `rank` of `world` transforms in the iNTT stage */
 int p2hot_shard_columns(size_t W, int world, int rank, size_t *first, size_t *count);
 /* from_values / from_coeffs (fri/oracle.rs:57-112) of this rank's share, DEVICE pointers, asynchronous:

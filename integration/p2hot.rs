@@ -298,6 +298,7 @@ extern "C" {
     pub fn p2hot_comm_destroy(comm: *mut P2hotComm);
     pub fn p2hot_comm_rank(comm: *const P2hotComm) -> c_int;
     pub fn p2hot_comm_world(comm: *const P2hotComm) -> c_int;
+    pub fn p2hot_comm_selftest(comm: *mut P2hotComm, bytes: usize) -> c_int;
     pub fn p2hot_shard_columns(W: usize, world: c_int, rank: c_int, first: *mut usize, count: *mut usize) -> c_int;
     pub fn p2hot_commit_sharded_dev(
         ctx: *mut P2hotCtx, comm: *mut P2hotComm, d_cols_local: *const u64, col_stride: usize, W: usize, log_n: c_uint, rate_bits: c_uint,

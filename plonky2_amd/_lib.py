@@ -124,6 +124,7 @@ SIGNATURES = {
     "p2hot_comm_destroy": (None, [vp]),
     "p2hot_comm_rank": (i, [vp]),
     "p2hot_comm_world": (i, [vp]),
+    "p2hot_comm_selftest": (i, [vp, sz]),
     "p2hot_shard_columns": (i, [sz, i, i, C.POINTER(sz), C.POINTER(sz)]),
     "p2hot_commit_sharded_dev": (i, [vp, vp, vp, sz, sz, u, u, u, i, i, u, vp, vp, sz, vp, vp, vp]),
     "p2hot_group_create": (i, [i, C.POINTER(i), C.POINTER(vp)]),

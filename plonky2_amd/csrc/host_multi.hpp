@@ -225,6 +225,9 @@ static int gather_start(std::vector<p2hot_comm *> &cs, std::vector<u64 *> &base,
         P2_TRY(comm_events(cs[s], slot + 1));
         P2_HIP(ctx, hipEventRecord(cs[s]->ev_ready[slot], ctx->stream));
     }
+    // live timing (p2hot_profile_enable): the span of this exchange on rank 0's communication stream, waits for the peers'
+    // slices included -- what a slow scaling curve is diagnosed with ("exchange" next to the compute kernels of the same rank)
+    ProfScope exchange_scope(c0->ctx, "exchange", c0->comm_stream, true);
     const bool rccl_path = c0->kind == p2hot_comm::RCCL || (c0->kind == p2hot_comm::GROUP && c0->group->use_rccl);
     if (rccl_path) {
         rccl::Api &a = rccl::api();
@@ -422,6 +425,44 @@ extern "C" int p2hot_commit_sharded_dev(p2hot_ctx *ctx, p2hot_comm *comm, const 
     std::vector<p2hot_comm *> cs{comm};
     std::vector<ShardArgs> as{ShardArgs{d_cols_local, col_stride, d_coeffs_all, d_lde, lde_stride, d_leaves, d_digests, d_cap}};
     return sharded_commit_core(cs, as, p, is_values, gather_digests, pipeline_chunks);
+}
+
+// Preflight of a process-per-GPU communicator: every rank contributes a `bytes`-sized slice of a known pattern, the slices
+// are all-gathered exactly as the commit does it (grouped broadcasts / the caller's transport, the communication stream, the
+// event hand-over), and every rank checks every slice.  A broken binding, a missing peer path or a transport that returns
+// early fails HERE with a named cause instead of as a wrong cap (or a hang) inside the timed region.
+extern "C" int p2hot_comm_selftest(p2hot_comm *comm, size_t bytes) {
+    if (!comm || !comm->ctx) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = comm->ctx;
+    DeviceGuard dev_guard_(ctx);
+    if (comm->kind == p2hot_comm::GROUP) P2_FAIL(ctx, P2HOT_EINVAL, "comm_selftest: use it on a process-per-GPU communicator");
+    if (bytes == 0 || bytes % 8) P2_FAIL(ctx, P2HOT_EINVAL, "comm_selftest: bytes must be a positive multiple of 8");
+    const size_t world = (size_t)comm->world, words = bytes / 8;
+    u64 *d = nullptr;
+    P2_HIP(ctx, hipMalloc((void **)&d, world * bytes));
+    std::vector<u64> host(world * words, ~0ull);
+    for (size_t i = 0; i < words; ++i) host[(size_t)comm->rank * words + i] = ((u64)(comm->rank + 1) << 40) ^ (i * 0x9E3779B97F4A7C15ull);
+    int rc = P2HOT_OK;
+    auto body = [&]() -> int {
+        P2_HIP(ctx, hipMemcpyAsync(d, host.data(), world * bytes, hipMemcpyHostToDevice, ctx->stream));
+        std::vector<p2hot_comm *> cs{comm};
+        std::vector<u64 *> base{d};
+        std::vector<size_t> offs(world);
+        for (size_t r = 0; r < world; ++r) offs[r] = r * bytes;
+        P2_TRY(gather_start(cs, base, offs, bytes, 0));
+        P2_TRY(gather_wait(cs, 0));
+        P2_HIP(ctx, hipMemcpyAsync(host.data(), d, world * bytes, hipMemcpyDeviceToHost, ctx->stream));
+        P2_HIP(ctx, stream_sync(ctx));
+        for (size_t r = 0; r < world; ++r)
+            for (size_t i = 0; i < words; ++i)
+                if (host[r * words + i] != (((u64)(r + 1) << 40) ^ (i * 0x9E3779B97F4A7C15ull)))
+                    P2_FAIL(ctx, P2HOT_ECOMM, "comm_selftest: rank %d did not receive rank %zu's slice (word %zu): the %s transport delivered nothing or stale data",
+                            comm->rank, r, i, comm->kind == p2hot_comm::RCCL ? "RCCL" : "caller-supplied");
+        return P2HOT_OK;
+    };
+    rc = body();
+    (void)hipFree(d);
+    return rc;
 }
 
 extern "C" int p2hot_shard_columns(size_t W, int world, int rank, size_t *first, size_t *count) {

@@ -176,6 +176,11 @@ class Communicator:
             engine.check(engine.lib.p2hot_comm_create_callback(engine.ctx, rank, world, self._cb, None, C.byref(h)))
         self._h = h
 
+    def selftest(self, nbytes=1 << 20):
+        """collective preflight: a pattern slice per rank all-gathered and checked on every rank (p2hot_comm_selftest)"""
+        if self.world > 1 or self.transport == "rccl":
+            self.engine.check(self.engine.lib.p2hot_comm_selftest(self._h, nbytes))
+
     def close(self):
         if self._h and getattr(self.engine, "_ctx", None):
             self.engine.lib.p2hot_comm_destroy(self._h)

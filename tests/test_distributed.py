@@ -35,6 +35,7 @@ def _worker(rank, world, port, W, log_n, rb, cap, is_values, chunks, q):
         job = ShardedCommit(eng, W, log_n, rb, cap, is_values=is_values, rank=rank, world=world, dist=dist, want_leaves=True,
                             pipeline_chunks=chunks)
         c0, c1 = job.column_range
+        job.comm.selftest(4096)  # the bench's preflight: a pattern slice per rank through the same exchange path
         for _ in range(2):  # buffers are reused across steps
             r = job.run(eng.dev(cols[c0:c1]))
         o = ora.commit(cols, rb, cap, is_values)
@@ -62,6 +63,59 @@ def test_sharded_commit_gloo(world, W, log_n, rb, cap, is_values, chunks):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert res == [(r, True) for r in range(world)]
+
+
+def _worker_sync_env(rank, world, port, sync, q):
+    """P2HOT_SYNC_COLLECTIVES read from the environment (the switch bench.py's users flip): one synchronous coefficient
+    all-gather (1) or the pipelined chunks (unset); and a transport that delivers nothing is caught by the preflight"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if sync:
+        os.environ["P2HOT_SYNC_COLLECTIVES"] = "1"
+    else:
+        os.environ.pop("P2HOT_SYNC_COLLECTIVES", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import p2oracle as ora
+        from plonky2_amd import _lib
+        from plonky2_amd.distributed import Communicator, ShardedCommit
+        from tests.emu_backend import emu_engine
+        eng = emu_engine()
+        W, log_n, rb, cap = 13, 5, 3, 4
+        cols = rand_field(np.random.default_rng(4321), W, 1 << log_n)
+        job = ShardedCommit(eng, W, log_n, rb, cap, is_values=True, rank=rank, world=world, dist=dist)
+        ok = job.pipeline_chunks == (1 if sync else 8)
+        job.comm.selftest()
+        c0, c1 = job.column_range
+        r = job.run(eng.dev(cols[c0:c1]))
+        o = ora.commit(cols, rb, cap, True)
+        ok = ok and bool((eng.host(r["cap"]) == o["cap"]).all() and (eng.host(r["coeffs"]) == o["coeffs"]).all())
+        broken = Communicator(eng, rank, world, dist, transport="null")  # a hook that returns success without moving anything
+        try:
+            broken.selftest(64)
+            ok = False
+        except _lib.P2HotError as e:
+            ok = ok and "did not receive" in str(e)
+        broken.close()
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sync", [False, True])
+def test_sharded_commit_gloo_sync_and_pipelined_env(sync):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sync_env, args=(r, world, port, sync, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(r, True) for r in range(world)]
 
 
 def _worker_sharded_digests(rank, world, port, W, log_n, rb, cap, q):

@@ -211,7 +211,7 @@ def test_polynomial_batch_wire_format(eng):
     """write_polynomial_batch / write_merkle_tree byte layout (util/serialization/mod.rs:1417-1431, :1744-1763)"""
     import struct
     from plonky2_amd.fri.oracle import PolynomialBatch
-    from plonky2_amd.util.serialization import read_polynomial_batch, write_polynomial_batch
+    from tests.wire_format import read_polynomial_batch, write_polynomial_batch
     rng = np.random.default_rng(44)
     co = rand_field(rng, 3, 4, noncanonical=True)
     b = PolynomialBatch.from_coeffs(co, 1, False, 1, engine=eng)
@@ -296,7 +296,7 @@ def _fri_proof_verifies(eng, ora, log_n, widths, rb, cap, arity, pow_bits, nq, b
     assert vc.get_n_challenges(2) == c.get_n_challenges(2)                 # prover and verifier transcripts agree to the end
 
     # wire format (serialization/mod.rs:1595-1611): length as the reference lays it out, round trip, re-verification
-    from plonky2_amd.util.serialization import read_fri_proof, write_fri_proof
+    from tests.wire_format import read_fri_proof, write_fri_proof
     blob = write_fri_proof(proof)
     ncap, N = 1 << cap, n << rb
     expect, m = 32 * ncap * len(arity), N
