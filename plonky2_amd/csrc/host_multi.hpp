@@ -21,6 +21,7 @@
 // RCCL is bound at run time (dlopen: the copy PyTorch already loaded if there is one, else /opt/rocm's), so libp2hot.so
 // carries no link-time dependency on it and two RCCL copies never meet in one process.
 #pragma once
+#include <chrono>
 
 #ifndef P2HOT_EMU
 #include <dlfcn.h>
@@ -214,7 +215,13 @@ static int gather_start(std::vector<p2hot_comm *> &cs, std::vector<u64 *> &base,
     if (c0->kind == p2hot_comm::CALLBACK) {  // the host application's collective: synchronous, after the slice is complete
         p2hot_ctx *ctx = c0->ctx;
         P2_HIP(ctx, stream_sync(ctx));
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = c0->fn(c0->user, base[0], offsets.data(), world, bytes, (void *)ctx->stream);
+        if (ctx->profiling) {  // the host application's collective is synchronous: its wall time is the exchange span
+            auto &acc = ctx->prof_acc["exchange"];
+            acc.first += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            acc.second += 1;
+        }
         if (rc != 0) P2_FAIL(ctx, P2HOT_ECOMM, "the caller-supplied all-gather failed (%d)", rc);
         return P2HOT_OK;
     }
