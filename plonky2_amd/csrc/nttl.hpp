@@ -32,6 +32,10 @@ constexpr int NT = 512;
 #ifndef P2HOT_LIMB_MIN_WAVES
 #define P2HOT_LIMB_MIN_WAVES 4
 #endif
+#ifndef P2HOT_LIMB_DIRECT_CONTIG
+#define P2HOT_LIMB_DIRECT_CONTIG 0
+#endif
+constexpr bool LIMB_DIRECT_CONTIG = P2HOT_LIMB_DIRECT_CONTIG != 0;  // contiguous pass: store the last round's outputs from registers
 constexpr int LIMB_MIN_WAVES = P2HOT_LIMB_MIN_WAVES;  // waves per SIMD the register allocation must allow (4: <= 128 VGPRs)
 
 struct L4 {
@@ -260,7 +264,7 @@ __device__ __forceinline__ void load_inputs(const u64 *gin, unsigned log_stride,
 // are fetched from `next_gin` (if not null) so that their latency hides behind the rest of this tile.
 template <bool INV, int LOG_R, int LOG_C, int SCALE, int LAST, int RI>
 __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, const W2 *ltw, const u64 *lu, u64 (&raw)[8],
-                                           const u64 *next_gin, unsigned log_stride, size_t z, size_t base0) {
+                                           const u64 *next_gin, u64 *gout, unsigned log_stride, size_t z, size_t base0) {
     constexpr int P = round_bits(LOG_R, RI);
     constexpr int LOG_RB = round_log_rb(LOG_R, RI);
     constexpr int S_LOG = LOG_RB - P;
@@ -324,26 +328,59 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
                 if constexpr (BORROW) y = limb_mul(y, uf[k]);
                 tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = y;
             }
-        } else if constexpr (LAST == LAST_UNIT) {
-#pragma unroll
-            for (int q = 0; q < (1 << P); ++q) tile[ntt::pad_idx(((i0 + (unsigned)q) << LOG_C) + c)] = conv_unit(x[q]);
         } else {
-            u64 w0, w1, w2, w3;
-            if constexpr (LAST == LAST_CONST) {
-                w0 = ra.wlast[0], w1 = ra.wlast[1], w2 = ra.wlast[2], w3 = ra.wlast[3];
-            } else {  // wave-uniform: scalar loads
-                const W2 *sb = ra.sbase + (((z << (log_stride - LOG_C)) + (base0 >> LOG_C)) << 1);
-                w0 = sb[0].a, w1 = sb[0].b, w2 = sb[1].a, w3 = sb[1].b;
-            }
+            // the tile's last round.  A strided pass finishes here: inter-pass twiddle w_{n'}^(col * k1) from the per-pass table (laid
+            // out like a block; the host always supplies it) and the store, straight from registers -- a unit's rows are
+            // consecutive, so 2^LOG_C lanes still write 2^LOG_C * 8 contiguous bytes per row.  The contiguous pass goes through
+            // LDS once more for coalescing.
+            u64 y[1 << P];
+            if constexpr (LAST == LAST_UNIT) {
 #pragma unroll
-            for (int q = 0; q < (1 << P); ++q)
-                tile[ntt::pad_idx(((i0 + (unsigned)q) << LOG_C) + c)] = convmul(x[q], w0, w1, w2, w3);
+                for (int q = 0; q < (1 << P); ++q) y[q] = conv_unit(x[q]);
+            } else {
+                u64 w0, w1, w2, w3;
+                if constexpr (LAST == LAST_CONST) {
+                    w0 = ra.wlast[0], w1 = ra.wlast[1], w2 = ra.wlast[2], w3 = ra.wlast[3];
+                } else {  // wave-uniform: scalar loads
+                    const W2 *sb = ra.sbase + (((z << (log_stride - LOG_C)) + (base0 >> LOG_C)) << 1);
+                    w0 = sb[0].a, w1 = sb[0].b, w2 = sb[1].a, w3 = sb[1].b;
+                }
+#pragma unroll
+                for (int q = 0; q < (1 << P); ++q) y[q] = convmul(x[q], w0, w1, w2, w3);
+            }
+            if constexpr (LOG_C > 0) {
+                const u32 off0 = ((i0 << log_stride) + c) * 8u;  // bytes; the row steps q << log_stride are wave-uniform
+                const char *tw = reinterpret_cast<const char *>(ra.twid + base0);
+                char *go = reinterpret_cast<char *>(gout);
+#pragma unroll
+                for (int q = 0; q < (1 << P); ++q) {
+                    const size_t step = ((size_t)q << log_stride) * 8;
+                    const u64 v_ = limb_mul(y[q], *reinterpret_cast<const u64 *>(tw + step + off0));
+                    *reinterpret_cast<u64 *>(go + step + off0) = a.canon_out ? gl::canon(v_) : v_;
+                }
+            } else if constexpr (P == 3 && LIMB_DIRECT_CONTIG) {
+                // the contiguous pass: a unit's eight outputs are 64 consecutive bytes of the block -- four 16-byte stores
+                W2 *go = reinterpret_cast<W2 *>(gout + i0);
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    W2 pr;
+                    pr.a = a.canon_out ? gl::canon(y[q]) : y[q];
+                    pr.b = a.canon_out ? gl::canon(y[q + 1]) : y[q + 1];
+                    go[q >> 1] = pr;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < (1 << P); ++q) tile[ntt::pad_idx(i0 + (unsigned)q)] = y[q];
+            }
         }
     }
     // the next round (and the store phase) reads what this one wrote: a wave's own 512 elements once the sub-blocks are that small
-    round_sync<(LOG_RB + LOG_C <= 9)>();
-    if constexpr (RI + 1 < n_rounds(LOG_R))
-        limb_round<INV, LOG_R, LOG_C, SCALE, LAST, RI + 1>(ra, tile, ltw, lu, raw, next_gin, log_stride, z, base0);
+    if constexpr (RI + 1 < n_rounds(LOG_R)) {
+        round_sync<(LOG_RB + LOG_C <= 9)>();
+        limb_round<INV, LOG_R, LOG_C, SCALE, LAST, RI + 1>(ra, tile, ltw, lu, raw, next_gin, gout, log_stride, z, base0);
+    } else if constexpr (LOG_C == 0 && !(P == 3 && LIMB_DIRECT_CONTIG)) {
+        round_sync<(LOG_RB + LOG_C <= 9)>();  // the contiguous pass's store phase reads what this round wrote
+    }
 }
 
 // One pass over 2^LOG_R x 2^LOG_C tiles (LOG_R + LOG_C = 12); LOG_C = 0 is the contiguous (last) pass.
@@ -355,7 +392,6 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
     P2HOT_DYN_SHARED(u64, tile);
     const ntt::PassArgs &a = ra.a;
     const unsigned tid = threadIdx.x;
-    constexpr unsigned C = 1u << LOG_C;
     W2 *ltw = reinterpret_cast<W2 *>(tile + ntt::TILE_WORDS_PADDED);
     u64 *lu = reinterpret_cast<u64 *>(ltw + limb_tables_w2(LOG_R));
     for (unsigned e = tid; e < (unsigned)limb_tables_w2(LOG_R); e += NT) ltw[e] = ra.tw_all[e];
@@ -393,27 +429,12 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
             } else if (t + 1 < n_tiles) {
                 next = tile_in(t + 1, z_begin);
             }
-            limb_round<INV, LOG_R, LOG_C, SCALE, LAST, 0>(ra, tile, ltw, lu, raw, next, log_stride, z, base0);
-            if constexpr (LOG_C == 0) {
+            limb_round<INV, LOG_R, LOG_C, SCALE, LAST, 0>(ra, tile, ltw, lu, raw, next, out, log_stride, z, base0);
+            if constexpr (LOG_C == 0 && !(round_bits(LOG_R, n_rounds(LOG_R) - 1) == 3 && LIMB_DIRECT_CONTIG)) {
 #pragma unroll
                 for (unsigned j = 0; j < 8; ++j) {
                     const u64 v = tile[ntt::pad_idx(e0 + 64 * j)];
                     out[e0 + 64 * j] = a.canon_out ? gl::canon(v) : v;
-                }
-            } else {
-                // inter-pass twiddle w_{n'}^(base * k1) from the per-pass table (laid out like a block; the host always supplies
-                // it: blocks of <= 2^24 elements), then the store in runs of C elements.
-                // element e = U + lane with U = 512 w + 64 j wave-uniform: row (U >> LOG_C) + (lane >> LOG_C), column (U + lane) mod C
-                const unsigned lane = tid & 63u;
-                const u32 off0 = (((lane >> LOG_C) << log_stride) + (lane & (C - 1))) * 8u;  // bytes, per lane
-                const unsigned U0 = wave_uniform(tid >> 6) * 512u;
-#pragma unroll 2
-                for (unsigned j = 0; j < 8; ++j) {
-                    const unsigned U = U0 + 64 * j;
-                    const size_t step = ((size_t)(U >> LOG_C) << log_stride) + (U & (C - 1));
-                    const u64 w = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ra.twid + base0 + step) + off0);
-                    u64 v = limb_mul(tile[ntt::pad_idx(e0 + 64 * j)], w);
-                    *reinterpret_cast<u64 *>(reinterpret_cast<char *>(out + step) + off0) = a.canon_out ? gl::canon(v) : v;
                 }
             }
             __syncthreads();  // the next tile's first round overwrites what other waves may still be reading
