@@ -237,7 +237,12 @@ int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bit
  *   p2hot_cols        a device-resident Vec<PolynomialValues> / Vec<PolynomialCoeffs> ([W][n]) that never visits the host
  *   p2hot_challenger  the Fiat-Shamir transcript (above)
  * A context runs ONE host-pointer call at a time; a second thread entering gets P2HOT_EBUSY (plonky2 calls these
- * from the main thread, outside its rayon closures). */
+ * from the main thread, outside its rayon closures).  Serialised by the library (busy guard): p2hot_commit*, p2hot_cols_upload,
+ * p2hot_batch_coeffs / _rows / _paths / _digests, p2hot_eval_openings, p2hot_prove_openings, p2hot_partial_products,
+ * p2hot_quotient_chunks, p2hot_ctx_trim.  p2hot_batch_free / p2hot_cols_free may be called from any thread at any time (a
+ * Drop, a finaliser): the block cache has its own lock.  Everything else -- the *_dev building blocks, p2hot_fri_commit,
+ * p2hot_fri_pow, p2hot_challenger_* -- enqueues on the context's stream without a guard: the CALLER serialises those with
+ * each other and with the host-pointer calls of the same context (the Rust shim holds the context behind a Mutex). */
 #define P2HOT_EBUSY 5        /* another host-pointer call is running on this context */
 #define P2HOT_ECOMM 6        /* collective (RCCL / caller-supplied transport) failure in the multi-GPU mode */
 #define P2HOT_KEEP_VALUES 1u /* from_values: keep the input values on the device (p2hot_batch_values) */
@@ -266,7 +271,9 @@ int p2hot_commit_salted(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, u
                         uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out,
                         p2hot_batch **handle_out);
 /* the same on a device-resident column set (the output of p2hot_partial_products / p2hot_quotient_chunks, or an upload).
- * CONSUMES `cols`, on success and on failure: its block becomes the batch's coefficients or kept values, or is released. */
+ * CONSUMES `cols` -- its block becomes the batch's coefficients or kept values, or is released -- on success and on failure,
+ * except for the two failures detected before the set is touched: P2HOT_EBUSY, and P2HOT_EINVAL for a null set, a set of
+ * another context or a borrowed view (p2hot_batch_values): then the caller still owns the handle. */
 int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate_bits, unsigned cap_height, int is_values,
                       unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out,
                       p2hot_batch **handle_out);

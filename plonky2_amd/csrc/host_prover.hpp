@@ -229,8 +229,10 @@ extern "C" int p2hot_commit_salted(p2hot_ctx *ctx, const uint64_t *const *cols, 
                        digests_out, cap_out, handle_out);
 }
 
-// from_values / from_coeffs on a device-resident column set.  CONSUMES `cols` (on success and on failure): its block
-// becomes the batch's coefficients (from_coeffs) or its kept values (from_values with P2HOT_KEEP_VALUES), or is released.
+// from_values / from_coeffs on a device-resident column set.  CONSUMES `cols` -- its block becomes the batch's coefficients
+// (from_coeffs) or its kept values (from_values with P2HOT_KEEP_VALUES), or is released -- on success and on every failure
+// EXCEPT the two that are detected before the set is touched: P2HOT_EBUSY (another call is running on the context) and
+// P2HOT_EINVAL for a null set, a set of another context or a borrowed view (p2hot_batch_values); then the caller still owns it.
 extern "C" int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate_bits, unsigned cap_height, int is_values,
                                  unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out,
                                  uint64_t *cap_out, p2hot_batch **handle_out) {
@@ -507,6 +509,7 @@ extern "C" void p2hot_batch_free(p2hot_batch *b) {
 extern "C" int p2hot_ctx_trim(p2hot_ctx *ctx) {
     P2_ENTER(ctx);
     P2_HIP(ctx, stream_sync(ctx));
+    std::lock_guard<std::mutex> pool_lock_(ctx->pool_mu);
     for (auto &blk : ctx->pool_free) (void)hipFree(blk.first);
     ctx->pool_free.clear();
     return P2HOT_OK;
@@ -832,9 +835,14 @@ static int prove_openings_core(p2hot_ctx *ctx, const p2hot_fri_batch_info *batch
     if (rc == P2HOT_OK && best == ~0ull) {
         // no witness among the first 2^(pow_bits + 5) candidates (probability e^-32): rewind the transcript to before the
         // grind, search the rest of the range with a host check per chunk, and replay the tail
-        P2_HIP(ctx, hipMemcpyAsync(challenger->d, d_chsave, sizeof(fri::Challenger), hipMemcpyDeviceToDevice, ctx->stream));
-        P2_TRY(pow_continue_host(ctx, challenger, fp->proof_of_work_bits, (unsigned long long *)d_best, pow_next, &best));
-        rc = sync_checked(ctx, tail(), "prove_openings");
+        // (errors go through rc + sync_checked like the main path: the PoolBuf blocks must not return to the cache while
+        // enqueued work still references them)
+        auto fallback = [&]() -> int {
+            P2_HIP(ctx, hipMemcpyAsync(challenger->d, d_chsave, sizeof(fri::Challenger), hipMemcpyDeviceToDevice, ctx->stream));
+            P2_TRY(pow_continue_host(ctx, challenger, fp->proof_of_work_bits, (unsigned long long *)d_best, pow_next, &best));
+            return tail();
+        };
+        rc = sync_checked(ctx, fallback(), "prove_openings");
     }
     if (rc == P2HOT_OK) proof->pow_witness = best;
     // a sharded batch: the initial trees' rows and paths come from the ranks that own them

@@ -333,44 +333,42 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
             // out like a block; the host always supplies it) and the store, straight from registers -- a unit's rows are
             // consecutive, so 2^LOG_C lanes still write 2^LOG_C * 8 contiguous bytes per row.  The contiguous pass goes through
             // LDS once more for coalescing.
-            u64 y[1 << P];
-            if constexpr (LAST == LAST_UNIT) {
-#pragma unroll
-                for (int q = 0; q < (1 << P); ++q) y[q] = conv_unit(x[q]);
-            } else {
-                u64 w0, w1, w2, w3;
-                if constexpr (LAST == LAST_CONST) {
-                    w0 = ra.wlast[0], w1 = ra.wlast[1], w2 = ra.wlast[2], w3 = ra.wlast[3];
-                } else {  // wave-uniform: scalar loads
-                    const W2 *sb = ra.sbase + (((z << (log_stride - LOG_C)) + (base0 >> LOG_C)) << 1);
-                    w0 = sb[0].a, w1 = sb[0].b, w2 = sb[1].a, w3 = sb[1].b;
-                }
-#pragma unroll
-                for (int q = 0; q < (1 << P); ++q) y[q] = convmul(x[q], w0, w1, w2, w3);
+            u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            if constexpr (LAST == LAST_CONST) {
+                w0 = ra.wlast[0], w1 = ra.wlast[1], w2 = ra.wlast[2], w3 = ra.wlast[3];
+            } else if constexpr (LAST == LAST_TILE) {  // wave-uniform: scalar loads
+                const W2 *sb = ra.sbase + (((z << (log_stride - LOG_C)) + (base0 >> LOG_C)) << 1);
+                w0 = sb[0].a, w1 = sb[0].b, w2 = sb[1].a, w3 = sb[1].b;
             }
-            if constexpr (LOG_C > 0) {
+            auto conv_last = [&](const L4 &v_) { return LAST == LAST_UNIT ? conv_unit(v_) : convmul(v_, w0, w1, w2, w3); };
+            if constexpr (LOG_C > 0 && P <= 2) {  // (a radix-8 last round keeps too much alive: it goes through LDS like the contiguous pass)
                 const u32 off0 = ((i0 << log_stride) + c) * 8u;  // bytes; the row steps q << log_stride are wave-uniform
                 const char *tw = reinterpret_cast<const char *>(ra.twid + base0);
                 char *go = reinterpret_cast<char *>(gout);
 #pragma unroll
                 for (int q = 0; q < (1 << P); ++q) {
                     const size_t step = ((size_t)q << log_stride) * 8;
-                    const u64 v_ = limb_mul(y[q], *reinterpret_cast<const u64 *>(tw + step + off0));
+                    const u64 v_ = limb_mul(conv_last(x[q]), *reinterpret_cast<const u64 *>(tw + step + off0));
                     *reinterpret_cast<u64 *>(go + step + off0) = a.canon_out ? gl::canon(v_) : v_;
+#ifndef P2HOT_EMU
+                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four outputs at a time: the twiddle loads are not hoisted past this
+#endif
                 }
             } else if constexpr (P == 3 && LIMB_DIRECT_CONTIG) {
                 // the contiguous pass: a unit's eight outputs are 64 consecutive bytes of the block -- four 16-byte stores
+                // (measured slower than the LDS round trip: 5.01 vs 4.87 ms for the LDE's pass; off by default)
                 W2 *go = reinterpret_cast<W2 *>(gout + i0);
 #pragma unroll
                 for (int q = 0; q < 8; q += 2) {
                     W2 pr;
-                    pr.a = a.canon_out ? gl::canon(y[q]) : y[q];
-                    pr.b = a.canon_out ? gl::canon(y[q + 1]) : y[q + 1];
+                    pr.a = conv_last(x[q]);
+                    pr.b = conv_last(x[q + 1]);
+                    if (a.canon_out) pr.a = gl::canon(pr.a), pr.b = gl::canon(pr.b);
                     go[q >> 1] = pr;
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < (1 << P); ++q) tile[ntt::pad_idx(i0 + (unsigned)q)] = y[q];
+                for (int q = 0; q < (1 << P); ++q) tile[ntt::pad_idx(((i0 + (unsigned)q) << LOG_C) + c)] = conv_last(x[q]);
             }
         }
     }
@@ -378,8 +376,8 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
     if constexpr (RI + 1 < n_rounds(LOG_R)) {
         round_sync<(LOG_RB + LOG_C <= 9)>();
         limb_round<INV, LOG_R, LOG_C, SCALE, LAST, RI + 1>(ra, tile, ltw, lu, raw, next_gin, gout, log_stride, z, base0);
-    } else if constexpr (LOG_C == 0 && !(P == 3 && LIMB_DIRECT_CONTIG)) {
-        round_sync<(LOG_RB + LOG_C <= 9)>();  // the contiguous pass's store phase reads what this round wrote
+    } else if constexpr (LOG_C == 0 ? !(P == 3 && LIMB_DIRECT_CONTIG) : P == 3) {
+        round_sync<(LOG_RB + LOG_C <= 9)>();  // the store phase reads what this round wrote
     }
 }
 
@@ -430,11 +428,27 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
                 next = tile_in(t + 1, z_begin);
             }
             limb_round<INV, LOG_R, LOG_C, SCALE, LAST, 0>(ra, tile, ltw, lu, raw, next, out, log_stride, z, base0);
-            if constexpr (LOG_C == 0 && !(round_bits(LOG_R, n_rounds(LOG_R) - 1) == 3 && LIMB_DIRECT_CONTIG)) {
+            constexpr int LAST_P = round_bits(LOG_R, n_rounds(LOG_R) - 1);
+            if constexpr (LOG_C == 0 && !(LAST_P == 3 && LIMB_DIRECT_CONTIG)) {
 #pragma unroll
                 for (unsigned j = 0; j < 8; ++j) {
                     const u64 v = tile[ntt::pad_idx(e0 + 64 * j)];
                     out[e0 + 64 * j] = a.canon_out ? gl::canon(v) : v;
+                }
+            } else if constexpr (LOG_C > 0 && LAST_P == 3) {
+                // a strided pass whose last round is radix 8 (2^9 and 2^6 rows): inter-pass twiddle + store from LDS.
+                // element e = U + lane with U = 512 w + 64 j wave-uniform: row (U >> LOG_C) + (lane >> LOG_C), column (U + lane) mod C
+                constexpr unsigned C = 1u << LOG_C;
+                const unsigned lane = tid & 63u;
+                const u32 off0 = (((lane >> LOG_C) << log_stride) + (lane & (C - 1))) * 8u;  // bytes, per lane
+                const unsigned U0 = wave_uniform(tid >> 6) * 512u;
+#pragma unroll 2
+                for (unsigned j = 0; j < 8; ++j) {
+                    const unsigned U = U0 + 64 * j;
+                    const size_t step = ((size_t)(U >> LOG_C) << log_stride) + (U & (C - 1));
+                    const u64 w = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ra.twid + base0 + step) + off0);
+                    u64 v = limb_mul(tile[ntt::pad_idx(e0 + 64 * j)], w);
+                    *reinterpret_cast<u64 *>(reinterpret_cast<char *>(out + step) + off0) = a.canon_out ? gl::canon(v) : v;
                 }
             }
             __syncthreads();  // the next tile's first round overwrites what other waves may still be reading

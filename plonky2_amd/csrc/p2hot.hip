@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -28,6 +29,7 @@ struct p2hot_ctx {
     u64 alpha_stage[2] = {0, 0};   // host staging of an extension challenge (outlives the asynchronous copy)
     std::atomic<bool> busy{false};  // a host-pointer entry point is running on this context (see CallGuard)
     u64 *tables = nullptr;  // fwd_lo, fwd_hi, inv_lo, inv_hi (65536 each)
+    unsigned *pinned_oob = nullptr;  // host-pinned landing word of d_oob (p2hot_ctx_sync)
     unsigned *d_oob = nullptr;  // raised by gathers that were handed an out-of-range row / leaf index (device-resident indices)
     ntt::RootTable fwd{}, inv{};
     u64 *local_fwd = nullptr, *local_inv = nullptr;  // [2^m + e] = w_{2^m}^(+-e), m <= TILE_LOG
@@ -73,6 +75,7 @@ struct p2hot_ctx {
     std::map<std::tuple<int, unsigned, unsigned>, u64 *> twid_cache;
     // grow-only cache of device blocks for the host-pointer entry points: a fresh hipMalloc of the 9 GB LDE matrix
     // costs up to a second (the driver clears VRAM), so blocks go back to this list instead of hipFree
+    std::mutex pool_mu;  // pool_free / pool_live / scratch bookkeeping: frees may come from another thread (a Drop, a GC finaliser)
     std::vector<std::pair<void *, size_t>> pool_free;  // (pointer, capacity)
     std::map<void *, size_t> pool_live;  // (inverse, log_nblk, log_r) -> inter-pass twiddle table
     // live per-kernel timing (HIP events on the launch stream), off by default
@@ -232,6 +235,7 @@ static int h2d_columns(p2hot_ctx *ctx, void *d_dst, const uint64_t *const *cols,
 
 static int scratch_get(p2hot_ctx *ctx, int slot, size_t bytes, void **out) {
     DeviceGuard dev_guard_(ctx);
+    std::lock_guard<std::mutex> pool_lock_(ctx->pool_mu);
     auto &s = ctx->scratch[slot];
     if (s.cap < bytes) {
         if (s.p) {
@@ -250,6 +254,7 @@ static int scratch_get(p2hot_ctx *ctx, int slot, size_t bytes, void **out) {
 // block cache of the host-pointer entry points (see p2hot_ctx::pool_free)
 static int pool_alloc(p2hot_ctx *ctx, size_t bytes, void **out) {
     DeviceGuard dev_guard_(ctx);
+    std::lock_guard<std::mutex> pool_lock_(ctx->pool_mu);
     if (bytes == 0) bytes = 8;
     size_t best = ctx->pool_free.size();
     for (size_t k = 0; k < ctx->pool_free.size(); ++k) {
@@ -277,6 +282,7 @@ static int pool_alloc(p2hot_ctx *ctx, size_t bytes, void **out) {
 }
 static void pool_release(p2hot_ctx *ctx, void *p) {
     DeviceGuard dev_guard_(ctx);
+    std::lock_guard<std::mutex> pool_lock_(ctx->pool_mu);
     if (!p) return;
     auto it = ctx->pool_live.find(p);
     if (it == ctx->pool_live.end()) return;
@@ -386,6 +392,7 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
         if (s.p) (void)hipFree(s.p);
     if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned_oob) (void)hipHostFree(ctx->pinned_oob);
     if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);
     delete ctx;
 }
@@ -398,24 +405,26 @@ extern "C" int p2hot_ctx_set_stream(p2hot_ctx *ctx, void *hip_stream) {
     return P2HOT_OK;
 }
 
-// reads and clears the out-of-range flag of the device-index gathers (the stream must be idle)
-static int check_oob(p2hot_ctx *ctx) {
+// p2hot_ctx_sync: ONE synchronisation -- the out-of-range flag of the device-index gathers travels to a pinned word by an
+// asynchronous copy enqueued in front of it
+extern "C" int p2hot_ctx_sync(p2hot_ctx *ctx) {
+    if (!ctx) return P2HOT_EINVAL;
+    DeviceGuard dev_guard_(ctx);
     unsigned f = 0;
-    P2_HIP(ctx, hipMemcpyAsync(&f, ctx->d_oob, 4, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned *slot = &f;
+#ifndef P2HOT_EMU
+    if (!ctx->pinned_oob && hipHostMalloc((void **)&ctx->pinned_oob, 64, hipHostMallocDefault) != hipSuccess) ctx->pinned_oob = nullptr;
+    if (ctx->pinned_oob) slot = ctx->pinned_oob;
+#endif
+    P2_HIP(ctx, hipMemcpyAsync(slot, ctx->d_oob, 4, hipMemcpyDeviceToHost, ctx->stream));
     P2_HIP(ctx, stream_sync(ctx));
+    f = *slot;
     if (f) {
         P2_HIP(ctx, hipMemsetAsync(ctx->d_oob, 0, 4, ctx->stream));
         P2_FAIL(ctx, P2HOT_EINVAL, "an earlier %s was given an index out of range (the reference panics on the slice index); its output rows are zero",
                 (f & 1) ? "p2hot_gather_rows_dev" : "p2hot_merkle_paths_dev");
     }
     return P2HOT_OK;
-}
-
-extern "C" int p2hot_ctx_sync(p2hot_ctx *ctx) {
-    if (!ctx) return P2HOT_EINVAL;
-    DeviceGuard dev_guard_(ctx);
-    P2_HIP(ctx, stream_sync(ctx));
-    return check_oob(ctx);
 }
 
 extern "C" const char *p2hot_last_error(const p2hot_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }

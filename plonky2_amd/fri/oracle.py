@@ -173,10 +173,13 @@ class PolynomialBatch:
         W, log_n = dc.width, dc.degree_log
         cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
         h = C.c_void_p()
-        handle, dc._h = dc._h, None  # consumed by the library
-        eng.check(eng.lib.p2hot_commit_cols(eng.ctx, handle, rate_bits, cap_height, 1 if is_values else 0,
-                                            _lib.KEEP_VALUES if (keep_values and is_values) else 0, None, None, None,
-                                            cap.ctypes.data, C.byref(h)))
+        handle, dc._h = dc._h, None  # consumed by the library ...
+        rc = eng.lib.p2hot_commit_cols(eng.ctx, handle, rate_bits, cap_height, 1 if is_values else 0,
+                                       _lib.KEEP_VALUES if (keep_values and is_values) else 0, None, None, None,
+                                       cap.ctypes.data, C.byref(h))
+        if rc == _lib.EBUSY:
+            dc._h = handle  # ... except when the call never started (include/p2hot.h): the set is still ours
+        eng.check(rc)
         return cls(eng, h, W, log_n, rate_bits, cap_height, cap)
 
     def values(self):
