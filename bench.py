@@ -218,6 +218,66 @@ def recursion_lines(eng, torch, out):
         del inter, d_lde, d_dig, d_cap
     out["recursion_commit_many"] = rec
 
+    # (a') M whole opening-proof pipelines per call: three p2hot_commit_many (wires 135, Zs 20 from values, quotient 16 from
+    # coefficients: host columns in, handles out) + p2hot_prove_openings_many (171 polynomials at zeta, 155 at g*zeta, arity 16 x2,
+    # PoW 16 bits, 28 queries) -- the FRI side of M recursion-size proofs; the proofs of one call are checked to be equal
+    import ctypes as C
+    from plonky2_amd import _lib
+    cols_w, cols_z, cols_q = (splitmix_columns_numpy(b0, w, n) for b0, w in ((0, 135), (1000, 20), (2000, 16)))
+    widths = (135, 20, 16)
+    allp = [(oi, pi) for oi, w in enumerate(widths) for pi in range(w)]
+    nxt = [(oi, pi) for oi, w in enumerate(widths[:2]) for pi in range(w)]
+    arrs = [((C.c_uint32 * len(pl))(*[o for o, _ in pl]), (C.c_uint32 * len(pl))(*[q for _, q in pl])) for pl in (allp, nxt)]
+    arity = (C.c_uint * 2)(4, 4)
+    fp = _lib.FriParams(rb, cap, 16, 28, arity, 2, 0, 0, 0)
+    rec = {"workload": "M x (3 p2hot_commit_many from host columns + p2hot_prove_openings_many) at 2^12 rows: the commitments and the "
+                       "opening proof of M recursion-size proofs per call (OpeningSet evaluation and the permutation argument excluded)", "M": {}}
+    for M in (1, 8, 64):
+        def pipeline():
+            handles = []
+            for cols_, w, isv in ((cols_w, 135, 1), (cols_z, 20, 1), (cols_q, 16, 0)):
+                ptrs = (C.c_void_p * (M * w))(*([cols_[e].ctypes.data for e in range(w)] * M))
+                hs = (C.c_void_p * M)()
+                eng.check(eng.lib.p2hot_commit_many(eng.ctx, ptrs, M, w, log_n, rb, cap, isv, None, None, None, hs))
+                handles.append(hs)
+            chs = []
+            for _ in range(M):
+                h = C.c_void_p()
+                eng.check(eng.lib.p2hot_challenger_create(eng.ctx, C.byref(h)))
+                chs.append(h)
+            lay = _lib.FriProofLayout()
+            h0 = (C.c_void_p * 3)(handles[0][0], handles[1][0], handles[2][0])
+            eng.check(eng.lib.p2hot_fri_proof_sizes(h0, 3, C.byref(fp), C.byref(lay)))
+            bufs = [[np.zeros(max(1, getattr(lay, k + "_words")), dtype=np.uint64) for k in ("caps", "final_poly", "initial_leaves", "initial_paths", "step_evals", "step_paths")]
+                    for _ in range(M)]
+            proofs = (_lib.FriProof * M)()
+            infos = (_lib.FriBatchInfo * 2)()
+            for k, (pt, (oi, pi)) in enumerate(zip(((3, 5), (21, 5)), arrs)):
+                infos[k].point[0], infos[k].point[1] = pt
+                infos[k].oracle_index, infos[k].poly_index, infos[k].n_polys = oi, pi, len(oi)
+            bp = (C.POINTER(_lib.FriBatchInfo) * M)(*([C.cast(infos, C.POINTER(_lib.FriBatchInfo))] * M))
+            nb = (C.c_size_t * M)(*([2] * M))
+            hs_all = (C.c_void_p * (3 * M))(*[handles[o][m] for m in range(M) for o in range(3)])
+            for m in range(M):
+                b = bufs[m]
+                proofs[m] = _lib.FriProof(b[0].ctypes.data, b[1].ctypes.data, 0, None, b[2].ctypes.data, b[3].ctypes.data, b[4].ctypes.data, b[5].ctypes.data)
+            cp = (C.c_void_p * M)(*chs)
+            eng.check(eng.lib.p2hot_prove_openings_many(eng.ctx, M, bp, nb, hs_all, 3, cp, C.byref(fp), proofs))
+            same = all(int(proofs[m].pow_witness) == int(proofs[0].pow_witness) and (bufs[m][1] == bufs[0][1]).all() for m in range(M))
+            for h in chs:
+                eng.lib.p2hot_challenger_destroy(h)
+            for hs in handles:
+                for m in range(M):
+                    eng.lib.p2hot_batch_free(hs[m])
+            return same
+        pipeline()
+        reps = 10 if M < 64 else 4
+        t0 = time.perf_counter()
+        ok = all([pipeline() for _ in range(reps)])
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        rec["M"][str(M)] = {"ms": ms, "proofs_per_s": M / ms * 1e3, "proofs_equal": bool(ok)}
+    out["recursion_pipeline_many"] = rec
+
     # (b) whole per-proof paths through the host-pointer entry points, K contexts side by side
     cols = splitmix_columns_numpy(0, W, n)
     zs = splitmix_columns_numpy(1000, 20, n)

@@ -379,6 +379,14 @@ int p2hot_fri_proof_sizes(const p2hot_batch *const *oracles, size_t n_oracles, c
 int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *batches, size_t n_batches,
                          const p2hot_batch *const *oracles, size_t n_oracles, p2hot_challenger *challenger,
                          const p2hot_fri_params *params, p2hot_fri_proof *proof);
+/* M independent opening proofs side by side (recursion workloads: many 2^12-row proofs, each a latency-bound chain of small
+ * launches).  Proof j opens oracles[j * n_oracles .. + n_oracles) (handles of THIS context, e.g. from p2hot_commit_many) at
+ * batches[j][0 .. n_batches[j]) with transcript challengers[j] and fills proofs[j]; every proof is computed exactly as by
+ * p2hot_prove_openings (same buffers, same transcript afterwards).  Inside, up to 4 sibling contexts of the same GPU --
+ * own streams, driven by their own host threads -- run the proofs concurrently. */
+int p2hot_prove_openings_many(p2hot_ctx *ctx, size_t M, const p2hot_fri_batch_info *const *batches, const size_t *n_batches,
+                              const p2hot_batch *const *oracles, size_t n_oracles, p2hot_challenger *const *challengers,
+                              const p2hot_fri_params *fp, p2hot_fri_proof *proofs);
 
 /* all_wires_permutation_partial_products (plonk/prover.rs:356-449) on device-resident columns: wires = columns
  * [wires_first_col, +num_routed) of `wires` (e.g. p2hot_batch_values of the wires commitment), sigmas likewise (the

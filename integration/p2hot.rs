@@ -280,6 +280,10 @@ extern "C" {
         ctx: *mut P2hotCtx, batches: *const P2hotFriBatchInfo, n_batches: usize, oracles: *const *const P2hotBatch, n_oracles: usize,
         challenger: *mut P2hotChallenger, params: *const P2hotFriParams, proof: *mut P2hotFriProof,
     ) -> c_int;
+    pub fn p2hot_prove_openings_many(
+        ctx: *mut P2hotCtx, M: usize, batches: *const *const P2hotFriBatchInfo, n_batches: *const usize, oracles: *const *const P2hotBatch,
+        n_oracles: usize, challengers: *const *mut P2hotChallenger, fp: *const P2hotFriParams, proofs: *mut P2hotFriProof,
+    ) -> c_int;
     pub fn p2hot_partial_products(
         ctx: *mut P2hotCtx, wires: *const P2hotCols, wires_first_col: usize, sigmas: *const P2hotCols, sigmas_first_col: usize,
         k_is: *const u64, num_routed: c_uint, degree: c_uint, betas: *const u64, gammas: *const u64, num_challenges: c_uint,

@@ -116,6 +116,8 @@ SIGNATURES = {
     "p2hot_fri_proof_sizes": (i, [C.POINTER(vp), sz, C.POINTER(FriParams), C.POINTER(FriProofLayout)]),
     "p2hot_prove_openings": (i, [vp, C.POINTER(FriBatchInfo), sz, C.POINTER(vp), sz, vp, C.POINTER(FriParams),
                                  C.POINTER(FriProof)]),
+    "p2hot_prove_openings_many": (i, [vp, sz, C.POINTER(C.POINTER(FriBatchInfo)), C.POINTER(sz), C.POINTER(vp), sz, C.POINTER(vp),
+                                      C.POINTER(FriParams), C.POINTER(FriProof)]),
     "p2hot_partial_products": (i, [vp, vp, sz, vp, sz, vp, u, u, vp, vp, u, vp, C.POINTER(vp)]),
     "p2hot_quotient_chunks": (i, [vp, C.POINTER(vp), u, u, u, C.POINTER(vp)]),
     "p2hot_comm_unique_id": (i, [vp]),

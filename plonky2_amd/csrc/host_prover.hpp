@@ -13,6 +13,7 @@
 
 #include <atomic>
 #include <functional>
+#include <thread>
 
 // one call at a time per context: a second thread entering gets P2HOT_EBUSY instead of a data race on the scratch blocks
 struct CallGuard {
@@ -667,6 +668,98 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
                                    oracles[o]->lde_stride, oracles[o]->coef_stride});
     }
     return prove_openings_core(ctx, batches, n_batches, views, oracles[0]->log_n, challenger, fp, proof, nullptr);
+}
+
+// ------------------------------------------------------------------ M opening proofs side by side
+// A recursion-size opening proof (2^12 rows) is a chain of small launches -- about 36 dependent challenger permutations, tree
+// levels of a few hundred nodes -- that leaves the chip almost idle.  M independent proofs therefore run on up to 4 sibling
+// contexts of the same GPU (their own streams, scratch and block caches), each driven by its own host thread, so that the
+// launches of different proofs overlap on the device.  Every proof is computed by the same prove_openings_core as a single
+// p2hot_prove_openings call: results are identical, buffer by buffer.
+static int helper_contexts(p2hot_ctx *ctx, size_t want) {
+    while (ctx->helpers.size() < want) {
+        hipStream_t st = nullptr;
+#ifndef P2HOT_EMU
+        P2_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+#endif
+        p2hot_ctx *h = nullptr;
+        int rc = p2hot_ctx_create(ctx->device, (void *)st, &h);
+        if (rc != P2HOT_OK) {
+            ctx->err = std::string("prove_openings_many: helper context: ") + (h ? h->err : "allocation failed");
+            if (h) p2hot_ctx_destroy(h);
+            return rc;
+        }
+        h->quad_threshold = ctx->quad_threshold;
+        h->row_threshold = ctx->row_threshold;
+        p2hot_challenger *hc = nullptr;
+        rc = p2hot_challenger_create(h, &hc);
+        if (rc != P2HOT_OK) {
+            ctx->err = "prove_openings_many: helper challenger: " + h->err;
+            p2hot_ctx_destroy(h);
+            return rc;
+        }
+        ctx->helpers.push_back(h);
+        ctx->helper_streams.push_back(st);
+        ctx->helper_challengers.push_back(hc);
+    }
+    return P2HOT_OK;
+}
+
+extern "C" int p2hot_prove_openings_many(p2hot_ctx *ctx, size_t M, const p2hot_fri_batch_info *const *batches, const size_t *n_batches,
+                                         const p2hot_batch *const *oracles, size_t n_oracles, p2hot_challenger *const *challengers,
+                                         const p2hot_fri_params *fp, p2hot_fri_proof *proofs) {
+    P2_ENTER(ctx);
+    if (M == 0) return P2HOT_OK;
+    if (!batches || !n_batches || !oracles || n_oracles == 0 || !challengers || !proofs) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings_many: null argument");
+    std::vector<std::vector<OracleView>> views(M);
+    for (size_t j = 0; j < M; ++j) {
+        if (!challengers[j] || challengers[j]->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings_many: challenger %zu is null or belongs to another context", j);
+        for (size_t o = 0; o < n_oracles; ++o) {
+            const p2hot_batch *B = oracles[j * n_oracles + o];
+            if (!B || B->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings_many: oracle %zu of proof %zu is null or belongs to another context", o, j);
+            if (B->log_n != oracles[0]->log_n || (fp && (B->rate_bits != fp->rate_bits || B->cap_height != fp->cap_height)))
+                P2_FAIL(ctx, P2HOT_EINVAL, "prove_openings_many: oracle %zu of proof %zu was committed with another degree / rate / cap height", o, j);
+            views[j].push_back(OracleView{B->d_coef, B->d_lde, B->d_dig, B->W, B->N, B->S, B->lde_stride, B->coef_stride});
+        }
+    }
+    size_t k_max = 4;  // sibling contexts: 2 and 4 measured 1.8-1.9x a single stream, 8+ no better (P2HOT_MANY_HELPERS overrides; tools/pom_trace.py)
+    if (const char *e = getenv("P2HOT_MANY_HELPERS")) k_max = std::max<size_t>(1, std::min<size_t>(64, (size_t)strtoull(e, nullptr, 10)));
+    const size_t K = std::min<size_t>(M, k_max);
+    P2_TRY(helper_contexts(ctx, K));
+    P2_HIP(ctx, stream_sync(ctx));  // the oracles and transcripts were produced on this context's stream
+    const unsigned log_n = oracles[0]->log_n;
+    std::vector<int> rcs(K, P2HOT_OK);
+    std::vector<std::string> errs(K);
+    auto work = [&](size_t k) {
+        p2hot_ctx *h = ctx->helpers[k];
+        p2hot_challenger *hc = ctx->helper_challengers[k];
+        DeviceGuard dev_guard_(h);
+        CallGuard guard_(h);
+        for (size_t j = k; j < M && rcs[k] == P2HOT_OK; j += K) {
+            auto one = [&]() -> int {
+                P2_HIP(h, hipMemcpyAsync(hc->d, challengers[j]->d, sizeof(fri::Challenger), hipMemcpyDeviceToDevice, h->stream));
+                P2_TRY(prove_openings_core(h, batches[j], n_batches[j], views[j], log_n, hc, fp, &proofs[j], nullptr));
+                P2_HIP(h, hipMemcpyAsync(challengers[j]->d, hc->d, sizeof(fri::Challenger), hipMemcpyDeviceToDevice, h->stream));
+                P2_HIP(h, stream_sync(h));
+                return P2HOT_OK;
+            };
+            rcs[k] = one();
+            if (rcs[k] != P2HOT_OK) errs[k] = "proof " + std::to_string(j) + ": " + h->err;
+        }
+    };
+#ifdef P2HOT_EMU
+    for (size_t k = 0; k < K; ++k) work(k);  // the kernel emulator is single-threaded
+#else
+    {
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < K; ++k) th.emplace_back(work, k);
+        work(0);
+        for (auto &t : th) t.join();
+    }
+#endif
+    for (size_t k = 0; k < K; ++k)
+        if (rcs[k] != P2HOT_OK) P2_FAIL(ctx, rcs[k], "prove_openings_many: %s", errs[k].c_str());
+    return P2HOT_OK;
 }
 
 static int prove_openings_core(p2hot_ctx *ctx, const p2hot_fri_batch_info *batches, size_t n_batches, const std::vector<OracleView> &views,

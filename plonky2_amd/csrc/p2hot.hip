@@ -75,6 +75,9 @@ struct p2hot_ctx {
     std::map<std::tuple<int, unsigned, unsigned>, u64 *> twid_cache;
     // grow-only cache of device blocks for the host-pointer entry points: a fresh hipMalloc of the 9 GB LDE matrix
     // costs up to a second (the driver clears VRAM), so blocks go back to this list instead of hipFree
+    std::vector<p2hot_ctx *> helpers;   // p2hot_prove_openings_many: sibling contexts on the same GPU, each with its own stream
+    std::vector<hipStream_t> helper_streams;
+    std::vector<struct p2hot_challenger *> helper_challengers;
     std::mutex pool_mu;  // pool_free / pool_live / scratch bookkeeping: frees may come from another thread (a Drop, a GC finaliser)
     std::vector<std::pair<void *, size_t>> pool_free;  // (pointer, capacity)
     std::map<void *, size_t> pool_live;  // (inverse, log_nblk, log_r) -> inter-pass twiddle table
@@ -368,10 +371,19 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     return P2HOT_OK;
 }
 
+extern "C" void p2hot_challenger_destroy(struct p2hot_challenger *ch);
 extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)stream_sync(ctx);
+    for (size_t k = 0; k < ctx->helpers.size(); ++k) {
+        if (k < ctx->helper_challengers.size()) p2hot_challenger_destroy(ctx->helper_challengers[k]);
+        p2hot_ctx_destroy(ctx->helpers[k]);
+#ifndef P2HOT_EMU
+        if (k < ctx->helper_streams.size() && ctx->helper_streams[k]) (void)hipStreamDestroy(ctx->helper_streams[k]);
+#endif
+    }
+    ctx->helpers.clear();
 #ifndef P2HOT_EMU
     if (ctx->side) {
         (void)hipStreamSynchronize(ctx->side);

@@ -468,3 +468,67 @@ def test_pow_witness_outside_the_first_search_range(eng, ora, monkeypatch):
     pad[:32] = quo
     ora.fri_commit(pad, 2, 1, [2], oc)
     assert ora.fri_pow(oc, 9) == p0["pow_witness"]
+
+
+@pytest.mark.parametrize("M", [1, 3, 11])
+def test_prove_openings_many_equals_single_calls(eng, ora, M):
+    """p2hot_prove_openings_many: M independent opening proofs on sibling contexts of the same GPU (own streams, host threads);
+    every proof's buffers and the transcript afterwards equal a single p2hot_prove_openings call's (fri/oracle.rs:176-237)"""
+    import ctypes as C
+    from plonky2_amd import _lib
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    from plonky2_amd.iop.challenger import Challenger
+    rng = np.random.default_rng(500 + M)
+    log_n, rb, cap, widths, arity, Q = 6, 3, 2, [5, 3], [2, 1], 4
+    n = 1 << log_n
+    ab = (C.c_uint * len(arity))(*arity)
+    fp = _lib.FriParams(rb, cap, 3, Q, ab, len(arity), 0, 0, 0)
+    oracles = [[PolynomialBatch.from_coeffs(rand_field(rng, w, n), rb, False, cap, engine=eng) for w in widths] for _ in range(M)]
+    allp = [(oi, pi) for oi, w in enumerate(widths) for pi in range(w)]
+    oi_arr = (C.c_uint32 * len(allp))(*[o for o, _ in allp])
+    pi_arr = (C.c_uint32 * len(allp))(*[p for _, p in allp])
+    points = [[int(x) for x in rand_field(rng, 2)] for _ in range(M)]
+    lay = _lib.FriProofLayout()
+    h0 = (C.c_void_p * len(widths))(*[o._h for o in oracles[0]])
+    assert eng.lib.p2hot_fri_proof_sizes(h0, len(widths), C.byref(fp), C.byref(lay)) == _lib.OK
+    names = ("caps", "final_poly", "initial_leaves", "initial_paths", "step_evals", "step_paths")
+
+    def run(many):
+        chs = [Challenger(eng) for _ in range(M)]
+        for j, ch in enumerate(chs):
+            ch.observe_elements(np.arange(j, j + 5, dtype=np.uint64))
+        bufs = [{k: np.zeros(max(1, getattr(lay, k + "_words")), dtype=np.uint64) for k in names} for _ in range(M)]
+        qidx = [np.zeros(Q, dtype=np.uint64) for _ in range(M)]
+        infos = []
+        for j in range(M):
+            inf = (_lib.FriBatchInfo * 1)()
+            inf[0].point[0], inf[0].point[1] = points[j]
+            inf[0].oracle_index, inf[0].poly_index, inf[0].n_polys = oi_arr, pi_arr, len(allp)
+            infos.append(inf)
+        proofs = (_lib.FriProof * M)()
+        for j in range(M):
+            b = bufs[j]
+            proofs[j] = _lib.FriProof(b["caps"].ctypes.data, b["final_poly"].ctypes.data, 0, qidx[j].ctypes.data, b["initial_leaves"].ctypes.data,
+                                      b["initial_paths"].ctypes.data, b["step_evals"].ctypes.data, b["step_paths"].ctypes.data)
+        if many:
+            bp = (C.POINTER(_lib.FriBatchInfo) * M)(*[C.cast(inf, C.POINTER(_lib.FriBatchInfo)) for inf in infos])
+            nb = (C.c_size_t * M)(*([1] * M))
+            hs = (C.c_void_p * (M * len(widths)))(*[o._h for row in oracles for o in row])
+            cp = (C.c_void_p * M)(*[ch._h for ch in chs])
+            eng.check(eng.lib.p2hot_prove_openings_many(eng.ctx, M, bp, nb, hs, len(widths), cp, C.byref(fp), proofs))
+        else:
+            for j in range(M):
+                hs = (C.c_void_p * len(widths))(*[o._h for o in oracles[j]])
+                eng.check(eng.lib.p2hot_prove_openings(eng.ctx, infos[j], 1, hs, len(widths), chs[j]._h, C.byref(fp), C.byref(proofs[j])))
+        return bufs, qidx, [int(proofs[j].pow_witness) for j in range(M)], [ch.get_n_challenges(3) for ch in chs]
+
+    a, b = run(False), run(True)
+    for j in range(M):
+        for k in names:
+            assert (a[0][j][k] == b[0][j][k]).all(), (j, k)
+        assert (a[1][j] == b[1][j]).all() and a[2][j] == b[2][j] and a[3][j] == b[3][j], j
+    assert len({tuple(x["final_poly"].tolist()) for x in b[0]}) == M  # the proofs are different proofs
+    # argument errors name the proof
+    bad = (C.c_void_p * (M * len(widths)))(*([None] * (M * len(widths))))
+    cp = (C.c_void_p * M)(*[Challenger(eng)._h for _ in range(M)])
+    assert eng.lib.p2hot_prove_openings_many(eng.ctx, M, None, None, bad, len(widths), cp, C.byref(fp), None) == _lib.EINVAL
