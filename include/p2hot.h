@@ -113,7 +113,9 @@ int p2hot_merkle_dev(p2hot_ctx *ctx, const uint64_t *d_leaves, int layout, size_
                      uint64_t *d_digests, uint64_t *d_cap);
 /* Field-arithmetic self test (goldilocks_field.rs:245-320, :402-415): for count operand pairs writes six arrays of
  * `count` words to d_out: a*b by the compiler-scheduled multiply, by the hand-scheduled single stream, by the 3-way
- * interleaved stream, a+b, a-b (all canonical), and a 0/1 flag that the other two mul3 lanes agreed. */
+ * interleaved stream, a+b, a-b (all canonical), and a word that is 0 unless a hand-written instruction stream disagreed
+ * with the compiler-scheduled arithmetic (bit 0 the other two mul3 lanes, 1 the low-register multiply, 2 the
+ * power-of-two twiddle multiplies, 3 / 4 the MDS row recombinations fold1 / fold3, 5 / 6 the two-stream mul2 / fold2). */
 int p2hot_field_selftest_dev(p2hot_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, size_t count, uint64_t *d_out);
 /* rows of a column-major matrix of `rows` rows: d_out[q][c] = d_colmajor[c * col_stride + d_idx[q]]
  * (PolynomialBatch::get_lde_values / MerkleTree::get, fri/oracle.rs:142-147, merkle_tree.rs:227).

@@ -15,13 +15,14 @@
 //          the high word and one SIGNED multiply-add (v_mad_i64_i32, e * -1), which writes the 64-bit result pair
 //                                                                               (goldilocks_field.rs:402-415)
 // Temporaries are fixed VGPR/SGPR pairs (declared as clobbers) because inline-asm operands cannot
-// name the halves of a 64-bit register pair.  The C fallback (emulator build) is gl::mul.
+// name the halves of a 64-bit register pair.  The emulator build runs these blocks either through its instruction
+// interpreter (asm_block.h: the same template strings, hazard- and clobber-checked) or, by default, as gl::mul.
 #pragma once
+#include "asm_block.h"
 #include "gl.hpp"
 
 namespace gl {
 
-#ifndef P2HOT_EMU
 // stream register sets: P, M, Q pairs + two SGPR carry pairs
 #define P2_SA "v[70:71]", "v70", "v71", "v[72:73]", "v72", "v73", "v[74:75]", "v74", "v75", "s[40:41]", "s[42:43]"
 #define P2_SB "v[76:77]", "v76", "v77", "v[78:79]", "v78", "v79", "v[80:81]", "v80", "v81", "s[44:45]", "s[46:47]"
@@ -51,19 +52,51 @@ namespace gl {
 
 // r[k] = a[k] * b[k] (mod P), k = 0..2; any representatives in, any representative out
 __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
+    if (!P2_ASM_INTERPRETED()) {  // emulator build with the interpreter off (constant-false in the product)
+        for (int k = 0; k < 3; ++k) r[k] = mul(a[k], b[k]);
+        return;
+    }
     u64 ra, rb, rc;
-    asm(P2_ROW(P2_ST1) P2_ROW(P2_ST2) P2_ROW(P2_ST3) P2_ROW(P2_ST4) P2_ROW(P2_ST5) P2_ROW(P2_ST6) P2_ROW(P2_ST7)
-            P2_ROW(P2_ST8) P2_ROW(P2_ST9) P2_ROW(P2_ST10) P2_ROW(P2_ST11) P2_ROW(P2_ST12) P2_ROW(P2_ST13)
-                P2_ROW(P2_ST14)
-        : [ra0] "=&v"(ra), [rb0] "=&v"(rb), [rc0] "=&v"(rc)
-        : [xa0] "v"((u32)a[0]), [xa1] "v"((u32)(a[0] >> 32)), [ya0] "v"((u32)b[0]), [ya1] "v"((u32)(b[0] >> 32)),
-          [xb0] "v"((u32)a[1]), [xb1] "v"((u32)(a[1] >> 32)), [yb0] "v"((u32)b[1]), [yb1] "v"((u32)(b[1] >> 32)),
-          [xc0] "v"((u32)a[2]), [xc1] "v"((u32)(a[2] >> 32)), [yc0] "v"((u32)b[2]), [yc1] "v"((u32)(b[2] >> 32))
-        : "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84",
-          "v85", "v86", "v87", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51");
+    P2_ASM(P2_ROW(P2_ST1) P2_ROW(P2_ST2) P2_ROW(P2_ST3) P2_ROW(P2_ST4) P2_ROW(P2_ST5) P2_ROW(P2_ST6) P2_ROW(P2_ST7)
+               P2_ROW(P2_ST8) P2_ROW(P2_ST9) P2_ROW(P2_ST10) P2_ROW(P2_ST11) P2_ROW(P2_ST12) P2_ROW(P2_ST13)
+                   P2_ROW(P2_ST14),
+           (P2_O([ra0], "=&v", ra), P2_O([rb0], "=&v", rb), P2_O([rc0], "=&v", rc)),
+           (P2_I([xa0], "v", (u32)a[0]), P2_I([xa1], "v", (u32)(a[0] >> 32)), P2_I([ya0], "v", (u32)b[0]),
+            P2_I([ya1], "v", (u32)(b[0] >> 32)), P2_I([xb0], "v", (u32)a[1]), P2_I([xb1], "v", (u32)(a[1] >> 32)),
+            P2_I([yb0], "v", (u32)b[1]), P2_I([yb1], "v", (u32)(b[1] >> 32)), P2_I([xc0], "v", (u32)a[2]),
+            P2_I([xc1], "v", (u32)(a[2] >> 32)), P2_I([yc0], "v", (u32)b[2]), P2_I([yc1], "v", (u32)(b[2] >> 32))),
+           ("v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85",
+            "v86", "v87", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51"));
     r[0] = ra;
     r[1] = rb;
     r[2] = rc;
+}
+
+// ---- mul2: two interleaved streams (what is left of a group of independent products after the threes) ----
+// One foreign instruction sits between a carry producer and its consumer, so the four adjacent producer/consumer rows
+// (5->6, 6->7, 8->9, 10->11) are followed by one more wait state each (`s_nop 0`): 28 instructions + 4 single wait states
+// instead of two single streams' 28 + 10 double ones.
+#define P2_NOP0 "s_nop 0\n\t"
+#define P2_ROW2(ST)                                                  \
+    P2_APPLY(ST, P2_SA, "xa0", "xa1", "ya0", "ya1", "ra0", "ra1")    \
+    P2_APPLY(ST, P2_SB, "xb0", "xb1", "yb0", "yb1", "rb0", "rb1")
+__device__ __forceinline__ void mul2(const u64 a[2], const u64 b[2], u64 r[2]) {
+    if (!P2_ASM_INTERPRETED()) {
+        for (int k = 0; k < 2; ++k) r[k] = mul(a[k], b[k]);
+        return;
+    }
+    u64 ra, rb;
+    P2_ASM(P2_ROW2(P2_ST1) P2_ROW2(P2_ST2) P2_ROW2(P2_ST3) P2_ROW2(P2_ST4) P2_ROW2(P2_ST5) P2_NOP0 P2_ROW2(P2_ST6) P2_NOP0
+               P2_ROW2(P2_ST7) P2_ROW2(P2_ST8) P2_NOP0 P2_ROW2(P2_ST9) P2_ROW2(P2_ST10) P2_NOP0 P2_ROW2(P2_ST11)
+                   P2_ROW2(P2_ST12) P2_ROW2(P2_ST13) P2_ROW2(P2_ST14),
+           (P2_O([ra0], "=&v", ra), P2_O([rb0], "=&v", rb)),
+           (P2_I([xa0], "v", (u32)a[0]), P2_I([xa1], "v", (u32)(a[0] >> 32)), P2_I([ya0], "v", (u32)b[0]),
+            P2_I([ya1], "v", (u32)(b[0] >> 32)), P2_I([xb0], "v", (u32)a[1]), P2_I([xb1], "v", (u32)(a[1] >> 32)),
+            P2_I([yb0], "v", (u32)b[1]), P2_I([yb1], "v", (u32)(b[1] >> 32))),
+           ("v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "s40", "s41", "s42", "s43",
+            "s44", "s45", "s46", "s47"));
+    r[0] = ra;
+    r[1] = rb;
 }
 
 // ---- mul1: one multiplication as a single stream (dependent S-box chains of the partial rounds) ----
@@ -77,22 +110,24 @@ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
     P2_A1(P2_ST10, SET) P2_NOP P2_A1(P2_ST11, SET) P2_A1(P2_ST12, SET) P2_A1(P2_ST13, SET) P2_A1(P2_ST14, SET)
 
 __device__ __forceinline__ u64 mul1(u64 a, u64 b) {
+    if (!P2_ASM_INTERPRETED()) return mul(a, b);
     u64 ra;
-    asm(P2_MUL1_BODY(P2_SA)
-        : [ra0] "=&v"(ra)
-        : [xa0] "v"((u32)a), [xa1] "v"((u32)(a >> 32)), [ya0] "v"((u32)b), [ya1] "v"((u32)(b >> 32))
-        : "v70", "v71", "v72", "v73", "v74", "v75", "s40", "s41", "s42", "s43");
+    P2_ASM(P2_MUL1_BODY(P2_SA), (P2_O([ra0], "=&v", ra)),
+           (P2_I([xa0], "v", (u32)a), P2_I([xa1], "v", (u32)(a >> 32)), P2_I([ya0], "v", (u32)b),
+            P2_I([ya1], "v", (u32)(b >> 32))),
+           ("v70", "v71", "v72", "v73", "v74", "v75", "s40", "s41", "s42", "s43"));
     return ra;
 }
 
 // the same stream on a low register set, for kernels that must stay within 64 VGPRs (the NTT passes)
 #define P2_SN "v[58:59]", "v58", "v59", "v[60:61]", "v60", "v61", "v[62:63]", "v62", "v63", "s[60:61]", "s[62:63]"
 __device__ __forceinline__ u64 mul1_lowregs(u64 a, u64 b) {
+    if (!P2_ASM_INTERPRETED()) return mul(a, b);
     u64 ra;
-    asm(P2_MUL1_BODY(P2_SN)
-        : [ra0] "=&v"(ra)
-        : [xa0] "v"((u32)a), [xa1] "v"((u32)(a >> 32)), [ya0] "v"((u32)b), [ya1] "v"((u32)(b >> 32))
-        : "v58", "v59", "v60", "v61", "v62", "v63", "s60", "s61", "s62", "s63");
+    P2_ASM(P2_MUL1_BODY(P2_SN), (P2_O([ra0], "=&v", ra)),
+           (P2_I([xa0], "v", (u32)a), P2_I([xa1], "v", (u32)(a >> 32)), P2_I([ya0], "v", (u32)b),
+            P2_I([ya1], "v", (u32)(b >> 32))),
+           ("v58", "v59", "v60", "v61", "v62", "v63", "s60", "s61", "s62", "s63"));
     return ra;
 }
 
@@ -108,34 +143,8 @@ __device__ __forceinline__ u64 mul1_lowregs(u64 a, u64 b) {
 #define P2_FD3(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_cndmask_b32 " M0 ", 0, -1, " C1 "\n\t"
 #define P2_FD4(P, P0, P1, M, M0, M1, Q, Q0, Q1, C1, C2, a0, a1, b0, b1, r0, r1) "v_mad_u64_u32 %[" r0 "], " C1 ", " M0 ", 1, " P "\n\t"
 
-// y[k] = al[k] + ah[k] * 2^32 (mod P), k = 0..2, for al, ah < 2^63
-__device__ __forceinline__ void fold3(const u64 al[3], const u64 ah[3], u64 y[3]) {
-    u64 ra, rb, rc;  // 64-bit outputs: the last instruction of a stream writes the register pair
-    asm(P2_ROW(P2_FD1) P2_ROW(P2_FD2) P2_ROW(P2_FD3) P2_ROW(P2_FD4)
-        : [ra0] "=&v"(ra), [rb0] "=&v"(rb), [rc0] "=&v"(rc)
-        : [xa0] "v"(al[0]), [ya0] "v"((u32)ah[0]), [ya1] "v"((u32)(ah[0] >> 32)), [xb0] "v"(al[1]), [yb0] "v"((u32)ah[1]),
-          [yb1] "v"((u32)(ah[1] >> 32)), [xc0] "v"(al[2]), [yc0] "v"((u32)ah[2]), [yc1] "v"((u32)(ah[2] >> 32))
-        : "v70", "v71", "v72", "v76", "v77", "v78", "v82", "v83", "v84", "s40", "s41", "s44", "s45", "s48", "s49");
-    y[0] = ra;
-    y[1] = rb;
-    y[2] = rc;
-}
-// one row recombination as a single stream (the batched partial rounds' single rows), explicit wait states
-__device__ __forceinline__ u64 fold1(u64 al, u64 ah) {
-    u64 ra;
-    asm(P2_A1(P2_FD1, P2_SA) P2_A1(P2_FD2, P2_SA) P2_NOP P2_A1(P2_FD3, P2_SA) P2_A1(P2_FD4, P2_SA)
-        : [ra0] "=&v"(ra)
-        : [xa0] "v"(al), [ya0] "v"((u32)ah), [ya1] "v"((u32)(ah >> 32))
-        : "v70", "v71", "v72", "s40", "s41");
-    return ra;
-}
-#else
-__host__ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
-    for (int k = 0; k < 3; ++k) r[k] = mul(a[k], b[k]);
-}
-__host__ __device__ __forceinline__ u64 mul1(u64 a, u64 b) { return mul(a, b); }
-__host__ __device__ __forceinline__ u64 mul1_lowregs(u64 a, u64 b) { return mul(a, b); }
-__host__ __device__ __forceinline__ u64 fold1(u64 al, u64 ah) {
+// the C statement of one row recombination (the emulator's fast path)
+__host__ __device__ __forceinline__ u64 fold_row_c(u64 al, u64 ah) {
     u32 k1;
     u32 w1 = addc32((u32)(al >> 32), (u32)ah, 0u, &k1);
     u32 w2 = (u32)(ah >> 32) + k1;
@@ -143,16 +152,47 @@ __host__ __device__ __forceinline__ u64 fold1(u64 al, u64 ah) {
     u64 t = (u64)w2 * 0xFFFFFFFFu + lo64;
     return fold_carry(t, t < lo64);
 }
-__host__ __device__ __forceinline__ void fold3(const u64 al[3], const u64 ah[3], u64 y[3]) {
-    for (int k = 0; k < 3; ++k) {
-        u32 k1;
-        u32 w1 = addc32((u32)(al[k] >> 32), (u32)ah[k], 0u, &k1);
-        u32 w2 = (u32)(ah[k] >> 32) + k1;
-        u64 lo64 = ((u64)w1 << 32) | (u32)al[k];
-        u64 t = (u64)w2 * 0xFFFFFFFFu + lo64;
-        y[k] = fold_carry(t, t < lo64);
+
+// y[k] = al[k] + ah[k] * 2^32 (mod P), k = 0..2, for al, ah < 2^63
+__device__ __forceinline__ void fold3(const u64 al[3], const u64 ah[3], u64 y[3]) {
+    if (!P2_ASM_INTERPRETED()) {
+        for (int k = 0; k < 3; ++k) y[k] = fold_row_c(al[k], ah[k]);
+        return;
     }
+    u64 ra, rb, rc;  // 64-bit outputs: the last instruction of a stream writes the register pair
+    P2_ASM(P2_ROW(P2_FD1) P2_ROW(P2_FD2) P2_ROW(P2_FD3) P2_ROW(P2_FD4),
+           (P2_O([ra0], "=&v", ra), P2_O([rb0], "=&v", rb), P2_O([rc0], "=&v", rc)),
+           (P2_I([xa0], "v", al[0]), P2_I([ya0], "v", (u32)ah[0]), P2_I([ya1], "v", (u32)(ah[0] >> 32)),
+            P2_I([xb0], "v", al[1]), P2_I([yb0], "v", (u32)ah[1]), P2_I([yb1], "v", (u32)(ah[1] >> 32)),
+            P2_I([xc0], "v", al[2]), P2_I([yc0], "v", (u32)ah[2]), P2_I([yc1], "v", (u32)(ah[2] >> 32))),
+           ("v70", "v71", "v72", "v76", "v77", "v78", "v82", "v83", "v84", "s40", "s41", "s44", "s45", "s48", "s49"));
+    y[0] = ra;
+    y[1] = rb;
+    y[2] = rc;
 }
-#endif
+// two row recombinations, interleaved (one more wait state after the carry row)
+__device__ __forceinline__ void fold2(const u64 al[2], const u64 ah[2], u64 y[2]) {
+    if (!P2_ASM_INTERPRETED()) {
+        for (int k = 0; k < 2; ++k) y[k] = fold_row_c(al[k], ah[k]);
+        return;
+    }
+    u64 ra, rb;
+    P2_ASM(P2_ROW2(P2_FD1) P2_ROW2(P2_FD2) P2_NOP0 P2_ROW2(P2_FD3) P2_ROW2(P2_FD4),
+           (P2_O([ra0], "=&v", ra), P2_O([rb0], "=&v", rb)),
+           (P2_I([xa0], "v", al[0]), P2_I([ya0], "v", (u32)ah[0]), P2_I([ya1], "v", (u32)(ah[0] >> 32)),
+            P2_I([xb0], "v", al[1]), P2_I([yb0], "v", (u32)ah[1]), P2_I([yb1], "v", (u32)(ah[1] >> 32))),
+           ("v70", "v71", "v72", "v76", "v77", "v78", "s40", "s41", "s44", "s45"));
+    y[0] = ra;
+    y[1] = rb;
+}
+// one row recombination as a single stream (the batched partial rounds' single rows), explicit wait states
+__device__ __forceinline__ u64 fold1(u64 al, u64 ah) {
+    if (!P2_ASM_INTERPRETED()) return fold_row_c(al, ah);
+    u64 ra;
+    P2_ASM(P2_A1(P2_FD1, P2_SA) P2_A1(P2_FD2, P2_SA) P2_NOP P2_A1(P2_FD3, P2_SA) P2_A1(P2_FD4, P2_SA),
+           (P2_O([ra0], "=&v", ra)), (P2_I([xa0], "v", al), P2_I([ya0], "v", (u32)ah), P2_I([ya1], "v", (u32)(ah >> 32))),
+           ("v70", "v71", "v72", "s40", "s41"));
+    return ra;
+}
 
 }  // namespace gl

@@ -14,6 +14,7 @@
 #include "poseidon.hpp"
 #include "poseidon4.hpp"
 #include "poseidon16.hpp"
+#include "ntt.hpp"
 
 namespace merkle {
 using gl::u32;
@@ -212,7 +213,8 @@ __global__ void permute_batch_kernel(u64 *states, size_t count) {
 
 // field-arithmetic self-test primitive: out[0][t] = a*b by the compiler-scheduled multiply, out[1][t] by the
 // hand-scheduled single stream (mul1), out[2][t] by the 3-way interleaved stream (mul3, lanes grouped in
-// threes of consecutive elements), out[3][t] = a+b, out[4][t] = a-b.  All canonical.  Used by the edge-value
+// threes of consecutive elements), out[3][t] = a+b, out[4][t] = a-b, out[5][t] = 0 or a bit per hand-written stream that
+// disagreed with the compiler's arithmetic.  All canonical.  Used by the edge-value
 // grid test (the reference's field/src/prime_field_testing.rs:8-17 pattern).
 __global__ void field_selftest_kernel(const u64 *a, const u64 *b, size_t count, u64 *out) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -224,7 +226,38 @@ __global__ void field_selftest_kernel(const u64 *a, const u64 *b, size_t count, 
     u64 aa[3] = {x, y, x}, bb[3] = {y, x, x}, rr[3];
     gl::mul3(aa, bb, rr);
     u64 ok = (gl::canon(rr[1]) == gl::canon(rr[0])) && (gl::canon(rr[2]) == gl::canon(gl::mul(x, x))) ? 0 : 1;
-    out[2 * count + t] = gl::canon(rr[0]) + ok * 0;  // rr[0]
+    // the other hand-written streams against the compiler's arithmetic, one flag bit each:
+    // 2 = the low-register single stream, 4 = the power-of-two twiddle multiplies of the radix-8 butterflies (ntt.hpp),
+    // 8 / 16 = the MDS row recombinations fold1 / fold3 on accumulators below 2^63, 32 / 64 = the two-stream mul2 / fold2
+    if (gl::canon(gl::mul1_lowregs(x, y)) != gl::canon(gl::mul(x, y))) ok |= 2;
+#define P2_CHK_POW2(S)                                                                                              \
+    if (gl::canon(ntt::mul_pow2_asm<S>(x)) != gl::canon(gl::mul(x, (S) < 64 ? 1ull << ((S) & 63) : 0xFFFFFFFFull << (((S) - 64) & 31)))) \
+        ok |= 4;
+    P2_CHK_POW2(12) P2_CHK_POW2(24) P2_CHK_POW2(36) P2_CHK_POW2(48) P2_CHK_POW2(60) P2_CHK_POW2(72) P2_CHK_POW2(84)
+    P2_CHK_POW2(1) P2_CHK_POW2(31) P2_CHK_POW2(33) P2_CHK_POW2(63) P2_CHK_POW2(65) P2_CHK_POW2(95)
+#undef P2_CHK_POW2
+    {
+        const u64 al = x >> 1, ah = y >> 1;  // al + ah * 2^32
+        const u64 want = gl::canon(gl::add(al, gl::mul(ah, 1ull << 32)));
+        if (gl::canon(gl::fold1(al, ah)) != want) ok |= 8;
+        const u64 al3[3] = {al, ah, al ^ 0x2AAAAAAAAAAAAAAAull}, ah3[3] = {ah, al, ah};
+        u64 y3[3];
+        gl::fold3(al3, ah3, y3);
+        for (int k = 0; k < 3; ++k)
+            if (gl::canon(y3[k]) != gl::canon(gl::add(al3[k], gl::mul(ah3[k], 1ull << 32)))) ok |= 16;
+    }
+    {
+        const u64 a2[2] = {x, y ^ 0x9E3779B97F4A7C15ull}, b2[2] = {y, x};
+        u64 r2[2];
+        gl::mul2(a2, b2, r2);
+        if (gl::canon(r2[0]) != gl::canon(gl::mul(x, y)) || gl::canon(r2[1]) != gl::canon(gl::mul(a2[1], x))) ok |= 32;
+        const u64 l2[2] = {x >> 1, y >> 1}, h2[2] = {y >> 1, x >> 1};
+        u64 f2[2];
+        gl::fold2(l2, h2, f2);
+        for (int k = 0; k < 2; ++k)
+            if (gl::canon(f2[k]) != gl::canon(gl::add(l2[k], gl::mul(h2[k], 1ull << 32)))) ok |= 64;
+    }
+    out[2 * count + t] = gl::canon(rr[0]);
     out[5 * count + t] = ok;
     out[3 * count + t] = gl::canon(gl::add(x, y));
     out[4 * count + t] = gl::canon(gl::sub(x, y));

@@ -160,65 +160,65 @@ __device__ __forceinline__ u64 mul_pow2_c(u64 x, int s) {  // x * 2^s (mod P), 0
 // with the carry / borrow folds done as in gl_mul3.hpp (e = carry - borrow, one signed multiply-add).
 template <int S>
 __device__ __forceinline__ u64 mul_pow2_asm(u64 x) {
-#ifdef P2HOT_EMU
-    return mul_pow2_c(x, S);
-#else
+    if (!P2_ASM_INTERPRETED()) return mul_pow2_c(x, S);  // emulator build with the interpreter off (constant-false in the product)
     static_assert(S > 0 && S < 96 && S != 32 && S != 64, "shift handled elsewhere");
     const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
     u64 r, t, c1;
     u32 m;
     if (S < 32) {
         u32 h;
-        asm("v_lshlrev_b64 %[t], %[s], %[x]\n\t"
-            "v_lshrrev_b32 %[h], %[rs], %[x1]\n\t"
-            "v_mad_u64_u32 %[t], %[c1], %[h], -1, %[t]\n\t"
-            "s_nop 1\n\t"
-            "v_cndmask_b32 %[m], 0, -1, %[c1]\n\t"
-            "v_mad_u64_u32 %[r], %[c1], %[m], 1, %[t]"
-            : [r] "=&v"(r), [t] "=&v"(t), [h] "=&v"(h), [m] "=&v"(m), [c1] "=&s"(c1)
-            : [x] "v"(x), [x1] "v"(x1), [s] "n"(S), [rs] "n"(32 - S));
+        P2_ASM_NC("v_lshlrev_b64 %[t], %[s], %[x]\n\t"
+                  "v_lshrrev_b32 %[h], %[rs], %[x1]\n\t"
+                  "v_mad_u64_u32 %[t], %[c1], %[h], -1, %[t]\n\t"
+                  "s_nop 1\n\t"
+                  "v_cndmask_b32 %[m], 0, -1, %[c1]\n\t"
+                  "v_mad_u64_u32 %[r], %[c1], %[m], 1, %[t]",
+                  (P2_O([r], "=&v", r), P2_O([t], "=&v", t), P2_O([h], "=&v", h), P2_O([m], "=&v", m), P2_O([c1], "=&s", c1)),
+                  (P2_I([x], "v", x), P2_I([x1], "v", x1), P2_I([s], "n", S), P2_I([rs], "n", 32 - S)));
     } else if (S < 64) {
         u64 c2;
         u32 a, b, cc, t0, t1;
-        asm("v_lshlrev_b32 %[a], %[s], %[x0]\n\t"             // hi word of the low 64 bits (the low word is 0)
-            "v_alignbit_b32 %[b], %[x1], %[x0], %[rs]\n\t"    // bits 64..95 of x << S
-            "v_lshrrev_b32 %[cc], %[rs], %[x1]\n\t"           // bits 96.. of x << S
-            "v_sub_co_u32 %[t0], %[c1], 0, %[cc]\n\t"
-            "s_nop 1\n\t"
-            "v_subb_co_u32 %[t1], %[c1], %[a], 0, %[c1]\n\t"  // {t0, t1} = lo64 - hi.hi, borrow c1
-            : [a] "=&v"(a), [b] "=&v"(b), [cc] "=&v"(cc), [t0] "=&v"(t0), [t1] "=&v"(t1), [c1] "=&s"(c1)
-            : [x0] "v"(x0), [x1] "v"(x1), [s] "n"(S - 32), [rs] "n"(64 - S));
+        P2_ASM_NC("v_lshlrev_b32 %[a], %[s], %[x0]\n\t"             // hi word of the low 64 bits (the low word is 0)
+                  "v_alignbit_b32 %[b], %[x1], %[x0], %[rs]\n\t"    // bits 64..95 of x << S
+                  "v_lshrrev_b32 %[cc], %[rs], %[x1]\n\t"           // bits 96.. of x << S
+                  "v_sub_co_u32 %[t0], %[c1], 0, %[cc]\n\t"
+                  "s_nop 1\n\t"
+                  "v_subb_co_u32 %[t1], %[c1], %[a], 0, %[c1]\n\t",  // {t0, t1} = lo64 - hi.hi, borrow c1
+                  (P2_O([a], "=&v", a), P2_O([b], "=&v", b), P2_O([cc], "=&v", cc), P2_O([t0], "=&v", t0),
+                   P2_O([t1], "=&v", t1), P2_O([c1], "=&s", c1)),
+                  (P2_I([x0], "v", x0), P2_I([x1], "v", x1), P2_I([s], "n", S - 32), P2_I([rs], "n", 64 - S)));
         t = ((u64)t1 << 32) | t0;
-        asm("v_mad_u64_u32 %[t], %[c2], %[b], -1, %[t]\n\t"   // + hi.lo * (2^32-1), carry c2
-            "s_nop 1\n\t"
-            "v_cndmask_b32 %[m], 0, 1, %[c2]\n\t"
-            "v_subb_co_u32 %[m], %[c1], %[m], 0, %[c1]\n\t"   // e = carry - borrow
-            : [t] "+v"(t), [m] "=&v"(m), [c2] "=&s"(c2), [c1] "+s"(c1)
-            : [b] "v"(b));
-        t += (u64)m << 32;                                      // u + (e << 32) - e
-        asm("v_mad_i64_i32 %[r], %[c2], %[m], -1, %[t]" : [r] "=&v"(r), [c2] "=&s"(c2) : [m] "v"(m), [t] "v"(t));
+        P2_ASM_NC("v_mad_u64_u32 %[t], %[c2], %[b], -1, %[t]\n\t"   // + hi.lo * (2^32-1), carry c2
+                  "s_nop 1\n\t"
+                  "v_cndmask_b32 %[m], 0, 1, %[c2]\n\t"
+                  "v_subb_co_u32 %[m], %[c1], %[m], 0, %[c1]\n\t",   // e = carry - borrow
+                  (P2_O([t], "+v", t), P2_O([m], "=&v", m), P2_O([c2], "=&s", c2), P2_O([c1], "+s", c1)), (P2_I([b], "v", b)));
+        t += (u64)m << 32;                                          // u + (e << 32) - e
+        P2_ASM_NC("v_mad_i64_i32 %[r], %[c2], %[m], -1, %[t]", (P2_O([r], "=&v", r), P2_O([c2], "=&s", c2)),
+                  (P2_I([m], "v", m), P2_I([t], "v", t)));
     } else {
         u64 y;
         u32 l0;
-        asm("v_lshlrev_b32 %[l0], %[s], %[x0]\n\t"
-            "v_lshrrev_b64 %[y], %[rs], %[x]\n\t"             // x >> (96 - S)
-            "v_mad_u64_u32 %[t], %[c1], %[l0], -1, 0"           // l0 * (2^32-1)
-            : [l0] "=&v"(l0), [y] "=&v"(y), [t] "=&v"(t), [c1] "=&s"(c1)
-            : [x0] "v"(x0), [x] "v"(x), [s] "n"(S - 64), [rs] "n"(96 - S));
+        P2_ASM_NC("v_lshlrev_b32 %[l0], %[s], %[x0]\n\t"
+                  "v_lshrrev_b64 %[y], %[rs], %[x]\n\t"             // x >> (96 - S)
+                  "v_mad_u64_u32 %[t], %[c1], %[l0], -1, 0",            // l0 * (2^32-1)
+                  (P2_O([l0], "=&v", l0), P2_O([y], "=&v", y), P2_O([t], "=&v", t), P2_O([c1], "=&s", c1)),
+                  (P2_I([x0], "v", x0), P2_I([x], "v", x), P2_I([s], "n", S - 64), P2_I([rs], "n", 96 - S)));
         u32 d0, d1;
-        asm("v_sub_co_u32 %[d0], %[c1], %[t0], %[y0]\n\t"
-            "s_nop 1\n\t"
-            "v_subb_co_u32 %[d1], %[c1], %[t1], %[y1], %[c1]\n\t"
-            "s_nop 1\n\t"
-            "v_cndmask_b32 %[m], 0, -1, %[c1]\n\t"            // e = -borrow
-            "v_add_u32 %[d1], %[d1], %[m]"
-            : [d0] "=&v"(d0), [d1] "=&v"(d1), [m] "=&v"(m), [c1] "=&s"(c1)
-            : [t0] "v"((u32)t), [t1] "v"((u32)(t >> 32)), [y0] "v"((u32)y), [y1] "v"((u32)(y >> 32)));
+        P2_ASM_NC("v_sub_co_u32 %[d0], %[c1], %[t0], %[y0]\n\t"
+                  "s_nop 1\n\t"
+                  "v_subb_co_u32 %[d1], %[c1], %[t1], %[y1], %[c1]\n\t"
+                  "s_nop 1\n\t"
+                  "v_cndmask_b32 %[m], 0, -1, %[c1]\n\t"            // e = -borrow
+                  "v_add_u32 %[d1], %[d1], %[m]",
+                  (P2_O([d0], "=&v", d0), P2_O([d1], "=&v", d1), P2_O([m], "=&v", m), P2_O([c1], "=&s", c1)),
+                  (P2_I([t0], "v", (u32)t), P2_I([t1], "v", (u32)(t >> 32)), P2_I([y0], "v", (u32)y),
+                   P2_I([y1], "v", (u32)(y >> 32))));
         t = ((u64)d1 << 32) | d0;
-        asm("v_mad_i64_i32 %[r], %[c1], %[m], -1, %[t]" : [r] "=&v"(r), [c1] "=&s"(c1) : [m] "v"(m), [t] "v"(t));
+        P2_ASM_NC("v_mad_i64_i32 %[r], %[c1], %[m], -1, %[t]", (P2_O([r], "=&v", r), P2_O([c1], "=&s", c1)),
+                  (P2_I([m], "v", m), P2_I([t], "v", t)));
     }
     return r;
-#endif
 }
 
 __device__ __forceinline__ u64 mul_pow2(u64 x, int s) {  // x * 2^s (mod P), 0 <= s < 96, s constant after unrolling

@@ -35,6 +35,18 @@ constexpr int NT = 512;
 #ifndef P2HOT_LIMB_DIRECT_CONTIG
 #define P2HOT_LIMB_DIRECT_CONTIG 0
 #endif
+#ifndef P2HOT_LIMB_DEFER
+#define P2HOT_LIMB_DEFER 1
+#endif
+#ifndef P2HOT_LIMB_MUL3
+#define P2HOT_LIMB_MUL3 1
+#endif
+constexpr bool LIMB_DEFER = P2HOT_LIMB_DEFER != 0;  // a borrowed first-round table defers its small factor to a later round's table
+#ifndef P2HOT_LIMB_FOLD3
+#define P2HOT_LIMB_FOLD3 1
+#endif
+constexpr bool LIMB_FOLD3 = P2HOT_LIMB_FOLD3 != 0;  // a unit's conversions fold their accumulator pairs three at a time (gl::fold3)
+constexpr bool LIMB_MUL3 = P2HOT_LIMB_MUL3 != 0;    // independent general multiplies of a unit go through gl::mul3 streams
 constexpr bool LIMB_DIRECT_CONTIG = P2HOT_LIMB_DIRECT_CONTIG != 0;  // contiguous pass: store the last round's outputs from registers
 constexpr int LIMB_MIN_WAVES = P2HOT_LIMB_MIN_WAVES;  // waves per SIMD the register allocation must allow (4: <= 128 VGPRs)
 
@@ -140,25 +152,64 @@ __host__ __device__ __forceinline__ void dft_limbs(L4 (&x)[1 << P]) {
     }
 }
 
-// sum_i L_i * W_i (mod P) for non-negative limbs L_i < 2^29 and W_i < 2^64: two 4-term multiply-add chains + one fold
+// sum_i L_i * W_i (mod P) for non-negative limbs L_i < 2^29 and W_i < 2^64: two 4-term multiply-add chains (the value is
+// al + ah * 2^32, both below 2^63) + one fold
+struct Acc {
+    u64 al, ah;
+};
+__device__ __forceinline__ Acc convmul_acc(const L4 &v, u64 w0, u64 w1, u64 w2, u64 w3) {
+    Acc r;
+    r.al = (u64)v.l[0] * (u32)w0;
+    r.ah = (u64)v.l[0] * (u32)(w0 >> 32);
+    r.al += (u64)v.l[1] * (u32)w1;
+    r.ah += (u64)v.l[1] * (u32)(w1 >> 32);
+    r.al += (u64)v.l[2] * (u32)w2;
+    r.ah += (u64)v.l[2] * (u32)(w2 >> 32);
+    r.al += (u64)v.l[3] * (u32)w3;
+    r.ah += (u64)v.l[3] * (u32)(w3 >> 32);
+    return r;
+}
 __device__ __forceinline__ u64 convmul(const L4 &v, u64 w0, u64 w1, u64 w2, u64 w3) {
-    u64 al = (u64)v.l[0] * (u32)w0;
-    u64 ah = (u64)v.l[0] * (u32)(w0 >> 32);
-    al += (u64)v.l[1] * (u32)w1;
-    ah += (u64)v.l[1] * (u32)(w1 >> 32);
-    al += (u64)v.l[2] * (u32)w2;
-    ah += (u64)v.l[2] * (u32)(w2 >> 32);
-    al += (u64)v.l[3] * (u32)w3;
-    ah += (u64)v.l[3] * (u32)(w3 >> 32);
-    return gl::fold1(al, ah);
+    const Acc r = convmul_acc(v, w0, w1, w2, w3);
+    return gl::fold1(r.al, r.ah);
 }
 
 // the same with W_i = B^i (no twiddle: frequency 0, or the last round of a tile)
+__device__ __forceinline__ Acc conv_unit_acc(const L4 &v) {
+    Acc r;
+    r.al = (u64)v.l[3] * (u32)B3 + v.l[0];
+    r.al += (u64)v.l[1] << 24;
+    r.ah = (u64)v.l[3] * (u32)(B3 >> 32) + ((u64)v.l[2] << 16);
+    return r;
+}
 __device__ __forceinline__ u64 conv_unit(const L4 &v) {
-    u64 al = (u64)v.l[3] * (u32)B3 + v.l[0];
-    al += (u64)v.l[1] << 24;
-    u64 ah = (u64)v.l[3] * (u32)(B3 >> 32) + ((u64)v.l[2] << 16);
-    return gl::fold1(al, ah);
+    const Acc r = conv_unit_acc(v);
+    return gl::fold1(r.al, r.ah);
+}
+
+// y[q] = fold(acc_of(q)), q < N, three rows per interleaved gl::fold3 stream (then two, then one): the single-stream fold
+// stalls its wave two wait states per row, and a unit has 2^P independent rows
+template <int N, class AccF>
+__device__ __forceinline__ void fold_groups(AccF acc_of, u64 (&y)[N]) {
+    constexpr int N3 = N / 3 * 3;
+#pragma unroll
+    for (int q = 0; q < N3; q += 3) {
+        const Acc a0 = acc_of(q), a1 = acc_of(q + 1), a2 = acc_of(q + 2);
+        const u64 al[3] = {a0.al, a1.al, a2.al}, ah[3] = {a0.ah, a1.ah, a2.ah};
+        u64 r[3];
+        gl::fold3(al, ah, r);
+        y[q] = r[0], y[q + 1] = r[1], y[q + 2] = r[2];
+    }
+    if constexpr (N - N3 == 2) {
+        const Acc a0 = acc_of(N3), a1 = acc_of(N3 + 1);
+        const u64 al[2] = {a0.al, a1.al}, ah[2] = {a0.ah, a1.ah};
+        u64 r[2];
+        gl::fold2(al, ah, r);
+        y[N3] = r[0], y[N3 + 1] = r[1];
+    } else if constexpr (N - N3 == 1) {
+        const Acc a0 = acc_of(N3);
+        y[N3] = gl::fold1(a0.al, a0.ah);
+    }
 }
 
 struct LimbPassArgs {
@@ -196,8 +247,23 @@ constexpr int round_log_rb(int log_r, int r) {
 // 3584 distinct twiddles from 448 + 56 table entries, and 51 KB of LDS per workgroup (three workgroups per CU).
 constexpr int TW_S_MAX_LOG = 6;
 constexpr bool round_borrows(int log_r, int r) { return round_log_rb(log_r, r) - round_bits(log_r, r) > TW_S_MAX_LOG; }
+// The small factor of a borrowed round-0 twiddle, w_{R}^(a * k0) (a = the low p0 bits of the unit's lo, k0 = the output's
+// frequency), is the same for all inputs of every later unit as long as that unit's inputs differ neither in their low p0
+// position bits (= a) nor in their top p0 position bits (= the block k0 went to): it commutes with those rounds and is
+// ABSORBED by the table of the round whose own twiddle index is exactly a (S_LOG == p0) -- that table becomes
+// w_{Rb}^(a * k) * w_{R}^(a * k0), one slab per k0 (wave-uniform: a wave owns one first-round block), frequency 0 included.
+// For the 4096-point tile (rounds 3+3+3+3): round 2, 8 * 8 * 8 entries = 16 KiB, and round 0 loses its second multiply.
+constexpr int absorb_round(int log_r) {  // the round that absorbs, or -1: then round 0 keeps its second multiply
+    if (!LIMB_DEFER || !round_borrows(log_r, 0)) return -1;
+    for (int r = 1; r < n_rounds(log_r); ++r)
+        if (round_log_rb(log_r, r) - round_bits(log_r, r) == round_bits(log_r, 0)) return r;
+    return -1;
+}
+constexpr bool round_absorbs(int log_r, int r) { return absorb_round(log_r) == r; }
+constexpr bool defers(int log_r) { return absorb_round(log_r) >= 0; }
 constexpr int round_table_w2(int log_r, int r) {  // W2 entries of round r's own table
     const int s = round_log_rb(log_r, r) - round_bits(log_r, r);
+    if (round_absorbs(log_r, r)) return ((1 << round_bits(log_r, 0)) * (1 << round_bits(log_r, r)) * 2) << s;
     return (s == 0 || round_borrows(log_r, r)) ? 0 : (((1 << round_bits(log_r, r)) - 1) * 2) << s;
 }
 constexpr int round_table_off(int log_r, int r) {
@@ -207,11 +273,47 @@ constexpr int round_table_off(int log_r, int r) {
 }
 constexpr int limb_tables_w2(int log_r) { return round_table_off(log_r, n_rounds(log_r)); }
 constexpr int UFAC_WORDS = 64;  // u[a * 8 + k], a < 8, k < 8 (only round 0 ever borrows)
+constexpr bool uses_ufac(int log_r) { return round_borrows(log_r, 0) && !defers(log_r); }
 constexpr size_t limb_shmem_bytes(int log_r) {
-    return (size_t)8 * ntt::TILE_WORDS_PADDED + (size_t)16 * limb_tables_w2(log_r) + (round_borrows(log_r, 0) ? 8 * UFAC_WORDS : 0);
+    return (size_t)8 * ntt::TILE_WORDS_PADDED + (size_t)16 * limb_tables_w2(log_r) + (uses_ufac(log_r) ? 8 * UFAC_WORDS : 0);
 }
 
 __device__ __forceinline__ u64 limb_mul(u64 a, u64 b) { return gl::mul1(a, b); }
+// v[q] *= w[q] for N independent pairs: three-stream gl::mul3 blocks (no wait states, three chains in flight) where the
+// build asks for them, single streams otherwise
+template <int N>
+__device__ __forceinline__ void limb_mul_n(u64 (&v)[N], const u64 (&w)[N]) {
+    if constexpr (LIMB_MUL3) {
+        int q = 0;
+#pragma unroll
+        for (; q + 3 <= N; q += 3) {
+            const u64 a3[3] = {v[q], v[q + 1], v[q + 2]}, b3[3] = {w[q], w[q + 1], w[q + 2]};
+            u64 r3[3];
+            gl::mul3(a3, b3, r3);
+            v[q] = r3[0], v[q + 1] = r3[1], v[q + 2] = r3[2];
+        }
+        if (N - q == 2) {
+            const u64 a2[2] = {v[q], v[q + 1]}, b2[2] = {w[q], w[q + 1]};
+            u64 r2[2];
+            gl::mul2(a2, b2, r2);
+            v[q] = r2[0], v[q + 1] = r2[1];
+        } else if (N - q == 1) {
+            v[q] = limb_mul(v[q], w[q]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[q] = limb_mul(v[q], w[q]);
+    }
+}
+// A wave-uniform constant the optimiser must not see through.  The bias limb O3 is the ONLY contribution to some limbs of a
+// unit's outputs (a split word has l3 = 0), and hipcc turns "known 2^27 times a table word" into two 64-bit shifts, four
+// masks and two 64-bit adds where the general path is two multiply-adds.
+__device__ __forceinline__ u32 opaque_u32(u32 c) {
+#ifndef P2HOT_EMU
+    asm("" : "+s"(c));
+#endif
+    return c;
+}
 __device__ __forceinline__ unsigned wave_uniform(unsigned v) {
 #ifdef P2HOT_EMU
     return v;
@@ -269,6 +371,7 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
     constexpr int LOG_RB = round_log_rb(LOG_R, RI);
     constexpr int S_LOG = LOG_RB - P;
     constexpr bool BORROW = round_borrows(LOG_R, RI);
+    constexpr bool ABSORB = round_absorbs(LOG_R, RI);
     static_assert(!BORROW || (RI == 0 && round_bits(LOG_R, 1) == P && S_LOG - P <= TW_S_MAX_LOG), "borrowed table shape");
     constexpr int T_LOG = BORROW ? S_LOG - P : S_LOG;  // log2 of the table's columns
     constexpr int T_OFF = round_table_off(LOG_R, BORROW ? RI + 1 : RI);
@@ -300,8 +403,10 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
             // coset scale s_z^t, t = i * stride + base0 + c: the (i, c) part from a tile-shaped table, the base0 part (uniform)
             // in the last round's conversion (LAST_TILE)
             const u64 *sr = ra.srow2 + (z << TILE_LOG) + (i0 << LOG_C) + c;
+            u64 sw[1 << P];
 #pragma unroll
-            for (int q = 0; q < (1 << P); ++q) v[q] = limb_mul(v[q], sr[(size_t)q << (S_LOG + LOG_C)]);
+            for (int q = 0; q < (1 << P); ++q) sw[q] = sr[(size_t)q << (S_LOG + LOG_C)];
+            limb_mul_n<(1 << P)>(v, sw);
         } else if constexpr (FIRST && SCALE == ntt::SCALE_TABLE) {  // single-pass transform: the row table is everything
 #pragma unroll
             for (int q = 0; q < (1 << P); ++q) v[q] = limb_mul(v[q], a.srow[z * (1u << LOG_R) + i0 + ((unsigned)q << S_LOG)]);
@@ -314,19 +419,50 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
         x[0].l[0] += O0;
         x[0].l[1] += O1;
         x[0].l[2] += O2;
-        x[0].l[3] += O3;
+        x[0].l[3] += opaque_u32(O3);
         dft_limbs<P, INV>(x);
         if constexpr (S_LOG > 0) {
-            const W2 *tw = ltw + T_OFF + (BORROW ? lo >> P : lo);
-            const u64 *uf = lu + (lo & ((1u << P) - 1)) * 8;
-            tile[ntt::pad_idx((i0 << LOG_C) + c)] = conv_unit(x[0]);
+            if constexpr (LIMB_FOLD3 && !(BORROW && !defers(LOG_R))) {
+                // all 2^P accumulator pairs of the unit, folded three rows per stream
+                constexpr int P0 = round_bits(LOG_R, 0);
+                [[maybe_unused]] const unsigned k0 = ABSORB ? (unsigned)(__brev(hi >> (LOG_R - P0 - LOG_RB)) >> (32 - P0)) : 0u;
+                const W2 *tw = ABSORB ? ltw + T_OFF + ((k0 << (P + 1)) << T_LOG) + lo : ltw + T_OFF + (BORROW ? lo >> P : lo);
+                u64 y[1 << P];
+                fold_groups<(1 << P)>(
+                    [&](int q) {
+                        if (!ABSORB && q == 0) return conv_unit_acc(x[0]);
+                        const unsigned k = q ? (unsigned)(__brev((unsigned)q) >> (32 - P)) : 0u;
+                        const unsigned e = ABSORB ? k * 2 : (k - 1) * 2;
+                        const W2 wa = tw[e << T_LOG], wb = tw[(e + 1) << T_LOG];
+                        return convmul_acc(x[q], wa.a, wa.b, wb.a, wb.b);
+                    },
+                    y);
 #pragma unroll
-            for (int q = 1; q < (1 << P); ++q) {
-                const unsigned k = (unsigned)(__brev((unsigned)q) >> (32 - P));
-                const W2 wa = tw[((k - 1) * 2) << T_LOG], wb = tw[((k - 1) * 2 + 1) << T_LOG];
-                u64 y = convmul(x[q], wa.a, wa.b, wb.a, wb.b);
-                if constexpr (BORROW) y = limb_mul(y, uf[k]);
-                tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = y;
+                for (int q = 0; q < (1 << P); ++q) tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = y[q];
+            } else if constexpr (ABSORB) {
+                // this round's twiddle times the factor round 0 deferred: slab k0 = the frequency whose first-round block
+                // this unit lies in (position bits LOG_R-P0 .. LOG_R-1, bit-reversed), every output converts through the table
+                constexpr int P0 = round_bits(LOG_R, 0);
+                const unsigned k0 = (unsigned)(__brev(hi >> (LOG_R - P0 - LOG_RB)) >> (32 - P0));
+                const W2 *tw = ltw + T_OFF + ((k0 << (P + 1)) << T_LOG) + lo;
+#pragma unroll
+                for (int q = 0; q < (1 << P); ++q) {
+                    const unsigned k = q ? (unsigned)(__brev((unsigned)q) >> (32 - P)) : 0u;
+                    const W2 wa = tw[(k * 2) << T_LOG], wb = tw[(k * 2 + 1) << T_LOG];
+                    tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = convmul(x[q], wa.a, wa.b, wb.a, wb.b);
+                }
+            } else {
+                const W2 *tw = ltw + T_OFF + (BORROW ? lo >> P : lo);
+                [[maybe_unused]] const u64 *uf = lu + (lo & ((1u << P) - 1)) * 8;
+                tile[ntt::pad_idx((i0 << LOG_C) + c)] = conv_unit(x[0]);
+#pragma unroll
+                for (int q = 1; q < (1 << P); ++q) {
+                    const unsigned k = (unsigned)(__brev((unsigned)q) >> (32 - P));
+                    const W2 wa = tw[((k - 1) * 2) << T_LOG], wb = tw[((k - 1) * 2 + 1) << T_LOG];
+                    u64 y = convmul(x[q], wa.a, wa.b, wb.a, wb.b);
+                    if constexpr (BORROW && !defers(LOG_R)) y = limb_mul(y, uf[k]);  // (deferred: absorbed by a later round's table)
+                    tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = y;
+                }
             }
         } else {
             // the tile's last round.  A strided pass finishes here: inter-pass twiddle w_{n'}^(col * k1) from the per-pass table (laid
@@ -341,18 +477,38 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
                 w0 = sb[0].a, w1 = sb[0].b, w2 = sb[1].a, w3 = sb[1].b;
             }
             auto conv_last = [&](const L4 &v_) { return LAST == LAST_UNIT ? conv_unit(v_) : convmul(v_, w0, w1, w2, w3); };
+            auto conv_last_all = [&](u64 (&y_)[1 << P]) {  // y_[q] = conv_last(x[q])
+                if constexpr (LIMB_FOLD3) {
+                    fold_groups<(1 << P)>(
+                        [&](int q) { return LAST == LAST_UNIT ? conv_unit_acc(x[q]) : convmul_acc(x[q], w0, w1, w2, w3); }, y_);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < (1 << P); ++q) y_[q] = conv_last(x[q]);
+                }
+            };
             if constexpr (LOG_C > 0 && P <= 2) {  // (a radix-8 last round keeps too much alive: it goes through LDS like the contiguous pass)
                 const u32 off0 = ((i0 << log_stride) + c) * 8u;  // bytes; the row steps q << log_stride are wave-uniform
                 const char *tw = reinterpret_cast<const char *>(ra.twid + base0);
                 char *go = reinterpret_cast<char *>(gout);
+                if constexpr (LIMB_MUL3) {
+                    u64 y[1 << P], t[1 << P];
 #pragma unroll
-                for (int q = 0; q < (1 << P); ++q) {
-                    const size_t step = ((size_t)q << log_stride) * 8;
-                    const u64 v_ = limb_mul(conv_last(x[q]), *reinterpret_cast<const u64 *>(tw + step + off0));
-                    *reinterpret_cast<u64 *>(go + step + off0) = a.canon_out ? gl::canon(v_) : v_;
+                    for (int q = 0; q < (1 << P); ++q) t[q] = *reinterpret_cast<const u64 *>(tw + ((size_t)q << log_stride) * 8 + off0);
+                    conv_last_all(y);
+                    limb_mul_n<(1 << P)>(y, t);
+#pragma unroll
+                    for (int q = 0; q < (1 << P); ++q)
+                        *reinterpret_cast<u64 *>(go + ((size_t)q << log_stride) * 8 + off0) = a.canon_out ? gl::canon(y[q]) : y[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < (1 << P); ++q) {
+                        const size_t step = ((size_t)q << log_stride) * 8;
+                        const u64 v_ = limb_mul(conv_last(x[q]), *reinterpret_cast<const u64 *>(tw + step + off0));
+                        *reinterpret_cast<u64 *>(go + step + off0) = a.canon_out ? gl::canon(v_) : v_;
 #ifndef P2HOT_EMU
-                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four outputs at a time: the twiddle loads are not hoisted past this
+                        if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four outputs at a time: the twiddle loads are not hoisted past this
 #endif
+                    }
                 }
             } else if constexpr (P == 3 && LIMB_DIRECT_CONTIG) {
                 // the contiguous pass: a unit's eight outputs are 64 consecutive bytes of the block -- four 16-byte stores
@@ -367,8 +523,10 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
                     go[q >> 1] = pr;
                 }
             } else {
+                u64 y[1 << P];
+                conv_last_all(y);
 #pragma unroll
-                for (int q = 0; q < (1 << P); ++q) tile[ntt::pad_idx(((i0 + (unsigned)q) << LOG_C) + c)] = conv_last(x[q]);
+                for (int q = 0; q < (1 << P); ++q) tile[ntt::pad_idx(((i0 + (unsigned)q) << LOG_C) + c)] = y[q];
             }
         }
     }
@@ -393,7 +551,7 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
     W2 *ltw = reinterpret_cast<W2 *>(tile + ntt::TILE_WORDS_PADDED);
     u64 *lu = reinterpret_cast<u64 *>(ltw + limb_tables_w2(LOG_R));
     for (unsigned e = tid; e < (unsigned)limb_tables_w2(LOG_R); e += NT) ltw[e] = ra.tw_all[e];
-    if constexpr (round_borrows(LOG_R, 0))
+    if constexpr (uses_ufac(LOG_R))
         if (tid < (unsigned)UFAC_WORDS) lu[tid] = ra.ufac[tid];
     __syncthreads();
     const unsigned log_stride = LOG_C ? a.log_nblk - LOG_R : 0u;  // the contiguous pass is the last one: blocks of one tile
@@ -465,6 +623,19 @@ __global__ void limb_twiddle_kernel(W2 *t, unsigned log_rb, unsigned p, ntt::Roo
     const u32 lo = (u32)(idx & (S - 1)), k = (u32)(idx >> s_log) + 1;
     const u64 w = ntt::root_pow(roots, (u32)(((u64)lo * k) << (32 - log_rb)));
     W2 *o = t + ((size_t)(k - 1) * 2 << s_log) + lo;
+    o[0] = W2{gl::canon(w), gl::canon(gl::mul(w, B1))};
+    o[S] = W2{gl::canon(gl::mul(w, B2)), gl::canon(gl::mul(w, B3))};
+}
+// The table of a round that absorbs the first round's deferred factor (round_absorbs): slab k0, frequency k, column a:
+// t[(((k0 << p) + k) * 2 + h) << s_log | a] = 4-form of w_{2^log_rb}^(a * k) * w_{2^log_r}^(a * k0), s_log = log_rb - p
+__global__ void limb_twiddle_absorb_kernel(W2 *t, unsigned log_r, unsigned log_rb, unsigned p, ntt::RootTable roots) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned s_log = log_rb - p;  // = the first round's radix bits
+    const size_t S = (size_t)1 << s_log;
+    if (idx >= (S << p) * S) return;
+    const u32 a = (u32)(idx & (S - 1)), k = (u32)(idx >> s_log) & ((1u << p) - 1), k0 = (u32)(idx >> (s_log + p));
+    const u64 w = ntt::root_pow(roots, (u32)(((u64)a * k) << (32 - log_rb)) + (u32)(((u64)a * k0) << (32 - log_r)));
+    W2 *o = t + ((size_t)(((k0 << p) + k) * 2) << s_log) + a;
     o[0] = W2{gl::canon(w), gl::canon(gl::mul(w, B1))};
     o[S] = W2{gl::canon(gl::mul(w, B2)), gl::canon(gl::mul(w, B3))};
 }

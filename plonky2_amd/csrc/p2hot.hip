@@ -557,12 +557,19 @@ static int limb_tables(p2hot_ctx *ctx, bool inverse, unsigned log_r, p2hot_ctx::
         for (int r = 0; r < nttl::n_rounds((int)log_r); ++r) {
             const unsigned p = (unsigned)nttl::round_bits((int)log_r, r), log_rb = (unsigned)nttl::round_log_rb((int)log_r, r);
             if (nttl::round_table_w2((int)log_r, r) == 0) continue;  // no table twiddles (last round) or a borrowed table
+            if (nttl::round_absorbs((int)log_r, r)) {  // this round's twiddles times the factor round 0 deferred
+                const size_t count = (size_t)nttl::round_table_w2((int)log_r, r) / 2;
+                P2HOT_LAUNCH(nttl::limb_twiddle_absorb_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream,
+                             lt.tw_all + nttl::round_table_off((int)log_r, r), log_r, log_rb, p, inverse ? ctx->inv : ctx->fwd);
+                P2_LAUNCH_CHECK(ctx);
+                continue;
+            }
             const size_t count = ((((size_t)1 << p) - 1) << (log_rb - p));
             P2HOT_LAUNCH(nttl::limb_twiddle_kernel, dim3(cdiv(count, 256)), dim3(256), 0, ctx->stream,
                          lt.tw_all + nttl::round_table_off((int)log_r, r), log_rb, p, inverse ? ctx->inv : ctx->fwd);
             P2_LAUNCH_CHECK(ctx);
         }
-        if (nttl::round_borrows((int)log_r, 0)) {
+        if (nttl::uses_ufac((int)log_r)) {
             P2_HIP(ctx, hipMalloc((void **)&lt.ufac, (size_t)8 * nttl::UFAC_WORDS));
             P2HOT_LAUNCH(nttl::limb_ufac_kernel, dim3(1), dim3(64), 0, ctx->stream, lt.ufac, log_r, inverse ? ctx->inv : ctx->fwd);
             P2_LAUNCH_CHECK(ctx);

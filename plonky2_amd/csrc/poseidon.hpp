@@ -83,61 +83,66 @@ __device__ __forceinline__ u32 opaque_const(u32 c) {
 // its 12 multiply-adds, the first of which reads the constant from its SGPR pair as the addend.
 template <u32 C>
 __device__ __forceinline__ void mds_term(u64 (&al)[3], u64 (&ah)[3], u32 l0, u32 h0, u32 l1, u32 h1, u32 l2, u32 h2) {
-#ifndef P2HOT_EMU
+    if (!P2_ASM_INTERPRETED()) {  // emulator build with the interpreter off (constant-false in the product)
+        al[0] += (u64)l0 * C;
+        ah[0] += (u64)h0 * C;
+        al[1] += (u64)l1 * C;
+        ah[1] += (u64)h1 * C;
+        al[2] += (u64)l2 * C;
+        ah[2] += (u64)h2 * C;
+        return;
+    }
     u64 d;
-    asm("v_mad_u64_u32 %0, %6, %7, %13, %0\n\t"
-        "v_mad_u64_u32 %1, %6, %8, %13, %1\n\t"
-        "v_mad_u64_u32 %2, %6, %9, %13, %2\n\t"
-        "v_mad_u64_u32 %3, %6, %10, %13, %3\n\t"
-        "v_mad_u64_u32 %4, %6, %11, %13, %4\n\t"
-        "v_mad_u64_u32 %5, %6, %12, %13, %5"
-        : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "=&s"(d)
-        : "v"(l0), "v"(h0), "v"(l1), "v"(h1), "v"(l2), "v"(h2), "n"(C));
-#else
-    al[0] += (u64)l0 * C;
-    ah[0] += (u64)h0 * C;
-    al[1] += (u64)l1 * C;
-    ah[1] += (u64)h1 * C;
-    al[2] += (u64)l2 * C;
-    ah[2] += (u64)h2 * C;
-#endif
+    P2_ASM_NC("v_mad_u64_u32 %0, %6, %7, %13, %0\n\t"
+              "v_mad_u64_u32 %1, %6, %8, %13, %1\n\t"
+              "v_mad_u64_u32 %2, %6, %9, %13, %2\n\t"
+              "v_mad_u64_u32 %3, %6, %10, %13, %3\n\t"
+              "v_mad_u64_u32 %4, %6, %11, %13, %4\n\t"
+              "v_mad_u64_u32 %5, %6, %12, %13, %5",
+              (P2_O(, "+v", al[0]), P2_O(, "+v", ah[0]), P2_O(, "+v", al[1]), P2_O(, "+v", ah[1]), P2_O(, "+v", al[2]),
+               P2_O(, "+v", ah[2]), P2_O(, "=&s", d)),
+              (P2_I(, "v", l0), P2_I(, "v", h0), P2_I(, "v", l1), P2_I(, "v", h1), P2_I(, "v", l2), P2_I(, "v", h2),
+               P2_I(, "n", C)));
 }
 // the first term (C[0] = 17): starts the six chains from the six wave-uniform 64-bit addends k (SGPR pairs) or from 0
 template <bool HAS_K>
 __device__ __forceinline__ void mds_first(u64 (&al)[3], u64 (&ah)[3], u32 l0, u32 h0, u32 l1, u32 h1, u32 l2, u32 h2,
                                           const u64 *k) {
-#ifndef P2HOT_EMU
+    if (!P2_ASM_INTERPRETED()) {
+        const u64 z[6] = {0, 0, 0, 0, 0, 0};
+        const u64 *kk = HAS_K ? k : z;
+        al[0] = (u64)l0 * 17u + kk[0];
+        ah[0] = (u64)h0 * 17u + kk[1];
+        al[1] = (u64)l1 * 17u + kk[2];
+        ah[1] = (u64)h1 * 17u + kk[3];
+        al[2] = (u64)l2 * 17u + kk[4];
+        ah[2] = (u64)h2 * 17u + kk[5];
+        return;
+    }
     u64 d;
     if (HAS_K) {
-        asm("v_mad_u64_u32 %0, %6, %7, 17, %13\n\t"
-            "v_mad_u64_u32 %1, %6, %8, 17, %14\n\t"
-            "v_mad_u64_u32 %2, %6, %9, 17, %15\n\t"
-            "v_mad_u64_u32 %3, %6, %10, 17, %16\n\t"
-            "v_mad_u64_u32 %4, %6, %11, 17, %17\n\t"
-            "v_mad_u64_u32 %5, %6, %12, 17, %18"
-            : "=&v"(al[0]), "=&v"(ah[0]), "=&v"(al[1]), "=&v"(ah[1]), "=&v"(al[2]), "=&v"(ah[2]), "=&s"(d)
-            : "v"(l0), "v"(h0), "v"(l1), "v"(h1), "v"(l2), "v"(h2), "s"(k[0]), "s"(k[1]), "s"(k[2]), "s"(k[3]), "s"(k[4]),
-              "s"(k[5]));
+        P2_ASM_NC("v_mad_u64_u32 %0, %6, %7, 17, %13\n\t"
+                  "v_mad_u64_u32 %1, %6, %8, 17, %14\n\t"
+                  "v_mad_u64_u32 %2, %6, %9, 17, %15\n\t"
+                  "v_mad_u64_u32 %3, %6, %10, 17, %16\n\t"
+                  "v_mad_u64_u32 %4, %6, %11, 17, %17\n\t"
+                  "v_mad_u64_u32 %5, %6, %12, 17, %18",
+                  (P2_O(, "=&v", al[0]), P2_O(, "=&v", ah[0]), P2_O(, "=&v", al[1]), P2_O(, "=&v", ah[1]),
+                   P2_O(, "=&v", al[2]), P2_O(, "=&v", ah[2]), P2_O(, "=&s", d)),
+                  (P2_I(, "v", l0), P2_I(, "v", h0), P2_I(, "v", l1), P2_I(, "v", h1), P2_I(, "v", l2), P2_I(, "v", h2),
+                   P2_I(, "s", k[0]), P2_I(, "s", k[1]), P2_I(, "s", k[2]), P2_I(, "s", k[3]), P2_I(, "s", k[4]),
+                   P2_I(, "s", k[5])));
     } else {
-        asm("v_mad_u64_u32 %0, %6, %7, 17, 0\n\t"
-            "v_mad_u64_u32 %1, %6, %8, 17, 0\n\t"
-            "v_mad_u64_u32 %2, %6, %9, 17, 0\n\t"
-            "v_mad_u64_u32 %3, %6, %10, 17, 0\n\t"
-            "v_mad_u64_u32 %4, %6, %11, 17, 0\n\t"
-            "v_mad_u64_u32 %5, %6, %12, 17, 0"
-            : "=&v"(al[0]), "=&v"(ah[0]), "=&v"(al[1]), "=&v"(ah[1]), "=&v"(al[2]), "=&v"(ah[2]), "=&s"(d)
-            : "v"(l0), "v"(h0), "v"(l1), "v"(h1), "v"(l2), "v"(h2));
+        P2_ASM_NC("v_mad_u64_u32 %0, %6, %7, 17, 0\n\t"
+                  "v_mad_u64_u32 %1, %6, %8, 17, 0\n\t"
+                  "v_mad_u64_u32 %2, %6, %9, 17, 0\n\t"
+                  "v_mad_u64_u32 %3, %6, %10, 17, 0\n\t"
+                  "v_mad_u64_u32 %4, %6, %11, 17, 0\n\t"
+                  "v_mad_u64_u32 %5, %6, %12, 17, 0",
+                  (P2_O(, "=&v", al[0]), P2_O(, "=&v", ah[0]), P2_O(, "=&v", al[1]), P2_O(, "=&v", ah[1]),
+                   P2_O(, "=&v", al[2]), P2_O(, "=&v", ah[2]), P2_O(, "=&s", d)),
+                  (P2_I(, "v", l0), P2_I(, "v", h0), P2_I(, "v", l1), P2_I(, "v", h1), P2_I(, "v", l2), P2_I(, "v", h2)));
     }
-#else
-    const u64 z[6] = {0, 0, 0, 0, 0, 0};
-    const u64 *kk = HAS_K ? k : z;
-    al[0] = (u64)l0 * 17u + kk[0];
-    ah[0] = (u64)h0 * 17u + kk[1];
-    al[1] = (u64)l1 * 17u + kk[2];
-    ah[1] = (u64)h1 * 17u + kk[3];
-    al[2] = (u64)l2 * 17u + kk[4];
-    ah[2] = (u64)h2 * 17u + kk[5];
-#endif
 }
 
 // MDS layer fused with the NEXT round's constant layer:
