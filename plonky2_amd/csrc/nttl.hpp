@@ -43,9 +43,10 @@ constexpr int NT = 512;
 #endif
 constexpr bool LIMB_DEFER = P2HOT_LIMB_DEFER != 0;  // a borrowed first-round table defers its small factor to a later round's table
 #ifndef P2HOT_LIMB_FOLD3
-#define P2HOT_LIMB_FOLD3 1
+#define P2HOT_LIMB_FOLD3 0
 #endif
-constexpr bool LIMB_FOLD3 = P2HOT_LIMB_FOLD3 != 0;  // a unit's conversions fold their accumulator pairs three at a time (gl::fold3)
+constexpr bool LIMB_FOLD3 = P2HOT_LIMB_FOLD3 != 0;  // a unit's conversions fold their accumulator pairs three at a time (gl::fold3): measured
+                                                    // SLOWER (LDE contiguous pass 4.69 vs 4.56 ms: 116 VGPRs instead of 101), off
 constexpr bool LIMB_MUL3 = P2HOT_LIMB_MUL3 != 0;    // independent general multiplies of a unit go through gl::mul3 streams
 constexpr bool LIMB_DIRECT_CONTIG = P2HOT_LIMB_DIRECT_CONTIG != 0;  // contiguous pass: store the last round's outputs from registers
 constexpr int LIMB_MIN_WAVES = P2HOT_LIMB_MIN_WAVES;  // waves per SIMD the register allocation must allow (4: <= 128 VGPRs)

@@ -125,3 +125,9 @@ def test_commit_and_fri_commit_through_the_asm(emu_asm, ora):
     o = ora.fri_commit(pad, rb, cap, [2, 2], och)
     assert all((t.cap.entries == c).all() for t, c in zip(trees, o["caps"]))
     assert (final == o["final"]).all() and (betas == o["betas"]).all()
+
+
+def test_prove_openings_through_the_asm(emu_asm, ora):
+    """the whole opening proof (final_poly, FRI commit phase, grind, query rounds) with every hand-written stream interpreted"""
+    from tests import test_prove_openings as tpo
+    tpo.test_final_poly_and_prove_openings_vs_oracle(emu_asm, ora, 5, [3, 2], 3, 2, [2])
