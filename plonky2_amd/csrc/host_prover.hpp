@@ -134,7 +134,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     // The PCIe copies run on the side stream beside the compute stream.  Column blocks are uploaded, transformed (iNTT)
     // and extended (LDE) one after the other -- the upload of block b+1 overlaps the transforms of block b -- and the
     // coefficient blocks go back to the host while the leaf sponge runs.  Small batches are one block.
-    const size_t kBlockCols = (W >= 32 && W * n >= ((size_t)1 << 22)) ? 16 : (W ? W : 1);
+    const size_t kBlockCols = ctx->host_block_cols ? ctx->host_block_cols : (W >= 32 && W * n >= ((size_t)1 << 22)) ? 16 : (W ? W : 1);
     const size_t nb = W ? (W + kBlockCols - 1) / kBlockCols : 0;
     std::vector<hipEvent_t> up, done;
     hipStream_t copy_stream = ctx->stream;
@@ -142,6 +142,24 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     const bool two_streams = nb > 1;
     if (two_streams) copy_stream = ctx->side;
 #endif
+    // With more than one block the leaf sponge does not wait for the last column: after each block's LDE it absorbs the
+    // 8-column chunks that are complete (its state parked in a scratch block between launches), so the hashing -- three
+    // quarters of the commit -- runs beside the uploads still in flight instead of behind them.
+    const bool chunked = ctx->host_chunked_hash && nb > 1 && LW > 8 && LW <= 0xFFFFFFFFull;
+    PoolBuf d_state(ctx);
+    ForestGeom geom{};
+    unsigned hashed = 0;  // columns the sponge has absorbed (a multiple of 8 until the end)
+    if (chunked) {
+        P2_TRY(pool_alloc(ctx, (size_t)12 * N * 8, &d_state.p));
+        P2_TRY(forest_geom(ctx, log_N, cap_height, 0, N, d_dig.u(), d_cap.u(), &geom));
+    }
+    auto absorb_upto = [&](size_t cols_done) -> int {  // cols_done leaf columns of d_lde are final
+        const unsigned end = cols_done >= LW ? (unsigned)LW : (unsigned)(cols_done / 8 * 8);
+        if (end <= hashed) return P2HOT_OK;
+        P2_TRY(hash_leaves_chunks(ctx, ctx->stream, merkle::ColMajorReader{d_lde.u(), N}, LW, geom, N, hashed, end, d_state.u()));
+        hashed = end;
+        return P2HOT_OK;
+    };
     auto body = [&]() -> int {
 #ifndef P2HOT_EMU
         if (two_streams) {
@@ -177,6 +195,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             if (two_streams) P2_HIP(ctx, hipEventRecord(done[b], ctx->stream));
 #endif
             P2_TRY(p2hot_coset_lde_dev(ctx, blk, cnt, n, log_n, rate_bits, gl::COSET_SHIFT, 0, N, d_lde.u() + c0 * N, N));
+            if (chunked) P2_TRY(absorb_upto(c0 + cnt < W || S ? c0 + cnt : LW));
         }
         if (S) {
             // the salt vectors are LDE-value columns in natural order (oracle.rs:133-137): like the LDE values they reach the
@@ -185,7 +204,12 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             P2_TRY(h2d_columns(ctx, d_salt.u(), salt_cols, S, N * 8, W * n * 8, W * n * 8 + S * N * 8, ctx->stream));
             P2_TRY(launch_bitrev(ctx, d_salt.u(), d_lde.u() + W * N, S, N, N, log_N));
         }
-        P2_TRY(p2hot_merkle_dev(ctx, d_lde.u(), 0, N, LW, log_N, cap_height, 0, N, d_dig.u(), d_cap.u()));
+        if (chunked) {
+            P2_TRY(absorb_upto(LW));  // what is left (the salts' chunks)
+            P2_TRY(merkle_levels(ctx, geom, N));
+        } else {
+            P2_TRY(p2hot_merkle_dev(ctx, d_lde.u(), 0, N, LW, log_N, cap_height, 0, N, d_dig.u(), d_cap.u()));
+        }
         if (leaves_out && LW) P2_TRY(p2hot_transpose_dev(ctx, d_lde.u(), N, LW, N, d_leaves.u()));
         // coefficient blocks go back while the leaf sponge runs: queued behind the uploads on the copy stream, each
         // waiting for its block's transform only

@@ -80,6 +80,48 @@ __global__ void __launch_bounds__(256) hash_leaves_kernel(Reader rd, unsigned W,
     for (int i = 0; i < 4; ++i) dst[i] = gl::canon(s[i]);
 }
 
+// The same sponge in column ranges, for the host-pointer commit whose columns arrive over PCIe block by block: one launch
+// absorbs the chunks [off_begin, off_end) (multiples of 8, or off_end = W) of every leaf and parks the sponge state between
+// launches in `state` (word i of leaf t at state[i * leaf_count + t]; only the words the next absorb does not overwrite are
+// kept, the ones the last MDS layer computed).  The launch that reaches W writes the digests.  W > 8 (a narrower leaf is one
+// chunk: hash_leaves_kernel).
+template <class Reader>
+__global__ void __launch_bounds__(256) hash_leaves_chunks_kernel(Reader rd, unsigned W, size_t leaf_offset, size_t leaf_count,
+                                                                unsigned h, u64 *digests, u64 *cap, unsigned off_begin,
+                                                                unsigned off_end, u64 *state) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= leaf_count) return;
+    const size_t L = leaf_offset + t;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = 0;
+    if (off_begin) {  // words the chunk at off_begin overwrites (or that were never computed) stay 0 until it does
+        const unsigned nxt = W - off_begin < 8 ? W - off_begin : 8;
+#pragma unroll
+        for (unsigned i = 0; i < 12; ++i)
+            if (i >= 3 * (nxt / 3)) s[i] = state[(size_t)i * leaf_count + t];
+    }
+    for (unsigned off = off_begin; off < off_end; off += 8) {
+        unsigned cnt = W - off < 8 ? W - off : 8;
+#pragma unroll
+        for (unsigned i = 0; i < 8; ++i)
+            if (i < cnt) s[i] = rd(L, off + i);
+        const unsigned next = off + 8 < W ? (W - off - 8 < 8 ? W - off - 8 : 8) : 0;
+        const unsigned keep = off + 8 < W ? (0xFu << (next / 3)) & 0xFu : 0x3u;
+        poseidon::permute(s, keep);
+    }
+    if (off_end >= W) {
+        u64 *dst = node_slot(digests, cap, h, 0, L);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = gl::canon(s[i]);
+    } else {
+        const unsigned nxt = W - off_end < 8 ? W - off_end : 8;
+#pragma unroll
+        for (unsigned i = 0; i < 12; ++i)
+            if (i >= 3 * (nxt / 3)) state[(size_t)i * leaf_count + t] = s[i];
+    }
+}
+
 // one tree level: node j = two_to_one(children 2j, 2j+1 of level-1) (merkle_tree.rs:108-112)
 __global__ void __launch_bounds__(256) merkle_level_kernel(u64 *digests, u64 *cap, unsigned h, unsigned level,
                                                           size_t n_nodes) {

@@ -40,6 +40,8 @@ struct p2hot_ctx {
         u64 *ufac = nullptr;
     };
     std::map<std::pair<int, unsigned>, LimbTables> limb_tw_cache;  // (inverse, log_r) -> the round tables of a 2^log_r-row tile
+    size_t host_block_cols = 0;     // > 0: p2hot_commit uploads / transforms this many columns per block whatever the size (tests)
+    bool host_chunked_hash = true;  // p2hot_commit: the leaf sponge absorbs each block's columns as soon as they are extended
     unsigned limb_tiles_log = 4;  // contiguous limb passes: a workgroup stages its tables once for 2^this tiles (P2HOT_LIMB_TILES_LOG)
     // second stream: the VALU-bound leaf sponge of coset block b runs beside the wait-bound NTT of block b+1
     hipStream_t side = nullptr;
@@ -111,6 +113,8 @@ struct ProfScope {
             (void)hipEventRecord(e1, stream);
             ctx->prof.push_back({name, e0, e1});
         }
+#else
+        if (ctx->profiling) ctx->prof_acc[name].second += 1;  // the emulator has no clock: launches only
 #endif
     }
 };
@@ -330,6 +334,8 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     if (const char *e = getenv("P2HOT_LIMB_TILES_LOG")) ctx->limb_tiles_log = (unsigned)atoi(e);
     if (const char *e = getenv("P2HOT_NTT_ZLOOP_MIN")) ctx->zloop_min_groups = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HORNER_2L_MIN")) ctx->horner_two_level_min = (size_t)strtoull(e, nullptr, 10);
+    if (const char *e = getenv("P2HOT_HOST_BLOCK_COLS")) ctx->host_block_cols = (size_t)strtoull(e, nullptr, 10);
+    if (const char *e = getenv("P2HOT_HOST_CHUNKED_HASH")) ctx->host_chunked_hash = atoi(e) != 0;
     // start values of p2hot_tune_quad / p2hot_tune_row for every context of the process, the ones p2hot_group_create makes
     // included (the kernel emulator's test tier lowers them: emulated cross-lane exchanges are slow)
     if (const char *e = getenv("P2HOT_TUNE_QUAD")) ctx->quad_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -1012,6 +1018,18 @@ static int hash_leaves_range(p2hot_ctx *ctx, hipStream_t stream, Reader rd, size
         P2HOT_LAUNCH((merkle::hash_leaves_kernel<Reader>), dim3(cdiv(count, 256)), dim3(256), 0, stream, rd, (unsigned)W,
                      leaf_offset, count, g.h, g.dig, g.cap);
     }
+    P2_LAUNCH_CHECK(ctx);
+    return P2HOT_OK;
+}
+
+// the chunks [off_begin, off_end) of every leaf's sponge (merkle::hash_leaves_chunks_kernel); `state` holds 12 * count words
+template <class Reader>
+static int hash_leaves_chunks(p2hot_ctx *ctx, hipStream_t stream, Reader rd, size_t W, const ForestGeom &g, size_t count,
+                              unsigned off_begin, unsigned off_end, u64 *state) {
+    if (count == 0 || off_begin >= off_end) return P2HOT_OK;
+    ProfScope ps(ctx, "hash_leaves", stream, true);
+    P2HOT_LAUNCH((merkle::hash_leaves_chunks_kernel<Reader>), dim3(cdiv(count, 256)), dim3(256), 0, stream, rd, (unsigned)W,
+                 (size_t)0, count, g.h, g.dig, g.cap, off_begin, off_end, state);
     P2_LAUNCH_CHECK(ctx);
     return P2HOT_OK;
 }

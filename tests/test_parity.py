@@ -443,6 +443,55 @@ def test_host_pointer_commit_abi(eng, ora):
     eng.lib.p2hot_batch_free(handle)
 
 
+@pytest.mark.parametrize("W,log_n,rb,cap,S,block", [(37, 5, 3, 2, 0, 16), (37, 5, 3, 2, 4, 16), (135, 4, 1, 0, 0, 16),
+                                                     (24, 3, 2, 5, 0, 8), (20, 4, 0, 1, 4, 3), (9, 3, 1, 2, 0, 5)])
+def test_host_commit_in_blocks_hashes_as_columns_arrive(eng, ora, monkeypatch, W, log_n, rb, cap, S, block):
+    """p2hot_commit with more than one column block (what every commit of >= 2^22 values does): the leaf sponge absorbs the
+    complete 8-column chunks after each block's LDE, its state parked between launches, the salts' chunks last
+    (hashing.rs:118-145 overwrite-mode sponge, oracle.rs:123-137 salts) -- same tree as the one-launch sponge and the oracle;
+    block widths that are not multiples of the sponge rate, a last chunk shorter than the rate, all-cap trees"""
+    import ctypes as C
+    from plonky2_amd.engine import Engine
+    monkeypatch.setenv("P2HOT_HOST_BLOCK_COLS", str(block))
+    e2 = Engine(0, lib=eng.lib, memory=eng.mem)  # a context that splits every commit into blocks of `block` columns
+    try:
+        rng = np.random.default_rng(W * 7 + S)
+        n, N = 1 << log_n, 1 << (log_n + rb)
+        cols = [rand_field(rng, n, noncanonical=True) for _ in range(W)]
+        salts = rand_field(rng, max(S, 1), N, noncanonical=True)
+        o = ora.commit_salted(np.stack(cols), salts[:S], rb, cap, True) if S else ora.commit(np.stack(cols), rb, cap, True)
+        ptrs = (C.c_void_p * W)(*[c.ctypes.data for c in cols])
+        sptrs = (C.c_void_p * max(S, 1))(*[salts[j].ctypes.data for j in range(max(S, 1))])
+        for chunked in ("1", "0"):
+            monkeypatch.setenv("P2HOT_HOST_CHUNKED_HASH", chunked)
+            e3 = e2 if chunked == "1" else Engine(0, lib=eng.lib, memory=eng.mem)
+            coeffs = np.zeros((W, n), dtype=np.uint64)
+            leaves = np.zeros((N, W + S), dtype=np.uint64)
+            digests = np.zeros((max(eng.num_digests(log_n + rb, cap), 1), 4), dtype=np.uint64)
+            capv = np.zeros((1 << cap, 4), dtype=np.uint64)
+            h = C.c_void_p()
+            e3.profile(True)
+            e3.check(e3.lib.p2hot_commit_salted(e3.ctx, ptrs, W, log_n, rb, cap, 1, 0, sptrs if S else None, S, coeffs.ctypes.data,
+                                                leaves.ctypes.data, digests.ctypes.data, capv.ctypes.data, C.byref(h)))
+            launches = e3.profile_results()["hash_leaves"]["launches"]
+            e3.profile(False)
+            # chunked: one sponge launch per block that completes at least one new 8-column chunk (+ the salts' launch)
+            done, want = 0, 0
+            for c_end in list(range(block, W, block)) + [W] + ([W + S] if S else []):
+                end = c_end if c_end >= W + S else c_end // 8 * 8
+                want, done = want + (end > done), max(done, end)
+            assert launches == (want if chunked == "1" else 1), (chunked, launches, want)
+            assert (coeffs == o["coeffs"] % np.uint64(P)).all() and (leaves == o["leaves"]).all(), chunked
+            assert (capv == o["cap"]).all(), chunked
+            nd = eng.num_digests(log_n + rb, cap)
+            assert nd == 0 or (digests[:nd] == o["digests"]).all(), chunked
+            e3.lib.p2hot_batch_free(h)
+            if e3 is not e2:
+                e3.close()
+    finally:
+        e2.close()
+
+
 # ---------------------------------------------------------------- Challenger / FRI
 def test_challenger_vs_oracle(eng, ora):
     from plonky2_amd.iop.challenger import Challenger
