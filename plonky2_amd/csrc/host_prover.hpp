@@ -135,7 +135,19 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     // and extended (LDE) one after the other -- the upload of block b+1 overlaps the transforms of block b -- and the
     // coefficient blocks go back to the host while the leaf sponge runs.  Small batches are one block.
     const size_t kBlockCols = ctx->host_block_cols ? ctx->host_block_cols : (W >= 32 && W * n >= ((size_t)1 << 22)) ? 16 : (W ? W : 1);
-    const size_t nb = W ? (W + kBlockCols - 1) / kBlockCols : 0;
+    // block b = columns [blk0[b], blk0[b + 1]).  The first upload has nothing to hide behind, so when there are several blocks
+    // the first one is half as wide (a multiple of the sponge rate where it can be)
+    std::vector<size_t> blk0;
+    {
+        size_t c = 0;
+        const size_t first = (!ctx->host_block_cols && kBlockCols >= 16 && W > kBlockCols) ? kBlockCols / 2 : kBlockCols;
+        while (c < W) {
+            blk0.push_back(c);
+            c += (c == 0 ? first : kBlockCols);
+        }
+        blk0.push_back(W);
+    }
+    const size_t nb = W ? blk0.size() - 1 : 0;
     std::vector<hipEvent_t> up, done;
     hipStream_t copy_stream = ctx->stream;
 #ifndef P2HOT_EMU
@@ -174,7 +186,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         }
 #endif
         for (size_t b = 0; b < nb; ++b) {
-            const size_t c0 = b * kBlockCols, cnt = (c0 + kBlockCols <= W ? kBlockCols : W - c0);
+            const size_t c0 = blk0[b], cnt = blk0[b + 1] - c0;
             u64 *blk = d_work.u() + c0 * n;
             u64 *land = keep_vals ? d_vals.u() + c0 * n : blk;  // where the upload lands
             P2_TRY(h2d_columns(ctx, land, cols + c0, cnt, n * 8, c0 * n * 8, W * n * 8 + S * N * 8, copy_stream));
@@ -215,7 +227,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         // waiting for its block's transform only
         if (coeffs_out)
             for (size_t b = 0; b < nb; ++b) {
-                const size_t c0 = b * kBlockCols, cnt = (c0 + kBlockCols <= W ? kBlockCols : W - c0);
+                const size_t c0 = blk0[b], cnt = blk0[b + 1] - c0;
 #ifndef P2HOT_EMU
                 if (two_streams) P2_HIP(ctx, hipStreamWaitEvent(ctx->side, done[b], 0));
 #endif
