@@ -46,7 +46,8 @@ constexpr bool LIMB_DEFER = P2HOT_LIMB_DEFER != 0;  // a borrowed first-round ta
 #define P2HOT_LIMB_FOLD3 0
 #endif
 constexpr bool LIMB_FOLD3 = P2HOT_LIMB_FOLD3 != 0;  // a unit's conversions fold their accumulator pairs three at a time (gl::fold3): measured
-                                                    // SLOWER (LDE contiguous pass 4.69 vs 4.56 ms: 116 VGPRs instead of 101), off
+                                                    // SLOWER (LDE contiguous pass 4.69 vs 4.56 ms: 116 VGPRs instead of 101), and so did
+                                                    // pairs (= 2: 4.83 vs 4.71 ms, 114 VGPRs); off
 constexpr bool LIMB_MUL3 = P2HOT_LIMB_MUL3 != 0;    // independent general multiplies of a unit go through gl::mul3 streams
 constexpr bool LIMB_DIRECT_CONTIG = P2HOT_LIMB_DIRECT_CONTIG != 0;  // contiguous pass: store the last round's outputs from registers
 constexpr int LIMB_MIN_WAVES = P2HOT_LIMB_MIN_WAVES;  // waves per SIMD the register allocation must allow (4: <= 128 VGPRs)
@@ -192,6 +193,21 @@ __device__ __forceinline__ u64 conv_unit(const L4 &v) {
 // stalls its wave two wait states per row, and a unit has 2^P independent rows
 template <int N, class AccF>
 __device__ __forceinline__ void fold_groups(AccF acc_of, u64 (&y)[N]) {
+    if constexpr (P2HOT_LIMB_FOLD3 == 2) {  // pairs: two rows per gl::fold2 stream (two accumulator pairs alive instead of three)
+#pragma unroll
+        for (int q = 0; q + 2 <= N; q += 2) {
+            const Acc a0 = acc_of(q), a1 = acc_of(q + 1);
+            const u64 al[2] = {a0.al, a1.al}, ah[2] = {a0.ah, a1.ah};
+            u64 r[2];
+            gl::fold2(al, ah, r);
+            y[q] = r[0], y[q + 1] = r[1];
+        }
+        if constexpr (N & 1) {
+            const Acc a0 = acc_of(N - 1);
+            y[N - 1] = gl::fold1(a0.al, a0.ah);
+        }
+        return;
+    }
     constexpr int N3 = N / 3 * 3;
 #pragma unroll
     for (int q = 0; q < N3; q += 3) {
