@@ -33,9 +33,7 @@ class AsmTier:
 
 @pytest.fixture(scope="module")
 def tier(emu):
-    import os
-    from tests.emu_backend import _SO
-    return AsmTier(C.CDLL(os.path.abspath(_SO)))  # the same library object the engine bound (dlopen is refcounted)
+    return AsmTier(emu.lib)  # the library the emulator engine is bound to (tests/emu/libp2hot_emu.so, or an ASAN build of it)
 
 
 @pytest.fixture
@@ -58,7 +56,7 @@ def test_the_checker_catches_what_it_claims(tier):
     assert tier.lib.p2hot_emu_asm_negative_tests() == 0x7F
 
 
-def test_field_streams_on_the_reference_edge_grid(emu_asm):
+def test_field_asm_streams_on_the_reference_edge_grid(emu_asm):
     """mul1 / mul3 / mul1_lowregs / mul_pow2_asm<S> (every shift the butterflies use and the boundary shifts) / fold1 / fold3
     against big-integer arithmetic and the compiler's streams (field/src/prime_field_testing.rs:8-17 grid)"""
     tp.test_field_ops_edge_grid(emu_asm)
