@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -40,6 +41,7 @@ struct p2hot_ctx {
         u64 *ufac = nullptr;
     };
     std::map<std::pair<int, unsigned>, LimbTables> limb_tw_cache;  // (inverse, log_r) -> the round tables of a 2^log_r-row tile
+    std::set<const void *> lds_opted;  // kernels whose large dynamic LDS request was registered (lds_opt_in)
     size_t host_block_cols = 0;     // > 0: p2hot_commit uploads / transforms this many columns per block whatever the size (tests)
     bool host_chunked_hash = true;  // p2hot_commit: the leaf sponge absorbs each block's columns as soon as they are extended
     unsigned limb_tiles_log = 4;  // contiguous limb passes: a workgroup stages its tables once for 2^this tiles (P2HOT_LIMB_TILES_LOG)
@@ -586,6 +588,19 @@ static int limb_tables(p2hot_ctx *ctx, bool inverse, unsigned log_r, p2hot_ctx::
     return P2HOT_OK;
 }
 
+// A kernel that asks for more than 48 KiB of dynamic LDS says so once per context (the contiguous limb pass sits at exactly
+// 64 KiB, the most a launch gets without this; gfx950 has 160 KiB per workgroup)
+static int lds_opt_in(p2hot_ctx *ctx, const void *kernel, size_t shm) {
+#ifndef P2HOT_EMU
+    if (shm <= ((size_t)48 << 10) || ctx->lds_opted.count(kernel)) return P2HOT_OK;
+    P2_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    ctx->lds_opted.insert(kernel);
+#else
+    (void)ctx, (void)kernel, (void)shm;
+#endif
+    return P2HOT_OK;
+}
+
 static bool limb_supported(unsigned log_r, unsigned log_c) {
     if (log_r + log_c != (unsigned)nttl::TILE_LOG) return false;
     return log_r == 12 || (log_r >= 4 && log_r <= 10);
@@ -622,8 +637,12 @@ static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse
     ra.sbase = sbase;
     // the last conversion multiplies by 1 (LAST_UNIT), by a constant (LAST_CONST: the inverse transform's 1/n) or -- the
     // strided first pass of a coset LDE -- by the tile's share of the coset scale (LAST_TILE)
-#define P2_LIMB(INVF, LR, MODE, LASTM) \
-    P2HOT_LAUNCH((nttl::ntt_limbpass_kernel<INVF, LR, 12 - LR, MODE, LASTM>), grid, dim3(nttl::NT), shm, ctx->stream, ra)
+#define P2_LIMB(INVF, LR, MODE, LASTM)                                                                     \
+    do {                                                                                                   \
+        auto kfn_ = nttl::ntt_limbpass_kernel<INVF, LR, 12 - LR, MODE, LASTM>;                             \
+        P2_TRY(lds_opt_in(ctx, reinterpret_cast<const void *>(kfn_), shm));                                \
+        P2HOT_LAUNCH(kfn_, grid, dim3(nttl::NT), shm, ctx->stream, ra);                                    \
+    } while (0)
 #define P2_LIMB_DIR(LR, MODE, LASTM) do { if (inverse) P2_LIMB(true, LR, MODE, LASTM); else P2_LIMB(false, LR, MODE, LASTM); } while (0)
 #define P2_LIMB_MODE(LR)                                                                                          \
     do {                                                                                                          \
@@ -636,9 +655,9 @@ static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse
     if (a.scale_mode == ntt::SCALE_TABLE && a.log_r != 12 && (!srow2 || !sbase)) P2_FAIL(ctx, P2HOT_EINVAL, "limb pass: missing coset scale tables");
     if (wlast) {
         if (inverse)
-            P2HOT_LAUNCH((nttl::ntt_limbpass_kernel<true, 12, 0, ntt::SCALE_NONE, nttl::LAST_CONST>), grid, dim3(nttl::NT), shm, ctx->stream, ra);
+            P2_LIMB(true, 12, ntt::SCALE_NONE, nttl::LAST_CONST);
         else
-            P2HOT_LAUNCH((nttl::ntt_limbpass_kernel<false, 12, 0, ntt::SCALE_NONE, nttl::LAST_CONST>), grid, dim3(nttl::NT), shm, ctx->stream, ra);
+            P2_LIMB(false, 12, ntt::SCALE_NONE, nttl::LAST_CONST);
         return P2HOT_OK;
     }
     switch (a.log_r) {
