@@ -472,13 +472,23 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
                 const W2 *tw = ltw + T_OFF + (BORROW ? lo >> P : lo);
                 [[maybe_unused]] const u64 *uf = lu + (lo & ((1u << P) - 1)) * 8;
                 tile[ntt::pad_idx((i0 << LOG_C) + c)] = conv_unit(x[0]);
+                [[maybe_unused]] u64 yb[(1 << P) - 1], ub[(1 << P) - 1];
 #pragma unroll
                 for (int q = 1; q < (1 << P); ++q) {
                     const unsigned k = (unsigned)(__brev((unsigned)q) >> (32 - P));
                     const W2 wa = tw[((k - 1) * 2) << T_LOG], wb = tw[((k - 1) * 2 + 1) << T_LOG];
                     u64 y = convmul(x[q], wa.a, wa.b, wb.a, wb.b);
-                    if constexpr (BORROW && !defers(LOG_R)) y = limb_mul(y, uf[k]);  // (deferred: absorbed by a later round's table)
-                    tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = y;
+                    if constexpr (BORROW && !defers(LOG_R) && !LIMB_MUL3) y = limb_mul(y, uf[k]);  // (deferred: absorbed by a later round's table)
+                    if constexpr (BORROW && !defers(LOG_R) && LIMB_MUL3) {
+                        yb[q - 1] = y, ub[q - 1] = uf[k];
+                    } else {
+                        tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = y;
+                    }
+                }
+                if constexpr (BORROW && !defers(LOG_R) && LIMB_MUL3) {  // the second factors of the unit's outputs, three streams at a time
+                    limb_mul_n<(1 << P) - 1>(yb, ub);
+#pragma unroll
+                    for (int q = 1; q < (1 << P); ++q) tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = yb[q - 1];
                 }
             }
         } else {
@@ -617,13 +627,31 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
                 const unsigned lane = tid & 63u;
                 const u32 off0 = (((lane >> LOG_C) << log_stride) + (lane & (C - 1))) * 8u;  // bytes, per lane
                 const unsigned U0 = wave_uniform(tid >> 6) * 512u;
+                if constexpr (LIMB_MUL3) {  // the thread's eight products as three-stream blocks
+                    u64 v8[8], w8[8];
+#pragma unroll
+                    for (unsigned j = 0; j < 8; ++j) {
+                        const unsigned U = U0 + 64 * j;
+                        const size_t step = ((size_t)(U >> LOG_C) << log_stride) + (U & (C - 1));
+                        w8[j] = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ra.twid + base0 + step) + off0);
+                        v8[j] = tile[ntt::pad_idx(e0 + 64 * j)];
+                    }
+                    limb_mul_n<8>(v8, w8);
+#pragma unroll
+                    for (unsigned j = 0; j < 8; ++j) {
+                        const unsigned U = U0 + 64 * j;
+                        const size_t step = ((size_t)(U >> LOG_C) << log_stride) + (U & (C - 1));
+                        *reinterpret_cast<u64 *>(reinterpret_cast<char *>(out + step) + off0) = a.canon_out ? gl::canon(v8[j]) : v8[j];
+                    }
+                } else {
 #pragma unroll 2
-                for (unsigned j = 0; j < 8; ++j) {
-                    const unsigned U = U0 + 64 * j;
-                    const size_t step = ((size_t)(U >> LOG_C) << log_stride) + (U & (C - 1));
-                    const u64 w = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ra.twid + base0 + step) + off0);
-                    u64 v = limb_mul(tile[ntt::pad_idx(e0 + 64 * j)], w);
-                    *reinterpret_cast<u64 *>(reinterpret_cast<char *>(out + step) + off0) = a.canon_out ? gl::canon(v) : v;
+                    for (unsigned j = 0; j < 8; ++j) {
+                        const unsigned U = U0 + 64 * j;
+                        const size_t step = ((size_t)(U >> LOG_C) << log_stride) + (U & (C - 1));
+                        const u64 w = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ra.twid + base0 + step) + off0);
+                        u64 v = limb_mul(tile[ntt::pad_idx(e0 + 64 * j)], w);
+                        *reinterpret_cast<u64 *>(reinterpret_cast<char *>(out + step) + off0) = a.canon_out ? gl::canon(v) : v;
+                    }
                 }
             }
             __syncthreads();  // the next tile's first round overwrites what other waves may still be reading
