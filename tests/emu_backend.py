@@ -70,6 +70,8 @@ def emu_lib():
         subprocess.check_call(["make", "-C", _DIR, "-s"])
         _lib_cache = _lib.load(_SO)
         assert _lib_cache.p2hot_is_emulated() == 1
+        if os.environ.get("P2HOT_EMU_ASM") == "1":  # the whole tier through the instruction interpreter (slow: ~30x on Poseidon)
+            _lib_cache.p2hot_emu_asm(1)
     return _lib_cache
 
 

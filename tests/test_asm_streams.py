@@ -40,11 +40,11 @@ def tier(emu):
 def emu_asm(emu, tier):
     """the emulator engine with the instruction interpreter on; the test must have executed asm blocks without a report"""
     before = tier.stats()
-    assert tier.lib.p2hot_emu_asm(1) == 0
+    was = tier.lib.p2hot_emu_asm(1)  # (already on when the whole tier runs under P2HOT_EMU_ASM=1)
     try:
         yield emu
     finally:
-        tier.lib.p2hot_emu_asm(0)
+        tier.lib.p2hot_emu_asm(was)
     after = tier.stats()
     assert after["errors"] == before["errors"], after["first_error"]
     assert after["blocks"] > before["blocks"], "no asm block was interpreted: the test did not reach a hand-written stream"
