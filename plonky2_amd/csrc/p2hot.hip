@@ -66,6 +66,7 @@ struct p2hot_ctx {
     size_t pinned_cap = 0, pinned_used = 0;
     unsigned char *pinned_up = nullptr;  // upload staging: many short host columns -> one contiguous pinned block -> one copy
     size_t pinned_up_cap = 0;
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};  // one per half of the staging block when an upload takes several slices
     std::vector<DeferredCopy> deferred;
     bool in_host_call = false;       // set by the host-pointer entry points (they end in stream_sync)
     size_t horner_two_level_min = 4096;  // divide_by_linear: more chunks than this -> carries in two levels (P2HOT_HORNER_2L_MIN)
@@ -237,6 +238,35 @@ static int h2d_columns(p2hot_ctx *ctx, void *d_dst, const uint64_t *const *cols,
             return P2HOT_OK;
         }
     }
+#ifndef P2HOT_EMU
+    // More short columns than the staging block holds (p2hot_commit_many of dozens of recursion-size proofs: thousands of 32 KB
+    // vectors, each ~10 us of host time as a pageable copy): the block's two halves take slices in turn, a half being refilled
+    // once the copy that read it has finished.
+    if (ctx->in_host_call && count > 1 && bytes <= ((size_t)1 << 20) && stage_off == 0 && stage_total == count * bytes) {
+        if (ctx->pinned_up_cap < kMaxStage) {
+            if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);
+            ctx->pinned_up = nullptr;
+            ctx->pinned_up_cap = 0;
+            if (hipHostMalloc((void **)&ctx->pinned_up, kMaxStage, hipHostMallocDefault) == hipSuccess) ctx->pinned_up_cap = kMaxStage;
+        }
+        for (int k = 0; k < 2 && ctx->pinned_up; ++k)
+            if (!ctx->stage_ev[k] && hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming) != hipSuccess) ctx->stage_ev[k] = nullptr;
+        if (ctx->pinned_up && ctx->stage_ev[0] && ctx->stage_ev[1]) {
+            const size_t half = ctx->pinned_up_cap / 2, per = half / bytes;
+            size_t k = 0;
+            for (size_t c0 = 0; c0 < count; c0 += per, ++k) {
+                const size_t cnt = std::min(per, count - c0);
+                unsigned char *slot = ctx->pinned_up + (k & 1) * half;
+                if (k >= 2) P2_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k & 1]));
+                for (size_t c = 0; c < cnt; ++c)
+                    std::copy((const unsigned char *)cols[c0 + c], (const unsigned char *)cols[c0 + c] + bytes, slot + c * bytes);
+                P2_HIP(ctx, hipMemcpyAsync((unsigned char *)d_dst + c0 * bytes, slot, cnt * bytes, hipMemcpyHostToDevice, stream));
+                P2_HIP(ctx, hipEventRecord(ctx->stage_ev[k & 1], stream));
+            }
+            return P2HOT_OK;
+        }
+    }
+#endif
     for (size_t c = 0; c < count; ++c)
         P2_HIP(ctx, hipMemcpyAsync((unsigned char *)d_dst + c * bytes, cols[c], bytes, hipMemcpyHostToDevice, stream));
     return P2HOT_OK;
@@ -413,6 +443,10 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
     if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_oob) (void)hipHostFree(ctx->pinned_oob);
+#ifndef P2HOT_EMU
+    for (int k = 0; k < 2; ++k)
+        if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
+#endif
     if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);
     delete ctx;
 }
