@@ -242,7 +242,8 @@ static int h2d_columns(p2hot_ctx *ctx, void *d_dst, const uint64_t *const *cols,
     // More short columns than the staging block holds (p2hot_commit_many of dozens of recursion-size proofs: thousands of 32 KB
     // vectors, each ~10 us of host time as a pageable copy): the block's two halves take slices in turn, a half being refilled
     // once the copy that read it has finished.
-    if (ctx->in_host_call && count > 1 && bytes <= ((size_t)1 << 20) && stage_off == 0 && stage_total == count * bytes) {
+    // (only where the per-copy overhead outweighs the copy itself: beyond ~128 KB a pageable copy moves faster than one core stages it)
+    if (ctx->in_host_call && count > 1 && bytes <= ((size_t)128 << 10) && stage_off == 0 && stage_total == count * bytes) {
         if (ctx->pinned_up_cap < kMaxStage) {
             if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);
             ctx->pinned_up = nullptr;
