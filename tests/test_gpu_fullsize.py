@@ -363,3 +363,28 @@ def test_host_pointer_commit_pipelined_path(gpu, ora, is_values, want_leaves):
     gpu.check(gpu.lib.p2hot_batch_rows(handle, idx.ctypes.data, 3, rows.ctypes.data))
     assert (rows == o["leaves"][idx.astype(np.int64)]).all()
     gpu.lib.p2hot_batch_free(handle)
+
+
+@pytest.mark.gpu
+def test_commit_many_upload_in_staging_slices(gpu):
+    """p2hot_commit_many of more short host columns than the 64 MB pinned staging block holds (20 recursion-size proofs:
+    2700 vectors of 32 KB = 84 MB): the block's halves take slices in turn; every proof's cap equals the single-proof
+    commitment of the same columns and distinct proofs stay distinct (fri/oracle.rs:57-79)"""
+    import ctypes as C
+    import numpy as np
+    from plonky2_amd.util.synthetic import splitmix_columns_numpy
+    eng = gpu
+    M, W, log_n, rb, cap = 20, 135, 12, 3, 4
+    n = 1 << log_n
+    sets = [splitmix_columns_numpy(1000 * (m % 3), W, n) for m in range(M)]  # three different proofs, repeated
+    ptrs = (C.c_void_p * (M * W))(*[sets[m][e].ctypes.data for m in range(M) for e in range(W)])
+    caps = np.zeros((M, 1 << cap, 4), dtype=np.uint64)
+    coeffs = np.zeros((M, W, n), dtype=np.uint64)
+    eng.check(eng.lib.p2hot_commit_many(eng.ctx, ptrs, M, W, log_n, rb, cap, 1, coeffs.ctypes.data, None, caps.ctypes.data, None))
+    for k in range(3):
+        one = (C.c_void_p * W)(*[sets[k][e].ctypes.data for e in range(W)])
+        c1, co1 = np.zeros((1 << cap, 4), dtype=np.uint64), np.zeros((W, n), dtype=np.uint64)
+        eng.check(eng.lib.p2hot_commit(eng.ctx, one, W, log_n, rb, cap, 1, 0, co1.ctypes.data, None, None, c1.ctypes.data, None))
+        for m in range(k, M, 3):
+            assert (caps[m] == c1).all() and (coeffs[m] == co1).all(), (k, m)
+    assert (caps[0] != caps[1]).any() and (caps[1] != caps[2]).any()
