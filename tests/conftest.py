@@ -66,3 +66,22 @@ def rand_field(rng, *shape, noncanonical=False):
         small = rng.integers(0, 2**32 - 1, size=shape, dtype=np.uint64)
         a = np.where(m, small + np.uint64(P), a)
     return a
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """P2HOT_EMU_ASM=1 (the whole CPU tier through the emulator's instruction interpreter): any hazard / clobber / definition
+    report of the interpreter fails the run, and the run must have interpreted something"""
+    if os.environ.get("P2HOT_EMU_ASM") != "1":
+        return
+    import ctypes as C
+    from tests import emu_backend
+    lib = emu_backend._lib_cache
+    if lib is None:
+        return
+    lib.p2hot_emu_asm_stats.restype = C.c_ulonglong
+    lib.p2hot_emu_asm_stats.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_char_p, C.c_size_t]
+    blocks, errors, buf = C.c_ulonglong(), C.c_ulonglong(), C.create_string_buffer(1024)
+    n = lib.p2hot_emu_asm_stats(C.byref(blocks), C.byref(errors), buf, 1024)
+    print("\n[gcn_asm] %d instructions in %d asm blocks interpreted, %d reports %s" % (n, blocks.value, errors.value, buf.value.decode()))
+    if errors.value:
+        session.exitstatus = 1
