@@ -367,14 +367,14 @@ def test_host_pointer_commit_pipelined_path(gpu, ora, is_values, want_leaves):
 
 @pytest.mark.gpu
 def test_commit_many_upload_in_staging_slices(gpu):
-    """p2hot_commit_many of more short host columns than the 64 MB pinned staging block holds (20 recursion-size proofs:
-    2700 vectors of 32 KB = 84 MB): the block's halves take slices in turn; every proof's cap equals the single-proof
+    """p2hot_commit_many of more short host columns than the 64 MB pinned staging block holds (32 recursion-size proofs:
+    4320 vectors of 32 KB = 135 MB): the block's halves take slices in turn; every proof's cap equals the single-proof
     commitment of the same columns and distinct proofs stay distinct (fri/oracle.rs:57-79)"""
     import ctypes as C
     import numpy as np
     from plonky2_amd.util.synthetic import splitmix_columns_numpy
     eng = gpu
-    M, W, log_n, rb, cap = 20, 135, 12, 3, 4
+    M, W, log_n, rb, cap = 32, 135, 12, 3, 4
     n = 1 << log_n
     sets = [splitmix_columns_numpy(1000 * (m % 3), W, n) for m in range(M)]  # three different proofs, repeated
     ptrs = (C.c_void_p * (M * W))(*[sets[m][e].ctypes.data for m in range(M) for e in range(W)])
