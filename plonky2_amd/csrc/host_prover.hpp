@@ -165,10 +165,19 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         P2_TRY(pool_alloc(ctx, (size_t)12 * N * 8, &d_state.p));
         P2_TRY(forest_geom(ctx, log_N, cap_height, 0, N, d_dig.u(), d_cap.u(), &geom));
     }
-    auto absorb_upto = [&](size_t cols_done) -> int {  // cols_done leaf columns of d_lde are final
-        const unsigned end = cols_done >= LW ? (unsigned)LW : (unsigned)(cols_done / 8 * 8);
+    // When the digests go back to the host the tail -- the last chunk(s) of the sponge and the tree levels -- runs per group of
+    // cap subtrees: a group's slice of the digest array is contiguous in the reference layout, so it can travel while the next
+    // groups are hashed.  (A copy into pageable memory holds the calling thread until it is done: every group's kernels are
+    // enqueued first, the copies are issued after them.)
+    size_t tail_groups = 1;
+    if (chunked && digests_out && nd)
+        while (tail_groups < 8 && tail_groups * 2 <= ((size_t)1 << cap_height) && (N / (tail_groups * 2)) >= ctx->host_tail_min_leaves)
+            tail_groups *= 2;
+    std::vector<hipEvent_t> tail_ev;
+    auto absorb_upto = [&](size_t cols_done, bool may_finish) -> int {  // cols_done leaf columns of d_lde are final
+        const unsigned end = (cols_done >= LW && may_finish) ? (unsigned)LW : (unsigned)((cols_done < LW ? cols_done : LW - 1) / 8 * 8);
         if (end <= hashed) return P2HOT_OK;
-        P2_TRY(hash_leaves_chunks(ctx, ctx->stream, merkle::ColMajorReader{d_lde.u(), N}, LW, geom, N, hashed, end, d_state.u()));
+        P2_TRY(hash_leaves_chunks(ctx, ctx->stream, merkle::ColMajorReader{d_lde.u(), N}, LW, geom, N, hashed, end, d_state.u(), N));
         hashed = end;
         return P2HOT_OK;
     };
@@ -207,7 +216,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             if (two_streams) P2_HIP(ctx, hipEventRecord(done[b], ctx->stream));
 #endif
             P2_TRY(p2hot_coset_lde_dev(ctx, blk, cnt, n, log_n, rate_bits, gl::COSET_SHIFT, 0, N, d_lde.u() + c0 * N, N));
-            if (chunked) P2_TRY(absorb_upto(c0 + cnt < W || S ? c0 + cnt : LW));
+            if (chunked) P2_TRY(absorb_upto(c0 + cnt, tail_groups == 1 && !S));  // (a grouped tail keeps the last chunk)
         }
         if (S) {
             // the salt vectors are LDE-value columns in natural order (oracle.rs:133-137): like the LDE values they reach the
@@ -216,8 +225,26 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             P2_TRY(h2d_columns(ctx, d_salt.u(), salt_cols, S, N * 8, W * n * 8, W * n * 8 + S * N * 8, ctx->stream));
             P2_TRY(launch_bitrev(ctx, d_salt.u(), d_lde.u() + W * N, S, N, N, log_N));
         }
-        if (chunked) {
-            P2_TRY(absorb_upto(LW));  // what is left (the salts' chunks)
+        if (chunked && tail_groups > 1) {
+            const size_t cnt = N / tail_groups;
+            for (size_t g = 0; g < tail_groups; ++g) {
+                ForestGeom gg;
+                P2_TRY(forest_geom(ctx, log_N, cap_height, g * cnt, cnt, d_dig.u(), d_cap.u(), &gg));
+                P2_TRY(hash_leaves_chunks(ctx, ctx->stream, merkle::ColMajorReader{d_lde.u() + g * cnt, N}, LW, gg, cnt, hashed,
+                                          (unsigned)LW, d_state.u() + g * cnt, N));
+                P2_TRY(merkle_levels(ctx, gg, cnt));
+#ifndef P2HOT_EMU
+                if (two_streams) {
+                    hipEvent_t e;
+                    P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    tail_ev.push_back(e);
+                    P2_HIP(ctx, hipEventRecord(e, ctx->stream));
+                }
+#endif
+            }
+            hashed = (unsigned)LW;
+        } else if (chunked) {
+            P2_TRY(absorb_upto(LW, true));  // what is left (the salts' chunks)
             P2_TRY(merkle_levels(ctx, geom, N));
         } else {
             P2_TRY(p2hot_merkle_dev(ctx, d_lde.u(), 0, N, LW, log_N, cap_height, 0, N, d_dig.u(), d_cap.u()));
@@ -234,7 +261,18 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
                 P2_HIP(ctx, hipMemcpyAsync(coeffs_out + c0 * n, d_work.u() + c0 * n, cnt * n * 8, hipMemcpyDeviceToHost, copy_stream));
             }
         if (leaves_out && LW) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, LW * N * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (digests_out && nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
+        if (digests_out && nd && tail_groups > 1) {  // the groups' digest slices, each behind its group's levels only
+            const size_t cnt = N / tail_groups, sub_leaves = N >> cap_height, sub_words = 8 * (sub_leaves - 1);
+            for (size_t g = 0; g < tail_groups; ++g) {
+                const size_t w0 = (g * cnt / sub_leaves) * sub_words, nw = (cnt / sub_leaves) * sub_words;
+#ifndef P2HOT_EMU
+                if (two_streams) P2_HIP(ctx, hipStreamWaitEvent(copy_stream, tail_ev[g], 0));
+#endif
+                P2_HIP(ctx, hipMemcpyAsync(digests_out + w0, d_dig.u() + w0, nw * 8, hipMemcpyDeviceToHost, copy_stream));
+            }
+        } else if (digests_out && nd) {
+            P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
+        }
         if (cap_out) P2_TRY(d2h(ctx, cap_out, d_cap.p, cap_words * 8));
         return P2HOT_OK;
     };
@@ -244,6 +282,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     if (two_streams) e1 = hipStreamSynchronize(ctx->side);
     for (hipEvent_t ev : up) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : done) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : tail_ev) (void)hipEventDestroy(ev);
 #endif
     rc = sync_checked(ctx, rc, "commit");
     if (rc == P2HOT_OK && e1 != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "commit: %s", hipGetErrorString(e1));

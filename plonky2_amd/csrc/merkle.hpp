@@ -82,13 +82,13 @@ __global__ void __launch_bounds__(256) hash_leaves_kernel(Reader rd, unsigned W,
 
 // The same sponge in column ranges, for the host-pointer commit whose columns arrive over PCIe block by block: one launch
 // absorbs the chunks [off_begin, off_end) (multiples of 8, or off_end = W) of every leaf and parks the sponge state between
-// launches in `state` (word i of leaf t at state[i * leaf_count + t]; only the words the next absorb does not overwrite are
+// launches in `state` (word i of leaf t at state[i * state_stride + t]; only the words the next absorb does not overwrite are
 // kept, the ones the last MDS layer computed).  The launch that reaches W writes the digests.  W > 8 (a narrower leaf is one
 // chunk: hash_leaves_kernel).
 template <class Reader>
 __global__ void __launch_bounds__(256) hash_leaves_chunks_kernel(Reader rd, unsigned W, size_t leaf_offset, size_t leaf_count,
                                                                 unsigned h, u64 *digests, u64 *cap, unsigned off_begin,
-                                                                unsigned off_end, u64 *state) {
+                                                                unsigned off_end, u64 *state, size_t state_stride) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= leaf_count) return;
     const size_t L = leaf_offset + t;
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) hash_leaves_chunks_kernel(Reader rd, unsi
         const unsigned nxt = W - off_begin < 8 ? W - off_begin : 8;
 #pragma unroll
         for (unsigned i = 0; i < 12; ++i)
-            if (i >= 3 * (nxt / 3)) s[i] = state[(size_t)i * leaf_count + t];
+            if (i >= 3 * (nxt / 3)) s[i] = state[(size_t)i * state_stride + t];
     }
     for (unsigned off = off_begin; off < off_end; off += 8) {
         unsigned cnt = W - off < 8 ? W - off : 8;
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) hash_leaves_chunks_kernel(Reader rd, unsi
         const unsigned nxt = W - off_end < 8 ? W - off_end : 8;
 #pragma unroll
         for (unsigned i = 0; i < 12; ++i)
-            if (i >= 3 * (nxt / 3)) state[(size_t)i * leaf_count + t] = s[i];
+            if (i >= 3 * (nxt / 3)) state[(size_t)i * state_stride + t] = s[i];
     }
 }
 

@@ -43,6 +43,7 @@ struct p2hot_ctx {
     std::map<std::pair<int, unsigned>, LimbTables> limb_tw_cache;  // (inverse, log_r) -> the round tables of a 2^log_r-row tile
     std::set<const void *> lds_opted;  // kernels whose large dynamic LDS request was registered (lds_opt_in)
     size_t host_block_cols = 0;     // > 0: p2hot_commit uploads / transforms this many columns per block whatever the size (tests)
+    size_t host_tail_min_leaves = (size_t)1 << 18;  // ... and the tail per group of cap subtrees of at least this many leaves (P2HOT_HOST_TAIL_MIN_LEAVES)
     bool host_chunked_hash = true;  // p2hot_commit: the leaf sponge absorbs each block's columns as soon as they are extended
     unsigned limb_tiles_log = 4;  // contiguous limb passes: a workgroup stages its tables once for 2^this tiles (P2HOT_LIMB_TILES_LOG)
     // second stream: the VALU-bound leaf sponge of coset block b runs beside the wait-bound NTT of block b+1
@@ -369,6 +370,7 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     if (const char *e = getenv("P2HOT_HORNER_2L_MIN")) ctx->horner_two_level_min = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HOST_BLOCK_COLS")) ctx->host_block_cols = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HOST_CHUNKED_HASH")) ctx->host_chunked_hash = atoi(e) != 0;
+    if (const char *e = getenv("P2HOT_HOST_TAIL_MIN_LEAVES")) ctx->host_tail_min_leaves = (size_t)strtoull(e, nullptr, 10);
     // start values of p2hot_tune_quad / p2hot_tune_row for every context of the process, the ones p2hot_group_create makes
     // included (the kernel emulator's test tier lowers them: emulated cross-lane exchanges are slow)
     if (const char *e = getenv("P2HOT_TUNE_QUAD")) ctx->quad_threshold = (size_t)strtoull(e, nullptr, 10);
@@ -1076,14 +1078,15 @@ static int hash_leaves_range(p2hot_ctx *ctx, hipStream_t stream, Reader rd, size
     return P2HOT_OK;
 }
 
-// the chunks [off_begin, off_end) of every leaf's sponge (merkle::hash_leaves_chunks_kernel); `state` holds 12 * count words
+// the chunks [off_begin, off_end) of the sponge of `count` leaves (reader, geometry and state all relative to the first of
+// them; merkle::hash_leaves_chunks_kernel); word i of leaf t is parked at state[i * state_stride + t]
 template <class Reader>
 static int hash_leaves_chunks(p2hot_ctx *ctx, hipStream_t stream, Reader rd, size_t W, const ForestGeom &g, size_t count,
-                              unsigned off_begin, unsigned off_end, u64 *state) {
+                              unsigned off_begin, unsigned off_end, u64 *state, size_t state_stride) {
     if (count == 0 || off_begin >= off_end) return P2HOT_OK;
     ProfScope ps(ctx, "hash_leaves", stream, true);
     P2HOT_LAUNCH((merkle::hash_leaves_chunks_kernel<Reader>), dim3(cdiv(count, 256)), dim3(256), 0, stream, rd, (unsigned)W,
-                 (size_t)0, count, g.h, g.dig, g.cap, off_begin, off_end, state);
+                 (size_t)0, count, g.h, g.dig, g.cap, off_begin, off_end, state, state_stride);
     P2_LAUNCH_CHECK(ctx);
     return P2HOT_OK;
 }

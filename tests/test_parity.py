@@ -462,9 +462,12 @@ def test_host_commit_in_blocks_hashes_as_columns_arrive(eng, ora, monkeypatch, W
         o = ora.commit_salted(np.stack(cols), salts[:S], rb, cap, True) if S else ora.commit(np.stack(cols), rb, cap, True)
         ptrs = (C.c_void_p * W)(*[c.ctypes.data for c in cols])
         sptrs = (C.c_void_p * max(S, 1))(*[salts[j].ctypes.data for j in range(max(S, 1))])
-        for chunked in ("1", "0"):
-            monkeypatch.setenv("P2HOT_HOST_CHUNKED_HASH", chunked)
-            e3 = e2 if chunked == "1" else Engine(0, lib=eng.lib, memory=eng.mem)
+        for chunked in ("1", "0", "grouped"):
+            monkeypatch.setenv("P2HOT_HOST_CHUNKED_HASH", "0" if chunked == "0" else "1")
+            # "grouped": the tail (last chunk + tree levels) per group of cap subtrees, each group's digest slice copied back
+            # behind its own levels (the default from 2^18 leaves per group)
+            monkeypatch.setenv("P2HOT_HOST_TAIL_MIN_LEAVES", "1" if chunked == "grouped" else str(1 << 40))
+            e3 = Engine(0, lib=eng.lib, memory=eng.mem)
             coeffs = np.zeros((W, n), dtype=np.uint64)
             leaves = np.zeros((N, W + S), dtype=np.uint64)
             digests = np.zeros((max(eng.num_digests(log_n + rb, cap), 1), 4), dtype=np.uint64)
@@ -476,18 +479,22 @@ def test_host_commit_in_blocks_hashes_as_columns_arrive(eng, ora, monkeypatch, W
             launches = e3.profile_results()["hash_leaves"]["launches"]
             e3.profile(False)
             # chunked: one sponge launch per block that completes at least one new 8-column chunk (+ the salts' launch)
+            nd_ = eng.num_digests(log_n + rb, cap)
+            groups = 1
+            while chunked == "grouped" and nd_ and groups < 8 and groups * 2 <= (1 << cap):
+                groups *= 2
             done, want = 0, 0
-            for c_end in list(range(block, W, block)) + [W] + ([W + S] if S else []):
-                end = c_end if c_end >= W + S else c_end // 8 * 8
+            for c_end in list(range(block, W, block)) + [W] + ([W + S] if S and groups == 1 else []):
+                end = c_end if (c_end >= W + S and groups == 1) else min(c_end, W + S - 1) // 8 * 8
                 want, done = want + (end > done), max(done, end)
-            assert launches == (want if chunked == "1" else 1), (chunked, launches, want)
+            want += groups if groups > 1 else 0
+            assert launches == (1 if chunked == "0" else want), (chunked, launches, want)
             assert (coeffs == o["coeffs"] % np.uint64(P)).all() and (leaves == o["leaves"]).all(), chunked
             assert (capv == o["cap"]).all(), chunked
             nd = eng.num_digests(log_n + rb, cap)
             assert nd == 0 or (digests[:nd] == o["digests"]).all(), chunked
             e3.lib.p2hot_batch_free(h)
-            if e3 is not e2:
-                e3.close()
+            e3.close()
     finally:
         e2.close()
 
