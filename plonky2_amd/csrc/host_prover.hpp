@@ -157,7 +157,10 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     // With more than one block the leaf sponge does not wait for the last column: after each block's LDE it absorbs the
     // 8-column chunks that are complete (its state parked in a scratch block between launches), so the hashing -- three
     // quarters of the commit -- runs beside the uploads still in flight instead of behind them.
-    const bool chunked = ctx->host_chunked_hash && nb > 1 && LW > 8 && LW <= 0xFFFFFFFFull;
+    // (not when the row-major leaf matrix goes back as well: that copy -- 9 GB at C3 -- is the long pole and can start as soon
+    // as every column is extended, so the transforms run first and the whole sponge runs beside the copy instead)
+    const bool leaves_first = ctx->host_leaves_first && leaves_out && LW && nb > 1;
+    const bool chunked = ctx->host_chunked_hash && nb > 1 && LW > 8 && LW <= 0xFFFFFFFFull && !leaves_first;
     PoolBuf d_state(ctx);
     ForestGeom geom{};
     unsigned hashed = 0;  // columns the sponge has absorbed (a multiple of 8 until the end)
@@ -174,6 +177,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         while (tail_groups < 8 && tail_groups * 2 <= ((size_t)1 << cap_height) && (N / (tail_groups * 2)) >= ctx->host_tail_min_leaves)
             tail_groups *= 2;
     std::vector<hipEvent_t> tail_ev;
+    [[maybe_unused]] hipEvent_t leaves_ev = nullptr;
     auto absorb_upto = [&](size_t cols_done, bool may_finish) -> int {  // cols_done leaf columns of d_lde are final
         const unsigned end = (cols_done >= LW && may_finish) ? (unsigned)LW : (unsigned)((cols_done < LW ? cols_done : LW - 1) / 8 * 8);
         if (end <= hashed) return P2HOT_OK;
@@ -225,6 +229,15 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             P2_TRY(h2d_columns(ctx, d_salt.u(), salt_cols, S, N * 8, W * n * 8, W * n * 8 + S * N * 8, ctx->stream));
             P2_TRY(launch_bitrev(ctx, d_salt.u(), d_lde.u() + W * N, S, N, N, log_N));
         }
+        if (leaves_first) {  // the row-major matrix before the sponge: its copy starts while the leaves are hashed
+            P2_TRY(p2hot_transpose_dev(ctx, d_lde.u(), N, LW, N, d_leaves.u()));
+#ifndef P2HOT_EMU
+            if (two_streams) {
+                P2_HIP(ctx, hipEventCreateWithFlags(&leaves_ev, hipEventDisableTiming));
+                P2_HIP(ctx, hipEventRecord(leaves_ev, ctx->stream));
+            }
+#endif
+        }
         if (chunked && tail_groups > 1) {
             const size_t cnt = N / tail_groups;
             for (size_t g = 0; g < tail_groups; ++g) {
@@ -249,7 +262,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         } else {
             P2_TRY(p2hot_merkle_dev(ctx, d_lde.u(), 0, N, LW, log_N, cap_height, 0, N, d_dig.u(), d_cap.u()));
         }
-        if (leaves_out && LW) P2_TRY(p2hot_transpose_dev(ctx, d_lde.u(), N, LW, N, d_leaves.u()));
+        if (leaves_out && LW && !leaves_first) P2_TRY(p2hot_transpose_dev(ctx, d_lde.u(), N, LW, N, d_leaves.u()));
         // coefficient blocks go back while the leaf sponge runs: queued behind the uploads on the copy stream, each
         // waiting for its block's transform only
         if (coeffs_out)
@@ -260,7 +273,16 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
 #endif
                 P2_HIP(ctx, hipMemcpyAsync(coeffs_out + c0 * n, d_work.u() + c0 * n, cnt * n * 8, hipMemcpyDeviceToHost, copy_stream));
             }
-        if (leaves_out && LW) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, LW * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (leaves_out && LW) {
+            hipStream_t ls = ctx->stream;
+#ifndef P2HOT_EMU
+            if (leaves_ev) {
+                P2_HIP(ctx, hipStreamWaitEvent(copy_stream, leaves_ev, 0));
+                ls = copy_stream;
+            }
+#endif
+            P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, LW * N * 8, hipMemcpyDeviceToHost, ls));
+        }
         if (digests_out && nd && tail_groups > 1) {  // the groups' digest slices, each behind its group's levels only
             const size_t cnt = N / tail_groups, sub_leaves = N >> cap_height, sub_words = 8 * (sub_leaves - 1);
             for (size_t g = 0; g < tail_groups; ++g) {
@@ -283,6 +305,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     for (hipEvent_t ev : up) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : done) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : tail_ev) (void)hipEventDestroy(ev);
+    if (leaves_ev) (void)hipEventDestroy(leaves_ev);
 #endif
     rc = sync_checked(ctx, rc, "commit");
     if (rc == P2HOT_OK && e1 != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "commit: %s", hipGetErrorString(e1));

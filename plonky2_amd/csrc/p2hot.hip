@@ -44,6 +44,7 @@ struct p2hot_ctx {
     std::set<const void *> lds_opted;  // kernels whose large dynamic LDS request was registered (lds_opt_in)
     size_t host_block_cols = 0;     // > 0: p2hot_commit uploads / transforms this many columns per block whatever the size (tests)
     size_t host_tail_min_leaves = (size_t)1 << 18;  // ... and the tail per group of cap subtrees of at least this many leaves (P2HOT_HOST_TAIL_MIN_LEAVES)
+    bool host_leaves_first = true;  // p2hot_commit with leaves_out: transforms, then the leaf matrix's copy beside the sponge (P2HOT_HOST_LEAVES_FIRST)
     bool host_chunked_hash = true;  // p2hot_commit: the leaf sponge absorbs each block's columns as soon as they are extended
     unsigned limb_tiles_log = 4;  // contiguous limb passes: a workgroup stages its tables once for 2^this tiles (P2HOT_LIMB_TILES_LOG)
     // second stream: the VALU-bound leaf sponge of coset block b runs beside the wait-bound NTT of block b+1
@@ -370,6 +371,7 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     if (const char *e = getenv("P2HOT_HORNER_2L_MIN")) ctx->horner_two_level_min = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HOST_BLOCK_COLS")) ctx->host_block_cols = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HOST_CHUNKED_HASH")) ctx->host_chunked_hash = atoi(e) != 0;
+    if (const char *e = getenv("P2HOT_HOST_LEAVES_FIRST")) ctx->host_leaves_first = atoi(e) != 0;
     if (const char *e = getenv("P2HOT_HOST_TAIL_MIN_LEAVES")) ctx->host_tail_min_leaves = (size_t)strtoull(e, nullptr, 10);
     // start values of p2hot_tune_quad / p2hot_tune_row for every context of the process, the ones p2hot_group_create makes
     // included (the kernel emulator's test tier lowers them: emulated cross-lane exchanges are slow)

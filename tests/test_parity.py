@@ -462,7 +462,9 @@ def test_host_commit_in_blocks_hashes_as_columns_arrive(eng, ora, monkeypatch, W
         o = ora.commit_salted(np.stack(cols), salts[:S], rb, cap, True) if S else ora.commit(np.stack(cols), rb, cap, True)
         ptrs = (C.c_void_p * W)(*[c.ctypes.data for c in cols])
         sptrs = (C.c_void_p * max(S, 1))(*[salts[j].ctypes.data for j in range(max(S, 1))])
-        for chunked in ("1", "0", "grouped"):
+        for chunked in ("1", "0", "grouped", "leaves"):
+            # "leaves": the row-major leaf matrix is asked for as well -- the transforms then run first and ONE sponge launch runs
+            # beside the matrix's copy (the copy is the long pole); the other variants leave the leaves behind the handle
             monkeypatch.setenv("P2HOT_HOST_CHUNKED_HASH", "0" if chunked == "0" else "1")
             # "grouped": the tail (last chunk + tree levels) per group of cap subtrees, each group's digest slice copied back
             # behind its own levels (the default from 2^18 leaves per group)
@@ -474,8 +476,13 @@ def test_host_commit_in_blocks_hashes_as_columns_arrive(eng, ora, monkeypatch, W
             capv = np.zeros((1 << cap, 4), dtype=np.uint64)
             h = C.c_void_p()
             e3.profile(True)
+            want_leaves = chunked in ("0", "leaves")
             e3.check(e3.lib.p2hot_commit_salted(e3.ctx, ptrs, W, log_n, rb, cap, 1, 0, sptrs if S else None, S, coeffs.ctypes.data,
-                                                leaves.ctypes.data, digests.ctypes.data, capv.ctypes.data, C.byref(h)))
+                                                leaves.ctypes.data if want_leaves else None, digests.ctypes.data, capv.ctypes.data,
+                                                C.byref(h)))
+            if not want_leaves:  # the rows from the handle instead
+                idx = np.arange(N, dtype=np.uint64)
+                e3.check(e3.lib.p2hot_batch_rows(h, idx.ctypes.data, N, leaves.ctypes.data))
             launches = e3.profile_results()["hash_leaves"]["launches"]
             e3.profile(False)
             # chunked: one sponge launch per block that completes at least one new 8-column chunk (+ the salts' launch)
@@ -488,7 +495,7 @@ def test_host_commit_in_blocks_hashes_as_columns_arrive(eng, ora, monkeypatch, W
                 end = c_end if (c_end >= W + S and groups == 1) else min(c_end, W + S - 1) // 8 * 8
                 want, done = want + (end > done), max(done, end)
             want += groups if groups > 1 else 0
-            assert launches == (1 if chunked == "0" else want), (chunked, launches, want)
+            assert launches == (1 if want_leaves else want), (chunked, launches, want)
             assert (coeffs == o["coeffs"] % np.uint64(P)).all() and (leaves == o["leaves"]).all(), chunked
             assert (capv == o["cap"]).all(), chunked
             nd = eng.num_digests(log_n + rb, cap)
