@@ -150,8 +150,11 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     const size_t nb = W ? blk0.size() - 1 : 0;
     std::vector<hipEvent_t> up, done;
     hipStream_t copy_stream = ctx->stream;
+    // a large leaf matrix going back to the host gets the copy stream even when the columns are one block (W < 32: the Zs and
+    // quotient commitments): its copy then runs beside the sponge as well
+    const bool big_leaves = ctx->host_leaves_first && leaves_out && LW && nb >= 1 && LW * N * 8 >= ((size_t)64 << 20);
 #ifndef P2HOT_EMU
-    const bool two_streams = nb > 1;
+    const bool two_streams = nb > 1 || big_leaves;
     if (two_streams) copy_stream = ctx->side;
 #endif
     // With more than one block the leaf sponge does not wait for the last column: after each block's LDE it absorbs the
@@ -159,7 +162,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     // quarters of the commit -- runs beside the uploads still in flight instead of behind them.
     // (not when the row-major leaf matrix goes back as well: that copy -- 9 GB at C3 -- is the long pole and can start as soon
     // as every column is extended, so the transforms run first and the whole sponge runs beside the copy instead)
-    const bool leaves_first = ctx->host_leaves_first && leaves_out && LW && nb > 1;
+    const bool leaves_first = ctx->host_leaves_first && leaves_out && LW && (nb > 1 || big_leaves);
     const bool chunked = ctx->host_chunked_hash && nb > 1 && LW > 8 && LW <= 0xFFFFFFFFull && !leaves_first;
     PoolBuf d_state(ctx);
     ForestGeom geom{};
