@@ -145,7 +145,7 @@ def host_pointer_lines(eng, out, reps):
     import ctypes as C
     rb, cap = 3, 4
 
-    def run(name, W, log_n, what, want_coeffs, want_digests, want_leaves, gname, reps=reps):
+    def run(name, W, log_n, what, want_coeffs, want_digests, want_leaves, gname, reps=reps, is_values=1):
         n, N = 1 << log_n, 1 << (log_n + rb)
         cols = [np.ascontiguousarray(c) for c in splitmix_columns_numpy(0, W, n)]
         ptrs = (C.c_void_p * W)(*[c.ctypes.data for c in cols])
@@ -159,8 +159,8 @@ def host_pointer_lines(eng, out, reps):
 
         def once():
             h = C.c_void_p()
-            eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, 0, ptr(coeffs), ptr(leaves), ptr(digests), capv.ctypes.data,
-                                           C.byref(h)))
+            eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, is_values, 0, ptr(coeffs), ptr(leaves), ptr(digests),
+                                           capv.ctypes.data, C.byref(h)))
             eng.lib.p2hot_batch_free(h)
         once()
         t0 = time.perf_counter()
@@ -178,6 +178,11 @@ def host_pointer_lines(eng, out, reps):
         True, False, False, "c3_wires")
     run("host_c3_wires_leaves_back", 135, 20, base + "coefficients + digests + cap + the 9.1 GB row-major leaf matrix out (P2HOT_LEAVES=host)",
         True, True, True, "c3_wires", reps=2)
+    # the other two commitments of a proof in the shim's default mode (leaves back): one column block each
+    run("host_c3_zs_leaves_back", 20, 20, "p2hot_commit (host pointers, pageable memory) C3 Zs + partial products: from_values W=20, 2^20 rows; "
+        "coefficients + digests + cap + the 1.3 GB leaf matrix out", True, True, True, "c3_zs_partial_products", reps=3)
+    run("host_c3_quotient_leaves_back", 16, 20, "p2hot_commit (host pointers, pageable memory) C3 quotient chunks: from_coeffs W=16, 2^20 rows; "
+        "digests + cap + the 1.1 GB leaf matrix out", False, True, True, "c3_quotient_chunks", reps=3, is_values=0)
     run("host_k12_wires", 135, 12, "p2hot_commit (host pointers) at recursion size: W=135, 2^12 rows, rate 1/8, cap 4; coefficients + digests + cap out",
         True, True, False, None, reps=20)
 
