@@ -506,6 +506,52 @@ def test_host_commit_in_blocks_hashes_as_columns_arrive(eng, ora, monkeypatch, W
         e2.close()
 
 
+def test_host_commit_in_blocks_random_shapes(eng, ora, monkeypatch):
+    """the chunked sponge, the grouped tail and the leaves-first order over random widths (around the sponge rate and its
+    multiples), block widths, salts, cap heights incl. all-cap trees: every output equals the oracle's"""
+    import ctypes as C
+    from plonky2_amd.engine import Engine
+    rng = np.random.default_rng(20260925)
+    monkeypatch.setenv("P2HOT_HOST_TAIL_MIN_LEAVES", "1")
+    for trial in range(12 if not is_gpu(eng) else 30):
+        W = int(rng.choice([9, 10, 15, 16, 17, 23, 24, 25, 31, 40, 41]))
+        block = int(rng.choice([1, 3, 7, 8, 9, 16]))
+        S = int(rng.choice([0, 0, 4]))
+        log_n, rb = int(rng.integers(2, 6)), int(rng.integers(0, 4))
+        cap = int(rng.integers(0, log_n + rb + 1))
+        want_leaves, want_dig = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        monkeypatch.setenv("P2HOT_HOST_BLOCK_COLS", str(block))
+        e2 = Engine(0, lib=eng.lib, memory=eng.mem)
+        try:
+            n, N = 1 << log_n, 1 << (log_n + rb)
+            cols = [rand_field(rng, n, noncanonical=True) for _ in range(W)]
+            salts = rand_field(rng, max(S, 1), N, noncanonical=True)
+            o = ora.commit_salted(np.stack(cols), salts[:S], rb, cap, True) if S else ora.commit(np.stack(cols), rb, cap, True)
+            ptrs = (C.c_void_p * W)(*[c.ctypes.data for c in cols])
+            sptrs = (C.c_void_p * max(S, 1))(*[salts[j].ctypes.data for j in range(max(S, 1))])
+            coeffs = np.zeros((W, n), dtype=np.uint64)
+            leaves = np.zeros((N, W + S), dtype=np.uint64)
+            nd = eng.num_digests(log_n + rb, cap)
+            digests = np.zeros((max(nd, 1), 4), dtype=np.uint64)
+            capv = np.zeros((1 << cap, 4), dtype=np.uint64)
+            h = C.c_void_p()
+            e2.check(e2.lib.p2hot_commit_salted(e2.ctx, ptrs, W, log_n, rb, cap, 1, 0, sptrs if S else None, S, coeffs.ctypes.data,
+                                                leaves.ctypes.data if want_leaves else None, digests.ctypes.data if want_dig else None,
+                                                capv.ctypes.data, C.byref(h)))
+            tag = (trial, W, block, S, log_n, rb, cap, want_leaves, want_dig)
+            assert (coeffs == o["coeffs"] % np.uint64(P)).all() and (capv == o["cap"]).all(), tag
+            if want_leaves:
+                assert (leaves == o["leaves"]).all(), tag
+            if want_dig and nd:
+                assert (digests[:nd] == o["digests"]).all(), tag
+            d2 = np.zeros((max(nd, 1), 4), dtype=np.uint64)
+            e2.check(e2.lib.p2hot_batch_digests(h, d2.ctypes.data))
+            assert nd == 0 or (d2[:nd] == o["digests"]).all(), tag
+            e2.lib.p2hot_batch_free(h)
+        finally:
+            e2.close()
+
+
 # ---------------------------------------------------------------- Challenger / FRI
 def test_challenger_vs_oracle(eng, ora):
     from plonky2_amd.iop.challenger import Challenger
