@@ -59,7 +59,8 @@ int p2hot_is_emulated(void);
 int p2hot_profile_enable(p2hot_ctx *ctx, int on);
 /* tuning knob for the NTT pass kernels (0 = LDS radix-2 layers, 3 = register radix 8 on carry-free 24-bit limbs
  * [default; 4096-element tiles, other tiles as 8], 8 = register radix 8 on 64-bit words, 4 = radix 16);
- * results are identical, only the speed differs */
+ * results are identical, only the speed differs.  ABI note: until round 2 `3` meant the 64-bit-word radix-8 kernels, which are
+ * `8` now; P2HOT_NTT_LIMB=0 in the environment is sticky (then `3` selects the word kernels as before). */
 int p2hot_tune_ntt(p2hot_ctx *ctx, int radix_bits);
 /* overlap the Poseidon leaf sponge of coset block b with the LDE of block b+1 on a second HIP stream (default 0: measured neutral on MI355X) */
 int p2hot_tune_overlap(p2hot_ctx *ctx, int on);
@@ -257,7 +258,8 @@ typedef struct p2hot_cols p2hot_cols;
  * coeffs_out [W][n], leaves_out [N][W], digests_out, cap_out: caller-allocated or NULL (anything not asked for is not
  * copied back: the leaf matrix is 9 GB at the C3 shape, and the query phase needs only a few dozen rows and paths).
  * handle_out (optional): the device-resident batch for p2hot_batch_rows / _paths / _coeffs, p2hot_eval_openings and
- * p2hot_prove_openings; free with p2hot_batch_free.  flags: P2HOT_KEEP_VALUES. */
+ * p2hot_prove_openings; free with p2hot_batch_free.  flags: P2HOT_KEEP_VALUES.
+ * W = 0 is P2HOT_EINVAL for every commit entry point (the reference panics on polynomials[0], fri/oracle.rs:90). */
 int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
                  unsigned cap_height, int is_values, unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out,
                  uint64_t *digests_out, uint64_t *cap_out, p2hot_batch **handle_out);
@@ -274,8 +276,9 @@ int p2hot_commit_salted(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, u
                         p2hot_batch **handle_out);
 /* the same on a device-resident column set (the output of p2hot_partial_products / p2hot_quotient_chunks, or an upload).
  * CONSUMES `cols` -- its block becomes the batch's coefficients or kept values, or is released -- on success and on failure,
- * except for the two failures detected before the set is touched: P2HOT_EBUSY, and P2HOT_EINVAL for a null set, a set of
- * another context or a borrowed view (p2hot_batch_values): then the caller still owns the handle. */
+ * except for the failures detected before the set is touched: P2HOT_EBUSY and EVERY P2HOT_EINVAL (a null set, a set of
+ * another context, a borrowed view (p2hot_batch_values), an empty set, a bad rate / cap height / flag word: all arguments are
+ * validated first).  After those two codes the caller still owns the handle. */
 int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate_bits, unsigned cap_height, int is_values,
                       unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out,
                       p2hot_batch **handle_out);

@@ -314,6 +314,7 @@ struct ShardPlan {
 static int shard_plan(p2hot_ctx *ctx, size_t W, unsigned log_n, unsigned rate_bits, unsigned cap_height, int world, ShardPlan *p,
                       bool by_columns = false) {
     P2_TRY(check_log(ctx, log_n + rate_bits, "commit_sharded"));
+    if (W == 0) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: no polynomials (the reference panics on polynomials[0], fri/oracle.rs:90)");
     if (world < 1 || (world & (world - 1))) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: world size %d is not a power of two", world);
     p->W = W;
     p->log_n = log_n;

@@ -111,7 +111,8 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     for (size_t j = 0; j < S; ++j)
         if (!salt_cols[j]) P2_FAIL(ctx, P2HOT_EINVAL, "commit: salt column %zu is null", j);
     P2_TRY(check_log(ctx, log_n + rate_bits, "commit"));
-    if (W > 0 && !cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit: null column table");
+    if (W == 0) P2_FAIL(ctx, P2HOT_EINVAL, "commit: no polynomials (the reference panics on polynomials[0], fri/oracle.rs:90)");
+    if (!cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit: null column table");
     if (flags & ~(unsigned)P2HOT_KEEP_VALUES) P2_FAIL(ctx, P2HOT_EINVAL, "commit: unknown flags %#x", flags);
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
     const unsigned log_N = log_n + rate_bits;
@@ -333,28 +334,28 @@ extern "C" int p2hot_commit_salted(p2hot_ctx *ctx, const uint64_t *const *cols, 
 
 // from_values / from_coeffs on a device-resident column set.  CONSUMES `cols` -- its block becomes the batch's coefficients
 // (from_coeffs) or its kept values (from_values with P2HOT_KEEP_VALUES), or is released -- on success and on every failure
-// EXCEPT the two that are detected before the set is touched: P2HOT_EBUSY (another call is running on the context) and
-// P2HOT_EINVAL for a null set, a set of another context or a borrowed view (p2hot_batch_values); then the caller still owns it.
+// EXCEPT P2HOT_EBUSY (another call is running on the context) and P2HOT_EINVAL (a null set, a set of another context, a borrowed
+// view, an empty set, a bad rate / cap height / flag word): every argument is validated before the set is touched, so those two
+// codes always mean "not consumed, the caller still owns the handle".
 extern "C" int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate_bits, unsigned cap_height, int is_values,
                                  unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out, uint64_t *digests_out,
                                  uint64_t *cap_out, p2hot_batch **handle_out) {
     P2_ENTER(ctx);
     if (handle_out) *handle_out = nullptr;
     if (!cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: null column set");
-    PoolBuf d_in(ctx);
+    // every argument is checked BEFORE the set is touched: any P2HOT_EINVAL (and P2HOT_EBUSY) means "not consumed"
+    if (cols->ctx != ctx || !cols->owned) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: the column set belongs to another context or is a borrowed view");
     const size_t W = cols->W;
     const unsigned log_n = cols->log_n;
-    {
-        const bool ok = cols->ctx == ctx && cols->owned;
-        if (ok) d_in.p = cols->d;
-        if (ok) delete cols;  // consumed; the block is now ours (a view or a foreign set is left alone)
-        if (!ok) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: the column set belongs to another context or is a borrowed view");
-    }
     P2_TRY(check_log(ctx, log_n + rate_bits, "commit_cols"));
+    if (W == 0) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: no polynomials (the reference panics on polynomials[0], fri/oracle.rs:90)");
     if (flags & ~(unsigned)P2HOT_KEEP_VALUES) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: unknown flags %#x", flags);
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
     const unsigned log_N = log_n + rate_bits;
     if (cap_height > log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: cap_height %u > log2(N) %u (merkle_tree.rs:195-200)", cap_height, log_N);
+    PoolBuf d_in(ctx);
+    d_in.p = cols->d;
+    delete cols;  // consumed from here on: the block is ours whatever happens below
     const size_t nd = p2hot_num_digests(log_N, cap_height), cap_words = (size_t)4 << cap_height;
     const bool keep_vals = is_values && handle_out && (flags & P2HOT_KEEP_VALUES);
     PoolBuf d_coef(ctx), d_lde(ctx), d_leaves(ctx), d_dig(ctx), d_cap(ctx);
@@ -405,7 +406,8 @@ extern "C" int p2hot_commit_many_dev(p2hot_ctx *ctx, uint64_t *d_cols, size_t M,
     if (!ctx) return P2HOT_EINVAL;
     DeviceGuard dev_guard_(ctx);
     P2_TRY(check_log(ctx, log_n + rate_bits, "commit_many"));
-    if (M == 0 || W == 0) return P2HOT_OK;
+    if (M == 0) return P2HOT_OK;
+    if (W == 0) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: no polynomials (the reference panics on polynomials[0], fri/oracle.rs:90)");
     if (M & (M - 1)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: the number of proofs (%zu) must be a power of two", M);
     unsigned lm = 0;
     while (((size_t)1 << lm) < M) ++lm;
@@ -435,7 +437,8 @@ extern "C" int p2hot_commit_many(p2hot_ctx *ctx, const uint64_t *const *cols, si
     if (handles_out)
         for (size_t m = 0; m < M; ++m) handles_out[m] = nullptr;
     P2_TRY(check_log(ctx, log_n + rate_bits, "commit_many"));
-    if (M == 0 || W == 0) return P2HOT_OK;
+    if (M == 0) return P2HOT_OK;
+    if (W == 0) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: no polynomials (the reference panics on polynomials[0], fri/oracle.rs:90)");
     if (M & (M - 1)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: the number of proofs (%zu) must be a power of two", M);
     if (!cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit_many: null column table");
     for (size_t i = 0; i < M * W; ++i)
@@ -611,9 +614,17 @@ extern "C" void p2hot_batch_free(p2hot_batch *b) {
 extern "C" int p2hot_ctx_trim(p2hot_ctx *ctx) {
     P2_ENTER(ctx);
     P2_HIP(ctx, stream_sync(ctx));
-    std::lock_guard<std::mutex> pool_lock_(ctx->pool_mu);
-    for (auto &blk : ctx->pool_free) (void)hipFree(blk.first);
-    ctx->pool_free.clear();
+    {
+        std::lock_guard<std::mutex> pool_lock_(ctx->pool_mu);
+        for (auto &blk : ctx->pool_free) (void)hipFree(blk.first);
+        ctx->pool_free.clear();
+    }
+    for (p2hot_ctx *h : ctx->helpers) {  // the sibling contexts of p2hot_prove_openings_many keep their own block caches
+        P2_HIP(ctx, stream_sync(h));
+        std::lock_guard<std::mutex> pool_lock_(h->pool_mu);
+        for (auto &blk : h->pool_free) (void)hipFree(blk.first);
+        h->pool_free.clear();
+    }
     return P2HOT_OK;
 }
 
@@ -790,8 +801,6 @@ static int helper_contexts(p2hot_ctx *ctx, size_t want) {
             if (h) p2hot_ctx_destroy(h);
             return rc;
         }
-        h->quad_threshold = ctx->quad_threshold;
-        h->row_threshold = ctx->row_threshold;
         p2hot_challenger *hc = nullptr;
         rc = p2hot_challenger_create(h, &hc);
         if (rc != P2HOT_OK) {
@@ -802,6 +811,18 @@ static int helper_contexts(p2hot_ctx *ctx, size_t want) {
         ctx->helpers.push_back(h);
         ctx->helper_streams.push_back(st);
         ctx->helper_challengers.push_back(hc);
+    }
+    // the parent's tuning knobs and profiling switch as they are NOW (p2hot_tune_* / p2hot_profile_enable may have been called
+    // since the helpers were made)
+    for (p2hot_ctx *h : ctx->helpers) {
+        h->quad_threshold = ctx->quad_threshold;
+        h->row_threshold = ctx->row_threshold;
+        h->use_regpass = ctx->use_regpass;
+        h->use_limb = ctx->use_limb;
+        h->ntt_radix_bits = ctx->ntt_radix_bits;
+        h->overlap = ctx->overlap;
+        h->horner_two_level_min = ctx->horner_two_level_min;
+        h->profiling = ctx->profiling;
     }
     return P2HOT_OK;
 }
@@ -858,6 +879,17 @@ extern "C" int p2hot_prove_openings_many(p2hot_ctx *ctx, size_t M, const p2hot_f
         for (auto &t : th) t.join();
     }
 #endif
+    if (ctx->profiling)  // the helpers' kernels belong to this call: their totals go to the parent's table
+        for (size_t k = 0; k < K; ++k) {
+            p2hot_ctx *h = ctx->helpers[k];
+            (void)p2hot_profile_json(h, 0);  // drains h's recorded events into h->prof_acc
+            for (auto &kv : h->prof_acc) {
+                auto &acc = ctx->prof_acc[kv.first];
+                acc.first += kv.second.first;
+                acc.second += kv.second.second;
+            }
+            h->prof_acc.clear();
+        }
     for (size_t k = 0; k < K; ++k)
         if (rcs[k] != P2HOT_OK) P2_FAIL(ctx, rcs[k], "prove_openings_many: %s", errs[k].c_str());
     return P2HOT_OK;

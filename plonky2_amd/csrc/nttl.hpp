@@ -346,10 +346,15 @@ __device__ __forceinline__ void round_sync() {
 #ifdef P2HOT_EMU
     __syncthreads();
 #else
-    if constexpr (WAVE_PRIVATE)
+    if constexpr (WAVE_PRIVATE) {
+        // the wave barrier alone is declared IntrNoMem: the wavefront-scope fences are what formally order this lane's LDS
+        // stores before the other lanes' LDS loads (no instruction is emitted for them; the LDS runs a wave's accesses in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-    else
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
         __syncthreads();
+    }
 #endif
 }
 

@@ -36,6 +36,7 @@ struct p2hot_ctx {
     u64 *local_fwd = nullptr, *local_inv = nullptr;  // [2^m + e] = w_{2^m}^(+-e), m <= TILE_LOG
     bool use_regpass = true;
     bool use_limb = true;  // 4096-element tiles run the carry-free limb passes (nttl.hpp); P2HOT_NTT_LIMB=0 selects the round-2 kernels
+    bool force_no_limb = false;  // P2HOT_NTT_LIMB=0 is sticky: a later p2hot_tune_ntt(ctx, 3) does not switch the limb passes back on
     struct LimbTables {
         nttl::W2 *tw_all = nullptr;
         u64 *ufac = nullptr;
@@ -68,6 +69,7 @@ struct p2hot_ctx {
     size_t pinned_cap = 0, pinned_used = 0;
     unsigned char *pinned_up = nullptr;  // upload staging: many short host columns -> one contiguous pinned block -> one copy
     size_t pinned_up_cap = 0;
+    bool pinned_up_busy = false;  // an asynchronous copy may still be reading the staging block (set by every staged upload)
     hipEvent_t stage_ev[2] = {nullptr, nullptr};  // one per half of the staging block when an upload takes several slices
     std::vector<DeferredCopy> deferred;
     bool in_host_call = false;       // set by the host-pointer entry points (they end in stream_sync)
@@ -226,7 +228,10 @@ static int h2d_columns(p2hot_ctx *ctx, void *d_dst, const uint64_t *const *cols,
     const size_t kMaxStage = (size_t)64 << 20;
     if (ctx->in_host_call && count > 1 && bytes <= ((size_t)1 << 20) && stage_total <= kMaxStage) {
         if (ctx->pinned_up_cap < stage_total) {
-            if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);  // idle: the previous call synchronised before returning
+            // growing the block: no copy staged earlier (this call or a previous one, either stream) may still be reading it
+            if (ctx->pinned_up && ctx->pinned_up_busy) (void)hipDeviceSynchronize();
+            ctx->pinned_up_busy = false;
+            if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);
             ctx->pinned_up = nullptr;
             ctx->pinned_up_cap = 0;
             const size_t want = std::max(stage_total, (size_t)8 << 20);
@@ -236,6 +241,7 @@ static int h2d_columns(p2hot_ctx *ctx, void *d_dst, const uint64_t *const *cols,
             unsigned char *slot = ctx->pinned_up + stage_off;
             for (size_t c = 0; c < count; ++c)
                 std::copy((const unsigned char *)cols[c], (const unsigned char *)cols[c] + bytes, slot + c * bytes);
+            ctx->pinned_up_busy = true;
             P2_HIP(ctx, hipMemcpyAsync(d_dst, slot, count * bytes, hipMemcpyHostToDevice, stream));
             return P2HOT_OK;
         }
@@ -247,6 +253,8 @@ static int h2d_columns(p2hot_ctx *ctx, void *d_dst, const uint64_t *const *cols,
     // (only where the per-copy overhead outweighs the copy itself: beyond ~128 KB a pageable copy moves faster than one core stages it)
     if (ctx->in_host_call && count > 1 && bytes <= ((size_t)128 << 10) && stage_off == 0 && stage_total == count * bytes) {
         if (ctx->pinned_up_cap < kMaxStage) {
+            if (ctx->pinned_up && ctx->pinned_up_busy) (void)hipDeviceSynchronize();
+            ctx->pinned_up_busy = false;
             if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);
             ctx->pinned_up = nullptr;
             ctx->pinned_up_cap = 0;
@@ -263,6 +271,7 @@ static int h2d_columns(p2hot_ctx *ctx, void *d_dst, const uint64_t *const *cols,
                 if (k >= 2) P2_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k & 1]));
                 for (size_t c = 0; c < cnt; ++c)
                     std::copy((const unsigned char *)cols[c0 + c], (const unsigned char *)cols[c0 + c] + bytes, slot + c * bytes);
+                ctx->pinned_up_busy = true;
                 P2_HIP(ctx, hipMemcpyAsync((unsigned char *)d_dst + c0 * bytes, slot, cnt * bytes, hipMemcpyHostToDevice, stream));
                 P2_HIP(ctx, hipEventRecord(ctx->stage_ev[k & 1], stream));
             }
@@ -365,7 +374,7 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
         if (b >= 6 && b <= 11) ctx->ntt_strided_bits = (unsigned)b;
     }
     if (const char *e = getenv("P2HOT_NTT_XCD_REMAP")) ctx->ntt_xcd_remap = atoi(e) != 0;
-    if (const char *e = getenv("P2HOT_NTT_LIMB")) ctx->use_limb = atoi(e) != 0;
+    if (const char *e = getenv("P2HOT_NTT_LIMB")) ctx->use_limb = atoi(e) != 0, ctx->force_no_limb = atoi(e) == 0;
     if (const char *e = getenv("P2HOT_LIMB_TILES_LOG")) ctx->limb_tiles_log = (unsigned)atoi(e);
     if (const char *e = getenv("P2HOT_NTT_ZLOOP_MIN")) ctx->zloop_min_groups = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HORNER_2L_MIN")) ctx->horner_two_level_min = (size_t)strtoull(e, nullptr, 10);
@@ -516,7 +525,8 @@ extern "C" int p2hot_tune_overlap(p2hot_ctx *ctx, int on) {
 extern "C" int p2hot_tune_ntt(p2hot_ctx *ctx, int radix_bits) {
     if (!ctx || (radix_bits != 0 && radix_bits != 3 && radix_bits != 4 && radix_bits != 8)) return P2HOT_EINVAL;
     ctx->use_regpass = radix_bits != 0;
-    ctx->use_limb = radix_bits == 3;  // 8: radix 8 on 64-bit words (the round-2 kernels), 3: radix 8 on 24-bit limbs
+    // 8: radix 8 on 64-bit words (the round-2 kernels), 3: radix 8 on 24-bit limbs -- unless the environment opted out of them
+    ctx->use_limb = radix_bits == 3 && !ctx->force_no_limb;
     if (radix_bits) ctx->ntt_radix_bits = radix_bits == 8 ? 3u : (unsigned)radix_bits;
     return P2HOT_OK;
 }
@@ -1152,6 +1162,7 @@ extern "C" int p2hot_commit_dev(p2hot_ctx *ctx, const uint64_t *d_cols, size_t c
     P2_TRY(check_log(ctx, log_n + rate_bits, "commit"));
     const size_t n = (size_t)1 << log_n;
     const unsigned log_N = log_n + rate_bits;
+    if (W == 0) P2_FAIL(ctx, P2HOT_EINVAL, "commit: no polynomials (the reference panics on polynomials[0], fri/oracle.rs:90)");
     if (W > 0 && (!d_cols || col_stride < n)) P2_FAIL(ctx, P2HOT_EINVAL, "commit: null columns or stride < n");
     if (W > 0 && !d_lde) P2_FAIL(ctx, P2HOT_EINVAL, "commit: d_lde is required");
     const u64 *coeff_src = d_cols;

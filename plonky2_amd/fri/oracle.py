@@ -177,8 +177,8 @@ class PolynomialBatch:
         rc = eng.lib.p2hot_commit_cols(eng.ctx, handle, rate_bits, cap_height, 1 if is_values else 0,
                                        _lib.KEEP_VALUES if (keep_values and is_values) else 0, None, None, None,
                                        cap.ctypes.data, C.byref(h))
-        if rc == _lib.EBUSY:
-            dc._h = handle  # ... except when the call never started (include/p2hot.h): the set is still ours
+        if rc in (_lib.EBUSY, _lib.EINVAL):
+            dc._h = handle  # ... except when the call never touched it (include/p2hot.h: both codes mean "not consumed")
         eng.check(rc)
         return cls(eng, h, W, log_n, rate_bits, cap_height, cap)
 

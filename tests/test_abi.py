@@ -7,6 +7,7 @@ import re
 import numpy as np
 import pytest
 
+from tests.conftest import P as P_
 from tests.conftest import ROOT
 
 
@@ -134,3 +135,44 @@ def test_one_host_call_at_a_time_per_context(emu):
     assert seen_busy, "the second caller was never refused while the commit was running"
     assert emu.lib.p2hot_ctx_trim(emu.ctx) == _lib.OK
     assert cap.any()
+
+
+def test_commit_without_polynomials_is_einval(eng):
+    """W = 0: the reference panics on polynomials[0] (fri/oracle.rs:90); every commit entry point returns P2HOT_EINVAL with a
+    message of its own (round-3 review: p2hot_commit returned P2HOT_OK and left a stale error text)"""
+    from plonky2_amd import _lib
+    cap = np.zeros((4, 4), dtype=np.uint64)
+    h = C.c_void_p()
+    rc = eng.lib.p2hot_commit(eng.ctx, None, 0, 4, 3, 2, 1, 0, None, None, None, cap.ctypes.data, C.byref(h))
+    assert rc == _lib.EINVAL and not h.value
+    assert b"no polynomials" in eng.lib.p2hot_last_error(eng.ctx)
+    rc = eng.lib.p2hot_commit_salted(eng.ctx, None, 0, 4, 3, 2, 1, 0, None, 0, None, None, None, cap.ctypes.data, None)
+    assert rc == _lib.EINVAL
+    rc = eng.lib.p2hot_commit_many(eng.ctx, None, 2, 0, 4, 3, 2, 1, None, None, None, None)
+    assert rc == _lib.EINVAL
+    assert eng.lib.p2hot_commit_many(eng.ctx, None, 0, 3, 4, 3, 2, 1, None, None, None, None) == _lib.OK  # no proofs: nothing to do
+    rc = eng.lib.p2hot_commit_dev(eng.ctx, None, 16, 0, 4, 3, 2, 1, 0, 128, None, 16, None, 128, None, None, None)
+    assert rc == _lib.EINVAL
+
+
+def test_commit_cols_einval_never_consumes_the_set(eng):
+    """every P2HOT_EINVAL of p2hot_commit_cols (bad rate / cap height / flags, a borrowed view) is raised
+    before the set is touched, so the caller still owns the handle -- and can commit it afterwards"""
+    from plonky2_amd import _lib
+    rng = np.random.default_rng(3)
+    W, log_n = 3, 5
+    cols = rng.integers(0, P_, size=(W, 1 << log_n), dtype=np.uint64)
+    ptrs = (C.c_void_p * W)(*[cols[c].ctypes.data for c in range(W)])
+    h = C.c_void_p()
+    assert eng.lib.p2hot_cols_upload(eng.ctx, ptrs, W, log_n, C.byref(h)) == _lib.OK
+    cap = np.zeros((4, 4), dtype=np.uint64)
+    out = C.c_void_p()
+    assert eng.lib.p2hot_commit_cols(eng.ctx, h, 3, 2, 1, 0xF0, None, None, None, cap.ctypes.data, C.byref(out)) == _lib.EINVAL  # flags
+    assert eng.lib.p2hot_commit_cols(eng.ctx, h, 3, 99, 1, 0, None, None, None, cap.ctypes.data, C.byref(out)) == _lib.EINVAL    # cap height
+    assert eng.lib.p2hot_commit_cols(eng.ctx, h, 60, 2, 1, 0, None, None, None, cap.ctypes.data, C.byref(out)) == _lib.EINVAL    # log N > 32
+    assert eng.lib.p2hot_cols_width(h) == W  # still alive, still ours
+    assert eng.lib.p2hot_commit_cols(eng.ctx, h, 3, 2, 1, 0, None, None, None, cap.ctypes.data, C.byref(out)) == _lib.OK
+    ref = np.zeros((4, 4), dtype=np.uint64)
+    assert eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, 3, 2, 1, 0, None, None, None, ref.ctypes.data, None) == _lib.OK
+    assert (cap == ref).all() and cap.any()
+    eng.lib.p2hot_batch_free(out)

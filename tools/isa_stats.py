@@ -13,7 +13,7 @@ CHEAP = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_x
 def kernel_body(lines, sub):
     start = None
     for i, l in enumerate(lines):
-        if l.startswith("_Z") and sub in l and l.rstrip().split(":")[0].endswith("E") and ":" in l:
+        if l.startswith("_Z") and ":" in l and sub in l.split(":")[0]:
             start = i
             break
     if start is None:
