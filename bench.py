@@ -76,18 +76,14 @@ def pmc_stale():
     return d.get("csrc_sha256_16") != csrc_hash()
 
 
-def ubench_cycles():
-    """{instruction: SIMD cycles per wave64 instruction at 2.4 GHz} from profiles/r03_ubench.txt (tools/ubench.hip on the
-    MI355X: 8 independent streams, 8 waves per SIMD, all 1024 SIMDs busy -- i.e. at the clock the chip sustains under that load)"""
-    out = {}
+def ubench_json():
+    """profiles/ubench.json (tools/ubench_pmc.sh + tools/ubench_summarize.py on the MI355X): per probe and per occupancy
+    (4 / 8 waves per SIMD) the TRUE shader cycles per wave64 instruction per SIMD (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs /
+    SQ_INSTS_VALU) and the clock the probe ran at"""
     try:
-        for line in open(os.path.join(ROOT, "profiles", "r03_ubench.txt")):
-            m = __import__("re").match(r"(.+?)\s+[\d.]+ ms\s+([\d.]+) cyc/inst/SIMD by wall", line)
-            if m:
-                out[m.group(1).strip()] = float(m.group(2))
+        return json.load(open(os.path.join(ROOT, "profiles", "ubench.json")))
     except Exception:
-        pass
-    return out
+        return None
 
 
 def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=45.0, golden_cap=None):
@@ -145,11 +141,13 @@ def host_pointer_lines(eng, out, reps):
     import ctypes as C
     rb, cap = 3, 4
 
-    def run(name, W, log_n, what, want_coeffs, want_digests, want_leaves, gname, reps=reps, is_values=1):
+    def run(name, W, log_n, what, want_coeffs, want_digests, want_leaves, gname, reps=reps, is_values=1, per_column=False):
         n, N = 1 << log_n, 1 << (log_n + rb)
         cols = [np.ascontiguousarray(c) for c in splitmix_columns_numpy(0, W, n)]
         ptrs = (C.c_void_p * W)(*[c.ctypes.data for c in cols])
         coeffs = np.zeros((W, n), dtype=np.uint64) if want_coeffs else None
+        # per_column: one destination per polynomial (what the Rust shim passes: W separate Vec<F>, P2HOT_COEFFS_PER_COLUMN)
+        table = (C.c_void_p * W)(*[coeffs[c].ctypes.data for c in range(W)]) if (per_column and want_coeffs) else None
         digests = np.zeros((eng.num_digests(log_n + rb, cap), 4), dtype=np.uint64) if want_digests else None
         leaves = np.zeros((N, W), dtype=np.uint64) if want_leaves else None   # touched here: page faults are not timed
         capv = np.zeros((1 << cap, 4), dtype=np.uint64)
@@ -159,7 +157,8 @@ def host_pointer_lines(eng, out, reps):
 
         def once():
             h = C.c_void_p()
-            eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, is_values, 0, ptr(coeffs), ptr(leaves), ptr(digests),
+            eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, is_values, 2 if table is not None else 0,
+                                           C.cast(table, C.c_void_p) if table is not None else ptr(coeffs), ptr(leaves), ptr(digests),
                                            capv.ctypes.data, C.byref(h)))
             eng.lib.p2hot_batch_free(h)
         once()
@@ -176,8 +175,9 @@ def host_pointer_lines(eng, out, reps):
         True, True, False, "c3_wires")
     run("host_c3_wires_digests_on_device", 135, 20, base + "coefficients + cap out; digests and leaves stay behind the handle (p2hot_batch_paths / _rows)",
         True, False, False, "c3_wires")
-    run("host_c3_wires_leaves_back", 135, 20, base + "coefficients + digests + cap + the 9.1 GB row-major leaf matrix out (P2HOT_LEAVES=host)",
-        True, True, True, "c3_wires", reps=2)
+    run("host_c3_wires_leaves_back", 135, 20, base + "coefficients (one destination per polynomial, P2HOT_COEFFS_PER_COLUMN) + digests + cap + the "
+        "9.1 GB row-major leaf matrix out: exactly the Rust shim's default call (P2HOT_LEAVES=host)",
+        True, True, True, "c3_wires", reps=2, per_column=True)
     # the other two commitments of a proof in the shim's default mode (leaves back): one column block each
     run("host_c3_zs_leaves_back", 20, 20, "p2hot_commit (host pointers, pageable memory) C3 Zs + partial products: from_values W=20, 2^20 rows; "
         "coefficients + digests + cap + the 1.3 GB leaf matrix out", True, True, True, "c3_zs_partial_products", reps=3)
@@ -185,6 +185,35 @@ def host_pointer_lines(eng, out, reps):
         "digests + cap + the 1.1 GB leaf matrix out", False, True, True, "c3_quotient_chunks", reps=3, is_values=0)
     run("host_k12_wires", 135, 12, "p2hot_commit (host pointers) at recursion size: W=135, 2^12 rows, rate 1/8, cap 4; coefficients + digests + cap out",
         True, True, False, None, reps=20)
+
+
+def host_tail_line(out):
+    """What the Rust shim (integration/p2hot.rs) does on the HOST after p2hot_commit_salted returns, priced on this box's cores
+    by tools/host_tail (C++: the same allocations and copies as the shim's Rust, one for one) next to the GPU call it follows.
+    Default mode (P2HOT_LEAVES=host): the leaf matrix stays the ONE flat buffer the library filled (MerkleTree::get serves
+    slices of it) and every polynomial is written into its own Vec by the library (P2HOT_COEFFS_PER_COLUMN): no host work
+    beyond W allocations.  `rows_*` are the alternatives: P2HOT_LEAVES=vec (Vec<Vec<F>> rebuilt in parallel) and the
+    round-3 shim's serial rebuild."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "host_tail")
+    try:
+        if not os.path.exists(exe):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tools", "host_tail.cpp")])
+        r = json.loads(subprocess.run([exe, "135", "20", "3", "21"], capture_output=True, text=True, timeout=300).stdout)
+    except Exception as ex:  # noqa: BLE001
+        out["host_tail_c3_wires"] = {"error": repr(ex)}
+        return
+    gpu = out.get("host_c3_wires_leaves_back", {}).get("ms")
+    rec = {"workload": "host work of the Rust shim after the C3 wires commit (W=135, 2^20 rows, leaves back), tools/host_tail.cpp on %d threads" % r["threads"],
+           "default_mode_ms": 0.0,
+           "default_mode": "P2HOT_LEAVES=host + P2HOT_COEFFS_PER_COLUMN: W Vec allocations, no copy (the flat leaf buffer moves into the DeviceTree)",
+           "split_coeffs_ms_if_flat": r["split_coeffs_ms"], "leaves_vec_parallel_ms": r["rows_parallel_ms"], "leaves_vec_serial_ms_round3": r["rows_serial_ms"],
+           "rows_sample": "2^%d of 2^23 rows, scaled" % r["rows_sample_log"], "gpu_call_ms": gpu}
+    if gpu:
+        rec["default_tail_over_gpu_call"] = 0.0
+        rec["vec_parallel_tail_over_gpu_call"] = r["rows_parallel_ms"] / gpu
+        rec["round3_serial_tail_over_gpu_call"] = r["rows_serial_ms"] / gpu
+    out["host_tail_c3_wires"] = rec
 
 
 def recursion_lines(eng, torch, out):
@@ -224,22 +253,30 @@ def recursion_lines(eng, torch, out):
     out["recursion_commit_many"] = rec
 
     # (a') M whole opening-proof pipelines per call: three p2hot_commit_many (wires 135, Zs 20 from values, quotient 16 from
-    # coefficients: host columns in, handles out) + p2hot_prove_openings_many (171 polynomials at zeta, 155 at g*zeta, arity 16 x2,
-    # PoW 16 bits, 28 queries) -- the FRI side of M recursion-size proofs; the proofs of one call are checked to be equal
+    # coefficients: host columns in, handles out) + p2hot_prove_openings_many (4 oracles, 255 polynomials at zeta, the 2 Z at g*zeta,
+    # arity 16 x2, PoW 16 bits, 28 queries) -- the FRI side of M recursion-size proofs; the proofs of one call are checked to be equal
     import ctypes as C
     from plonky2_amd import _lib
-    cols_w, cols_z, cols_q = (splitmix_columns_numpy(b0, w, n) for b0, w in ((0, 135), (1000, 20), (2000, 16)))
-    widths = (135, 20, 16)
+    cols_w, cols_z, cols_q, cols_cs = (splitmix_columns_numpy(b0, w, n) for b0, w in ((0, 135), (1000, 20), (2000, 16), (3000, 84)))
+    # get_fri_instance (plonk/circuit_data.rs:530-548): oracles [constants_sigmas 84, wires 135, Zs + partial products 20, quotient 16],
+    # all 255 polynomials at zeta, the 2 Z polynomials at g * zeta
+    widths = (84, 135, 20, 16)
     allp = [(oi, pi) for oi, w in enumerate(widths) for pi in range(w)]
-    nxt = [(oi, pi) for oi, w in enumerate(widths[:2]) for pi in range(w)]
+    nxt = [(2, pi) for pi in range(2)]
     arrs = [((C.c_uint32 * len(pl))(*[o for o, _ in pl]), (C.c_uint32 * len(pl))(*[q for _, q in pl])) for pl in (allp, nxt)]
     arity = (C.c_uint * 2)(4, 4)
     fp = _lib.FriParams(rb, cap, 16, 28, arity, 2, 0, 0, 0)
     rec = {"workload": "M x (3 p2hot_commit_many from host columns + p2hot_prove_openings_many) at 2^12 rows: the commitments and the "
-                       "opening proof of M recursion-size proofs per call (OpeningSet evaluation and the permutation argument excluded)", "M": {}}
+                       "opening proof of M recursion-size proofs per call on the reference's FRI instance (4 oracles, 255 polynomials at zeta, "
+                       "the 2 Z at g*zeta; the constants_sigmas commitments are the circuits', made once outside the timed calls; OpeningSet "
+                       "evaluation and the permutation argument excluded)", "M": {}}
     for M in (1, 8, 64):
+        cs_ptrs = (C.c_void_p * (M * 84))(*([cols_cs[e].ctypes.data for e in range(84)] * M))
+        cs_handles = (C.c_void_p * M)()
+        eng.check(eng.lib.p2hot_commit_many(eng.ctx, cs_ptrs, M, 84, log_n, rb, cap, 1, None, None, None, cs_handles))
+
         def pipeline():
-            handles = []
+            handles = [cs_handles]
             for cols_, w, isv in ((cols_w, 135, 1), (cols_z, 20, 1), (cols_q, 16, 0)):
                 ptrs = (C.c_void_p * (M * w))(*([cols_[e].ctypes.data for e in range(w)] * M))
                 hs = (C.c_void_p * M)()
@@ -251,8 +288,8 @@ def recursion_lines(eng, torch, out):
                 eng.check(eng.lib.p2hot_challenger_create(eng.ctx, C.byref(h)))
                 chs.append(h)
             lay = _lib.FriProofLayout()
-            h0 = (C.c_void_p * 3)(handles[0][0], handles[1][0], handles[2][0])
-            eng.check(eng.lib.p2hot_fri_proof_sizes(h0, 3, C.byref(fp), C.byref(lay)))
+            h0 = (C.c_void_p * 4)(handles[0][0], handles[1][0], handles[2][0], handles[3][0])
+            eng.check(eng.lib.p2hot_fri_proof_sizes(h0, 4, C.byref(fp), C.byref(lay)))
             bufs = [[np.zeros(max(1, getattr(lay, k + "_words")), dtype=np.uint64) for k in ("caps", "final_poly", "initial_leaves", "initial_paths", "step_evals", "step_paths")]
                     for _ in range(M)]
             proofs = (_lib.FriProof * M)()
@@ -262,16 +299,16 @@ def recursion_lines(eng, torch, out):
                 infos[k].oracle_index, infos[k].poly_index, infos[k].n_polys = oi, pi, len(oi)
             bp = (C.POINTER(_lib.FriBatchInfo) * M)(*([C.cast(infos, C.POINTER(_lib.FriBatchInfo))] * M))
             nb = (C.c_size_t * M)(*([2] * M))
-            hs_all = (C.c_void_p * (3 * M))(*[handles[o][m] for m in range(M) for o in range(3)])
+            hs_all = (C.c_void_p * (4 * M))(*[handles[o][m] for m in range(M) for o in range(4)])
             for m in range(M):
                 b = bufs[m]
                 proofs[m] = _lib.FriProof(b[0].ctypes.data, b[1].ctypes.data, 0, None, b[2].ctypes.data, b[3].ctypes.data, b[4].ctypes.data, b[5].ctypes.data)
             cp = (C.c_void_p * M)(*chs)
-            eng.check(eng.lib.p2hot_prove_openings_many(eng.ctx, M, bp, nb, hs_all, 3, cp, C.byref(fp), proofs))
+            eng.check(eng.lib.p2hot_prove_openings_many(eng.ctx, M, bp, nb, hs_all, 4, cp, C.byref(fp), proofs))
             same = all(int(proofs[m].pow_witness) == int(proofs[0].pow_witness) and (bufs[m][1] == bufs[0][1]).all() for m in range(M))
             for h in chs:
                 eng.lib.p2hot_challenger_destroy(h)
-            for hs in handles:
+            for hs in handles[1:]:
                 for m in range(M):
                     eng.lib.p2hot_batch_free(hs[m])
             return same
@@ -280,6 +317,8 @@ def recursion_lines(eng, torch, out):
         t0 = time.perf_counter()
         ok = all([pipeline() for _ in range(reps)])
         ms = (time.perf_counter() - t0) / reps * 1e3
+        for m in range(M):
+            eng.lib.p2hot_batch_free(cs_handles[m])
         rec["M"][str(M)] = {"ms": ms, "proofs_per_s": M / ms * 1e3, "proofs_equal": bool(ok)}
     out["recursion_pipeline_many"] = rec
 
@@ -287,8 +326,11 @@ def recursion_lines(eng, torch, out):
     cols = splitmix_columns_numpy(0, W, n)
     zs = splitmix_columns_numpy(1000, 20, n)
     quo = splitmix_columns_numpy(2000, 16, n)
+    cs = splitmix_columns_numpy(3000, 84, n)
 
     def one_proof(e):
+        if not hasattr(e, "_bench_cs"):  # the circuit's own commitment (CircuitBuilder::build): once per context, outside the proofs
+            e._bench_cs = PolynomialBatch.from_values(cs, rb, False, cap, engine=e)
         b_w = PolynomialBatch.from_values(cols, rb, False, cap, engine=e)
         b_z = PolynomialBatch.from_values(zs, rb, False, cap, engine=e)
         b_q = PolynomialBatch.from_coeffs(quo, rb, False, cap, engine=e)
@@ -296,14 +338,15 @@ def recursion_lines(eng, torch, out):
         ch.observe_elements(np.arange(8, dtype=np.uint64))
         zeta = ch.get_extension_challenge()
         gz = [(zeta[0] * 7) % P, zeta[1]]
-        oracles = [b_w, b_z, b_q]
-        eval_openings(oracles, [zeta, gz], e)
-        allp = [(oi, pi) for oi, w in enumerate((135, 20, 16)) for pi in range(w)]
-        nxt = [(oi, pi) for oi, w in enumerate((135, 20)) for pi in range(w)]
+        oracles = [e._bench_cs, b_w, b_z, b_q]
+        eval_openings(oracles, [zeta], e)   # OpeningSet::new (plonk/proof.rs:314-345): everything at zeta ...
+        eval_openings([b_z], [gz], e)       # ... and the Zs commitment at g * zeta
+        allp = [(oi, pi) for oi, w in enumerate((84, 135, 20, 16)) for pi in range(w)]
+        nxt = [(2, pi) for pi in range(2)]
         return prove_openings([FriBatchInfo(zeta, allp), FriBatchInfo(gz, nxt)], oracles, ch, rb, cap, [4, 4], 16, 28, engine=e)["pow_witness"]
 
-    rec = {"workload": "K host threads x (3 commits from host columns + OpeningSet + prove_openings) at 2^12 rows, one context and stream per "
-                       "thread, host-pointer entry points (PCIe included)", "K": {}}
+    rec = {"workload": "K host threads x (3 commits from host columns + OpeningSet + prove_openings on the reference's FRI instance: 4 oracles, 255 "
+                       "polynomials at zeta, the 2 Z at g*zeta) at 2^12 rows, one context and stream per thread, host-pointer entry points (PCIe included)", "K": {}}
     for K in (1, 4, 8):
         per, results, errs = 12, [None] * K, []
 
@@ -317,6 +360,7 @@ def recursion_lines(eng, torch, out):
                         results[k] = one_proof(e)
                     e.sync()
                     barrier.wait()
+                    del e._bench_cs
                     e.close()
             except Exception as ex:  # noqa: BLE001
                 errs.append(repr(ex))
@@ -379,6 +423,7 @@ def other_configs(eng, torch, reps=3):
     commit_line("c4_fibonacci_trace", 2, 22, 1, 4, True, eng.dev(fibonacci_trace(22)),
                 "C4: from_values W=2 (Fibonacci trace), 2^22 rows, rate 1/2, cap 4 (hash_or_noop leaves)")
     host_pointer_lines(eng, out, reps)
+    host_tail_line(out)
     recursion_lines(eng, torch, out)
     for name, log_n, rb in (("c3_fri_commit_phase", 20, 3), ("c4_fri_commit_phase", 22, 1)):
         planes = splitmix_columns_torch(torch, dev, 500, 2, 1 << log_n)
@@ -391,9 +436,17 @@ def other_configs(eng, torch, reps=3):
     def path_line(name, log_n, arity):
         n, rb, cap, nq = 1 << log_n, 3, 4, 28
         wires = splitmix_columns_torch(torch, dev, 0, 135, n)
-        sig = splitmix_columns_torch(torch, dev, 1000, 80, n)
+        cs = splitmix_columns_torch(torch, dev, 1000, 84, n)   # constants (4) + sigmas (80): prover_data, committed by build()
+        sig = cs[4:84]
         quo = splitmix_columns_torch(torch, dev, 2000, 16, n)
         k_is = [pow(14293326489335486720, j, P) for j in range(80)]
+        # CircuitBuilder::build's commitment (circuit_builder.rs:1182-1191): part of the circuit, not of a proof -> outside the timed path
+        b_cs = PolynomialBatch.from_values(cs, rb, False, cap, engine=eng)
+        # get_fri_instance (plonk/circuit_data.rs:530-548, :578-664): oracles [constants_sigmas, wires, Zs + partial products,
+        # quotient]; every polynomial (84 + 135 + 20 + 16 = 255) at zeta; the num_challenges = 2 Z polynomials at g * zeta
+        widths = (84, 135, 20, 16)
+        allp = [(oi, pi) for oi, W in enumerate(widths) for pi in range(W)]
+        nxt = [(2, pi) for pi in range(2)]
 
         def path():
             stage = {}
@@ -412,24 +465,26 @@ def other_configs(eng, torch, reps=3):
             lap("Zs + partial products commit (W=20, from_values)")
             b_q = PolynomialBatch.from_coeffs(quo, rb, False, cap, engine=eng)
             lap("quotient chunks commit (W=16, from_coeffs)")
-            oracles = [b_w, b_z, b_q]
+            oracles = [b_cs, b_w, b_z, b_q]
             ch = Challenger(eng)
             ch.observe_elements(np.arange(8, dtype=np.uint64))
             zeta = ch.get_extension_challenge()
             gz = [(zeta[0] * 7) % P, zeta[1]]
-            eval_openings(oracles, [zeta, gz], eng)
-            lap("OpeningSet (171 polynomials at 2 points)")
-            allp = [(oi, pi) for oi, W in enumerate((135, 20, 16)) for pi in range(W)]
-            nxt = [(oi, pi) for oi, W in enumerate((135, 20)) for pi in range(W)]
+            # OpeningSet::new (plonk/proof.rs:314-345): the four commitments at zeta, the Zs commitment again at g * zeta
+            eval_openings(oracles, [zeta], eng)
+            eval_openings([b_z], [gz], eng)
+            lap("OpeningSet (255 polynomials at zeta; the 20 of the Zs oracle at g*zeta, of which the proof keeps the 2 Z)")
             prove_openings([FriBatchInfo(zeta, allp), FriBatchInfo(gz, nxt)], oracles, ch, rb, cap, arity, 16, nq, engine=eng)
-            lap("prove_openings (final_poly, FRI commit, PoW 16 bits, 28 queries)")
+            lap("prove_openings (4 oracles: 255 polynomials at zeta + 2 at g*zeta; final_poly, FRI commit, PoW 16 bits, 28 queries x 4 initial trees)")
             return stage
 
         path()
         stages = [path() for _ in range(reps)]
         mean = {k: sum(s_[k] for s_ in stages) / reps for k in stages[0]}
-        out[name] = {"workload": "every SURVEY section-8 stage of one 2^%d-gate standard_recursion_config proof, back to back "
-                                 "(gate evaluation / witness generation excluded: out of scope)" % log_n,
+        out[name] = {"workload": "the SURVEY section-8 stages of one 2^%d-gate standard_recursion_config proof back to back, on the reference's own "
+                                 "FRI instance (get_fri_instance, plonk/circuit_data.rs:530-548: 4 oracles, 255 polynomials at zeta, the 2 Z at g*zeta); "
+                                 "the constants_sigmas commitment (W=84) belongs to CircuitBuilder::build and is made outside the timed path; "
+                                 "gate evaluation / witness generation excluded (out of scope)" % log_n,
                      "ms": sum(mean.values()), "stage_ms": {k: round(v, 3) for k, v in mean.items()}}
 
     path_line("per_proof_path_k20", 20, [4, 4, 4, 4])
@@ -486,21 +541,59 @@ def other_configs(eng, torch, reps=3):
 
 
 def valu_line(e, launches_per_step, h):
-    """issue-rate view of the dominant kernel: SQ_INSTS_VALU (committed PMC pass) over the live launch time, priced against
-    the rate tools/ubench.hip measured for the instruction class the kernel is made of (profiles/r03_ubench.txt)"""
-    if not e or not e.get("sq_insts_valu_per_launch"):
+    """Issue-rate view of the dominant kernel, everything in shader CYCLES (no assumed clock):
+      achieved   cycles per wave64 VALU instruction per SIMD of the kernel = GRBM_GUI_ACTIVE / 8 * 1024 / SQ_INSTS_VALU
+                 (committed PMC pass, profiles/pmc_traffic.json)
+      ceiling    the same quantity for the kernel's OWN instruction mix issued as dependency-free streams
+                 (tools/ubench.hip `mix hash_leaves`: 59 % multiply-adds, 25 % carry adds / subtracts, 6 % selects, 10 % moves and
+                 plain adds -- the static histogram of the kernel's loops, tools/isa_stats.py), measured the same way; the better of
+                 4 and 8 resident waves per SIMD (the kernel runs 4)
+      frac       ceiling / achieved: 1 = the SIMDs issue this mix as fast as they can issue it at all; the remainder is waits.
+    `classes` prices the single instruction classes the same way (why the NTT passes' cheap 32-bit adds pay)."""
+    if not e or not e.get("sq_insts_valu_per_launch") or not e.get("clock_ghz") or not e.get("ms_per_launch_under_pmc"):
         return None
-    ub = ubench_cycles()
-    vop3 = ub.get("v_mad_u64_u32", 4.66)   # carry / 64-bit / multiply-add class: what the Poseidon kernels issue
-    vop2 = ub.get("v_add_u32", 3.16)       # plain 32-bit VOP2
+    ub = ubench_json()
     n = e["sq_insts_valu_per_launch"] / launches_per_step
-    ach = n / (h["ms_per_launch"] * 1e-3) / 1e9
-    peak = 1024 * 2.4 / vop3
-    return {"kernel": "hash_leaves", "insts_per_launch": n, "unit": "Gwave-inst/s", "achieved": ach, "peak": peak, "frac": ach / peak,
-            "peak_vop2": 1024 * 2.4 / vop2, "clock_ghz_under_pmc": e.get("clock_ghz"),
-            "note": "peak = 1024 SIMDs x 2.4 GHz / %.2f cycles: the measured rate of a saturating stream of v_mad_u64_u32 "
-                    "(profiles/r03_ubench.txt; carry, 64-bit and VOP3 instructions measure the same, a plain 32-bit VOP2 %.2f); "
-                    "frac ~ 1 means the SIMDs cannot issue this instruction mix faster; SQ_INSTS_VALU from profiles/pmc_traffic.json" % (vop3, vop2)}
+    clock = e["clock_ghz"]
+    cyc = e["ms_per_launch_under_pmc"] * 1e-3 * clock * 1e9 * 1024 / e["sq_insts_valu_per_launch"]
+    out = {"kernel": "hash_leaves", "bound": "valu-issue", "wave_insts_per_launch": n, "clock_ghz_under_pmc": clock,
+           "cycles_per_inst": cyc, "live_Gwave_inst_per_s": n / (h["ms_per_launch"] * 1e-3) / 1e9,
+           "valu_busy_frac_pmc": e.get("valu_busy_frac"),
+           "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE, kernel duration under rocprofv3 --pmc)"}
+    if ub:
+        occ = ub.get("occupancy", {})
+        probes = {w: o["probes"].get("mix hash_leaves", {}) for w, o in occ.items()}
+        best = min((p_["cyc_per_inst"], w) for w, p_ in probes.items() if p_.get("cyc_per_inst")) if any(p_.get("cyc_per_inst") for p_ in probes.values()) else None
+        if best:
+            out.update({"ceiling_cycles_per_inst": best[0], "ceiling_probe": "tools/ubench.hip `mix hash_leaves` at %s waves per SIMD, %.2f GHz"
+                        % (best[1][1:], probes[best[1]]["clock_ghz"]), "frac": best[0] / cyc,
+                        "ceiling_by_occupancy": {w: round(p_["cyc_per_inst"], 3) for w, p_ in probes.items() if p_.get("cyc_per_inst")},
+                        "peak_Gwave_inst_per_s": 1024 * clock / best[0], "achieved_Gwave_inst_per_s": 1024 * clock / cyc})
+        out["classes_cycles_per_inst"] = {w: {c: round(v["cyc_per_inst_median"], 2) for c, v in o.get("classes", {}).items()} for w, o in occ.items()}
+        out["ubench_source"] = "profiles/ubench.json (tools/ubench_pmc.sh: every probe under rocprofv3 --pmc, true cycles)"
+    return out
+
+
+def roofline_line(vl, hbm_achieved, hash_bytes, perms, h, launches_per_step, e):
+    """The dominant kernel (the Poseidon leaf sponge) against the resource that bounds it.  It is integer-VALU-issue bound
+    (PMC traffic = 1.000 x its algorithmic bytes, 2-3 % of HBM peak), so `bound` is "valu": achieved / peak are wave64 VALU
+    instructions per second at the clock the kernel ran at (valu_line), and the HBM view the contract names is the
+    secondary figure under `hbm`."""
+    hbm = {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": hash_bytes}
+    common = {"kernel": "hash_leaves_kernel<ColMajorReader> (Poseidon leaf sponge)",
+              "traffic": e["hbm_bytes_per_launch"] / launches_per_step if e else None, "traffic_stale": pmc_stale(),
+              "launches_per_step": launches_per_step,
+              "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                "traffic_stale = the kernel sources changed since they were collected)",
+              **({"overlap": "launched on a second stream beside the next coset block's LDE; durations are wall "
+                             "time while sharing the GPU"} if launches_per_step > 1 else {}),
+              "note": "integer-VALU-issue bound (%.3g permutations per launch, %.2f Gperm/s, 13.2 k VALU instructions each); "
+                      "algorithmic bytes per launch = 8*W*rows + 32*rows = %d" % (perms, perms / (h["ms_per_launch"] * 1e-3) / 1e9, hash_bytes)}
+    if vl and vl.get("frac"):
+        return {**common, "bound": "valu", "achieved": vl["achieved_Gwave_inst_per_s"], "peak": vl["peak_Gwave_inst_per_s"],
+                "unit": "Gwave-inst/s", "frac": vl["frac"], "hbm": hbm}
+    return {**common, **hbm}  # no committed counters for this shape: the HBM view alone
 
 
 def ntt_roofline(kern, W, n_local, rows_local, steps, entry):
@@ -614,9 +707,15 @@ def main():
         except Exception as ex:  # noqa: BLE001
             raise SystemExit("bench preflight: the 1 MB all-gather through the %s transport failed on rank %d: %s" % (job.comm.transport, rank, ex))
         preflight["selftest_ms"] = (time.perf_counter() - t_pf) * 1e3
+        preflight["exchange"] = job.comm.exchange  # "allgather" / "broadcast": what the selftest's micro-timing of both kept
 
-    def step():
+    # the cap of EVERY timed step is kept (512 bytes each, an asynchronous device copy) and compared after the timed region
+    cap_log = eng.mem.zeros(max(args.steps, 1), (1 << cap) * 4)
+
+    def step(i=None):
         job.run(cols)
+        if i is not None:
+            cap_log[i].copy_(job.cap.reshape(-1))
 
     for _ in range(args.warmup):
         step()
@@ -626,8 +725,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -635,16 +734,18 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_results(reset=True)
     eng.profile(False)
-    # what was timed is checked: the cap of the last timed step against the oracle's golden cap of the same synthetic
+    # what was timed is checked: the cap of EVERY timed step against the oracle's golden cap of the same synthetic
     # columns (tests/golden/commit_caps.json: the headline shape and the 2 / 4 / 8-GPU weak-scaling shapes, C5 at 8)
     gname = {(135, 16, 3, 4): "c2_wires", (135, 20, 3, 4): "c3_wires", (135, 21, 3, 4): "scale2_wires", (135, 22, 3, 4): "scale4_wires",
              (135, 23, 3, 4): "c5_wires"}.get((W, log_n, rb, cap))
     g = golden(gname) if gname else None
     cap_checked = None
     if g is not None:
-        cap_checked = eng.host(job.cap).tolist() == g["cap"]
-        if not cap_checked:
-            raise SystemExit("bench: the Merkle cap of the timed commit differs from the oracle's golden cap")
+        caps_host = eng.host(cap_log).reshape(args.steps, 1 << cap, 4).tolist()
+        bad = [i for i, c in enumerate(caps_host) if c != g["cap"]]
+        cap_checked = not bad and args.steps > 0
+        if bad:
+            raise SystemExit("bench: the Merkle cap of timed step(s) %s differs from the oracle's golden cap" % bad[:8])
     rank_rows = None
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.mem.device if backend == "nccl" else "cpu")
@@ -679,6 +780,7 @@ def main():
         hash_bytes = 8 * W * rows_per_launch + 32 * rows_per_launch
         achieved = hash_bytes / (h["ms_per_launch"] * 1e-3) / 1e9
         perms = rows_per_launch * ((W + 7) // 8)
+        vl = valu_line(pmc_entry(W, log_n, rb, cap, world, "hash_leaves_kernel", "ColMajorReader"), launches_per_step, h)
         out = {
             "metric": "LDE+Poseidon-commit GFE/s", "value": fe / (dt / args.steps) / 1e9, "unit": "GFE/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -688,28 +790,20 @@ def main():
                                    "PoseidonGoldilocksConfig (%s)"
                                    % (W, log_n, 1 << rb, log_n + rb, cap, "--strong: the same total size at every --gpus" if args.strong else
                                       "C3 wires commit at --gpus 1; +1 bit of rows per doubling of GPUs"),
-                       "transport": None if world == 1 else {"rccl": "RCCL inside libp2hot (ncclBroadcast groups on the library's communication stream)",
+                       "exchange": None if world == 1 else job.comm.exchange,
+                       "transport": None if world == 1 else {"rccl": "RCCL inside libp2hot on the library's communication stream: %s, chosen by the preflight's micro-timing of both forms (P2HOT_EXCHANGE pins one)"
+                                                                    % ("ncclAllGather (pipelined column chunks through a chunk-major staging block)" if job.comm.exchange == "allgather" else "one grouped ncclBroadcast per slice"),
                                                                     "torch": "torch.distributed all_gather on device buffers (fallback: librccl could not be bound)",
                                                                     "gloo": "gloo through host staging (ranks sharing a GPU: a functional run, not a scaling number)"}.get(job.comm.transport, job.comm.transport),
                        "sharding": "none" if world == 1 else "LDE cosets over %d ranks; iNTT column-sharded, coefficients all-gathered in "
                                    "async column chunks overlapped with the NTTs; RCCL all-gather of %s" % (world, "digests + cap" if gather_digests else "the cap (digests stay with the row owner)")},
-            "roofline": {"kernel": "hash_leaves_kernel<ColMajorReader> (Poseidon leaf sponge)", "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (lambda e: e["hbm_bytes_per_launch"] / launches_per_step if e else None)(
-                             pmc_entry(W, log_n, rb, cap, world, "hash_leaves_kernel", "ColMajorReader")),
-                         "traffic_stale": pmc_stale(),
-                         "launches_per_step": launches_per_step,
-                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
-                                           "traffic_stale = the kernel sources changed since they were collected)",
-                         **({"overlap": "launched on a second stream beside the next coset block's LDE; durations are wall "
-                                        "time while sharing the GPU"} if launches_per_step > 1 else {}),
-                         "note": "integer-VALU bound by nature (%.3g permutations per launch, %.1f Gperm/s); "
-                                 "algorithmic bytes per launch = 8*W*rows + 32*rows = %d"
-                                 % (perms, perms / (h["ms_per_launch"] * 1e-3) / 1e9, hash_bytes)},
-            "valu": valu_line(pmc_entry(W, log_n, rb, cap, world, "hash_leaves_kernel", "ColMajorReader"), launches_per_step, h),
+            "roofline": roofline_line(vl, achieved, hash_bytes, perms, h, launches_per_step,
+                                      pmc_entry(W, log_n, rb, cap, world, "hash_leaves_kernel", "ColMajorReader")),
+            "valu": vl,
             "roofline_ntt": ntt_roofline(kern, W, n if world == 1 else n // world, rows_local, args.steps,
                                          lambda *needles: pmc_entry(W, log_n, rb, cap, world, *needles)),
             "cap_checked": cap_checked,
+            "caps_checked": args.steps if cap_checked else 0,
             **({"ranks": rank_rows} if rank_rows else {}),
             "kernels": kern,
             "algorithmic_bytes_per_step": ab,

@@ -249,6 +249,10 @@ int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bit
 #define P2HOT_EBUSY 5        /* another host-pointer call is running on this context */
 #define P2HOT_ECOMM 6        /* collective (RCCL / caller-supplied transport) failure in the multi-GPU mode */
 #define P2HOT_KEEP_VALUES 1u /* from_values: keep the input values on the device (p2hot_batch_values) */
+/* p2hot_commit / _salted / _cols: `coeffs_out` is a TABLE of W host pointers (cast from `uint64_t *const *`), polynomial c's
+ * n coefficients go to table[c] -- the caller's `polynomials: Vec<PolynomialCoeffs<F>>` (fri/oracle.rs:32) is W separate
+ * vectors, and with this flag each is filled in place instead of being split out of one flat block afterwards */
+#define P2HOT_COEFFS_PER_COLUMN 2u
 
 typedef struct p2hot_batch p2hot_batch;
 typedef struct p2hot_cols p2hot_cols;
@@ -258,7 +262,7 @@ typedef struct p2hot_cols p2hot_cols;
  * coeffs_out [W][n], leaves_out [N][W], digests_out, cap_out: caller-allocated or NULL (anything not asked for is not
  * copied back: the leaf matrix is 9 GB at the C3 shape, and the query phase needs only a few dozen rows and paths).
  * handle_out (optional): the device-resident batch for p2hot_batch_rows / _paths / _coeffs, p2hot_eval_openings and
- * p2hot_prove_openings; free with p2hot_batch_free.  flags: P2HOT_KEEP_VALUES.
+ * p2hot_prove_openings; free with p2hot_batch_free.  flags: P2HOT_KEEP_VALUES, P2HOT_COEFFS_PER_COLUMN.
  * W = 0 is P2HOT_EINVAL for every commit entry point (the reference panics on polynomials[0], fri/oracle.rs:90). */
 int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
                  unsigned cap_height, int is_values, unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out,
@@ -439,6 +443,11 @@ int p2hot_comm_world(const p2hot_comm *comm);
 /* preflight (collective: every rank calls it): a `bytes`-sized pattern slice per rank is all-gathered the way the commit
  * exchanges coefficients and caps, and every rank checks every slice; P2HOT_ECOMM with a named cause on failure */
 int p2hot_comm_selftest(p2hot_comm *comm, size_t bytes);
+/* How equal, contiguous slices (whole-rank coefficient slices, cap, digest slices; the pipelined column chunks through a
+ * chunk-major staging block) travel on an RCCL transport: 0 = one grouped ncclBroadcast per slice, 1 = ncclAllGather.  On an
+ * RCCL communicator p2hot_comm_selftest checks and times both and keeps the faster (rank 0's verdict, broadcast to all);
+ * p2hot_group_create does the same over its ranks; P2HOT_EXCHANGE=broadcast|allgather pins one.  -1 for a null handle. */
+int p2hot_comm_exchange_mode(const p2hot_comm *comm);
 /* columns [first, first + count) of W are the ones rank `rank` of `world` transforms in the iNTT stage */
 int p2hot_shard_columns(size_t W, int world, int rank, size_t *first, size_t *count);
 /* from_values / from_coeffs (fri/oracle.rs:57-112) of this rank's share, DEVICE pointers, asynchronous:
@@ -461,6 +470,7 @@ void p2hot_group_destroy(p2hot_group *group);
 int p2hot_group_size(const p2hot_group *group);
 p2hot_ctx *p2hot_group_ctx(p2hot_group *group, int i);
 int p2hot_group_uses_rccl(const p2hot_group *group);
+int p2hot_group_exchange_mode(const p2hot_group *group); /* see p2hot_comm_exchange_mode */
 const char *p2hot_group_last_error(const p2hot_group *group);
 /* from_values / from_coeffs over every GPU of the group, HOST pointers (the multi-GPU p2hot_commit): each GPU is sent
  * only the columns it transforms; coeffs_out / leaves_out / digests_out / cap_out (any may be NULL) are assembled from

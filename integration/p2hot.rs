@@ -15,10 +15,14 @@
 //! Environment:
 //!   P2HOT_LIB_DIR   directory of libp2hot.so (build.rs adds it to the link search path)
 //!   P2HOT_DEVICE    GPU index of the single-GPU context (default 0)
-//!   P2HOT_LEAVES    "host" (default): the leaf matrix of every commitment is copied back, so code that reads
-//!                   `merkle_tree.leaves` directly (the CPU quotient evaluation through `get_lde_values`, wire
-//!                   formats) works unchanged; "device": `leaves` stays empty, rows and Merkle paths are fetched from
-//!                   the GPU on demand (`MerkleTree::get` / `::prove`) -- 9 GB less PCIe traffic per wires commit.
+//!   P2HOT_LEAVES    "host" (default): the leaf matrix of every commitment is copied back ONCE, as one flat row-major
+//!                   buffer owned by the tree's `DeviceTree`; `merkle_tree.leaves` stays EMPTY and `MerkleTree::get` (which
+//!                   `get_lde_values`, the CPU quotient evaluation and the serializer go through) returns
+//!                   `&flat[i * w..(i + 1) * w]` -- no per-row allocation, no second copy (the round-3 shim rebuilt
+//!                   `Vec<Vec<F>>` serially: 8.4 M allocations + 9 GB per wires commitment at 2^20 gates);
+//!                   "vec": additionally materialises `merkle_tree.leaves: Vec<Vec<F>>` (in parallel, `par_chunks_exact`)
+//!                   for code that indexes the field directly; "device": nothing comes back, rows and Merkle paths are
+//!                   fetched from the GPU on demand (`MerkleTree::get` / `::prove`) -- 9 GB less PCIe traffic per wires commit.
 //!
 //!   P2HOT_DISABLE   "1": every call takes the unchanged CPU body (the same switch as `set_enabled(false)`)
 //!
@@ -39,6 +43,8 @@ use core::ffi::{c_char, c_int, c_uint, c_void};
 use core::sync::atomic::{AtomicBool, Ordering};
 use std::collections::HashMap;
 use std::sync::{Mutex, OnceLock};
+
+use plonky2_maybe_rayon::*;
 
 use crate::field::extension::{Extendable, FieldExtension};
 use crate::field::goldilocks_field::GoldilocksField;
@@ -154,6 +160,7 @@ pub type P2hotAllgatherFn = Option<
 
 pub const P2HOT_OK: c_int = 0;
 pub const P2HOT_KEEP_VALUES: c_uint = 1;
+pub const P2HOT_COEFFS_PER_COLUMN: c_uint = 2;
 
 #[link(name = "p2hot")]
 extern "C" {
@@ -303,6 +310,7 @@ extern "C" {
     pub fn p2hot_comm_rank(comm: *const P2hotComm) -> c_int;
     pub fn p2hot_comm_world(comm: *const P2hotComm) -> c_int;
     pub fn p2hot_comm_selftest(comm: *mut P2hotComm, bytes: usize) -> c_int;
+    pub fn p2hot_comm_exchange_mode(comm: *const P2hotComm) -> c_int;
     pub fn p2hot_shard_columns(W: usize, world: c_int, rank: c_int, first: *mut usize, count: *mut usize) -> c_int;
     pub fn p2hot_commit_sharded_dev(
         ctx: *mut P2hotCtx, comm: *mut P2hotComm, d_cols_local: *const u64, col_stride: usize, W: usize, log_n: c_uint, rate_bits: c_uint,
@@ -314,6 +322,7 @@ extern "C" {
     pub fn p2hot_group_size(group: *const P2hotGroup) -> c_int;
     pub fn p2hot_group_ctx(group: *mut P2hotGroup, i: c_int) -> *mut P2hotCtx;
     pub fn p2hot_group_uses_rccl(group: *const P2hotGroup) -> c_int;
+    pub fn p2hot_group_exchange_mode(group: *const P2hotGroup) -> c_int;
     pub fn p2hot_group_last_error(group: *const P2hotGroup) -> *const c_char;
     pub fn p2hot_group_commit(
         group: *mut P2hotGroup, cols: *const *const u64, W: usize, log_n: c_uint, rate_bits: c_uint, cap_height: c_uint, is_values: c_int,
@@ -387,6 +396,11 @@ fn leaves_on_device() -> bool {
     matches!(std::env::var("P2HOT_LEAVES").as_deref(), Ok("device"))
 }
 
+/// P2HOT_LEAVES=vec: also fill `merkle_tree.leaves` (for code that indexes the field instead of calling `get`)
+fn leaves_as_vecs() -> bool {
+    matches!(std::env::var("P2HOT_LEAVES").as_deref(), Ok("vec"))
+}
+
 static ENABLED: AtomicBool = AtomicBool::new(true);
 
 /// `false` sends every call down the unchanged CPU bodies (the bit-exact harness proves the same circuit both ways in
@@ -456,8 +470,12 @@ impl<T> Out<T> {
 pub struct DeviceTree<F: RichField> {
     batch: *mut P2hotBatch,
     width: usize,
+    num_leaves: usize,
     num_layers: usize,
-    /// rows fetched so far: `get` hands out `&[F]`, so fetched rows are kept (never moved) for the tree's lifetime
+    /// P2HOT_LEAVES=host (default): the whole leaf matrix, row-major [num_leaves][width], exactly the buffer the library
+    /// filled (`leaves_out`) -- ONE allocation; empty when the matrix stayed on the GPU
+    flat: Vec<F>,
+    /// rows fetched so far in the device mode: `get` hands out `&[F]`, so fetched rows are kept (never moved) for the tree's lifetime
     rows: Mutex<HashMap<usize, Box<[F]>>>,
 }
 unsafe impl<F: RichField> Send for DeviceTree<F> {}
@@ -468,8 +486,21 @@ impl<F: RichField> DeviceTree<F> {
         self.batch
     }
 
+    /// `leaves.len()` of the reference tree (merkle_tree.rs:234 passes it to merkle_tree_prove)
+    pub fn num_leaves(&self) -> usize {
+        self.num_leaves
+    }
+
+    /// words per leaf (salt columns included)
+    pub fn leaf_width(&self) -> usize {
+        self.width
+    }
+
     /// MerkleTree::get (merkle_tree.rs:227)
     pub fn row(&self, i: usize) -> &[F] {
+        if !self.flat.is_empty() {
+            return &self.flat[i * self.width..(i + 1) * self.width]; // panics on i >= num_leaves like `&self.leaves[i]`
+        }
         let mut cache = self.rows.lock().unwrap();
         if !cache.contains_key(&i) {
             let idx = [i as u64];
@@ -481,6 +512,15 @@ impl<F: RichField> DeviceTree<F> {
         let r: &[F] = &cache[&i];
         // SAFETY: the boxed slice is never removed or moved while `self` lives; only the map's buckets move.
         unsafe { core::slice::from_raw_parts(r.as_ptr(), r.len()) }
+    }
+
+    /// the reference's `leaves: Vec<Vec<F>>` (merkle_tree.rs:47) rebuilt from the flat buffer, rows in parallel
+    /// (P2HOT_LEAVES=vec, and the bit-exact harness, which compares the field itself)
+    pub fn leaves_as_vecs(&self) -> Vec<Vec<F>> {
+        if self.flat.is_empty() {
+            return (0..self.num_leaves).map(|i| self.row(i).to_vec()).collect();
+        }
+        self.flat.par_chunks_exact(self.width.max(1)).map(|r| r.to_vec()).collect()
     }
 
     /// merkle_tree_prove (merkle_tree.rs:151-190)
@@ -542,30 +582,36 @@ pub(crate) fn commit_with_salts<F: RichField + Extendable<D>, C: GenericConfig<D
     let salt_ptrs: Vec<*const u64> = salts.iter().map(|v| words(v)).collect();
     let on_device = leaves_on_device();
     let mut handle: *mut P2hotBatch = core::ptr::null_mut();
-    // `polynomials` always comes back (W * n words): the quotient evaluation and the openings read it on the host
-    let mut coeffs = Out::<F>::new(w * n, true);
+    // `polynomials` always comes back (W * n words): the quotient evaluation and the openings read it on the host.  One Vec per
+    // polynomial, filled IN PLACE by the library (P2HOT_COEFFS_PER_COLUMN): no flat block to split afterwards
+    let mut coeff_vecs: Vec<Out<F>> = (0..w).map(|_| Out::<F>::new(n, true)).collect();
+    let coeff_ptrs: Vec<*mut u64> = coeff_vecs.iter_mut().map(|o| o.ptr()).collect();
     let mut cap = Out::<<C::Hasher as Hasher<F>>::Hash>::new(1 << cap_height, true);
     let mut digests = Out::<<C::Hasher as Hasher<F>>::Hash>::new(num_digests, !on_device);
     let mut flat_leaves = Out::<F>::new(big_n * lw, !on_device);
     with_ctx(|ctx| {
         let rc = unsafe {
             p2hot_commit_salted(
-                ctx, ptrs.as_ptr(), w, log_n as c_uint, rate_bits as c_uint, cap_height as c_uint, is_values as c_int, 0,
-                salt_ptrs.as_ptr(), salt_ptrs.len(), coeffs.ptr(), flat_leaves.ptr(), digests.ptr(), cap.ptr(), &mut handle,
+                ctx, ptrs.as_ptr(), w, log_n as c_uint, rate_bits as c_uint, cap_height as c_uint, is_values as c_int, P2HOT_COEFFS_PER_COLUMN,
+                salt_ptrs.as_ptr(), salt_ptrs.len(), coeff_ptrs.as_ptr() as *mut u64, flat_leaves.ptr(), digests.ptr(), cap.ptr(), &mut handle,
             )
         };
         check(ctx, rc, "p2hot_commit_salted");
     });
-    let (coeffs, cap, digests, flat_leaves) = unsafe { (coeffs.finish(), cap.finish(), digests.finish(), flat_leaves.finish()) };
-    let polynomials = coeffs.chunks_exact(n.max(1)).map(|c| PolynomialCoeffs::new(c.to_vec())).collect();
-    // merkle_tree.leaves: N rows of W (oracle.rs:97-98); empty when the matrix stays on the GPU
-    let leaves: Vec<Vec<F>> = if on_device { Vec::new() } else { flat_leaves.chunks_exact(lw.max(1)).map(|r| r.to_vec()).collect() };
+    let (cap, digests, flat_leaves) = unsafe { (cap.finish(), digests.finish(), flat_leaves.finish()) };
+    // `polynomials` (oracle.rs:32): the W vectors the library filled (SAFETY: the call returned P2HOT_OK, every one holds n words)
+    let polynomials = coeff_vecs.into_iter().map(|o| PolynomialCoeffs::new(unsafe { o.finish() })).collect();
+    // merkle_tree.leaves (oracle.rs:97-98) is NOT rebuilt: the flat buffer the library filled moves into the DeviceTree and
+    // MerkleTree::get serves `&flat[i * lw..]`; the field itself stays empty unless P2HOT_LEAVES=vec asks for it
     let device = std::sync::Arc::new(DeviceTree {
         batch: handle,
         width: lw, // MerkleTree::get returns the whole leaf; get_lde_values strips the salt (oracle.rs:146)
+        num_leaves: big_n,
         num_layers: log_n + rate_bits - cap_height,
+        flat: flat_leaves,
         rows: Mutex::new(HashMap::new()),
     });
+    let leaves: Vec<Vec<F>> = if leaves_as_vecs() { device.leaves_as_vecs() } else { Vec::new() };
     PolynomialBatch {
         polynomials,
         merkle_tree: MerkleTree { leaves, digests, cap: MerkleCap(cap), device: Some(device) },
@@ -678,7 +724,7 @@ pub fn fri_committed_trees<F: RichField + Extendable<D>, C: GenericConfig<D, F =
     let mut trees = Vec::with_capacity(shapes.len());
     let (mut lo, mut dg) = (0usize, 0usize);
     for (i, &(n_leaves, width, nd)) in shapes.iter().enumerate() {
-        let leaves = leaves_flat[lo..lo + n_leaves * width].chunks_exact(width).map(|r| r.to_vec()).collect();
+        let leaves = leaves_flat[lo..lo + n_leaves * width].par_chunks_exact(width).map(|r| r.to_vec()).collect();
         trees.push(MerkleTree {
             leaves,
             digests: digests_flat[dg..dg + nd].to_vec(),
@@ -825,7 +871,7 @@ pub fn coeff_slices<F: Field>(polys: &[PolynomialCoeffs<F>]) -> Vec<&[F]> {
 // tree, not part of its value: two trees are equal when leaves, digests and cap are.
 impl<F: RichField> core::fmt::Debug for DeviceTree<F> {
     fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
-        write!(f, "DeviceTree({:p}, width {}, {} layers)", self.batch, self.width, self.num_layers)
+        write!(f, "DeviceTree({:p}, {} leaves of {}, {} layers, {} host words)", self.batch, self.num_leaves, self.width, self.num_layers, self.flat.len())
     }
 }
 impl<F: RichField> PartialEq for DeviceTree<F> {
@@ -874,14 +920,25 @@ mod tests {
         r
     }
 
-    fn assert_same_batch(cpu: &Batch, gpu: &Batch) {
+    /// `gpu` is compared twice: as the shim built it (default mode: `leaves` empty, the flat buffer behind `get`) -- rows through
+    /// `MerkleTree::get`, the serializer's bytes -- and then field by field after `leaves` is materialised from the flat buffer
+    fn assert_same_batch(cpu: &Batch, gpu: &mut Batch) {
         assert_eq!(cpu.polynomials, gpu.polynomials, "polynomials (oracle.rs:32)");
         assert_eq!(cpu.merkle_tree.cap, gpu.merkle_tree.cap, "merkle_tree.cap");
         assert_eq!(cpu.merkle_tree.digests, gpu.merkle_tree.digests, "merkle_tree.digests (reference layout, merkle_tree.rs:50-57)");
-        assert_eq!(cpu.merkle_tree.leaves, gpu.merkle_tree.leaves, "merkle_tree.leaves (LDE values, transposed, bit-reversed)");
         assert_eq!((cpu.degree_log, cpu.rate_bits, cpu.blinding), (gpu.degree_log, gpu.rate_bits, gpu.blinding));
-        assert_eq!(cpu, gpu); // the derived PartialEq (oracle.rs:29) over all of the above
-        // 8f-4 wire formats: the reference serializer over the shim-built structs (util/serialization/mod.rs:1417-1431, :1744-1763)
+        let big_n = cpu.merkle_tree.leaves.len();
+        if !leaves_as_vecs() {
+            assert!(gpu.merkle_tree.leaves.is_empty(), "default mode: the leaf matrix is ONE flat buffer behind MerkleTree::get");
+        }
+        assert_eq!(gpu.merkle_tree.device.as_ref().unwrap().num_leaves(), big_n);
+        for i in [0usize, 1, big_n / 2, big_n - 1] {
+            assert_eq!(cpu.merkle_tree.get(i), gpu.merkle_tree.get(i), "MerkleTree::get({i}) through the flat buffer");
+            assert_eq!(cpu.merkle_tree.prove(i), gpu.merkle_tree.prove(i), "MerkleTree::prove({i}) with `leaves` empty");
+            assert_eq!(cpu.get_lde_values(i, 1), gpu.get_lde_values(i, 1));
+        }
+        // 8f-4 wire formats: the reference serializer over the shim-built structs (util/serialization/mod.rs:1417-1431, :1744-1763);
+        // under the feature it reads the rows through `get`, so the flat buffer serialises to the same bytes
         let (mut a, mut b) = (Vec::<u8>::new(), Vec::<u8>::new());
         a.write_polynomial_batch(cpu).unwrap();
         b.write_polynomial_batch(gpu).unwrap();
@@ -890,22 +947,28 @@ mod tests {
         a.write_merkle_tree(&cpu.merkle_tree).unwrap();
         b.write_merkle_tree(&gpu.merkle_tree).unwrap();
         assert_eq!(a, b, "write_merkle_tree bytes");
+        // the field itself, rebuilt in parallel from the flat buffer (what P2HOT_LEAVES=vec does at commit time)
+        if gpu.merkle_tree.leaves.is_empty() {
+            gpu.merkle_tree.leaves = gpu.merkle_tree.device.as_ref().unwrap().leaves_as_vecs();
+        }
+        assert_eq!(cpu.merkle_tree.leaves, gpu.merkle_tree.leaves, "merkle_tree.leaves (LDE values, transposed, bit-reversed)");
+        assert_eq!(cpu, &*gpu); // the derived PartialEq (oracle.rs:29) over all of the above
     }
 
     /// from_values and from_coeffs at the widths of a proof's four commitments (constants_sigmas ~84, wires 135, Zs 20, quotient 16)
     #[test]
     fn commit_matches_the_cpu_prover() {
-        assert!(leaves_on_device() == false, "run the harness with P2HOT_LEAVES unset: it compares merkle_tree.leaves");
+        assert!(leaves_on_device() == false, "run the harness with P2HOT_LEAVES unset (or \"vec\"): it compares the whole leaf matrix");
         for &(w, log_n, rate_bits, cap_height) in &[(3usize, 5usize, 3usize, 4usize), (135, 12, 3, 4), (84, 12, 3, 4), (20, 12, 3, 4), (16, 13, 3, 4), (2, 10, 1, 0), (1, 0, 3, 0)] {
             let values: Vec<PolynomialValues<F>> = (0..w).map(|_| PolynomialValues::new(F::rand_vec(1 << log_n))).collect();
             let cpu = on_cpu(|| Batch::from_values(values.clone(), rate_bits, false, cap_height, &mut TimingTree::default(), None));
-            let gpu = Batch::from_values(values.clone(), rate_bits, false, cap_height, &mut TimingTree::default(), None);
+            let mut gpu = Batch::from_values(values.clone(), rate_bits, false, cap_height, &mut TimingTree::default(), None);
             assert!(gpu.merkle_tree.device.is_some(), "the p2hot body did not run");
-            assert_same_batch(&cpu, &gpu);
+            assert_same_batch(&cpu, &mut gpu);
             let polys: Vec<PolynomialCoeffs<F>> = values.into_iter().map(|v| PolynomialCoeffs::new(v.values)).collect();
             let cpu = on_cpu(|| Batch::from_coeffs(polys.clone(), rate_bits, false, cap_height, &mut TimingTree::default(), None));
-            let gpu = Batch::from_coeffs(polys, rate_bits, false, cap_height, &mut TimingTree::default(), None);
-            assert_same_batch(&cpu, &gpu);
+            let mut gpu = Batch::from_coeffs(polys, rate_bits, false, cap_height, &mut TimingTree::default(), None);
+            assert_same_batch(&cpu, &mut gpu);
             // MerkleTree::get / ::prove through the device handle
             let dev = gpu.merkle_tree.device.as_ref().unwrap();
             for i in [0usize, 1, (1 << (log_n + rate_bits)) - 1] {
@@ -932,7 +995,7 @@ mod tests {
             assert_eq!(gpu.polynomials, polys);
             assert_eq!(cpu_tree.cap, gpu.merkle_tree.cap);
             assert_eq!(cpu_tree.digests, gpu.merkle_tree.digests);
-            assert_eq!(cpu_tree.leaves, gpu.merkle_tree.leaves);
+            assert_eq!(cpu_tree.leaves, gpu.merkle_tree.device.as_ref().unwrap().leaves_as_vecs());
             // get_lde_values strips the salt (oracle.rs:142-147)
             assert_eq!(gpu.get_lde_values(3, 1).len(), w);
         }
@@ -987,11 +1050,11 @@ mod tests {
     /// (the CPU grind takes the smallest witness under the `p2hot` feature: fri/prover.rs, `find_first`)
     fn prove_both_ways(build: &dyn Fn() -> (CircuitData<F, C, D>, PartialWitness<F>)) -> Result<ProofTuple> {
         let (cpu_data, cpu_pw) = on_cpu(build);
-        let (gpu_data, gpu_pw) = build();
+        let (mut gpu_data, gpu_pw) = build();
         // CircuitBuilder::build commits constants + sigmas (circuit_builder.rs:1182-1191)
         assert_eq!(cpu_data.verifier_only.constants_sigmas_cap, gpu_data.verifier_only.constants_sigmas_cap);
         assert_eq!(cpu_data.verifier_only.circuit_digest, gpu_data.verifier_only.circuit_digest);
-        assert_same_batch(&cpu_data.prover_only.constants_sigmas_commitment, &gpu_data.prover_only.constants_sigmas_commitment);
+        assert_same_batch(&cpu_data.prover_only.constants_sigmas_commitment, &mut gpu_data.prover_only.constants_sigmas_commitment);
         let cpu_proof = on_cpu(|| prove::<F, C, D>(&cpu_data.prover_only, &cpu_data.common, cpu_pw, &mut TimingTree::default()))?;
         let gpu_proof = prove::<F, C, D>(&gpu_data.prover_only, &gpu_data.common, gpu_pw, &mut TimingTree::default())?;
         let (c, g) = (&cpu_proof.proof, &gpu_proof.proof);

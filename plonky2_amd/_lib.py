@@ -15,6 +15,7 @@ OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED, EBUSY, ECOMM = 0, 1, 2, 3, 4, 5, 6
 _ERR_NAMES = {EINVAL: "EINVAL", ENOMEM: "ENOMEM", EHIP: "EHIP", EUNSUPPORTED: "EUNSUPPORTED", EBUSY: "EBUSY",
               ECOMM: "ECOMM"}
 KEEP_VALUES = 1
+COEFFS_PER_COLUMN = 2
 
 vp = C.c_void_p
 sz = C.c_size_t
@@ -127,6 +128,7 @@ SIGNATURES = {
     "p2hot_comm_rank": (i, [vp]),
     "p2hot_comm_world": (i, [vp]),
     "p2hot_comm_selftest": (i, [vp, sz]),
+    "p2hot_comm_exchange_mode": (i, [vp]),
     "p2hot_shard_columns": (i, [sz, i, i, C.POINTER(sz), C.POINTER(sz)]),
     "p2hot_commit_sharded_dev": (i, [vp, vp, vp, sz, sz, u, u, u, i, i, u, vp, vp, sz, vp, vp, vp]),
     "p2hot_group_create": (i, [i, C.POINTER(i), C.POINTER(vp)]),
@@ -134,6 +136,7 @@ SIGNATURES = {
     "p2hot_group_size": (i, [vp]),
     "p2hot_group_ctx": (vp, [vp, i]),
     "p2hot_group_uses_rccl": (i, [vp]),
+    "p2hot_group_exchange_mode": (i, [vp]),
     "p2hot_group_last_error": (C.c_char_p, [vp]),
     "p2hot_group_commit": (i, [vp, C.POINTER(vp), sz, u, u, u, i, i, u, vp, vp, vp, vp, C.POINTER(vp)]),
     "p2hot_sharded_batch_open": (i, [vp, vp, sz, vp, vp]),

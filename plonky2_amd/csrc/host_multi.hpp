@@ -23,13 +23,17 @@
 #pragma once
 #include <chrono>
 
-#ifndef P2HOT_EMU
+#ifdef P2HOT_EMU
+#include "rccl_emu.h"  // the emulator's fake RCCL (tests/emu): same calls, device / stream / buffer identity enforced
+#else
 #include <dlfcn.h>
 #endif
 
+#include <cstring>
+#include <functional>
 #include <memory>
 
-// ---- the few RCCL entry points used (rccl.h:40-43, :187, :220, :236, :260, :339, :460, :591, :923-929) ----
+// ---- the few RCCL entry points used (rccl.h:40-43, :187, :220, :236, :260, :339, :460, :591 ncclBroadcast, :622 ncclAllGather, :923-929) ----
 namespace rccl {
 struct UniqueId {
     char internal[P2HOT_UNIQUE_ID_BYTES];
@@ -42,6 +46,7 @@ struct Api {
     int (*CommInitAll)(Comm *, int, const int *) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, Comm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -55,7 +60,16 @@ static Api &api() {
     if (tried) return a;
     tried = true;
 #ifdef P2HOT_EMU
-    a.err = "the kernel emulator build has no RCCL";
+    a.GetUniqueId = [](UniqueId *id) { return emu_ncclGetUniqueId(id->internal); };
+    a.CommInitRank = [](Comm *c, int n, UniqueId id, int r) { return emu_ncclCommInitRank(c, n, id.internal, r); };
+    a.CommInitAll = [](Comm *c, int n, const int *d) { return emu_ncclCommInitAll(c, n, d); };
+    a.CommDestroy = [](Comm c) { return emu_ncclCommDestroy(c); };
+    a.Broadcast = [](const void *s, void *r, size_t n, int dt, int root, Comm c, hipStream_t st) { return emu_ncclBroadcast(s, r, n, dt, root, c, st); };
+    a.AllGather = [](const void *s, void *r, size_t n, int dt, Comm c, hipStream_t st) { return emu_ncclAllGather(s, r, n, dt, c, st); };
+    a.GroupStart = []() { return emu_ncclGroupStart(); };
+    a.GroupEnd = []() { return emu_ncclGroupEnd(); };
+    a.GetErrorString = [](int rc) { return emu_ncclGetErrorString(rc); };
+    a.ok = true;
 #else
     const char *names[] = {"librccl.so", "librccl.so.1"};
     for (const char *n : names)  // the copy this process already uses (PyTorch's), so two RCCLs never meet
@@ -81,6 +95,7 @@ static Api &api() {
     a.CommInitAll = (int (*)(Comm *, int, const int *))sym("ncclCommInitAll");
     a.CommDestroy = (int (*)(Comm))sym("ncclCommDestroy");
     a.Broadcast = (int (*)(const void *, void *, size_t, int, int, Comm, hipStream_t))sym("ncclBroadcast");
+    a.AllGather = (int (*)(const void *, void *, size_t, int, Comm, hipStream_t))sym("ncclAllGather");
     a.GroupStart = (int (*)())sym("ncclGroupStart");
     a.GroupEnd = (int (*)())sym("ncclGroupEnd");
     a.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
@@ -100,6 +115,10 @@ struct p2hot_comm {
     p2hot_allgather_fn fn = nullptr;
     void *user = nullptr;
     p2hot_group *group = nullptr;
+    // how equal, contiguous slices travel on the RCCL transports: 0 = a grouped ncclBroadcast per slice (an all-gather with free
+    // placement), 1 = ncclAllGather (RCCL's tuned path; pipelined coefficient chunks then go through a chunk-major staging block).
+    // P2HOT_EXCHANGE=broadcast|allgather pins it, otherwise p2hot_comm_selftest / p2hot_group_create time both and pick.
+    int exchange_mode = 0;
     hipStream_t comm_stream = nullptr;  // collectives run here, beside the transforms on the context's stream
     std::vector<hipEvent_t> ev_ready, ev_done;  // per pipeline slot: "slice written" (compute -> comm), "gathered" (comm -> compute)
 };
@@ -119,8 +138,15 @@ struct p2hot_group {
         if (r_ != 0) P2_FAIL(ctx, P2HOT_ECOMM, "%s: %s", #call, rccl::api().GetErrorString ? rccl::api().GetErrorString(r_) : "?"); \
     } while (0)
 
+// P2HOT_EXCHANGE pins how equal contiguous slices travel: "broadcast" (0), "allgather" (1); anything else: measured (-1)
+static int exchange_mode_from_env() {
+    const char *e = getenv("P2HOT_EXCHANGE");
+    if (e && !strcmp(e, "broadcast")) return 0;
+    if (e && !strcmp(e, "allgather")) return 1;
+    return -1;
+}
+
 static int comm_events(p2hot_comm *c, size_t slots) {
-#ifndef P2HOT_EMU
     p2hot_ctx *ctx = c->ctx;
     P2_HIP(ctx, hipSetDevice(ctx->device));
     if (!c->comm_stream) P2_HIP(ctx, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
@@ -131,10 +157,6 @@ static int comm_events(p2hot_comm *c, size_t slots) {
         c->ev_ready.push_back(a);
         c->ev_done.push_back(b);
     }
-#else
-    (void)c;
-    (void)slots;
-#endif
     return P2HOT_OK;
 }
 
@@ -163,6 +185,7 @@ extern "C" int p2hot_comm_create_rccl(p2hot_ctx *ctx, int rank, int world, const
     std::copy(id, id + P2HOT_UNIQUE_ID_BYTES, (uint8_t *)uid.internal);
     P2_HIP(ctx, hipSetDevice(ctx->device));
     P2_NCCL(ctx, a.CommInitRank(&c->nccl, world, uid, rank));
+    c->exchange_mode = exchange_mode_from_env() == 1 && a.AllGather ? 1 : 0;  // unpinned: broadcasts until p2hot_comm_selftest has timed both
     P2_TRY(comm_events(c.get(), 1));
     *out = c.release();
     return P2HOT_OK;
@@ -185,7 +208,7 @@ extern "C" int p2hot_comm_create_callback(p2hot_ctx *ctx, int rank, int world, p
 
 extern "C" void p2hot_comm_destroy(p2hot_comm *c) {
     if (!c) return;
-#ifndef P2HOT_EMU
+    DeviceGuard restore_caller_device_(0);
     (void)hipSetDevice(c->ctx->device);
     if (c->comm_stream) {
         (void)hipStreamSynchronize(c->comm_stream);
@@ -193,7 +216,6 @@ extern "C" void p2hot_comm_destroy(p2hot_comm *c) {
     }
     for (auto e : c->ev_ready) (void)hipEventDestroy(e);
     for (auto e : c->ev_done) (void)hipEventDestroy(e);
-#endif
     if (c->nccl && rccl::api().ok) (void)rccl::api().CommDestroy(c->nccl);
     delete c;
 }
@@ -225,7 +247,6 @@ static int gather_start(std::vector<p2hot_comm *> &cs, std::vector<u64 *> &base,
         if (rc != 0) P2_FAIL(ctx, P2HOT_ECOMM, "the caller-supplied all-gather failed (%d)", rc);
         return P2HOT_OK;
     }
-#ifndef P2HOT_EMU
     for (size_t s = 0; s < cs.size(); ++s) {  // slice written on the compute stream -> visible to the comm stream
         p2hot_ctx *ctx = cs[s]->ctx;
         P2_HIP(ctx, hipSetDevice(ctx->device));
@@ -242,7 +263,19 @@ static int gather_start(std::vector<p2hot_comm *> &cs, std::vector<u64 *> &base,
             P2_HIP(cs[s]->ctx, hipSetDevice(cs[s]->ctx->device));
             P2_HIP(cs[s]->ctx, hipStreamWaitEvent(cs[s]->comm_stream, cs[s]->ev_ready[slot], 0));
         }
+        bool contiguous = true;  // rank r's slice directly behind rank r-1's: what ncclAllGather (in place) needs
+        for (int r = 1; r < world; ++r) contiguous = contiguous && offsets[(size_t)r] == offsets[0] + (size_t)r * bytes;
         P2_NCCL(c0->ctx, a.GroupStart());
+        if (c0->exchange_mode == 1 && contiguous && a.AllGather) {
+            for (size_t s = 0; s < cs.size(); ++s) {
+                char *recv = (char *)base[s] + offsets[0];
+                int rc = a.AllGather(recv + (size_t)cs[s]->rank * bytes, recv, bytes, rccl::kUint8, cs[s]->nccl, cs[s]->comm_stream);
+                if (rc != 0) {
+                    (void)a.GroupEnd();
+                    P2_FAIL(c0->ctx, P2HOT_ECOMM, "ncclAllGather: %s", a.GetErrorString(rc));
+                }
+            }
+        } else
         for (size_t s = 0; s < cs.size(); ++s)
             for (int r = 0; r < world; ++r) {
                 char *p = (char *)base[s] + offsets[r];
@@ -269,28 +302,16 @@ static int gather_start(std::vector<p2hot_comm *> &cs, std::vector<u64 *> &base,
         P2_HIP(cs[s]->ctx, hipSetDevice(cs[s]->ctx->device));
         P2_HIP(cs[s]->ctx, hipEventRecord(cs[s]->ev_done[slot], cs[s]->comm_stream));
     }
-#else
-    // emulator: the single-process group copies between the ranks' (host) buffers
-    for (size_t s = 0; s < cs.size(); ++s)
-        for (size_t r = 0; r < cs.size(); ++r)
-            if (r != s) memmove((char *)base[s] + offsets[r], (const char *)base[r] + offsets[r], bytes);
-    (void)slot;
-#endif
     return P2HOT_OK;
 }
 
 static int gather_wait(std::vector<p2hot_comm *> &cs, size_t slot) {
-#ifndef P2HOT_EMU
     if ((cs[0]->world == 1 && cs[0]->kind != p2hot_comm::RCCL) || cs[0]->kind == p2hot_comm::CALLBACK) return P2HOT_OK;
     for (auto *c : cs) {
         if (slot >= c->ev_done.size()) continue;
         P2_HIP(c->ctx, hipSetDevice(c->ctx->device));
         P2_HIP(c->ctx, hipStreamWaitEvent(c->ctx->stream, c->ev_done[slot], 0));
     }
-#else
-    (void)cs;
-    (void)slot;
-#endif
     return P2HOT_OK;
 }
 
@@ -351,6 +372,21 @@ static int sharded_commit_core(std::vector<p2hot_comm *> &cs, std::vector<ShardA
     // 1 + 2. column chunks: this rank's columns -> coefficient form in its slot, then the exchange of that chunk
     const size_t K = cpr ? std::max<size_t>(1, std::min<size_t>(pipeline_chunks ? pipeline_chunks : 1, cpr)) : 0;
     const size_t cpk = K ? (cpr + K - 1) / K : 0;
+    // ncclAllGather wants the ranks' slices of one exchange back to back.  Whole-rank slices of coeffs_all are (K = 1); the
+    // column chunks of the pipelined exchange are not (rank r's chunk k sits at row r*cpr + lo), so in the all-gather mode
+    // they travel through a chunk-major staging block [chunk][rank][columns of the chunk][n] -- the iNTT writes there, the LDE
+    // reads from there -- and one strided device copy per chunk files them into coeffs_all (`polynomials`, row = column index)
+    const bool rccl_path = cs[0]->kind == p2hot_comm::RCCL || (cs[0]->kind == p2hot_comm::GROUP && cs[0]->group->use_rccl);
+    const bool staged = rccl_path && cs[0]->exchange_mode == 1 && K > 1;
+    std::vector<u64 *> stage(L, nullptr);
+    if (staged)
+        for (size_t s = 0; s < L; ++s) {
+            P2_TRY(setdev(s));
+            P2_TRY(scratch_get(cs[s]->ctx, 3, (size_t)world * cpr * n * 8, (void **)&stage[s]));
+        }
+    auto slice_at = [&](size_t s, size_t r, size_t lo, size_t hi) -> u64 * {  // rank r's slice of chunk [lo, hi) on local rank s
+        return staged ? stage[s] + ((size_t)world * lo + r * (hi - lo)) * n : as[s].coeffs_all + (r * cpr + lo) * n;
+    };
     std::vector<std::pair<size_t, size_t>> spans;
     for (size_t k = 0; k < K; ++k) {
         const size_t lo = k * cpk, hi = std::min((k + 1) * cpk, cpr);
@@ -361,7 +397,7 @@ static int sharded_commit_core(std::vector<p2hot_comm *> &cs, std::vector<ShardA
             const size_t rank = (size_t)cs[s]->rank;
             const size_t c0 = std::min(W, rank * cpr), c1 = std::min(W, c0 + cpr), mine = c1 - c0;
             const size_t valid = lo < mine ? std::min(hi, mine) - lo : 0;  // my real (non-padding) columns in the chunk
-            u64 *slot = as[s].coeffs_all + (rank * cpr + lo) * n;
+            u64 *slot = slice_at(s, rank, lo, hi);
             for (size_t j = 0; j < valid; ++j)
                 P2_HIP(ctx, hipMemcpyAsync(slot + j * n, as[s].cols_local + (lo + j) * as[s].col_stride, n * 8, hipMemcpyDeviceToDevice,
                                            ctx->stream));
@@ -369,8 +405,8 @@ static int sharded_commit_core(std::vector<p2hot_comm *> &cs, std::vector<ShardA
         }
         std::vector<u64 *> base(L);
         std::vector<size_t> offs((size_t)world);
-        for (size_t s = 0; s < L; ++s) base[s] = as[s].coeffs_all;
-        for (int r = 0; r < world; ++r) offs[(size_t)r] = ((size_t)r * cpr + lo) * n * 8;
+        for (size_t s = 0; s < L; ++s) base[s] = staged ? stage[s] : as[s].coeffs_all;
+        for (int r = 0; r < world; ++r) offs[(size_t)r] = (size_t)(slice_at(0, (size_t)r, lo, hi) - base[0]) * 8;
         P2_TRY(gather_start(cs, base, offs, (hi - lo) * n * 8, spans.size()));
         spans.emplace_back(lo, hi);
     }
@@ -384,9 +420,12 @@ static int sharded_commit_core(std::vector<p2hot_comm *> &cs, std::vector<ShardA
             for (int r = 0; r < world; ++r) {
                 const size_t cb = (size_t)r * cpr + lo, ce = std::min(std::min((size_t)r * cpr + hi, W), ((size_t)r + 1) * cpr);
                 if (ce <= cb) continue;
-                P2_TRY(p2hot_coset_lde_dev(cs[s]->ctx, as[s].coeffs_all + cb * n, ce - cb, n, p.log_n, p.rate_bits, gl::COSET_SHIFT, row_begin,
+                P2_TRY(p2hot_coset_lde_dev(cs[s]->ctx, slice_at(s, (size_t)r, lo, hi), ce - cb, n, p.log_n, p.rate_bits, gl::COSET_SHIFT, row_begin,
                                            p.rows_per_rank, as[s].lde + cb * as[s].lde_stride, as[s].lde_stride));
             }
+            if (staged)  // the chunk's `world` slices -> rows r*cpr + lo .. of coeffs_all: one strided copy
+                P2_HIP(cs[s]->ctx, hipMemcpy2DAsync(as[s].coeffs_all + lo * n, cpr * n * 8, stage[s] + (size_t)world * lo * n, (hi - lo) * n * 8,
+                                                    (hi - lo) * n * 8, (size_t)world, hipMemcpyDeviceToDevice, cs[s]->ctx->stream));
         }
     }
     // leaf sponge + Merkle levels of this rank's rows (whole cosets, whole cap subtrees), straight from the column-major LDE
@@ -439,39 +478,113 @@ extern "C" int p2hot_commit_sharded_dev(p2hot_ctx *ctx, p2hot_comm *comm, const 
 // are all-gathered exactly as the commit does it (grouped broadcasts / the caller's transport, the communication stream, the
 // event hand-over), and every rank checks every slice.  A broken binding, a missing peer path or a transport that returns
 // early fails HERE with a named cause instead of as a wrong cap (or a hang) inside the timed region.
+// One pattern round trip through gather_start / gather_wait on `cs` (1 entry: a process-per-GPU communicator; world entries:
+// the single-process group): every rank contributes a `bytes`-sized slice, every rank checks every slice.  *ms (optional): the
+// best host-side time of `reps` exchanges (stream idle to stream idle).
+static int exchange_roundtrip(std::vector<p2hot_comm *> &cs, std::vector<u64 *> &d, size_t bytes, int reps, double *ms) {
+    const size_t world = (size_t)cs[0]->world, words = bytes / 8;
+    auto pat = [](size_t r, size_t i) { return ((u64)(r + 1) << 40) ^ (i * 0x9E3779B97F4A7C15ull); };
+    std::vector<size_t> offs(world);
+    for (size_t r = 0; r < world; ++r) offs[r] = r * bytes;
+    double best = 1e30;
+    for (int rep = 0; rep < reps; ++rep) {
+        std::vector<std::vector<u64>> host(cs.size());
+        for (size_t s = 0; s < cs.size(); ++s) {
+            p2hot_ctx *ctx = cs[s]->ctx;
+            P2_HIP(ctx, hipSetDevice(ctx->device));
+            host[s].assign(world * words, ~0ull);
+            for (size_t i = 0; i < words; ++i) host[s][(size_t)cs[s]->rank * words + i] = pat((size_t)cs[s]->rank, i);
+            P2_HIP(ctx, hipMemcpyAsync(d[s], host[s].data(), world * bytes, hipMemcpyHostToDevice, ctx->stream));
+            P2_HIP(ctx, stream_sync(ctx));
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        P2_TRY(gather_start(cs, d, offs, bytes, 0));
+        P2_TRY(gather_wait(cs, 0));
+        for (size_t s = 0; s < cs.size(); ++s) {
+            P2_HIP(cs[s]->ctx, hipSetDevice(cs[s]->ctx->device));
+            P2_HIP(cs[s]->ctx, stream_sync(cs[s]->ctx));
+        }
+        best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        for (size_t s = 0; s < cs.size(); ++s) {
+            p2hot_ctx *ctx = cs[s]->ctx;
+            P2_HIP(ctx, hipSetDevice(ctx->device));
+            P2_HIP(ctx, hipMemcpyAsync(host[s].data(), d[s], world * bytes, hipMemcpyDeviceToHost, ctx->stream));
+            P2_HIP(ctx, stream_sync(ctx));
+            for (size_t r = 0; r < world; ++r)
+                for (size_t i = 0; i < words; ++i)
+                    if (host[s][r * words + i] != pat(r, i))
+                        P2_FAIL(cs[0]->ctx, P2HOT_ECOMM, "comm_selftest: rank %d did not receive rank %zu's slice (word %zu) through %s: the %s transport delivered nothing or stale data",
+                                cs[s]->rank, r, i, cs[0]->exchange_mode == 1 ? "ncclAllGather" : "the grouped broadcasts",
+                                cs[0]->kind == p2hot_comm::CALLBACK ? "caller-supplied" : "RCCL");
+        }
+    }
+    if (ms) *ms = best;
+    return P2HOT_OK;
+}
+
+// Both RCCL exchange forms are checked, timed, and the faster one kept (unless P2HOT_EXCHANGE pins one).  `decide`: how the ranks
+// agree on ONE answer when each of them measured (process-per-GPU: rank 0's verdict is broadcast); null in the group (one thread).
+static int pick_exchange_mode(std::vector<p2hot_comm *> &cs, std::vector<u64 *> &d, size_t bytes, const std::function<int(int *)> &decide) {
+    const bool rccl_path = cs[0]->kind == p2hot_comm::RCCL || (cs[0]->kind == p2hot_comm::GROUP && cs[0]->group->use_rccl);
+    auto set_mode = [&](int m) {
+        for (auto *c : cs) c->exchange_mode = m;
+    };
+    if (!rccl_path || !rccl::api().AllGather) {
+        set_mode(0);
+        return exchange_roundtrip(cs, d, bytes, 1, nullptr);
+    }
+    const int pinned = exchange_mode_from_env();
+    double ms[2] = {0, 0};
+    for (int m = 0; m < 2; ++m) {
+        if (pinned >= 0 && m != pinned) continue;
+        set_mode(m);
+        P2_TRY(exchange_roundtrip(cs, d, bytes, pinned >= 0 ? 1 : 3, &ms[m]));
+    }
+    int mode = pinned >= 0 ? pinned : (ms[1] <= ms[0] ? 1 : 0);
+    if (pinned < 0 && decide) P2_TRY(decide(&mode));
+    set_mode(mode);
+    return P2HOT_OK;
+}
+
+// Preflight of a process-per-GPU communicator: every rank contributes a `bytes`-sized slice of a known pattern, the slices
+// are all-gathered exactly as the commit does it (grouped broadcasts and ncclAllGather / the caller's transport, the
+// communication stream, the event hand-over), and every rank checks every slice.  A broken binding, a missing peer path or a
+// transport that returns early fails HERE with a named cause instead of as a wrong cap (or a hang) inside the timed region.
+// On an RCCL communicator both exchange forms are timed and the faster one is kept for the commits that follow
+// (p2hot_comm_exchange_mode; rank 0's verdict is the communicator's, so every rank posts the same collectives).
 extern "C" int p2hot_comm_selftest(p2hot_comm *comm, size_t bytes) {
     if (!comm || !comm->ctx) return P2HOT_EINVAL;
     p2hot_ctx *ctx = comm->ctx;
     DeviceGuard dev_guard_(ctx);
     if (comm->kind == p2hot_comm::GROUP) P2_FAIL(ctx, P2HOT_EINVAL, "comm_selftest: use it on a process-per-GPU communicator");
     if (bytes == 0 || bytes % 8) P2_FAIL(ctx, P2HOT_EINVAL, "comm_selftest: bytes must be a positive multiple of 8");
-    const size_t world = (size_t)comm->world, words = bytes / 8;
+    const size_t world = (size_t)comm->world;
     u64 *d = nullptr;
-    P2_HIP(ctx, hipMalloc((void **)&d, world * bytes));
-    std::vector<u64> host(world * words, ~0ull);
-    for (size_t i = 0; i < words; ++i) host[(size_t)comm->rank * words + i] = ((u64)(comm->rank + 1) << 40) ^ (i * 0x9E3779B97F4A7C15ull);
-    int rc = P2HOT_OK;
-    auto body = [&]() -> int {
-        P2_HIP(ctx, hipMemcpyAsync(d, host.data(), world * bytes, hipMemcpyHostToDevice, ctx->stream));
-        std::vector<p2hot_comm *> cs{comm};
-        std::vector<u64 *> base{d};
-        std::vector<size_t> offs(world);
-        for (size_t r = 0; r < world; ++r) offs[r] = r * bytes;
-        P2_TRY(gather_start(cs, base, offs, bytes, 0));
-        P2_TRY(gather_wait(cs, 0));
-        P2_HIP(ctx, hipMemcpyAsync(host.data(), d, world * bytes, hipMemcpyDeviceToHost, ctx->stream));
+    P2_HIP(ctx, hipMalloc((void **)&d, world * bytes + 64));
+    std::vector<p2hot_comm *> cs{comm};
+    std::vector<u64 *> base{d};
+    auto decide = [&](int *mode) -> int {  // rank 0's measurement decides for everybody: 8 bytes broadcast from rank 0
+        rccl::Api &a = rccl::api();
+        u64 *flag = d + world * (bytes / 8);
+        u64 v = (u64)*mode;
+        P2_HIP(ctx, hipMemcpyAsync(flag, &v, 8, hipMemcpyHostToDevice, ctx->stream));
         P2_HIP(ctx, stream_sync(ctx));
-        for (size_t r = 0; r < world; ++r)
-            for (size_t i = 0; i < words; ++i)
-                if (host[r * words + i] != (((u64)(r + 1) << 40) ^ (i * 0x9E3779B97F4A7C15ull)))
-                    P2_FAIL(ctx, P2HOT_ECOMM, "comm_selftest: rank %d did not receive rank %zu's slice (word %zu): the %s transport delivered nothing or stale data",
-                            comm->rank, r, i, comm->kind == p2hot_comm::RCCL ? "RCCL" : "caller-supplied");
+        P2_NCCL(ctx, a.GroupStart());
+        int rc = a.Broadcast(flag, flag, 8, rccl::kUint8, 0, comm->nccl, comm->comm_stream);
+        P2_NCCL(ctx, a.GroupEnd());
+        if (rc != 0) P2_FAIL(ctx, P2HOT_ECOMM, "comm_selftest: ncclBroadcast of the exchange mode: %s", a.GetErrorString(rc));
+        P2_HIP(ctx, hipStreamSynchronize(comm->comm_stream));
+        P2_HIP(ctx, hipMemcpyAsync(&v, flag, 8, hipMemcpyDeviceToHost, ctx->stream));
+        P2_HIP(ctx, stream_sync(ctx));
+        *mode = (int)v;
         return P2HOT_OK;
     };
-    rc = body();
+    int rc = pick_exchange_mode(cs, base, bytes, comm->kind == p2hot_comm::RCCL && comm->world > 1 ? std::function<int(int *)>(decide) : nullptr);
     (void)hipFree(d);
     return rc;
 }
+
+extern "C" int p2hot_comm_exchange_mode(const p2hot_comm *c) { return c ? c->exchange_mode : -1; }
 
 extern "C" int p2hot_shard_columns(size_t W, int world, int rank, size_t *first, size_t *count) {
     if (world < 1 || rank < 0 || rank >= world || !first || !count) return P2HOT_EINVAL;
@@ -515,13 +628,11 @@ static int sharded_commit_columns_core(std::vector<p2hot_comm *> &cs, std::vecto
         P2_TRY(p2hot_coset_lde_dev(ctx, as[s].coeffs_local, cnt, n, p.log_n, p.rate_bits, gl::COSET_SHIFT, 0, N, as[s].lde_cols, N));
     }
     // all-to-all: rank d pulls, from every rank r, the rows [d*rpr, (d+1)*rpr) of r's columns into lde[c0_r ..][0 .. rpr)
-#ifndef P2HOT_EMU
     for (size_t s = 0; s < L; ++s) {
         P2_HIP(cs[s]->ctx, hipSetDevice(cs[s]->ctx->device));
         P2_TRY(comm_events(cs[s], 1));
         P2_HIP(cs[s]->ctx, hipEventRecord(cs[s]->ev_ready[0], cs[s]->ctx->stream));
     }
-#endif
     for (size_t d = 0; d < L; ++d) {
         p2hot_ctx *ctx = cs[d]->ctx;
         P2_HIP(ctx, hipSetDevice(ctx->device));
@@ -529,17 +640,12 @@ static int sharded_commit_columns_core(std::vector<p2hot_comm *> &cs, std::vecto
             size_t c0, cnt;
             cols_of(r, &c0, &cnt);
             if (cnt == 0) continue;
-            hipStream_t st = ctx->stream;
-#ifndef P2HOT_EMU
-            st = cs[d]->comm_stream;
+            hipStream_t st = cs[d]->comm_stream;
             P2_HIP(ctx, hipStreamWaitEvent(st, cs[r]->ev_ready[0], 0));
-#endif
             P2_HIP(ctx, hipMemcpy2DAsync(as[d].lde + c0 * rpr, rpr * 8, as[r].lde_cols + d * rpr, N * 8, rpr * 8, cnt, hipMemcpyDefault, st));
         }
-#ifndef P2HOT_EMU
         P2_HIP(ctx, hipEventRecord(cs[d]->ev_done[0], cs[d]->comm_stream));
         P2_HIP(ctx, hipStreamWaitEvent(ctx->stream, cs[d]->ev_done[0], 0));
-#endif
     }
     for (size_t s = 0; s < L; ++s) {  // leaf sponge + Merkle levels of the rank's rows
         p2hot_ctx *ctx = cs[s]->ctx;
@@ -571,17 +677,16 @@ extern "C" int p2hot_group_create(int n_gpus, const int *devices, p2hot_group **
     auto fail = [&](int rc) {
         for (auto *c : g->comm) p2hot_comm_destroy(c);
         for (auto *c : g->ctx) p2hot_ctx_destroy(c);
-#ifndef P2HOT_EMU
-        for (auto s : g->streams)
-            if (s) (void)hipStreamDestroy(s);
-#endif
+        for (size_t i = 0; i < g->streams.size(); ++i)
+            if (g->streams[i]) {
+                (void)hipSetDevice(g->devices[i]);
+                (void)hipStreamDestroy(g->streams[i]);
+            }
         return rc;
     };
     for (int i = 0; i < n_gpus; ++i) {
         hipStream_t st = nullptr;
-#ifndef P2HOT_EMU
         if (hipSetDevice(g->devices[(size_t)i]) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(P2HOT_EHIP);
-#endif
         g->streams.push_back(st);
         p2hot_ctx *c = nullptr;
         int rc = p2hot_ctx_create(g->devices[(size_t)i], st, &c);
@@ -607,8 +712,22 @@ extern "C" int p2hot_group_create(int n_gpus, const int *devices, p2hot_group **
         std::vector<rccl::Comm> comms((size_t)n_gpus);
         if (a.CommInitAll(comms.data(), n_gpus, g->devices.data()) != 0) return fail(P2HOT_ECOMM);
         for (int i = 0; i < n_gpus; ++i) g->comm[(size_t)i]->nccl = comms[(size_t)i];
+        // both exchange forms once over every rank (1 MB slices): checked, timed, the faster one kept (P2HOT_EXCHANGE pins one)
+        const size_t bytes = (size_t)1 << 20;
+        std::vector<u64 *> d((size_t)n_gpus, nullptr);
+        int rc = P2HOT_OK;
+        for (int i = 0; i < n_gpus && rc == P2HOT_OK; ++i) {
+            (void)hipSetDevice(g->devices[(size_t)i]);
+            if (hipMalloc((void **)&d[(size_t)i], (size_t)n_gpus * bytes) != hipSuccess) rc = P2HOT_ENOMEM;
+        }
+        if (rc == P2HOT_OK) rc = pick_exchange_mode(g->comm, d, bytes, nullptr);
+        for (int i = 0; i < n_gpus; ++i)
+            if (d[(size_t)i]) {
+                (void)hipSetDevice(g->devices[(size_t)i]);
+                (void)hipFree(d[(size_t)i]);
+            }
+        if (rc != P2HOT_OK) return fail(rc);
     }
-#ifndef P2HOT_EMU
     if (!g->use_rccl && distinct)
         for (int i = 0; i < n_gpus; ++i) {  // peer copies between distinct devices need peer access
             (void)hipSetDevice(g->devices[(size_t)i]);
@@ -616,7 +735,6 @@ extern "C" int p2hot_group_create(int n_gpus, const int *devices, p2hot_group **
                 if (j != i) (void)hipDeviceEnablePeerAccess(g->devices[(size_t)j], 0);
             (void)hipGetLastError();
         }
-#endif
     *out = g.release();
     return P2HOT_OK;
 }
@@ -626,19 +744,18 @@ extern "C" void p2hot_group_destroy(p2hot_group *g) {
     if (!g) return;
     for (auto *c : g->comm) p2hot_comm_destroy(c);
     for (auto *c : g->ctx) p2hot_ctx_destroy(c);
-#ifndef P2HOT_EMU
     for (size_t i = 0; i < g->streams.size(); ++i)
         if (g->streams[i]) {
             (void)hipSetDevice(g->devices[i]);
             (void)hipStreamDestroy(g->streams[i]);
         }
-#endif
     delete g;
 }
 
 extern "C" int p2hot_group_size(const p2hot_group *g) { return g ? (int)g->ctx.size() : 0; }
 extern "C" p2hot_ctx *p2hot_group_ctx(p2hot_group *g, int i) { return (g && i >= 0 && (size_t)i < g->ctx.size()) ? g->ctx[(size_t)i] : nullptr; }
 extern "C" int p2hot_group_uses_rccl(const p2hot_group *g) { return g && g->use_rccl ? 1 : 0; }
+extern "C" int p2hot_group_exchange_mode(const p2hot_group *g) { return g && !g->comm.empty() ? g->comm[0]->exchange_mode : -1; }
 extern "C" const char *p2hot_group_last_error(const p2hot_group *g) {
     if (!g) return "null group";
     for (auto *c : g->ctx)
@@ -759,9 +876,7 @@ extern "C" int p2hot_group_commit(p2hot_group *g, const uint64_t *const *cols, s
         p2hot_ctx *ctx = g->ctx[s];
         (void)hipSetDevice(ctx->device);
         hipError_t e = stream_sync(ctx);
-#ifndef P2HOT_EMU
         if (g->comm[s]->comm_stream) (void)hipStreamSynchronize(g->comm[s]->comm_stream);
-#endif
         if (rc == P2HOT_OK && e != hipSuccess) {
             ctx0->err = std::string("group_commit: ") + hipGetErrorString(e);
             rc = P2HOT_EHIP;

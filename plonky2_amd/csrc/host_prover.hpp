@@ -113,7 +113,12 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     P2_TRY(check_log(ctx, log_n + rate_bits, "commit"));
     if (W == 0) P2_FAIL(ctx, P2HOT_EINVAL, "commit: no polynomials (the reference panics on polynomials[0], fri/oracle.rs:90)");
     if (!cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit: null column table");
-    if (flags & ~(unsigned)P2HOT_KEEP_VALUES) P2_FAIL(ctx, P2HOT_EINVAL, "commit: unknown flags %#x", flags);
+    if (flags & ~(unsigned)(P2HOT_KEEP_VALUES | P2HOT_COEFFS_PER_COLUMN)) P2_FAIL(ctx, P2HOT_EINVAL, "commit: unknown flags %#x", flags);
+    // P2HOT_COEFFS_PER_COLUMN: coeffs_out is a table of W host pointers (one Vec per polynomial on the caller's side)
+    uint64_t *const *coeffs_cols = (flags & P2HOT_COEFFS_PER_COLUMN) ? reinterpret_cast<uint64_t *const *>(coeffs_out) : nullptr;
+    if (coeffs_cols)
+        for (size_t c = 0; c < W; ++c)
+            if (!coeffs_cols[c]) P2_FAIL(ctx, P2HOT_EINVAL, "commit: coefficient destination %zu is null", c);
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
     const unsigned log_N = log_n + rate_bits;
     if (cap_height > log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit: cap_height %u > log2(N) %u (merkle_tree.rs:195-200)", cap_height, log_N);
@@ -154,10 +159,8 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     // a large leaf matrix going back to the host gets the copy stream even when the columns are one block (W < 32: the Zs and
     // quotient commitments): its copy then runs beside the sponge as well
     const bool big_leaves = ctx->host_leaves_first && leaves_out && LW && nb >= 1 && LW * N * 8 >= ((size_t)64 << 20);
-#ifndef P2HOT_EMU
     const bool two_streams = nb > 1 || big_leaves;
     if (two_streams) copy_stream = ctx->side;
-#endif
     // With more than one block the leaf sponge does not wait for the last column: after each block's LDE it absorbs the
     // 8-column chunks that are complete (its state parked in a scratch block between launches), so the hashing -- three
     // quarters of the commit -- runs beside the uploads still in flight instead of behind them.
@@ -190,7 +193,6 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         return P2HOT_OK;
     };
     auto body = [&]() -> int {
-#ifndef P2HOT_EMU
         if (two_streams) {
             for (size_t b = 0; b < 2 * nb; ++b) {
                 hipEvent_t e;
@@ -201,18 +203,15 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             P2_HIP(ctx, hipEventRecord(ctx->join_event, ctx->stream));
             P2_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->join_event, 0));
         }
-#endif
         for (size_t b = 0; b < nb; ++b) {
             const size_t c0 = blk0[b], cnt = blk0[b + 1] - c0;
             u64 *blk = d_work.u() + c0 * n;
             u64 *land = keep_vals ? d_vals.u() + c0 * n : blk;  // where the upload lands
             P2_TRY(h2d_columns(ctx, land, cols + c0, cnt, n * 8, c0 * n * 8, W * n * 8 + S * N * 8, copy_stream));
-#ifndef P2HOT_EMU
             if (two_streams) {
                 P2_HIP(ctx, hipEventRecord(up[b], ctx->side));
                 P2_HIP(ctx, hipStreamWaitEvent(ctx->stream, up[b], 0));
             }
-#endif
             if (keep_vals) P2_HIP(ctx, hipMemcpyAsync(blk, land, cnt * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
             if (is_values) {  // "IFFT" (oracle.rs:65-69): the block becomes its coefficients in place
                 P2_TRY(ntt_natural(ctx, blk, cnt, n, log_n, true));
@@ -220,9 +219,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
                 P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(cnt * n, 256)), dim3(256), 0, ctx->stream, blk, cnt * n);
                 P2_LAUNCH_CHECK(ctx);
             }
-#ifndef P2HOT_EMU
             if (two_streams) P2_HIP(ctx, hipEventRecord(done[b], ctx->stream));
-#endif
             P2_TRY(p2hot_coset_lde_dev(ctx, blk, cnt, n, log_n, rate_bits, gl::COSET_SHIFT, 0, N, d_lde.u() + c0 * N, N));
             if (chunked) P2_TRY(absorb_upto(c0 + cnt, tail_groups == 1 && !S));  // (a grouped tail keeps the last chunk)
         }
@@ -235,12 +232,10 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         }
         if (leaves_first) {  // the row-major matrix before the sponge: its copy starts while the leaves are hashed
             P2_TRY(p2hot_transpose_dev(ctx, d_lde.u(), N, LW, N, d_leaves.u()));
-#ifndef P2HOT_EMU
             if (two_streams) {
                 P2_HIP(ctx, hipEventCreateWithFlags(&leaves_ev, hipEventDisableTiming));
                 P2_HIP(ctx, hipEventRecord(leaves_ev, ctx->stream));
             }
-#endif
         }
         if (chunked && tail_groups > 1) {
             const size_t cnt = N / tail_groups;
@@ -250,14 +245,12 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
                 P2_TRY(hash_leaves_chunks(ctx, ctx->stream, merkle::ColMajorReader{d_lde.u() + g * cnt, N}, LW, gg, cnt, hashed,
                                           (unsigned)LW, d_state.u() + g * cnt, N));
                 P2_TRY(merkle_levels(ctx, gg, cnt));
-#ifndef P2HOT_EMU
                 if (two_streams) {
                     hipEvent_t e;
                     P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
                     tail_ev.push_back(e);
                     P2_HIP(ctx, hipEventRecord(e, ctx->stream));
                 }
-#endif
             }
             hashed = (unsigned)LW;
         } else if (chunked) {
@@ -272,28 +265,27 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         if (coeffs_out)
             for (size_t b = 0; b < nb; ++b) {
                 const size_t c0 = blk0[b], cnt = blk0[b + 1] - c0;
-#ifndef P2HOT_EMU
                 if (two_streams) P2_HIP(ctx, hipStreamWaitEvent(ctx->side, done[b], 0));
-#endif
-                P2_HIP(ctx, hipMemcpyAsync(coeffs_out + c0 * n, d_work.u() + c0 * n, cnt * n * 8, hipMemcpyDeviceToHost, copy_stream));
+                if (coeffs_cols) {
+                    for (size_t c = c0; c < c0 + cnt; ++c)
+                        P2_HIP(ctx, hipMemcpyAsync(coeffs_cols[c], d_work.u() + c * n, n * 8, hipMemcpyDeviceToHost, copy_stream));
+                } else {
+                    P2_HIP(ctx, hipMemcpyAsync(coeffs_out + c0 * n, d_work.u() + c0 * n, cnt * n * 8, hipMemcpyDeviceToHost, copy_stream));
+                }
             }
         if (leaves_out && LW) {
             hipStream_t ls = ctx->stream;
-#ifndef P2HOT_EMU
             if (leaves_ev) {
                 P2_HIP(ctx, hipStreamWaitEvent(copy_stream, leaves_ev, 0));
                 ls = copy_stream;
             }
-#endif
             P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, LW * N * 8, hipMemcpyDeviceToHost, ls));
         }
         if (digests_out && nd && tail_groups > 1) {  // the groups' digest slices, each behind its group's levels only
             const size_t cnt = N / tail_groups, sub_leaves = N >> cap_height, sub_words = 8 * (sub_leaves - 1);
             for (size_t g = 0; g < tail_groups; ++g) {
                 const size_t w0 = (g * cnt / sub_leaves) * sub_words, nw = (cnt / sub_leaves) * sub_words;
-#ifndef P2HOT_EMU
                 if (two_streams) P2_HIP(ctx, hipStreamWaitEvent(copy_stream, tail_ev[g], 0));
-#endif
                 P2_HIP(ctx, hipMemcpyAsync(digests_out + w0, d_dig.u() + w0, nw * 8, hipMemcpyDeviceToHost, copy_stream));
             }
         } else if (digests_out && nd) {
@@ -304,13 +296,11 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     };
     int rc = body();
     hipError_t e1 = hipSuccess;
-#ifndef P2HOT_EMU
     if (two_streams) e1 = hipStreamSynchronize(ctx->side);
     for (hipEvent_t ev : up) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : done) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : tail_ev) (void)hipEventDestroy(ev);
     if (leaves_ev) (void)hipEventDestroy(leaves_ev);
-#endif
     rc = sync_checked(ctx, rc, "commit");
     if (rc == P2HOT_OK && e1 != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "commit: %s", hipGetErrorString(e1));
     if (rc == P2HOT_OK && handle_out) *handle_out = make_batch(ctx, d_lde, d_dig, d_work, keep_vals ? &d_vals : nullptr, W, log_n, rate_bits, cap_height, S);
@@ -349,7 +339,11 @@ extern "C" int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate
     const unsigned log_n = cols->log_n;
     P2_TRY(check_log(ctx, log_n + rate_bits, "commit_cols"));
     if (W == 0) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: no polynomials (the reference panics on polynomials[0], fri/oracle.rs:90)");
-    if (flags & ~(unsigned)P2HOT_KEEP_VALUES) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: unknown flags %#x", flags);
+    if (flags & ~(unsigned)(P2HOT_KEEP_VALUES | P2HOT_COEFFS_PER_COLUMN)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: unknown flags %#x", flags);
+    uint64_t *const *coeffs_cols = (flags & P2HOT_COEFFS_PER_COLUMN) ? reinterpret_cast<uint64_t *const *>(coeffs_out) : nullptr;
+    if (coeffs_cols)
+        for (size_t c = 0; c < W; ++c)
+            if (!coeffs_cols[c]) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: coefficient destination %zu is null", c);
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
     const unsigned log_N = log_n + rate_bits;
     if (cap_height > log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: cap_height %u > log2(N) %u (merkle_tree.rs:195-200)", cap_height, log_N);
@@ -379,7 +373,11 @@ extern "C" int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate
         }
         P2_TRY(p2hot_commit_dev(ctx, co, n, W, log_n, rate_bits, cap_height, 0, 0, N, nullptr, 0, d_lde.u(), N,
                                 leaves_out ? d_leaves.u() : nullptr, d_dig.u(), d_cap.u()));
-        if (coeffs_out && W) P2_HIP(ctx, hipMemcpyAsync(coeffs_out, co, W * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (coeffs_cols) {
+            for (size_t c = 0; c < W; ++c) P2_HIP(ctx, hipMemcpyAsync(coeffs_cols[c], co + c * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        } else if (coeffs_out && W) {
+            P2_HIP(ctx, hipMemcpyAsync(coeffs_out, co, W * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
         if (leaves_out && W) P2_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves.p, W * N * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (digests_out && nd) P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
         if (cap_out) P2_TRY(d2h(ctx, cap_out, d_cap.p, cap_words * 8));
@@ -791,9 +789,7 @@ extern "C" int p2hot_prove_openings(p2hot_ctx *ctx, const p2hot_fri_batch_info *
 static int helper_contexts(p2hot_ctx *ctx, size_t want) {
     while (ctx->helpers.size() < want) {
         hipStream_t st = nullptr;
-#ifndef P2HOT_EMU
         P2_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-#endif
         p2hot_ctx *h = nullptr;
         int rc = p2hot_ctx_create(ctx->device, (void *)st, &h);
         if (rc != P2HOT_OK) {

@@ -78,7 +78,7 @@ struct p2hot_ctx {
     struct Scratch {
         void *p = nullptr;
         size_t cap = 0;
-    } scratch[3];  // 0: NTT temporary, 1: final_poly, 2: FRI commit phase (grow-only, reused across calls)
+    } scratch[4];  // 0: NTT temporary, 1: final_poly, 2: FRI commit phase, 3: all-gather staging of the sharded commit (grow-only, reused across calls)
     // coset scale tables keyed by (log_n, rate_bits, shift, first block, block count, first-pass log_r)
     std::map<std::tuple<unsigned, unsigned, u64, size_t, size_t, unsigned>, u64 *> scale_cache;
     std::map<std::tuple<int, unsigned, unsigned>, u64 *> twid_cache;
@@ -101,6 +101,29 @@ struct p2hot_ctx {
     std::string prof_text;
 };
 
+// Makes the context's GPU the calling thread's current device for the scope (allocations, pinned memory and launches follow the
+// current device) and restores the caller's on exit.  Every entry point that takes a context holds one: after a p2hot_group_*
+// call -- which walks over the ranks' devices -- a single-context call on p2hot_group_ctx(group, r) must not inherit the last
+// rank's device.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const p2hot_ctx *ctx) {
+        if (!ctx) return;
+#ifdef P2HOT_EMU
+        if (emu::fault_no_device_guard) return;  // test hook of the emulator build: what a missing guard looks like (tests/test_emu_devices.py)
+#endif
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    explicit DeviceGuard(int keep_current) { (void)keep_current; if (hipGetDevice(&prev) == hipSuccess) switched = true; }  // restore only
+    ~DeviceGuard() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 // Brackets the launches of one kernel family with events when profiling is on.
 struct ProfScope {
     p2hot_ctx *ctx;
@@ -109,20 +132,19 @@ struct ProfScope {
     hipStream_t stream;
     ProfScope(p2hot_ctx *c, const char *n, hipStream_t st = nullptr, bool use_st = false)
         : ctx(c), name(n), stream(use_st ? st : c->stream) {
-#ifndef P2HOT_EMU
-        if (ctx->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
-            (void)hipEventRecord(e0, stream);
-#endif
+        if (!ctx->profiling) return;
+        // events belong to the device that is current when they are made and are recorded on a stream of that device: the
+        // multi-GPU loops construct and leave this scope with ANOTHER rank's device current (found by the emulated node,
+        // tests/test_emu_devices.py: hipEventRecord on rank 0's communication stream while the last rank's device was current)
+        DeviceGuard dev_guard_(ctx);
+        if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) (void)hipEventRecord(e0, stream);
     }
     ~ProfScope() {
-#ifndef P2HOT_EMU
         if (e0 && e1) {
+            DeviceGuard dev_guard_(ctx);
             (void)hipEventRecord(e1, stream);
             ctx->prof.push_back({name, e0, e1});
         }
-#else
-        if (ctx->profiling) ctx->prof_acc[name].second += 1;  // the emulator has no clock: launches only
-#endif
     }
 };
 
@@ -149,26 +171,6 @@ struct ProfScope {
     } while (0)
 
 #define P2_LAUNCH_CHECK(ctx) P2_HIP(ctx, hipGetLastError())
-
-// Makes the context's GPU the calling thread's current device for the scope (allocations, pinned memory and launches follow the
-// current device) and restores the caller's on exit.  Every entry point that takes a context holds one: after a p2hot_group_*
-// call -- which walks over the ranks' devices -- a single-context call on p2hot_group_ctx(group, r) must not inherit the last
-// rank's device.
-struct DeviceGuard {
-    int prev = -1;
-    bool switched = false;
-    explicit DeviceGuard(const p2hot_ctx *ctx) {
-        if (!ctx) return;
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
-    }
-    explicit DeviceGuard(int keep_current) { (void)keep_current; if (hipGetDevice(&prev) == hipSuccess) switched = true; }  // restore only
-    ~DeviceGuard() {
-        if (switched && prev >= 0) (void)hipSetDevice(prev);
-    }
-    DeviceGuard(const DeviceGuard &) = delete;
-    DeviceGuard &operator=(const DeviceGuard &) = delete;
-};
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
@@ -246,7 +248,6 @@ static int h2d_columns(p2hot_ctx *ctx, void *d_dst, const uint64_t *const *cols,
             return P2HOT_OK;
         }
     }
-#ifndef P2HOT_EMU
     // More short columns than the staging block holds (p2hot_commit_many of dozens of recursion-size proofs: thousands of 32 KB
     // vectors, each ~10 us of host time as a pageable copy): the block's two halves take slices in turn, a half being refilled
     // once the copy that read it has finished.
@@ -278,7 +279,6 @@ static int h2d_columns(p2hot_ctx *ctx, void *d_dst, const uint64_t *const *cols,
             return P2HOT_OK;
         }
     }
-#endif
     for (size_t c = 0; c < count; ++c)
         P2_HIP(ctx, hipMemcpyAsync((unsigned char *)d_dst + c * bytes, cols[c], bytes, hipMemcpyHostToDevice, stream));
     return P2HOT_OK;
@@ -389,10 +389,8 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     *out = ctx;  // returned even on failure so the caller can read last_error, then destroy
     P2_HIP(ctx, hipSetDevice(device));
     ctx->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream
-#ifndef P2HOT_EMU
     P2_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     P2_HIP(ctx, hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming));
-#endif
     P2_HIP(ctx, hipMalloc((void **)&ctx->tables, (4 * 65536 + 4 * (1u << ntt::TILE_LOG) + 1) * sizeof(u64)));
     ctx->d_oob = (unsigned *)(ctx->tables + 4 * 65536 + 4 * (1u << ntt::TILE_LOG));
     P2_HIP(ctx, hipMemsetAsync(ctx->d_oob, 0, 8, ctx->stream));
@@ -431,19 +429,15 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
     for (size_t k = 0; k < ctx->helpers.size(); ++k) {
         if (k < ctx->helper_challengers.size()) p2hot_challenger_destroy(ctx->helper_challengers[k]);
         p2hot_ctx_destroy(ctx->helpers[k]);
-#ifndef P2HOT_EMU
         if (k < ctx->helper_streams.size() && ctx->helper_streams[k]) (void)hipStreamDestroy(ctx->helper_streams[k]);
-#endif
     }
     ctx->helpers.clear();
-#ifndef P2HOT_EMU
     if (ctx->side) {
         (void)hipStreamSynchronize(ctx->side);
         (void)hipStreamDestroy(ctx->side);
     }
     for (auto e : ctx->fork_events) (void)hipEventDestroy(e);
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
-#endif
     for (auto &kv : ctx->scale_cache) (void)hipFree(kv.second);
     for (auto &kv : ctx->twid_cache) (void)hipFree(kv.second);
     for (auto &kv : ctx->limb_tw_cache) {
@@ -457,10 +451,8 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
     if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_oob) (void)hipHostFree(ctx->pinned_oob);
-#ifndef P2HOT_EMU
     for (int k = 0; k < 2; ++k)
         if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
-#endif
     if (ctx->pinned_up) (void)hipHostFree(ctx->pinned_up);
     delete ctx;
 }
@@ -480,10 +472,8 @@ extern "C" int p2hot_ctx_sync(p2hot_ctx *ctx) {
     DeviceGuard dev_guard_(ctx);
     unsigned f = 0;
     unsigned *slot = &f;
-#ifndef P2HOT_EMU
     if (!ctx->pinned_oob && hipHostMalloc((void **)&ctx->pinned_oob, 64, hipHostMallocDefault) != hipSuccess) ctx->pinned_oob = nullptr;
     if (ctx->pinned_oob) slot = ctx->pinned_oob;
-#endif
     P2_HIP(ctx, hipMemcpyAsync(slot, ctx->d_oob, 4, hipMemcpyDeviceToHost, ctx->stream));
     P2_HIP(ctx, stream_sync(ctx));
     f = *slot;
@@ -542,7 +532,7 @@ extern "C" int p2hot_profile_enable(p2hot_ctx *ctx, int on) {
 // {"kernel": {"ms": total, "launches": count}, ...}; reset != 0 clears the accumulators afterwards.
 extern "C" const char *p2hot_profile_json(p2hot_ctx *ctx, int reset) {
     if (!ctx) return "{}";
-#ifndef P2HOT_EMU
+    DeviceGuard dev_guard_(ctx);
     (void)stream_sync(ctx);
     for (auto &r : ctx->prof) {
         float ms = 0.f;
@@ -555,7 +545,6 @@ extern "C" const char *p2hot_profile_json(p2hot_ctx *ctx, int reset) {
         (void)hipEventDestroy(r.e1);
     }
     ctx->prof.clear();
-#endif
     std::string t = "{";
     bool first = true;
     for (auto &kv : ctx->prof_acc) {
@@ -1187,7 +1176,6 @@ extern "C" int p2hot_commit_dev(p2hot_ctx *ctx, const uint64_t *d_cols, size_t c
     }
     // "FFT + blinding" + "transpose LDEs" + reverse_index_bits (oracle.rs:91-98), "build Merkle tree" (oracle.rs:99-103)
     const size_t blocks = row_count >> log_n;
-#ifndef P2HOT_EMU
     if (ctx->overlap && W > 0 && blocks > 1 && row_count % n == 0) {
         // Coset blocks are independent: the LDE of block b+1 (wait-bound) runs on the main stream while the
         // Poseidon leaf sponge of block b (VALU-bound) runs on the side stream; the levels follow the join.
@@ -1210,7 +1198,6 @@ extern "C" int p2hot_commit_dev(p2hot_ctx *ctx, const uint64_t *d_cols, size_t c
         P2_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->join_event, 0));
         P2_TRY(merkle_levels(ctx, g, row_count));
     } else
-#endif
     {
         (void)blocks;
         P2_TRY(p2hot_coset_lde_dev(ctx, coeff_src, W, coeff_src_stride, log_n, rate_bits, gl::COSET_SHIFT, row_begin,

@@ -181,6 +181,14 @@ class Communicator:
         if self.world > 1 or self.transport == "rccl":
             self.engine.check(self.engine.lib.p2hot_comm_selftest(self._h, nbytes))
 
+    @property
+    def exchange(self):
+        """how equal slices travel on the RCCL transport: "allgather" (ncclAllGather) or "broadcast" (grouped ncclBroadcast);
+        decided by the selftest's micro-timing unless P2HOT_EXCHANGE pins it (include/p2hot.h, p2hot_comm_exchange_mode)"""
+        if self.transport != "rccl" or not self._h:
+            return None
+        return {0: "broadcast", 1: "allgather"}.get(self.engine.lib.p2hot_comm_exchange_mode(self._h))
+
     def close(self):
         if self._h and getattr(self.engine, "_ctx", None):
             self.engine.lib.p2hot_comm_destroy(self._h)
@@ -269,6 +277,11 @@ class GroupCommit:
     @property
     def uses_rccl(self):
         return bool(self.lib.p2hot_group_uses_rccl(self._h))
+
+    @property
+    def exchange(self):
+        """how equal slices travel over RCCL: "allgather" (ncclAllGather) or "broadcast" (grouped ncclBroadcast), see include/p2hot.h"""
+        return {0: "broadcast", 1: "allgather"}.get(self.lib.p2hot_group_exchange_mode(self._h), "none")
 
     def _check(self, rc):
         if rc != _lib.OK:

@@ -77,50 +77,64 @@ static inline unsigned atomicOr(unsigned *p, unsigned v) {
     return o;
 }
 
-// ---- host API subset (malloc-backed) ----
+// ---- host API subset: a small model of the HIP RUNTIME semantics the multi-GPU layer depends on (hip_emu.cpp) ----
+// * P2HOT_EMU_DEVICES "GPUs" (default 8).  Each host thread has a current device (hipSetDevice / hipGetDevice).
+// * hipMalloc returns page-aligned memory tagged with the device that was current; while another device is current the
+//   pages are PROT_NONE, so a kernel, a host loop or a memcpy that touches another GPU's memory faults, and the fault handler
+//   names the allocation, its device and the current device before aborting (an access from a thread whose OWN current device
+//   owns the pages is let through: protection is process-wide, the current device is per thread).
+// * Streams and events belong to the device that was current when they were created.  A launch, copy, memset, event record
+//   or stream wait issued on a stream of another device than the current one fails with hipErrorInvalidResourceHandle and a
+//   message (hipGetErrorString); so does recording an event on a stream of another device, or using a destroyed handle.
+// * Copies BETWEEN devices go through hipMemcpyAsync / hipMemcpy2DAsync only (explicit peer copies: counted, see emu::stats).
+// * A fake RCCL (ncclCommInitAll / ncclCommInitRank / grouped ncclBroadcast / ncclAllGather, rccl_emu.h) enforces per-rank
+//   device, stream and buffer identity and refuses collectives that would hang on the real library.
+// Work executes synchronously in program order: ordering bugs (a missing event wait) are NOT modelled.
 typedef int hipError_t;
 typedef void *hipStream_t;
 typedef void *hipEvent_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidDevice = 101, hipErrorInvalidResourceHandle = 400 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipGetDevice(int *d) {
-    *d = 0;
-    return hipSuccess;
-}
-static inline hipError_t hipMalloc(void **p, size_t n) {
-    *p = malloc(n ? n : 1);
-    return *p ? hipSuccess : hipErrorOutOfMemory;
-}
-static inline hipError_t hipFree(void *p) {
-    free(p);
-    return hipSuccess;
-}
-enum { hipHostMallocDefault = 0 };
-static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
-static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
-static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) {
-    memmove(d, s, n);
-    return hipSuccess;
-}
-static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) {
-    memmove(d, s, n);
-    return hipSuccess;
-}
-static inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height,
-                                          hipMemcpyKind, hipStream_t) {
-    for (size_t r = 0; r < height; ++r) memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width);
-    return hipSuccess;
-}
-static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
-    memset(d, v, n);
-    return hipSuccess;
-}
-static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
-static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) {
-    *f = *t = (size_t)1 << 34;
-    return hipSuccess;
-}
+enum { hipHostMallocDefault = 0, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+
+namespace emu {
+struct Stats {
+    unsigned long long peer_copies = 0, peer_bytes = 0;        // hipMemcpy* between two devices' allocations
+    unsigned long long nccl_broadcasts = 0, nccl_allgathers = 0, nccl_bytes = 0;
+    unsigned long long device_switches = 0, violations = 0;    // violations: API calls refused for a device / handle mismatch
+};
+extern Stats stats;
+extern bool fault_no_device_guard;  // test hook (p2hot_emu_fault): DeviceGuard becomes a no-op, so a mis-guarded entry point is visible
+int current_device();
+int device_of(const void *p);       // device owning the allocation that contains p, -1: host / unknown memory
+// kernel launch on `stream`: refused (sticky error for hipGetLastError) unless the stream belongs to the current device
+void launch_on(hipStream_t stream, dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
+}  // namespace emu
+
+hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int *d);
+hipError_t hipGetDeviceCount(int *n);
+hipError_t hipDeviceEnablePeerAccess(int peer, unsigned flags);
+hipError_t hipMalloc(void **p, size_t n);
+hipError_t hipFree(void *p);
+hipError_t hipHostMalloc(void **p, size_t n, unsigned flags);
+hipError_t hipHostFree(void *p);
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind kind, hipStream_t stream);
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind kind);
+hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, hipMemcpyKind kind,
+                            hipStream_t stream);
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t stream);
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
+hipError_t hipEventCreate(hipEvent_t *e);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipDeviceSynchronize();
+hipError_t hipGetLastError();
+const char *hipGetErrorString(hipError_t e);
+hipError_t hipMemGetInfo(size_t *f, size_t *t);

@@ -1,0 +1,583 @@
+// hip_emu_rt.cpp -- TEST INFRASTRUCTURE ONLY (see hip_emu.h): the emulated HIP runtime -- devices, device-tagged allocations
+// behind page protection, streams and events with device identity -- and a fake RCCL.  None of this is linked into the product.
+#include <signal.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <string>
+
+#include "hip_emu.h"
+#include "rccl_emu.h"
+
+namespace emu {
+Stats stats;
+bool fault_no_device_guard = false;
+
+namespace {
+struct Alloc {
+    size_t bytes = 0, mapped = 0;
+    int device = -1;   // -1: host (pinned) memory
+    bool open = true;  // pages currently readable / writable
+};
+std::mutex mu;                        // registry lock; never held while user memory is touched
+std::map<uintptr_t, Alloc> allocs;    // base address -> allocation
+int n_devices = 0;
+int open_device = 0;                  // the device whose allocations are currently accessible (process-wide)
+thread_local int tls_device = 0;
+thread_local std::string tls_error;
+thread_local hipError_t tls_sticky = hipSuccess;
+std::set<std::pair<int, int>> peer_enabled;
+
+struct Stream {
+    int device;
+};
+struct Event {
+    int device;
+    bool recorded = false;
+};
+std::set<void *> live_streams, live_events;
+
+size_t page() {
+    static const size_t p = (size_t)sysconf(_SC_PAGESIZE);
+    return p;
+}
+
+int device_count() {
+    if (n_devices == 0) {
+        const char *e = getenv("P2HOT_EMU_DEVICES");
+        n_devices = e ? std::max(1, atoi(e)) : 8;
+    }
+    return n_devices;
+}
+
+hipError_t violation(hipError_t code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    tls_error = std::string("hip_emu: ") + buf;
+    ++stats.violations;
+    if (getenv("P2HOT_EMU_TRACE")) fprintf(stderr, "%s\n", tls_error.c_str());
+    return code;
+}
+
+std::map<uintptr_t, Alloc>::iterator find_alloc(const void *p) {  // caller holds mu
+    const uintptr_t a = (uintptr_t)p;
+    auto it = allocs.upper_bound(a);
+    if (it == allocs.begin()) return allocs.end();
+    --it;
+    return a < it->first + std::max(it->second.bytes, it->second.mapped) ? it : allocs.end();
+}
+
+void set_open(std::map<uintptr_t, Alloc>::iterator it, bool open) {  // caller holds mu
+    if (it->second.device < 0 || it->second.open == open) return;
+    mprotect((void *)it->first, it->second.mapped, open ? (PROT_READ | PROT_WRITE) : PROT_NONE);
+    it->second.open = open;
+}
+
+// makes the device allocations containing the given pointers accessible for the lifetime of the object, whatever device is
+// current (the runtime's own copies: peer copies, device <-> host copies issued from another device's context)
+struct Access {
+    std::vector<uintptr_t> reopened;
+    Access(std::initializer_list<const void *> ptrs) {
+        std::lock_guard<std::mutex> l(mu);
+        for (const void *p : ptrs) {
+            auto it = find_alloc(p);
+            if (it != allocs.end() && !it->second.open) {
+                set_open(it, true);
+                reopened.push_back(it->first);
+            }
+        }
+    }
+    ~Access() {
+        std::lock_guard<std::mutex> l(mu);
+        for (uintptr_t b : reopened) {
+            auto it = allocs.find(b);
+            if (it != allocs.end() && it->second.device != open_device) set_open(it, false);
+        }
+    }
+};
+
+struct sigaction old_segv;
+void on_segv(int sig, siginfo_t *info, void *uctx) {
+    const void *addr = info->si_addr;
+    bool ours = false, let_through = false;
+    int dev = -1;
+    size_t bytes = 0;
+    uintptr_t base = 0;
+    if (mu.try_lock()) {
+        auto it = find_alloc(addr);
+        if (it != allocs.end() && it->second.device >= 0 && !it->second.open) {
+            ours = true;
+            dev = it->second.device;
+            bytes = it->second.bytes;
+            base = it->first;
+            if (dev == tls_device) {  // another thread switched the process-wide window: this thread's own device owns the pages
+                set_open(it, true);
+                let_through = true;
+            }
+        }
+        mu.unlock();
+    }
+    if (let_through) return;
+    if (ours) {
+        fprintf(stderr,
+                "hip_emu: DEVICE MEMORY FAULT: address %p lies in a %zu-byte allocation of device %d (base %p) but device %d is current "
+                "-- a kernel, a host loop or a copy touched another GPU's memory without an explicit peer copy\n",
+                addr, bytes, dev, (void *)base, tls_device);
+        fflush(stderr);
+        abort();
+    }
+    // not an emulated device allocation: hand the fault to whoever was installed before (pytest's faulthandler, the default action)
+    sigaction(SIGSEGV, &old_segv, nullptr);
+    (void)sig, (void)uctx;
+}
+
+void install_handler() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = on_segv;
+    sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGSEGV, &sa, &old_segv);
+}
+
+hipError_t check_stream(hipStream_t s, const char *what) {
+    if (!s) return hipSuccess;  // the null stream is the current device's
+    std::lock_guard<std::mutex> l(mu);
+    if (!live_streams.count(s)) return violation(hipErrorInvalidResourceHandle, "%s: the stream handle %p was destroyed or never created", what, s);
+    const int d = ((Stream *)s)->device;
+    if (d != tls_device)
+        return violation(hipErrorInvalidResourceHandle, "%s on a stream of device %d while device %d is current (hipSetDevice is missing or stale)", what, d,
+                         tls_device);
+    return hipSuccess;
+}
+
+int stream_device(hipStream_t s) { return s ? ((Stream *)s)->device : tls_device; }
+}  // namespace
+
+int current_device() { return tls_device; }
+
+int device_of(const void *p) {
+    std::lock_guard<std::mutex> l(mu);
+    auto it = find_alloc(p);
+    return it == allocs.end() ? -1 : it->second.device;
+}
+
+void launch_on(hipStream_t stream, dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body) {
+    hipError_t e = check_stream(stream, "kernel launch");
+    if (e != hipSuccess) {
+        tls_sticky = e;  // reported by the hipGetLastError that follows every launch
+        return;
+    }
+    launch(grid, block, shmem, body);
+}
+}  // namespace emu
+
+using namespace emu;
+
+hipError_t hipSetDevice(int d) {
+    if (d < 0 || d >= device_count()) return violation(hipErrorInvalidDevice, "hipSetDevice(%d): the emulated node has %d devices", d, device_count());
+    tls_device = d;
+    std::lock_guard<std::mutex> l(mu);
+    if (d != open_device) {
+        ++stats.device_switches;
+        for (auto it = allocs.begin(); it != allocs.end(); ++it)
+            if (it->second.device >= 0) set_open(it, it->second.device == d);
+        open_device = d;
+    }
+    return hipSuccess;
+}
+hipError_t hipGetDevice(int *d) {
+    *d = tls_device;
+    return hipSuccess;
+}
+hipError_t hipGetDeviceCount(int *n) {
+    *n = device_count();
+    return hipSuccess;
+}
+hipError_t hipDeviceEnablePeerAccess(int peer, unsigned) {
+    if (peer < 0 || peer >= device_count() || peer == tls_device) return violation(hipErrorInvalidDevice, "hipDeviceEnablePeerAccess(%d) from device %d", peer, tls_device);
+    std::lock_guard<std::mutex> l(mu);
+    peer_enabled.insert({tls_device, peer});
+    return hipSuccess;
+}
+
+hipError_t hipMalloc(void **p, size_t n) {
+    install_handler();
+    const size_t mapped = ((n ? n : 1) + page() - 1) / page() * page();
+    void *m = mmap(nullptr, mapped, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) {
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    std::lock_guard<std::mutex> l(mu);
+    Alloc a;
+    a.bytes = n;
+    a.mapped = mapped;
+    a.device = tls_device;
+    a.open = true;
+    auto it = allocs.emplace((uintptr_t)m, a).first;
+    if (tls_device != open_device) set_open(it, false);  // (another thread's device holds the window; this thread's first touch reopens it)
+    *p = m;
+    return hipSuccess;
+}
+hipError_t hipFree(void *p) {
+    if (!p) return hipSuccess;
+    std::lock_guard<std::mutex> l(mu);
+    auto it = allocs.find((uintptr_t)p);
+    if (it == allocs.end() || it->second.device < 0) return violation(hipErrorInvalidValue, "hipFree(%p): not the base of a live device allocation", p);
+    munmap(p, it->second.mapped);
+    allocs.erase(it);
+    return hipSuccess;
+}
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) {
+    *p = malloc(n ? n : 1);
+    if (!*p) return hipErrorOutOfMemory;
+    std::lock_guard<std::mutex> l(mu);
+    Alloc a;
+    a.bytes = n ? n : 1;
+    a.device = -1;
+    allocs.emplace((uintptr_t)*p, a);
+    return hipSuccess;
+}
+hipError_t hipHostFree(void *p) {
+    if (!p) return hipSuccess;
+    {
+        std::lock_guard<std::mutex> l(mu);
+        auto it = allocs.find((uintptr_t)p);
+        if (it == allocs.end() || it->second.device >= 0) return violation(hipErrorInvalidValue, "hipHostFree(%p): not a live pinned allocation", p);
+        allocs.erase(it);
+    }
+    free(p);
+    return hipSuccess;
+}
+
+static void count_peer(const void *d, const void *s, size_t n) {
+    const int dd = device_of(d), ds = device_of(s);
+    if (dd >= 0 && ds >= 0 && dd != ds) {
+        ++stats.peer_copies;
+        stats.peer_bytes += n;
+    }
+}
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t stream) {
+    hipError_t e = check_stream(stream, "hipMemcpyAsync");
+    if (e != hipSuccess) return e;
+    if (n == 0) return hipSuccess;
+    count_peer(d, s, n);
+    Access acc{d, s};
+    memmove(d, s, n);
+    return hipSuccess;
+}
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind k) { return hipMemcpyAsync(d, s, n, k, nullptr); }
+hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t stream) {
+    hipError_t e = check_stream(stream, "hipMemcpy2DAsync");
+    if (e != hipSuccess) return e;
+    if (width == 0 || height == 0) return hipSuccess;
+    count_peer(d, s, width * height);
+    Access acc{d, s};
+    for (size_t r = 0; r < height; ++r) memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width);
+    return hipSuccess;
+}
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t stream) {
+    hipError_t e = check_stream(stream, "hipMemsetAsync");
+    if (e != hipSuccess) return e;
+    const int dd = device_of(d);
+    if (dd >= 0 && dd != tls_device) return violation(hipErrorInvalidValue, "hipMemsetAsync on memory of device %d while device %d is current", dd, tls_device);
+    memset(d, v, n);
+    return hipSuccess;
+}
+
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
+    Stream *st = new Stream{tls_device};
+    std::lock_guard<std::mutex> l(mu);
+    live_streams.insert(st);
+    *s = st;
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s) {
+    std::lock_guard<std::mutex> l(mu);
+    if (!s || !live_streams.erase(s)) return violation(hipErrorInvalidResourceHandle, "hipStreamDestroy(%p): not a live stream", s);
+    delete (Stream *)s;
+    return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t s) {  // any device's stream may be synchronised from any thread
+    if (!s) return hipSuccess;
+    std::lock_guard<std::mutex> l(mu);
+    if (!live_streams.count(s)) return violation(hipErrorInvalidResourceHandle, "hipStreamSynchronize(%p): the stream was destroyed or never created", s);
+    return hipSuccess;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) {
+    Event *ev = new Event{tls_device};
+    std::lock_guard<std::mutex> l(mu);
+    live_events.insert(ev);
+    *e = ev;
+    return hipSuccess;
+}
+hipError_t hipEventCreate(hipEvent_t *e) { return hipEventCreateWithFlags(e, 0); }
+hipError_t hipEventDestroy(hipEvent_t e) {
+    std::lock_guard<std::mutex> l(mu);
+    if (!e || !live_events.erase(e)) return violation(hipErrorInvalidResourceHandle, "hipEventDestroy(%p): not a live event", e);
+    delete (Event *)e;
+    return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+    hipError_t rc = check_stream(s, "hipEventRecord");
+    if (rc != hipSuccess) return rc;
+    std::lock_guard<std::mutex> l(mu);
+    if (!live_events.count(e)) return violation(hipErrorInvalidResourceHandle, "hipEventRecord: the event %p was destroyed or never created", e);
+    Event *ev = (Event *)e;
+    if (ev->device != stream_device(s))
+        return violation(hipErrorInvalidResourceHandle, "hipEventRecord: an event of device %d recorded on a stream of device %d", ev->device, stream_device(s));
+    ev->recorded = true;
+    return hipSuccess;
+}
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
+    hipError_t rc = check_stream(s, "hipStreamWaitEvent");
+    if (rc != hipSuccess) return rc;
+    std::lock_guard<std::mutex> l(mu);
+    if (!live_events.count(e)) return violation(hipErrorInvalidResourceHandle, "hipStreamWaitEvent: the event %p was destroyed or never created", e);
+    return hipSuccess;  // (an event of ANOTHER device is fine: that is how the ranks' streams are ordered against each other)
+}
+hipError_t hipEventSynchronize(hipEvent_t e) {
+    std::lock_guard<std::mutex> l(mu);
+    if (!live_events.count(e)) return violation(hipErrorInvalidResourceHandle, "hipEventSynchronize: the event %p was destroyed or never created", e);
+    return hipSuccess;
+}
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    std::lock_guard<std::mutex> l(mu);
+    if (!live_events.count(a) || !live_events.count(b)) return violation(hipErrorInvalidResourceHandle, "hipEventElapsedTime: dead event");
+    *ms = 0.f;  // the emulator has no clock
+    return hipSuccess;
+}
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipGetLastError() {
+    hipError_t e = tls_sticky;
+    tls_sticky = hipSuccess;
+    return e;
+}
+const char *hipGetErrorString(hipError_t e) {
+    if (e != hipSuccess && !tls_error.empty()) return tls_error.c_str();
+    return e == hipErrorOutOfMemory ? "hip_emu: out of memory" : "hip_emu: error";
+}
+hipError_t hipMemGetInfo(size_t *f, size_t *t) {
+    *f = *t = (size_t)1 << 34;
+    return hipSuccess;
+}
+
+// ================================================================= fake RCCL
+// What the multi-GPU layer needs from the collectives library, with the rules whose violation hangs or corrupts on the real
+// one turned into errors: a communicator rank is bound to ONE device; the stream of a collective must belong to it; the
+// buffers must live on it (or be untracked test memory); one thread driving several ranks must bracket their calls with
+// ncclGroupStart / ncclGroupEnd, and every rank of the communicator must post the same sequence of collectives.
+namespace {
+struct Clique;
+struct Comm {
+    int rank, nranks, device;
+    std::shared_ptr<Clique> clique;
+};
+struct Clique {
+    std::vector<Comm *> members;
+};
+struct Op {
+    int kind;  // 0 broadcast, 1 all-gather
+    Comm *comm;
+    const void *send;
+    void *recv;
+    size_t bytes;
+    int root;
+};
+std::set<void *> live_comms;
+thread_local int group_depth = 0;
+thread_local std::vector<Op> queued;
+thread_local std::string nccl_error;
+unsigned long long uid_counter = 0;
+
+int nccl_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    nccl_error = std::string("rccl_emu: ") + buf;
+    ++stats.violations;
+    if (getenv("P2HOT_EMU_TRACE")) fprintf(stderr, "%s\n", nccl_error.c_str());
+    return code;
+}
+size_t dtype_bytes(int dt) { return dt == 0 || dt == 1 ? 1 : dt == 2 || dt == 3 || dt == 7 ? 4 : dt == 4 || dt == 5 || dt == 8 ? 8 : dt == 6 ? 2 : 0; }
+
+void move(void *d, const void *s, size_t n) {
+    if (d == s || n == 0) return;
+    Access acc{d, s};
+    memmove(d, s, n);
+    stats.nccl_bytes += n;
+}
+
+int validate(const char *what, Comm *c, const void *send, void *recv, hipStream_t stream) {
+    {
+        std::lock_guard<std::mutex> l(mu);
+        if (!live_comms.count(c)) return nccl_fail(4, "%s: the communicator %p was destroyed or never created", what, (void *)c);
+        if (stream && !live_streams.count(stream)) return nccl_fail(4, "%s: rank %d was handed a dead stream", what, c->rank);
+    }
+    const int sd = stream ? ((Stream *)stream)->device : tls_device;
+    if (sd != c->device)
+        return nccl_fail(5, "%s: rank %d of the communicator lives on device %d but its stream belongs to device %d (ncclInvalidUsage)", what, c->rank, c->device, sd);
+    for (const void *p : {send, (const void *)recv}) {
+        const int d = device_of(p);
+        if (d >= 0 && d != c->device)
+            return nccl_fail(5, "%s: rank %d (device %d) was handed a buffer of device %d", what, c->rank, c->device, d);
+    }
+    return 0;
+}
+
+int run_group(std::vector<Op> &ops) {
+    std::map<Clique *, std::map<int, std::vector<Op>>> by;  // clique -> rank -> ops in posting order
+    for (auto &o : ops) by[o.comm->clique.get()][o.comm->rank].push_back(o);
+    for (auto &kv : by) {
+        Clique *cl = kv.first;
+        auto &ranks = kv.second;
+        const size_t n_ops = ranks.begin()->second.size();
+        if (ranks.size() != cl->members.size())
+            return nccl_fail(5, "a collective group covers %zu of the %zu ranks of its communicator: the others never arrive (would hang)", ranks.size(), cl->members.size());
+        for (auto &r : ranks)
+            if (r.second.size() != n_ops) return nccl_fail(5, "rank %d posted %zu collectives, rank %d posted %zu (would hang)", r.first, r.second.size(), ranks.begin()->first, n_ops);
+        for (size_t k = 0; k < n_ops; ++k) {
+            const Op &o0 = ranks.begin()->second[k];
+            for (auto &r : ranks) {
+                const Op &o = r.second[k];
+                if (o.kind != o0.kind || o.bytes != o0.bytes || o.root != o0.root)
+                    return nccl_fail(5, "collective %zu differs between ranks (kind %d/%d, bytes %zu/%zu, root %d/%d): mismatched collectives", k, o.kind, o0.kind, o.bytes, o0.bytes, o.root, o0.root);
+            }
+            if (o0.kind == 0) {
+                if (o0.root < 0 || o0.root >= (int)cl->members.size()) return nccl_fail(4, "ncclBroadcast: root %d out of range", o0.root);
+                const void *src = ranks[o0.root][k].send;
+                for (auto &r : ranks) move(r.second[k].recv, src, o0.bytes);
+                ++stats.nccl_broadcasts;
+            } else {
+                // every rank's contribution is staged first: an in-place all-gather reads a slot another rank's copy may overwrite
+                std::vector<std::vector<unsigned char>> stage(ranks.size());
+                for (auto &r : ranks) {
+                    stage[(size_t)r.first].resize(o0.bytes);
+                    Access acc{r.second[k].send};
+                    memcpy(stage[(size_t)r.first].data(), r.second[k].send, o0.bytes);
+                }
+                for (auto &r : ranks)
+                    for (size_t q = 0; q < stage.size(); ++q) {
+                        Access acc{r.second[k].recv};
+                        memcpy((char *)r.second[k].recv + q * o0.bytes, stage[q].data(), o0.bytes);
+                        stats.nccl_bytes += o0.bytes;
+                    }
+                ++stats.nccl_allgathers;
+            }
+        }
+    }
+    return 0;
+}
+
+int post(Op o) {
+    if (group_depth > 0) {
+        queued.push_back(o);
+        return 0;
+    }
+    if (o.comm->nranks > 1)
+        return nccl_fail(5, "a collective on a %d-rank communicator outside ncclGroupStart / ncclGroupEnd from the one thread that drives every rank: "
+                            "the real library blocks here for ever", o.comm->nranks);
+    std::vector<Op> one{o};
+    return run_group(one);
+}
+}  // namespace
+
+extern "C" {
+int emu_ncclGetUniqueId(char *id128) {
+    memset(id128, 0, 128);
+    const unsigned long long c = ++uid_counter;
+    memcpy(id128, &c, sizeof c);
+    return 0;
+}
+int emu_ncclCommInitRank(void **comm, int nranks, const char *, int rank) {
+    if (nranks != 1 || rank != 0)
+        return nccl_fail(3, "ncclCommInitRank with %d ranks: the emulator runs one process; multi-rank communicators come from ncclCommInitAll "
+                            "(the process-per-GPU path is covered by the gloo tests through the caller-supplied transport)", nranks);
+    Comm *c = new Comm{0, 1, tls_device, std::make_shared<Clique>()};
+    c->clique->members.push_back(c);
+    std::lock_guard<std::mutex> l(mu);
+    live_comms.insert(c);
+    *comm = c;
+    return 0;
+}
+int emu_ncclCommInitAll(void **comms, int ndev, const int *devlist) {
+    if (ndev < 1) return nccl_fail(4, "ncclCommInitAll: %d devices", ndev);
+    for (int i = 0; i < ndev; ++i) {
+        const int d = devlist ? devlist[i] : i;
+        if (d < 0 || d >= device_count()) return nccl_fail(4, "ncclCommInitAll: device %d does not exist", d);
+        for (int j = 0; j < i; ++j)
+            if ((devlist ? devlist[j] : j) == d) return nccl_fail(4, "ncclCommInitAll: Duplicate GPU detected: rank %d and rank %d both on device %d", j, i, d);
+    }
+    auto cl = std::make_shared<Clique>();
+    std::lock_guard<std::mutex> l(mu);
+    for (int i = 0; i < ndev; ++i) {
+        Comm *c = new Comm{i, ndev, devlist ? devlist[i] : i, cl};
+        cl->members.push_back(c);
+        live_comms.insert(c);
+        comms[i] = c;
+    }
+    return 0;
+}
+int emu_ncclCommDestroy(void *comm) {
+    std::lock_guard<std::mutex> l(mu);
+    if (!live_comms.erase(comm)) return nccl_fail(4, "ncclCommDestroy(%p): not a live communicator", comm);
+    delete (Comm *)comm;
+    return 0;
+}
+int emu_ncclBroadcast(const void *send, void *recv, size_t count, int dtype, int root, void *comm, void *stream) {
+    Comm *c = (Comm *)comm;
+    int rc = validate("ncclBroadcast", c, send, recv, stream);
+    if (rc) return rc;
+    if (!dtype_bytes(dtype)) return nccl_fail(4, "ncclBroadcast: unknown datatype %d", dtype);
+    return post(Op{0, c, send, recv, count * dtype_bytes(dtype), root});
+}
+int emu_ncclAllGather(const void *send, void *recv, size_t sendcount, int dtype, void *comm, void *stream) {
+    Comm *c = (Comm *)comm;
+    int rc = validate("ncclAllGather", c, send, recv, stream);
+    if (rc) return rc;
+    if (!dtype_bytes(dtype)) return nccl_fail(4, "ncclAllGather: unknown datatype %d", dtype);
+    return post(Op{1, c, send, recv, sendcount * dtype_bytes(dtype), 0});
+}
+int emu_ncclGroupStart() {
+    ++group_depth;
+    return 0;
+}
+int emu_ncclGroupEnd() {
+    if (group_depth == 0) return nccl_fail(5, "ncclGroupEnd without ncclGroupStart");
+    if (--group_depth > 0) return 0;
+    std::vector<Op> ops;
+    ops.swap(queued);
+    return run_group(ops);
+}
+const char *emu_ncclGetErrorString(int rc) { return rc == 0 ? "no error" : (nccl_error.empty() ? "rccl_emu: error" : nccl_error.c_str()); }
+
+// ---- test hooks exported by the emulator build only
+void p2hot_emu_stats(unsigned long long out[8]) {
+    out[0] = stats.peer_copies, out[1] = stats.peer_bytes, out[2] = stats.nccl_broadcasts, out[3] = stats.nccl_allgathers;
+    out[4] = stats.nccl_bytes, out[5] = stats.device_switches, out[6] = stats.violations, out[7] = (unsigned long long)tls_device;
+}
+int p2hot_emu_fault(const char *what, int on) {
+    if (!strcmp(what, "no_device_guard")) {
+        fault_no_device_guard = on != 0;
+        return 0;
+    }
+    return 1;
+}
+int p2hot_emu_set_device(int d) { return hipSetDevice(d); }
+int p2hot_emu_device_of(const void *p) { return device_of(p); }
+}

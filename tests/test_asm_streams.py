@@ -128,4 +128,4 @@ def test_commit_and_fri_commit_through_the_asm(emu_asm, ora):
 def test_prove_openings_through_the_asm(emu_asm, ora):
     """the whole opening proof (final_poly, FRI commit phase, grind, query rounds) with every hand-written stream interpreted"""
     from tests import test_prove_openings as tpo
-    tpo.test_final_poly_and_prove_openings_vs_oracle(emu_asm, ora, 5, [3, 2], 3, 2, [2])
+    tpo.test_final_poly_and_prove_openings_vs_oracle(emu_asm, ora, 5, [3, 2], 3, 2, [2], None)

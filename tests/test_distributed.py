@@ -236,7 +236,14 @@ def test_group_and_comm_argument_errors():
     g.close()
     eng = emu_engine()
     h = C.c_void_p()
-    assert lib.p2hot_comm_create_rccl(eng.ctx, 0, 1, np.zeros(128, dtype=np.uint8).ctypes.data, C.byref(h)) == _lib.ECOMM  # no RCCL in the emulator
+    # the emulator's fake RCCL makes one-rank communicators (as the GPU tier does on the real library); a multi-rank
+    # ncclCommInitRank needs one process per rank, which the emulated node does not have: refused, not hung
+    uid = np.zeros(128, dtype=np.uint8)
+    assert lib.p2hot_comm_unique_id(uid.ctypes.data) == 0 and uid.any()
+    assert lib.p2hot_comm_create_rccl(eng.ctx, 0, 2, uid.ctypes.data, C.byref(h)) == _lib.ECOMM
+    assert lib.p2hot_comm_create_rccl(eng.ctx, 0, 1, uid.ctypes.data, C.byref(h)) == 0
+    assert lib.p2hot_comm_selftest(h, 4096) == 0
+    lib.p2hot_comm_destroy(h)
     cb = _lib.ALLGATHER_FN(lambda *a: 0)
     assert lib.p2hot_comm_create_callback(eng.ctx, 3, 8, cb, None, C.byref(h)) == 0
     assert (lib.p2hot_comm_rank(h), lib.p2hot_comm_world(h)) == (3, 8)

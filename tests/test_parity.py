@@ -239,7 +239,7 @@ def test_merkle_tree_vs_oracle(eng, ora, n, w, cap):
 # ---------------------------------------------------------------- PolynomialBatch
 COMMIT_CASES = [  # (W, log_n, rate_bits, cap_height, is_values)
     (3, 4, 3, 4, True), (9, 5, 3, 2, True), (135, 6, 3, 4, True), (2, 7, 1, 4, False), (16, 10, 3, 4, False),
-    (20, 9, 3, 4, True), (5, 13, 1, 0, True), (1, 3, 3, 6, True), (4, 2, 1, 3, True), (0, 3, 1, 2, True),
+    (20, 9, 3, 4, True), (5, 13, 1, 0, True), (1, 3, 3, 6, True), (4, 2, 1, 3, True),
     (1, 0, 0, 0, True), (2, 0, 3, 1, False),
 ]
 
@@ -265,6 +265,16 @@ def test_polynomial_batch_vs_oracle(eng, ora, W, log_n, rb, cap, is_values):
         # the row-major `leaves` output of p2hot_commit_dev is the same matrix
         r = eng.commit(eng.dev(cols), log_n, rb, cap, is_values, want_leaves=True)
         assert (eng.host(r["leaves"]) == o["leaves"]).all()
+
+
+def test_polynomial_batch_without_polynomials_is_refused(eng):
+    """W = 0: the reference panics on polynomials[0].len() (fri/oracle.rs:90); the mirror raises"""
+    from plonky2_amd import _lib
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    with pytest.raises(_lib.P2HotError, match="no polynomials"):
+        PolynomialBatch.from_values(np.zeros((0, 8), dtype=np.uint64), 1, False, 2, engine=eng)
+    with pytest.raises(_lib.P2HotError, match="no polynomials"):
+        eng.commit(eng.dev(np.zeros((0, 8), dtype=np.uint64)), 3, 1, 2, True)
 
 
 def test_commit_row_ranges_assemble_to_the_full_tree(eng, ora):
@@ -441,6 +451,23 @@ def test_host_pointer_commit_abi(eng, ora):
     eng.check(eng.lib.p2hot_batch_paths(handle, idx.ctypes.data, 3, paths.ctypes.data))
     assert (paths[1] == ora.merkle_prove(int(idx[1]), N, cap, o["digests"])).all() and (capv == o["cap"]).all()
     eng.lib.p2hot_batch_free(handle)
+    # P2HOT_COEFFS_PER_COLUMN: coeffs_out is a table of W destinations (the Rust side's Vec<PolynomialCoeffs>): each polynomial
+    # lands in its own vector, nothing to split afterwards
+    from plonky2_amd import _lib
+    dst = [np.zeros(n, dtype=np.uint64) for _ in range(W)]
+    table = (C.c_void_p * W)(*[d.ctypes.data for d in dst])
+    eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, _lib.COEFFS_PER_COLUMN, C.cast(table, C.c_void_p), None, None,
+                                   capv.ctypes.data, None))
+    assert (np.stack(dst) == o["coeffs"]).all() and (capv == o["cap"]).all()
+    h = C.c_void_p()
+    eng.check(eng.lib.p2hot_cols_upload(eng.ctx, ptrs, W, log_n, C.byref(h)))
+    dst = [np.zeros(n, dtype=np.uint64) for _ in range(W)]
+    table = (C.c_void_p * W)(*[d.ctypes.data for d in dst])
+    eng.check(eng.lib.p2hot_commit_cols(eng.ctx, h, rb, cap, 1, _lib.COEFFS_PER_COLUMN, C.cast(table, C.c_void_p), None, None, capv.ctypes.data, None))
+    assert (np.stack(dst) == o["coeffs"]).all() and (capv == o["cap"]).all()
+    table[W - 1] = None  # a null destination is refused before anything runs
+    assert eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, _lib.COEFFS_PER_COLUMN, C.cast(table, C.c_void_p), None, None,
+                                capv.ctypes.data, None) == _lib.EINVAL
 
 
 @pytest.mark.parametrize("W,log_n,rb,cap,S,block", [(37, 5, 3, 2, 0, 16), (37, 5, 3, 2, 4, 16), (135, 4, 1, 0, 0, 16),

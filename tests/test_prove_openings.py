@@ -37,9 +37,12 @@ def _oracle_final_poly(ora, batches, coeff_sets, alpha):
     return np.array(final.tolist(), dtype=np.uint64)
 
 
-@pytest.mark.parametrize("log_n,widths,rb,cap,arity", [(5, [3, 2], 3, 2, [2]), (8, [7, 4, 2], 3, 4, [4]), (0, [2], 1, 0, []),
-                                                        (7, [2, 2], 1, 4, [1, 2])])
-def test_final_poly_and_prove_openings_vs_oracle(eng, ora, log_n, widths, rb, cap, arity):
+# nxt = (oracle, count): the second opening batch.  The last case is the reference's own FRI instance in miniature
+# (plonk/circuit_data.rs:530-548, :578-664): four oracles -- constants_sigmas, wires, Zs + partial products, quotient --
+# every polynomial at zeta, and only the num_challenges = 2 Z polynomials (a SUB-RANGE of oracle 2) at g * zeta
+@pytest.mark.parametrize("log_n,widths,rb,cap,arity,nxt", [(5, [3, 2], 3, 2, [2], None), (8, [7, 4, 2], 3, 4, [4], None), (0, [2], 1, 0, [], None),
+                                                            (7, [2, 2], 1, 4, [1, 2], None), (6, [6, 9, 5, 4], 3, 4, [4], (2, 2))])
+def test_final_poly_and_prove_openings_vs_oracle(eng, ora, log_n, widths, rb, cap, arity, nxt):
     from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, final_poly_device, prove_openings
     from plonky2_amd.iop.challenger import Challenger
     rng = np.random.default_rng(log_n * 31 + len(widths))
@@ -51,7 +54,7 @@ def test_final_poly_and_prove_openings_vs_oracle(eng, ora, log_n, widths, rb, ca
     oracles_dev = [PolynomialBatch.from_coeffs(eng.dev(c), rb, False, cap, engine=eng) for c in cols]
     # two opening batches like plonky2's zeta / g*zeta (plonk_common.rs FRI_ORACLES): all polys at z0, the first oracle at z1
     all_polys = [(oi, pi) for oi, w in enumerate(widths) for pi in range(w)]
-    first = [(0, pi) for pi in range(widths[0])]
+    first = [(nxt[0], pi) for pi in range(nxt[1])] if nxt else [(0, pi) for pi in range(widths[0])]
     z0, z1 = rand_field(rng, 2), rand_field(rng, 2)
     batches = [FriBatchInfo(z0, all_polys), FriBatchInfo(z1, first)]
     ob = [(z0, all_polys), (z1, first)]
@@ -246,6 +249,12 @@ def test_fri_proof_passes_the_reference_verifier(eng, ora, log_n, widths, rb, ca
     _fri_proof_verifies(eng, ora, log_n, widths, rb, cap, arity, pow_bits, nq, blinded=())
 
 
+def test_fri_proof_of_the_plonky2_instance_shape_passes_the_reference_verifier(eng, ora):
+    """get_fri_instance (plonk/circuit_data.rs:530-548): 4 oracles (constants_sigmas, wires, Zs + partial products, quotient), all
+    polynomials at zeta, the 2 Z polynomials -- polynomials 0..1 of oracle 2 -- at g * zeta; four initial trees per query"""
+    _fri_proof_verifies(eng, ora, 7, [8, 13, 6, 4], 3, 4, [4], 5, 4, blinded=(), nxt=(2, 2))
+
+
 def test_fri_proof_over_blinded_oracles_passes_the_reference_verifier(eng, ora):
     """zero-knowledge configs (standard_recursion_zk_config): oracles 1 and 2 are salted (PlonkOracle::WIRES / ZS blinding,
     plonk/plonk_common.rs), oracle 0 is not (CONSTANTS_SIGMAS).  The opened leaves carry the salts, the Merkle paths
@@ -253,7 +262,7 @@ def test_fri_proof_over_blinded_oracles_passes_the_reference_verifier(eng, ora):
     _fri_proof_verifies(eng, ora, 6, [4, 5, 3], 3, 2, [2, 1], 4, 5, blinded=(1, 2))
 
 
-def _fri_proof_verifies(eng, ora, log_n, widths, rb, cap, arity, pow_bits, nq, blinded):
+def _fri_proof_verifies(eng, ora, log_n, widths, rb, cap, arity, pow_bits, nq, blinded, nxt=None):
     """The acceptance check of SURVEY 3.5: a proof produced on the device (commits, OpeningSet evaluations,
     prove_openings) verifies under a restatement of plonky2/src/fri/verifier.rs + challenges.rs that re-derives every
     challenge from the proof with the ORACLE's challenger; tampering with any part makes it fail."""
@@ -277,7 +286,7 @@ def _fri_proof_verifies(eng, ora, log_n, widths, rb, cap, arity, pow_bits, nq, b
     g = ora.root_of_unity(log_n)
     gz = [int(zeta[0]) * g % P, int(zeta[1]) * g % P]                      # zeta_next = g * zeta (plonk/prover.rs:338)
     all_polys = [(oi, pi) for oi, w in enumerate(widths) for pi in range(w)]
-    first = [(0, pi) for pi in range(widths[0])]
+    first = [(nxt[0], pi) for pi in range(nxt[1])] if nxt else [(0, pi) for pi in range(widths[0])]
     inst = [(zeta, all_polys), (gz, first)]                                # FriInstanceInfo.batches
     ev = eval_openings(oracles, [zeta, gz], eng)                           # [oracle][point][poly][2]
     openings = [[ev[oi][bi][pi] for (oi, pi) in polys] for bi, (_, polys) in enumerate(inst)]   # FriOpenings

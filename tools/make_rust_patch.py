@@ -5,9 +5,9 @@ The patch is the Rust side of the drop-in boundary: Cargo feature `p
 `plonky2/src/p2hot.rs` (= integration/p2hot.rs, verbatim) and the feature-gated early returns in
   fri/oracle.rs        from_values / from_coeffs / get_lde_values / prove_openings
   fri/prover.rs        fri_committed_trees
-  hash/merkle_tree.rs  `device` handle on MerkleTree, get / prove
+  hash/merkle_tree.rs  `device` handle on MerkleTree, get / num_leaves / prove (the leaf matrix may be ONE flat buffer behind it)
   iop/challenger.rs    accessor for the transcript state
-  util/serialization   the one other MerkleTree struct literal
+  util/serialization   the one other MerkleTree struct literal; write_merkle_tree reads rows through get / num_leaves
   fri/prover.rs        also: the grind takes the smallest witness under the feature; a test hook for the harness
 plus plonky2/examples/p2hot_dump_goldens.rs (= integration/p2hot_dump_goldens.rs, verbatim): the golden dumper.
 It is built by anchored edits of a scratch copy, so this script holds only the NEW lines and short
@@ -248,8 +248,43 @@ fn fri_prover_query_rounds<
             }
         }
         let siblings =
+'''),
+        # `leaves` may be empty with the leaf matrix behind `device` (one flat host buffer, or the GPU): the leaf count comes
+        # from `num_leaves`, which is `leaves.len()` in every other case
+        ('''            merkle_tree_prove::<F, H>(leaf_index, self.leaves.len(), cap_height, &self.digests);
+''', '''            merkle_tree_prove::<F, H>(leaf_index, self.num_leaves(), cap_height, &self.digests);
+'''),
+        ('''impl<F: RichField, H: Hasher<F>> MerkleTree<F, H> {
+    pub fn new(leaves: Vec<Vec<F>>, cap_height: usize) -> Self {
+''', '''impl<F: RichField, H: Hasher<F>> MerkleTree<F, H> {
+    /// Number of leaves. With the `p2hot` feature the leaf matrix may live behind `device` (one flat host buffer, or
+    /// the GPU) with `leaves` empty; otherwise this is `leaves.len()`.
+    pub fn num_leaves(&self) -> usize {
+        #[cfg(feature = "p2hot")]
+        if self.leaves.is_empty() {
+            if let Some(device) = &self.device {
+                return device.num_leaves();
+            }
+        }
+        self.leaves.len()
+    }
+
+    pub fn new(leaves: Vec<Vec<F>>, cap_height: usize) -> Self {
 ''')])
     edit(os.path.join(b, "plonky2/src/util/serialization/mod.rs"), [
+        # the serializer reads the rows through `get` / `num_leaves` (the same bytes: `get(i)` is `&leaves[i]` whenever `leaves`
+        # is populated), so a tree whose leaf matrix is one flat buffer behind its device handle serialises unchanged
+        ('''        self.write_usize(tree.leaves.len())?;
+        for i in 0..tree.leaves.len() {
+            self.write_usize(tree.leaves[i].len())?;
+            self.write_field_vec(&tree.leaves[i])?;
+        }
+''', '''        self.write_usize(tree.num_leaves())?;
+        for i in 0..tree.num_leaves() {
+            self.write_usize(tree.get(i).len())?;
+            self.write_field_vec(tree.get(i))?;
+        }
+'''),
         ('''        Ok(MerkleTree {
             leaves,
             digests,

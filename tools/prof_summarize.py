@@ -63,6 +63,7 @@ def main(tag):
     wr, nw, _ = counters(os.path.join(G, "pmc_write"))
     sq, ns, ms = counters(os.path.join(G, "pmc_sq"))
     sq2, ns2, ms2 = counters(os.path.join(G, "pmc_sq2"))
+    sq3, ns3, ms3 = counters(os.path.join(G, "pmc_sq3"))
     kernels = {}
     for k in sorted(set(fe) | set(wr)):
         n = max(nf.get(k, 0), nw.get(k, 0), 1)
@@ -75,6 +76,12 @@ def main(tag):
             if ms.get(k):
                 e["ms_per_launch_under_pmc"] = ms[k] / ns[k]
                 e["clock_ghz"] = sq[k].get("GRBM_GUI_ACTIVE", 0.0) / 8 / (ms[k] * 1e6)  # summed over the 8 XCDs
+        if k in sq3 and sq3[k].get("GRBM_GUI_ACTIVE"):
+            # VALU busy fraction: quad-cycles some wave had a VALU instruction executing / SIMD cycles (1024 SIMDs)
+            cyc = sq3[k]["GRBM_GUI_ACTIVE"] / 8
+            e["valu_busy_frac"] = sq3[k].get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (1024 * cyc)
+            e["lds_busy_frac"] = sq3[k].get("SQ_ACTIVE_INST_LDS", 0.0) * 4 / (1024 * cyc)
+            e["clock_ghz_sq3"] = cyc / (ms3[k] * 1e6) if ms3.get(k) else 0.0
         kernels[k] = e
     out = {"workload": {"W": 135, "log_n": 20, "rate_bits": 3, "cap_height": 4, "n_gpus": 1}, "csrc_sha256_16": csrc_hash(), "tag": tag,
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of `bench.py --steps 1 --warmup 0`; "
@@ -84,9 +91,10 @@ def main(tag):
            "kernels": kernels}
     json.dump(out, open(os.path.join(G, "%s_pmc_traffic.json" % tag), "w"), indent=1)
     with open(os.path.join(G, "%s_pmc_sq.txt" % tag), "w") as f:
-        for k in sorted(set(sq) | set(sq2)):
+        for k in sorted(set(sq) | set(sq2) | set(sq3)):
             c = dict(sq.get(k, {}))
             c.update(sq2.get(k, {}))
+            c.update({a: b for a, b in sq3.get(k, {}).items() if a not in c})
             f.write("%s launches %d ms %.6f %s\n" % (k, ns.get(k, ns2.get(k, 0)), ms.get(k, ms2.get(k, 0.0)), {a: "%.4g" % b for a, b in sorted(c.items())}))
     print({k: (v["launches"], round(v["hbm_bytes_per_launch"] / 1e9, 3), round(v.get("sq_insts_valu_per_launch", 0) / 1e9, 3)) for k, v in kernels.items()
            if v["hbm_bytes_per_launch"] > 1e8})

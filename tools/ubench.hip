@@ -2,10 +2,16 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench tools/ubench.hip ; run on the GPU box.
 // Every probe issues 8 independent copies of one instruction per loop iteration from a single
 // asm statement (so the compiler can neither fold nor pad them); 8 waves/SIMD resident.
-// Output: cycles per wave64 instruction per SIMD (2.0 = full rate on a SIMD-32).
+// Output: cycles per wave64 instruction per SIMD (2.0 = full rate on a SIMD-32) "by wall at an ASSUMED 2.4 GHz" -- the chip
+// clocks to its power budget, so that column is only comparable within one run.  The yardstick the bench uses comes from
+// tools/ubench_pmc.sh: the same probes under `rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU`, i.e. TRUE
+// shader cycles per instruction and the clock each probe ran at (tools/ubench_summarize.py -> profiles/r04_ubench.json).
+// usage: ubench [--waves N] [--only substring] [--json]   (N = resident waves per SIMD: 8 default, 4 = the leaf sponge's)
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 #define ITERS 65536
 
@@ -17,7 +23,7 @@
     : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), \
       "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])  \
     : "v"(c), "v"(d), "v"(e)                                                                         \
-    : "vcc", "s20", "s21"
+    : "vcc", "s20", "s21", "s22", "s23"
 
 #define I_ADD(i) "v_add_u32 %" #i ", %" #i ", %16"
 #define I_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %16"
@@ -79,6 +85,50 @@
 #define CHAIN_MAD "v_mad_u64_u32 %8, vcc, %16, %17, %8\n\tv_mad_u64_u32 %8, vcc, %17, %16, %8\n\tv_mad_u64_u32 %8, vcc, %16, %17, %8\n\t" \
                   "v_mad_u64_u32 %8, vcc, %17, %16, %8\n\tv_mad_u64_u32 %8, vcc, %16, %17, %8\n\tv_mad_u64_u32 %8, vcc, %17, %16, %8\n\t" \
                   "v_mad_u64_u32 %8, vcc, %16, %17, %8\n\tv_mad_u64_u32 %8, vcc, %17, %16, %8"
+
+// the leaf sponge's instruction mix as independent streams (32 slots: 19 multiply-adds, 4 v_subb, 2 v_addc, 2 v_add_co,
+// 2 v_cndmask, 1 v_mov, 2 v_add_u32): what the SIMD can issue when nothing waits on anything.  As in the kernel the multiply-adds
+// leave vcc alone (their carry-out goes to a scratch SGPR pair) and a carry consumer sits two instructions behind its producer
+// (generated by the snippet in the commit that added it; keep the 19 / 4 / 2 / 2 / 2 / 1 / 2 split when editing)
+#define MIX_HASH \
+    "v_mad_u64_u32 %8, s[22:23], %16, %17, %8\n\t" \
+    "v_mad_u64_u32 %9, s[22:23], %17, %16, %9\n\t" \
+    "v_add_co_u32 %0, vcc, %0, %16\n\t" \
+    "v_mad_u64_u32 %10, s[22:23], %16, %16, %10\n\t" \
+    "v_mad_u64_u32 %11, s[22:23], %16, %17, %11\n\t" \
+    "v_addc_co_u32 %1, vcc, %1, %16, vcc\n\t" \
+    "v_mad_u64_u32 %12, s[22:23], %17, %16, %12\n\t" \
+    "v_mad_u64_u32 %13, s[22:23], %16, %16, %13\n\t" \
+    "v_subb_co_u32 %2, vcc, %2, %17, vcc\n\t" \
+    "v_mad_u64_u32 %14, s[22:23], %16, %17, %14\n\t" \
+    "v_mad_u64_u32 %15, s[22:23], %17, %16, %15\n\t" \
+    "v_cndmask_b32 %3, %3, %17, vcc\n\t" \
+    "v_mad_u64_u32 %8, s[22:23], %16, %16, %8\n\t" \
+    "v_mad_u64_u32 %9, s[22:23], %16, %17, %9\n\t" \
+    "v_add_co_u32 %4, vcc, %4, %16\n\t" \
+    "v_mad_u64_u32 %10, s[22:23], %17, %16, %10\n\t" \
+    "v_mad_u64_u32 %11, s[22:23], %16, %16, %11\n\t" \
+    "v_subb_co_u32 %5, vcc, %5, %17, vcc\n\t" \
+    "v_mad_u64_u32 %12, s[22:23], %16, %17, %12\n\t" \
+    "v_mad_u64_u32 %13, s[22:23], %17, %16, %13\n\t" \
+    "v_addc_co_u32 %6, vcc, %6, %16, vcc\n\t" \
+    "v_mad_i64_i32 %14, s[22:23], %16, %16, %14\n\t" \
+    "v_mad_u64_u32 %15, s[22:23], %16, %17, %15\n\t" \
+    "v_subb_co_u32 %7, vcc, %7, %17, vcc\n\t" \
+    "v_mad_u64_u32 %8, s[22:23], %17, %16, %8\n\t" \
+    "v_add_u32 %0, %0, %16\n\t" \
+    "v_cndmask_b32 %1, %1, %17, vcc\n\t" \
+    "v_mad_u64_u32 %9, s[22:23], %16, %16, %9\n\t" \
+    "v_mov_b32 %2, %17\n\t" \
+    "v_subb_co_u32 %3, vcc, %3, %17, vcc\n\t" \
+    "v_add_u32 %4, %4, %16\n\t" \
+    "v_mad_u64_u32 %10, s[22:23], %16, %17, %10"
+// the limb NTT passes' mix (16 slots: 5 multiply-adds, 7 plain 32-bit add / sub / and, 2 carry adds, 1 v_alignbit, 1 v_lshl_add_u64)
+#define MIX_NTT                                                                                                   \
+    "v_mad_u64_u32 %8, vcc, %16, %17, %8\n\tv_add_u32 %0, %0, %16\n\tv_sub_u32 %1, %1, %16\n\tv_mad_u64_u32 %9, vcc, %16, %17, %9\n\t" \
+    "v_add_u32 %2, %2, %16\n\tv_and_b32 %3, %3, %16\n\tv_mad_u64_u32 %10, vcc, %16, %17, %10\n\tv_sub_u32 %4, %4, %16\n\t"            \
+    "v_add_co_u32 %5, vcc, %5, %16\n\tv_mad_u64_u32 %11, vcc, %16, %17, %11\n\tv_add_u32 %6, %6, %16\n\tv_addc_co_u32 %7, vcc, %7, %16, vcc\n\t" \
+    "v_mad_u64_u32 %12, vcc, %16, %17, %12\n\tv_sub_u32 %0, %0, %17\n\tv_alignbit_b32 %1, %1, %16, 24\n\tv_lshl_add_u64 %13, %13, 3, %13"
 
 #define R8B(INS) INS(8) "\n\t" INS(9) "\n\t" INS(10) "\n\t" INS(11) "\n\t" INS(12) "\n\t" INS(13) "\n\t" INS(14) "\n\t" INS(15)
 
@@ -144,6 +194,8 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t 
         if (OP == 45) asm volatile(MIX_ADD_MAD OPS);
         if (OP == 46) asm volatile(CHAIN_ADD OPS);
         if (OP == 47) asm volatile(CHAIN_MAD OPS);
+        if (OP == 48) asm volatile(MIX_HASH OPS);
+        if (OP == 49) asm volatile(MIX_NTT OPS);
     }
     uint64_t t1 = __builtin_readcyclecounter();
     uint64_t s = 0;
@@ -153,9 +205,14 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t 
     if ((threadIdx.x & 63) == 0) ticks[t >> 6] = t1 - t0;
 }
 
+static int g_waves = 8;        // resident waves per SIMD (blocks of 256 threads per CU)
+static const char *g_only = nullptr;
+static bool g_json = false;
+
 template <int OP>
-void run(const char *name) {
-    const int blocks = 256 * 8, threads = 256;  // 8 blocks/CU -> 8 waves/SIMD
+void run(const char *name, int per_iter = 8) {
+    if (g_only && !strstr(name, g_only)) return;
+    const int blocks = 256 * g_waves, threads = 256;  // g_waves blocks/CU -> g_waves waves/SIMD
     uint64_t *d, *tk;
     (void)hipMalloc(&d, (size_t)blocks * threads * 8);
     (void)hipMalloc(&tk, (size_t)blocks * threads / 64 * 8);
@@ -175,25 +232,33 @@ void run(const char *name) {
         if (ms < best) best = ms;
     }
     double waves_per_simd = (double)blocks * threads / 64 / 1024;
-    double inst_per_simd = waves_per_simd * ITERS * 8;
+    double inst_per_simd = waves_per_simd * ITERS * per_iter;
     double cycles = best * 1e-3 * 2.4e9;
     static uint64_t host_ticks[256 * 8 * 4];
     (void)hipMemcpy(host_ticks, tk, (size_t)blocks * threads / 64 * 8, hipMemcpyDeviceToHost);
     double avg = 0;
     for (int i = 0; i < blocks * threads / 64; ++i) avg += (double)host_ticks[i];
     avg /= (blocks * threads / 64);
-    // every wave shares its SIMD with waves_per_simd - 1 others: SIMD cycles per instruction =
-    // per-wave elapsed ticks / (instructions per wave * resident waves per SIMD)
-    printf("%-18s %7.3f ms  %5.2f cyc/inst/SIMD by wall@2.4GHz | %5.2f by s_memtime (ticks/wave %.0f, implied clock %.2f GHz)\n", name,
-           best, cycles / inst_per_simd, avg / (ITERS * 8.0 * waves_per_simd), avg, avg / (best * 1e-3) / 1e9);
+    if (g_json)
+        printf("{\"op\": %d, \"name\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.4f, \"wave_insts_per_simd\": %.0f, \"per_iter\": %d}\n", OP, name,
+               g_waves, best, inst_per_simd, per_iter);
+    else
+        printf("%-18s %7.3f ms  %5.2f cyc/inst/SIMD by wall@2.4GHz(assumed) | %5.2f ticks/inst by s_memtime (ticks/wave %.0f)\n", name, best,
+               cycles / inst_per_simd, avg / (ITERS * (double)per_iter * waves_per_simd), avg);
     (void)hipFree(tk);
     (void)hipFree(d);
 }
 
-int main() {
+int main(int argc, char **argv) {
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--waves") && i + 1 < argc) g_waves = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--only") && i + 1 < argc) g_only = argv[++i];
+        else if (!strcmp(argv[i], "--json")) g_json = true;
+    }
+    if (g_waves < 1 || g_waves > 8) g_waves = 8;
     hipDeviceProp_t p;
     (void)hipGetDeviceProperties(&p, 0);
-    printf("device %s  CUs %d  clock %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
+    if (!g_json) printf("device %s  CUs %d  clock %d kHz  waves/SIMD %d\n", p.gcnArchName, p.multiProcessorCount, p.clockRate, g_waves);
     run<0>("v_add_u32");
     run<19>("v_mov_b32");
     run<20>("v_xor_b32");
@@ -241,5 +306,7 @@ int main() {
     run<45>("mix 4add+4mad");
     run<46>("chain v_add_u32");
     run<47>("chain v_mad_u64");
+    run<48>("mix hash_leaves", 32);
+    run<49>("mix limb_ntt", 16);
     return 0;
 }
