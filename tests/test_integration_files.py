@@ -250,3 +250,108 @@ def test_golden_dumper_matches_the_python_side():
     for f in rr.COMMIT_FIELDS:
         assert '\\"%s\\"' % f in s, f
     assert hashlib.sha256(b"abc").hexdigest().startswith("ba7816bf")  # the layout both sides hash: u64 little endian
+
+
+# ---------------------------------------------------------------- API-surface linter for the uncompiled Rust (tests/rust_lint.py)
+@pytest.fixture(scope="module")
+def patched_reference():
+    ref = os.environ.get("P2_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "plonky2", "src")):
+        pytest.skip("the reference tree is only present in the build container")
+    import shutil
+    from tests import rust_lint as rl
+    top = rl.patched_tree(ref, PATCH)
+    yield rl.Reference(top)
+    shutil.rmtree(top, ignore_errors=True)
+
+
+def _lint(ref, src, example=False):
+    """every finding of tests/rust_lint.py on one Rust source, as strings"""
+    from tests import rust_lint as rl
+    out = []
+    for crate, path, name in rl.uses(src):
+        v = ref.item_visibility(crate, path, name)
+        if v is None:
+            out.append("use %s::%s::%s: no such item" % (crate, "::".join(path), name))
+        elif v == "private" or (example and v != "pub"):
+            out.append("use %s::%s::%s: the item is %s" % (crate, "::".join(path), name, v))
+    stripped = rl.strip(src)
+    local = set(re.findall(r"\bfn\s+(\w+)", stripped)) | set(re.findall(r"\blet\s+(?:mut\s+)?(\w+)\s*=\s*(?:move\s*)?\|", stripped))
+    for name, n_args, n_gen, _ in rl.calls(src):
+        if name in rl.STD_NAMES or name in local or name not in ref.fns:
+            continue
+        defs = ref.fns[name]
+        if n_args not in {a for a, _ in defs}:
+            out.append("call %s(..): %d arguments, the reference defines it with %s" % (name, n_args, sorted({a for a, _ in defs})))
+        elif n_gen is not None and n_gen not in {g for a, g in defs if a == n_args}:
+            out.append("call %s::<..>: %d generic arguments, the reference has %s" % (name, n_gen, sorted({g for a, g in defs if a == n_args})))
+    for name, fields, rest in rl.struct_literals(src, ref.structs):
+        if not any(fields == d or (rest and fields <= d) for d in ref.structs[name]):
+            out.append("literal %s { %s }: the (patched) definition has { %s }" % (name, ", ".join(sorted(fields)), " | ".join(", ".join(sorted(d)) for d in ref.structs[name])))
+    # fully qualified paths into the crate that are not `use`d: crate::a::b::name
+    for m in re.finditer(r"\bcrate((?:::[a-z_0-9]+)+)::(\w+)", stripped):
+        path, name = [x for x in m.group(1).split("::") if x], m.group(2)
+        if path and path[0] == "p2hot":
+            continue
+        if re.match(r"\s*use\b", stripped[stripped.rfind("\n", 0, m.start()) + 1:m.start()]):
+            continue
+        if ref.item_visibility("crate", path, name) in (None, "private"):
+            out.append("path crate::%s::%s: %s" % ("::".join(path), name, ref.item_visibility("crate", path, name) or "no such item"))
+    return out
+
+
+def test_rust_api_surface_of_the_shim_and_the_dumper(patched_reference):
+    """what the first `cargo build --features p2hot` would otherwise report: unresolved or private imports, wrong argument or
+    generic counts of the reference functions the shim calls (from_values, fri_proof, prove, observe_elements, write_merkle_tree,
+    the test hook, ...), struct literals (MerkleTree, FriProof, FriQueryStep, PolynomialBatch, ...) whose fields differ from the
+    patched definitions"""
+    ref = patched_reference
+    assert ref.fns["fri_proof"] == {(8, 3)} and ref.fns["from_values"] == {(6, 0)} and (4, 3) in ref.fns["prove"]
+    assert {"leaves", "digests", "cap", "device"} in ref.structs["MerkleTree"]      # the patch's field is part of the definition
+    assert ref.fns["num_leaves"] and ref.fns["p2hot_parts"] == {(0, 0)}              # ... and so are the items it adds
+    assert _lint(ref, open(RS).read()) == []
+    assert _lint(ref, open(DUMPER).read(), example=True) == []
+
+
+def test_rust_linter_catches_what_it_is_for(patched_reference):
+    """the linter's own negatives: each seeded mistake is reported (and nothing else)"""
+    ref, s = patched_reference, open(RS).read()
+
+    def one(old, new, needle):
+        assert s.count(old) >= 1, old
+        found = _lint(ref, s.replace(old, new, 1))
+        assert len(found) == 1 and needle in found[0], found
+    one("merkle_tree: MerkleTree { leaves, digests, cap: MerkleCap(cap), device: Some(device) },", "merkle_tree: MerkleTree { leaves, digests, cap: MerkleCap(cap) },",
+        "literal MerkleTree")
+    one("use crate::hash::merkle_tree::{MerkleCap, MerkleTree};", "use crate::hash::merkle_tree::{MerkleCap, MerkleTree, MerkleForest};", "no such item")
+    one("use crate::fri::structure::FriInstanceInfo;", "use crate::fri::prover::fri_committed_trees;\nuse crate::fri::structure::FriInstanceInfo;", "private")
+    one("Batch::from_values(values.clone(), rate_bits, false, cap_height, &mut TimingTree::default(), None)",
+        "Batch::from_values(values.clone(), rate_bits, false, cap_height, &mut TimingTree::default())", "call from_values")
+    one("prove::<F, C, D>(&data.prover_only, &data.common, PartialWitness::new(), &mut TimingTree::default())",
+        "prove::<F, C>(&data.prover_only, &data.common, PartialWitness::new(), &mut TimingTree::default())", "generic arguments")
+    one("crate::fri::prover::p2hot_fri_committed_trees_for_tests::<F, C, D>(", "crate::fri::prover::p2hot_fri_commit_trees_for_tests::<F, C, D>(", "no such item")
+    d = open(DUMPER).read()
+    m = re.search(r"fri_proof::<F, C, D>\(", d)
+    assert m, "the dumper calls the reference's fri_proof"
+    from tests import rust_lint as rl
+    e = rl.matching(d, m.end() - 1, "(", ")")
+    broken = d[:e] + ", None" + d[e:]
+    assert any("call fri_proof" in f for f in _lint(ref, broken, example=True))
+
+
+def test_leaf_matrix_is_one_flat_buffer_behind_get():
+    """round-3 review: the shim rebuilt merkle_tree.leaves with a serial per-row to_vec (8.4 M allocations + a second 9 GB copy per
+    wires commitment).  Now the buffer the library filled moves into the DeviceTree, `leaves` stays empty, MerkleTree::get /
+    num_leaves / prove and the serializer go through it, and `polynomials` are filled in place (P2HOT_COEFFS_PER_COLUMN)"""
+    s, p = open(RS).read(), open(PATCH).read()
+    body = s[s.index("pub(crate) fn commit_with_salts"):s.index("// Challenger <-> p2hot_challenger")]
+    assert "flat: flat_leaves" in body and "P2HOT_COEFFS_PER_COLUMN" in body
+    assert not re.search(r"\.chunks_exact\([^)]*\)\s*\.map\(\|\w+\|\s*\w+\.to_vec\(\)\)", body), "a serial per-row / per-column copy is back"
+    assert "if leaves_as_vecs() { device.leaves_as_vecs() } else { Vec::new() }" in body
+    assert re.search(r"fn row\(&self, i: usize\) -> &\[F\] \{\s*if !self\.flat\.is_empty\(\) \{\s*return &self\.flat\[i \* self\.width\.\.\(i \+ 1\) \* self\.width\]", s)
+    assert "self.flat.par_chunks_exact(" in s                                   # the Vec<Vec<F>> form, when asked for, is built in parallel
+    for needle in ("+    pub fn num_leaves(&self) -> usize {", "+            merkle_tree_prove::<F, H>(leaf_index, self.num_leaves(), cap_height, &self.digests);",
+                   "+        self.write_usize(tree.num_leaves())?;", "+            self.write_field_vec(tree.get(i))?;", "+                return device.num_leaves();"):
+        assert needle in p, needle
+    h = open(HDR).read()
+    assert "#define P2HOT_COEFFS_PER_COLUMN 2u" in h and "pub const P2HOT_COEFFS_PER_COLUMN: c_uint = 2;" in s
