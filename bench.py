@@ -562,11 +562,15 @@ def valu_line(e, launches_per_step, h):
            "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE, kernel duration under rocprofv3 --pmc)"}
     if ub:
         occ = ub.get("occupancy", {})
-        probes = {w: o["probes"].get("mix hash_leaves", {}) for w, o in occ.items()}
+        probes = {w + ("" if nm == "mix hash_leaves" else " x4"): o["probes"].get(nm, {}) for w, o in occ.items() for nm in ("mix hash_leaves", "mix hash_leaves x4")}
         best = min((p_["cyc_per_inst"], w) for w, p_ in probes.items() if p_.get("cyc_per_inst")) if any(p_.get("cyc_per_inst") for p_ in probes.values()) else None
         if best:
-            out.update({"ceiling_cycles_per_inst": best[0], "ceiling_probe": "tools/ubench.hip `mix hash_leaves` at %s waves per SIMD, %.2f GHz"
-                        % (best[1][1:], probes[best[1]]["clock_ghz"]), "frac": best[0] / cyc,
+            raw = best[0] / cyc
+            out.update({"ceiling_cycles_per_inst": best[0], "ceiling_probe": "tools/ubench.hip `mix hash_leaves` (%s: waves per SIMD, x4 = 128 instructions per loop trip), %.2f GHz"
+                        % (best[1][1:], probes[best[1]]["clock_ghz"]),
+                        # the probe is an EMPIRICAL ceiling (the fastest dependency-free arrangement of the mix that was measured), so a
+                        # kernel that is itself such an arrangement can tie it within the +-1 % scatter of two PMC runs: capped, raw kept
+                        "frac": min(1.0, raw), "frac_raw": raw,
                         "ceiling_by_occupancy": {w: round(p_["cyc_per_inst"], 3) for w, p_ in probes.items() if p_.get("cyc_per_inst")},
                         "peak_Gwave_inst_per_s": 1024 * clock / best[0], "achieved_Gwave_inst_per_s": 1024 * clock / cyc})
         out["classes_cycles_per_inst"] = {w: {c: round(v["cyc_per_inst_median"], 2) for c, v in o.get("classes", {}).items()} for w, o in occ.items()}

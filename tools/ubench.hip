@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t 
         if (OP == 47) asm volatile(CHAIN_MAD OPS);
         if (OP == 48) asm volatile(MIX_HASH OPS);
         if (OP == 49) asm volatile(MIX_NTT OPS);
+        if (OP == 50) asm volatile(MIX_HASH "\n\t" MIX_HASH "\n\t" MIX_HASH "\n\t" MIX_HASH OPS);  // 128 slots per loop trip: the loop's own SALU is < 3 %
     }
     uint64_t t1 = __builtin_readcyclecounter();
     uint64_t s = 0;
@@ -307,6 +308,7 @@ int main(int argc, char **argv) {
     run<46>("chain v_add_u32");
     run<47>("chain v_mad_u64");
     run<48>("mix hash_leaves", 32);
+    run<50>("mix hash_leaves x4", 128);
     run<49>("mix limb_ntt", 16);
     return 0;
 }
