@@ -141,7 +141,11 @@ def host_pointer_lines(eng, out, reps):
     import ctypes as C
     rb, cap = 3, 4
 
-    def run(name, W, log_n, what, want_coeffs, want_digests, want_leaves, gname, reps=reps, is_values=1, per_column=False):
+    def run(name, W, log_n, what, want_coeffs, want_digests, want_leaves, gname, reps=reps, is_values=1, per_column=False, leaves_mem="touched"):
+        """leaves_mem: where the leaf matrix lands -- "touched": pageable memory written before (no page fault in the timed calls);
+        "fresh": a NEW pageable buffer per call, as a Vec::with_capacity would be (first-touch faults while the copy runs);
+        "pinned": a block of the context's pinned cache (p2hot_host_alloc: what the Rust shim's flat leaf store uses), allocated and
+        freed around every call, i.e. reused from the cache after the first"""
         n, N = 1 << log_n, 1 << (log_n + rb)
         cols = [np.ascontiguousarray(c) for c in splitmix_columns_numpy(0, W, n)]
         ptrs = (C.c_void_p * W)(*[c.ctypes.data for c in cols])
@@ -149,18 +153,34 @@ def host_pointer_lines(eng, out, reps):
         # per_column: one destination per polynomial (what the Rust shim passes: W separate Vec<F>, P2HOT_COEFFS_PER_COLUMN)
         table = (C.c_void_p * W)(*[coeffs[c].ctypes.data for c in range(W)]) if (per_column and want_coeffs) else None
         digests = np.zeros((eng.num_digests(log_n + rb, cap), 4), dtype=np.uint64) if want_digests else None
-        leaves = np.zeros((N, W), dtype=np.uint64) if want_leaves else None   # touched here: page faults are not timed
+        leaves = np.zeros((N, W), dtype=np.uint64) if (want_leaves and leaves_mem == "touched") else None   # touched here: page faults are not timed
         capv = np.zeros((1 << cap, 4), dtype=np.uint64)
 
         def ptr(a):
             return a.ctypes.data if a is not None else None
 
         def once():
-            h = C.c_void_p()
+            h, blk, lv = C.c_void_p(), C.c_void_p(), ptr(leaves)
+            if want_leaves and leaves_mem == "fresh":
+                fresh = np.empty((N, W), dtype=np.uint64)  # untouched: mmap'd by the allocator, unmapped again when it is dropped
+                lv = fresh.ctypes.data
+            elif want_leaves and leaves_mem == "pinned":
+                eng.check(eng.lib.p2hot_host_alloc(eng.ctx, N * W * 8, C.byref(blk)))
+                lv = blk
             eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, is_values, 2 if table is not None else 0,
-                                           C.cast(table, C.c_void_p) if table is not None else ptr(coeffs), ptr(leaves), ptr(digests),
+                                           C.cast(table, C.c_void_p) if table is not None else ptr(coeffs), lv, ptr(digests),
                                            capv.ctypes.data, C.byref(h)))
             eng.lib.p2hot_batch_free(h)
+            if blk.value:
+                eng.lib.p2hot_host_free(eng.ctx, blk)
+        first_pin_ms = None
+        if want_leaves and leaves_mem == "pinned":  # what the FIRST commitment of a process pays: pinning the block (later ones reuse it)
+            eng.check(eng.lib.p2hot_ctx_trim(eng.ctx))
+            blk0 = C.c_void_p()
+            t0 = time.perf_counter()
+            eng.check(eng.lib.p2hot_host_alloc(eng.ctx, N * W * 8, C.byref(blk0)))
+            first_pin_ms = (time.perf_counter() - t0) * 1e3
+            eng.lib.p2hot_host_free(eng.ctx, blk0)
         once()
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -168,6 +188,7 @@ def host_pointer_lines(eng, out, reps):
         ms = (time.perf_counter() - t0) / reps * 1e3
         g = golden(gname) if gname else None
         out[name] = {"workload": what, "ms": ms, "GFE/s": W * N / ms / 1e6, "pcie_inclusive": True,
+                     **({"first_pin_ms": first_pin_ms} if first_pin_ms is not None else {}),
                      **({"cap_checked": capv.tolist() == g["cap"]} if g else {})}
 
     base = "p2hot_commit (host pointers, pageable memory) C3 wires: W=135, 2^20 rows, rate 1/8, cap 4; 1.1 GB of columns in, "
@@ -178,6 +199,10 @@ def host_pointer_lines(eng, out, reps):
     run("host_c3_wires_leaves_back", 135, 20, base + "coefficients (one destination per polynomial, P2HOT_COEFFS_PER_COLUMN) + digests + cap + the "
         "9.1 GB row-major leaf matrix out: exactly the Rust shim's default call (P2HOT_LEAVES=host)",
         True, True, True, "c3_wires", reps=2, per_column=True)
+    run("host_c3_wires_leaves_back_fresh_pages", 135, 20, base + "as host_c3_wires_leaves_back, but the 9.1 GB leaf matrix lands in a NEW pageable "
+        "buffer every call (what a fresh Vec is: a page fault per 4 KiB while the copy runs)", True, True, True, "c3_wires", reps=2, per_column=True, leaves_mem="fresh")
+    run("host_c3_wires_leaves_back_pinned", 135, 20, base + "as host_c3_wires_leaves_back, but the leaf matrix lands in a block of the context's PINNED "
+        "cache (p2hot_host_alloc / _free around every call: the Rust shim's flat leaf store)", True, True, True, "c3_wires", reps=2, per_column=True, leaves_mem="pinned")
     # the other two commitments of a proof in the shim's default mode (leaves back): one column block each
     run("host_c3_zs_leaves_back", 20, 20, "p2hot_commit (host pointers, pageable memory) C3 Zs + partial products: from_values W=20, 2^20 rows; "
         "coefficients + digests + cap + the 1.3 GB leaf matrix out", True, True, True, "c3_zs_partial_products", reps=3)
@@ -203,7 +228,7 @@ def host_tail_line(out):
     except Exception as ex:  # noqa: BLE001
         out["host_tail_c3_wires"] = {"error": repr(ex)}
         return
-    gpu = out.get("host_c3_wires_leaves_back", {}).get("ms")
+    gpu = (out.get("host_c3_wires_leaves_back_pinned") or out.get("host_c3_wires_leaves_back", {})).get("ms")
     rec = {"workload": "host work of the Rust shim after the C3 wires commit (W=135, 2^20 rows, leaves back), tools/host_tail.cpp on %d threads" % r["threads"],
            "default_mode_ms": 0.0,
            "default_mode": "P2HOT_LEAVES=host + P2HOT_COEFFS_PER_COLUMN: W Vec allocations, no copy (the flat leaf buffer moves into the DeviceTree)",
@@ -383,7 +408,7 @@ def recursion_lines(eng, torch, out):
     out["recursion_proofs_concurrent_contexts"] = rec
 
 
-def other_configs(eng, torch, reps=3):
+def other_configs(eng, torch, reps=3, only=None):
     """Driver-timed lines for the other BASELINE shapes (extra keys of the JSON line; the headline is unchanged):
     each is `reps` timed repetitions after one warm-up, inputs resident in HBM, synchronised wall time."""
     from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, eval_openings, prove_openings
@@ -411,6 +436,10 @@ def other_configs(eng, torch, reps=3):
             rec["cap_checked"] = eng.host(eng.commit(cols, log_n, rb, cap, is_values)["cap"]).tolist() == g["cap"]
         out[name] = rec
 
+    if only == "host":  # tooling: the PCIe-inclusive lines alone
+        host_pointer_lines(eng, out, reps)
+        host_tail_line(out)
+        return out
     commit_line("c2_wires", 135, 16, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 135, 1 << 16),
                 "C2: from_values W=135, 2^16 rows, rate 1/8, cap 4")
     commit_line("c3_constants_sigmas", 84, 20, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 84, 1 << 20),
@@ -642,6 +671,7 @@ def main():
     ap.add_argument("--strong", action="store_true", help="strong scaling: 2^log_n rows in TOTAL (the C3 commit split over the GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra driver-timed lines of the other BASELINE shapes")
+    ap.add_argument("--extra-only", default=None, help="tooling: only this group of extra lines (host)")
     args = ap.parse_args()
 
     import torch
@@ -816,7 +846,7 @@ def main():
         if world == 1 and not args.no_extra:
             del job, cols
             torch.cuda.empty_cache()
-            out["other_configs"] = other_configs(eng, torch)
+            out["other_configs"] = other_configs(eng, torch, only=args.extra_only)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, log_n, rb, cap, golden_cap=g["cap"] if g else None)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -325,6 +325,14 @@ int p2hot_batch_values(p2hot_batch *batch, p2hot_cols **out);
  * matrix costs up to a second; p2hot_ctx_trim gives the cached free blocks back to the driver) */
 void p2hot_batch_free(p2hot_batch *batch);
 int p2hot_ctx_trim(p2hot_ctx *ctx);
+/* PINNED host memory from a grow-only cache of the context, for output buffers that live as long as a commitment -- above all the
+ * flat leaf matrix (`leaves_out`, 9 GB at the C3 shape) the Rust shim keeps behind MerkleTree::get (hash/merkle_tree.rs:227).
+ * A device-to-host copy into pinned memory runs at the PCIe rate and touches no fresh page; a fresh pageable allocation of that
+ * size pays a page fault per 4 KiB while the copy runs, and a fresh PIN of that size costs seconds -- hence the cache: a block
+ * released with p2hot_host_free (any thread, any time: a Drop) is handed out again by the next p2hot_host_alloc of a similar
+ * size; p2hot_ctx_trim and p2hot_ctx_destroy give the cached blocks back to the OS.  Free every block before destroying the context. */
+int p2hot_host_alloc(p2hot_ctx *ctx, size_t bytes, void **out);
+void p2hot_host_free(p2hot_ctx *ctx, void *p);
 
 /* device-resident column sets */
 int p2hot_cols_upload(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, p2hot_cols **out);

@@ -272,6 +272,8 @@ extern "C" {
     pub fn p2hot_batch_values(batch: *mut P2hotBatch, out: *mut *mut P2hotCols) -> c_int;
     pub fn p2hot_batch_free(batch: *mut P2hotBatch);
     pub fn p2hot_ctx_trim(ctx: *mut P2hotCtx) -> c_int;
+    pub fn p2hot_host_alloc(ctx: *mut P2hotCtx, bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn p2hot_host_free(ctx: *mut P2hotCtx, p: *mut c_void);
     pub fn p2hot_cols_upload(ctx: *mut P2hotCtx, cols: *const *const u64, W: usize, log_n: c_uint, out: *mut *mut P2hotCols) -> c_int;
     pub fn p2hot_cols_download(cols: *mut P2hotCols, first: usize, count: usize, out: *mut u64) -> c_int;
     pub fn p2hot_cols_width(cols: *const P2hotCols) -> usize;
@@ -467,6 +469,57 @@ impl<T> Out<T> {
 // ------------------------------------------------------------------------------------------------
 // Device-resident tree: what MerkleTree::get / ::prove read when `leaves` / `digests` stayed on the GPU
 // ------------------------------------------------------------------------------------------------
+/// The leaf matrix on the host, row-major [num_leaves][width]: the ONE buffer the library's copy filled.  Pinned memory from the
+/// context's block cache when it can be had (`p2hot_host_alloc`: the 9 GB copy then runs at the PCIe rate and touches no fresh
+/// page, and the block is reused by the next commitment of that size), an ordinary Vec otherwise; empty = the matrix stayed on the GPU.
+enum FlatLeaves<F> {
+    Pinned { ptr: *mut F, len: usize },
+    Heap(Vec<F>),
+}
+impl<F> FlatLeaves<F> {
+    /// `len` elements for the library to fill; `ptr()` is what goes into `leaves_out`
+    fn for_output(len: usize) -> Self {
+        if len == 0 {
+            return FlatLeaves::Heap(Vec::new());
+        }
+        let mut p: *mut c_void = core::ptr::null_mut();
+        let rc = with_ctx(|ctx| unsafe { p2hot_host_alloc(ctx, len * core::mem::size_of::<F>(), &mut p) });
+        if rc == P2HOT_OK && !p.is_null() {
+            FlatLeaves::Pinned { ptr: p as *mut F, len }
+        } else {
+            FlatLeaves::Heap(Vec::with_capacity(len)) // filled through the spare capacity, `filled` sets the length
+        }
+    }
+    fn ptr(&mut self) -> *mut u64 {
+        match self {
+            FlatLeaves::Pinned { ptr, .. } => *ptr as *mut u64,
+            FlatLeaves::Heap(v) if v.capacity() > 0 => v.as_mut_ptr() as *mut u64,
+            FlatLeaves::Heap(_) => core::ptr::null_mut(),
+        }
+    }
+    /// SAFETY: the library call that received `ptr()` returned P2HOT_OK, i.e. it wrote all `len` elements
+    unsafe fn filled(mut self, len: usize) -> Self {
+        if let FlatLeaves::Heap(v) = &mut self {
+            v.set_len(if v.capacity() > 0 { len } else { 0 });
+        }
+        self
+    }
+    fn as_slice(&self) -> &[F] {
+        match self {
+            // SAFETY: `ptr` is a live pinned block of at least `len` initialised elements, owned by this value until Drop
+            FlatLeaves::Pinned { ptr, len } => unsafe { core::slice::from_raw_parts(*ptr, *len) },
+            FlatLeaves::Heap(v) => v.as_slice(),
+        }
+    }
+}
+impl<F> Drop for FlatLeaves<F> {
+    fn drop(&mut self) {
+        if let FlatLeaves::Pinned { ptr, .. } = self {
+            with_ctx(|ctx| unsafe { p2hot_host_free(ctx, *ptr as *mut c_void) }); // back to the context's cache, not to the OS
+        }
+    }
+}
+
 pub struct DeviceTree<F: RichField> {
     batch: *mut P2hotBatch,
     width: usize,
@@ -474,7 +527,7 @@ pub struct DeviceTree<F: RichField> {
     num_layers: usize,
     /// P2HOT_LEAVES=host (default): the whole leaf matrix, row-major [num_leaves][width], exactly the buffer the library
     /// filled (`leaves_out`) -- ONE allocation; empty when the matrix stayed on the GPU
-    flat: Vec<F>,
+    flat: FlatLeaves<F>,
     /// rows fetched so far in the device mode: `get` hands out `&[F]`, so fetched rows are kept (never moved) for the tree's lifetime
     rows: Mutex<HashMap<usize, Box<[F]>>>,
 }
@@ -498,8 +551,9 @@ impl<F: RichField> DeviceTree<F> {
 
     /// MerkleTree::get (merkle_tree.rs:227)
     pub fn row(&self, i: usize) -> &[F] {
-        if !self.flat.is_empty() {
-            return &self.flat[i * self.width..(i + 1) * self.width]; // panics on i >= num_leaves like `&self.leaves[i]`
+        let flat = self.flat.as_slice();
+        if !flat.is_empty() {
+            return &flat[i * self.width..(i + 1) * self.width]; // panics on i >= num_leaves like `&self.leaves[i]`
         }
         let mut cache = self.rows.lock().unwrap();
         if !cache.contains_key(&i) {
@@ -517,10 +571,11 @@ impl<F: RichField> DeviceTree<F> {
     /// the reference's `leaves: Vec<Vec<F>>` (merkle_tree.rs:47) rebuilt from the flat buffer, rows in parallel
     /// (P2HOT_LEAVES=vec, and the bit-exact harness, which compares the field itself)
     pub fn leaves_as_vecs(&self) -> Vec<Vec<F>> {
-        if self.flat.is_empty() {
+        let flat = self.flat.as_slice();
+        if flat.is_empty() {
             return (0..self.num_leaves).map(|i| self.row(i).to_vec()).collect();
         }
-        self.flat.par_chunks_exact(self.width.max(1)).map(|r| r.to_vec()).collect()
+        flat.par_chunks_exact(self.width.max(1)).map(|r| r.to_vec()).collect()
     }
 
     /// merkle_tree_prove (merkle_tree.rs:151-190)
@@ -588,7 +643,7 @@ pub(crate) fn commit_with_salts<F: RichField + Extendable<D>, C: GenericConfig<D
     let coeff_ptrs: Vec<*mut u64> = coeff_vecs.iter_mut().map(|o| o.ptr()).collect();
     let mut cap = Out::<<C::Hasher as Hasher<F>>::Hash>::new(1 << cap_height, true);
     let mut digests = Out::<<C::Hasher as Hasher<F>>::Hash>::new(num_digests, !on_device);
-    let mut flat_leaves = Out::<F>::new(big_n * lw, !on_device);
+    let mut flat_leaves = FlatLeaves::<F>::for_output(if on_device { 0 } else { big_n * lw });
     with_ctx(|ctx| {
         let rc = unsafe {
             p2hot_commit_salted(
@@ -598,7 +653,7 @@ pub(crate) fn commit_with_salts<F: RichField + Extendable<D>, C: GenericConfig<D
         };
         check(ctx, rc, "p2hot_commit_salted");
     });
-    let (cap, digests, flat_leaves) = unsafe { (cap.finish(), digests.finish(), flat_leaves.finish()) };
+    let (cap, digests, flat_leaves) = unsafe { (cap.finish(), digests.finish(), flat_leaves.filled(if on_device { 0 } else { big_n * lw })) };
     // `polynomials` (oracle.rs:32): the W vectors the library filled (SAFETY: the call returned P2HOT_OK, every one holds n words)
     let polynomials = coeff_vecs.into_iter().map(|o| PolynomialCoeffs::new(unsafe { o.finish() })).collect();
     // merkle_tree.leaves (oracle.rs:97-98) is NOT rebuilt: the flat buffer the library filled moves into the DeviceTree and
@@ -871,7 +926,7 @@ pub fn coeff_slices<F: Field>(polys: &[PolynomialCoeffs<F>]) -> Vec<&[F]> {
 // tree, not part of its value: two trees are equal when leaves, digests and cap are.
 impl<F: RichField> core::fmt::Debug for DeviceTree<F> {
     fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
-        write!(f, "DeviceTree({:p}, {} leaves of {}, {} layers, {} host words)", self.batch, self.num_leaves, self.width, self.num_layers, self.flat.len())
+        write!(f, "DeviceTree({:p}, {} leaves of {}, {} layers, {} host words)", self.batch, self.num_leaves, self.width, self.num_layers, self.flat.as_slice().len())
     }
 }
 impl<F: RichField> PartialEq for DeviceTree<F> {

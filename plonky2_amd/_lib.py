@@ -114,6 +114,8 @@ SIGNATURES = {
     "p2hot_cols_degree_log": (u, [vp]),
     "p2hot_cols_free": (None, [vp]),
     "p2hot_eval_openings": (i, [vp, C.POINTER(vp), sz, vp, sz, vp]),
+    "p2hot_host_alloc": (i, [vp, sz, C.POINTER(vp)]),
+    "p2hot_host_free": (None, [vp, vp]),
     "p2hot_fri_proof_sizes": (i, [C.POINTER(vp), sz, C.POINTER(FriParams), C.POINTER(FriProofLayout)]),
     "p2hot_prove_openings": (i, [vp, C.POINTER(FriBatchInfo), sz, C.POINTER(vp), sz, vp, C.POINTER(FriParams),
                                  C.POINTER(FriProof)]),

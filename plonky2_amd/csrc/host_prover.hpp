@@ -616,6 +616,8 @@ extern "C" int p2hot_ctx_trim(p2hot_ctx *ctx) {
         std::lock_guard<std::mutex> pool_lock_(ctx->pool_mu);
         for (auto &blk : ctx->pool_free) (void)hipFree(blk.first);
         ctx->pool_free.clear();
+        for (auto &blk : ctx->host_pool_free) (void)hipHostFree(blk.first);
+        ctx->host_pool_free.clear();
     }
     for (p2hot_ctx *h : ctx->helpers) {  // the sibling contexts of p2hot_prove_openings_many keep their own block caches
         P2_HIP(ctx, stream_sync(h));

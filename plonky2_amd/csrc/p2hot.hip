@@ -90,6 +90,9 @@ struct p2hot_ctx {
     std::mutex pool_mu;  // pool_free / pool_live / scratch bookkeeping: frees may come from another thread (a Drop, a GC finaliser)
     std::vector<std::pair<void *, size_t>> pool_free;  // (pointer, capacity)
     std::map<void *, size_t> pool_live;  // (inverse, log_nblk, log_r) -> inter-pass twiddle table
+    // the same for PINNED host blocks handed to the caller (p2hot_host_alloc): the flat leaf matrix behind MerkleTree::get
+    std::vector<std::pair<void *, size_t>> host_pool_free;
+    std::map<void *, size_t> host_pool_live;
     // live per-kernel timing (HIP events on the launch stream), off by default
     bool profiling = false;
     struct ProfRec {
@@ -340,6 +343,46 @@ static void pool_release(p2hot_ctx *ctx, void *p) {
     ctx->pool_free.emplace_back(p, it->second);
     ctx->pool_live.erase(it);
 }
+// ---- pinned host blocks for the caller (include/p2hot.h, p2hot_host_alloc)
+extern "C" int p2hot_host_alloc(p2hot_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return P2HOT_EINVAL;
+    *out = nullptr;
+    DeviceGuard dev_guard_(ctx);
+    std::lock_guard<std::mutex> pool_lock_(ctx->pool_mu);
+    if (bytes == 0) bytes = 8;
+    size_t best = ctx->host_pool_free.size();
+    for (size_t k = 0; k < ctx->host_pool_free.size(); ++k) {
+        const size_t cap = ctx->host_pool_free[k].second;
+        if (cap >= bytes && cap <= 2 * bytes + ((size_t)1 << 20) && (best == ctx->host_pool_free.size() || cap < ctx->host_pool_free[best].second)) best = k;
+    }
+    if (best != ctx->host_pool_free.size()) {
+        *out = ctx->host_pool_free[best].first;
+        ctx->host_pool_live[*out] = ctx->host_pool_free[best].second;
+        ctx->host_pool_free.erase(ctx->host_pool_free.begin() + best);
+        return P2HOT_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {  // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        for (auto &b : ctx->host_pool_free) (void)hipHostFree(b.first);
+        ctx->host_pool_free.clear();
+        e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) P2_FAIL(ctx, P2HOT_ENOMEM, "host_alloc: %zu pinned bytes: %s", bytes, hipGetErrorString(e));
+    }
+    ctx->host_pool_live[p] = bytes;
+    *out = p;
+    return P2HOT_OK;
+}
+extern "C" void p2hot_host_free(p2hot_ctx *ctx, void *p) {
+    if (!ctx || !p) return;
+    std::lock_guard<std::mutex> pool_lock_(ctx->pool_mu);
+    auto it = ctx->host_pool_live.find(p);
+    if (it == ctx->host_pool_live.end()) return;  // not ours (or freed twice): left alone
+    ctx->host_pool_free.emplace_back(p, it->second);
+    ctx->host_pool_live.erase(it);
+}
+
 namespace {
 struct PoolBuf {  // returns its block to the context's cache on scope exit (the owner syncs the stream first)
     p2hot_ctx *ctx;
@@ -446,6 +489,8 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
     }
     for (auto &b : ctx->pool_free) (void)hipFree(b.first);
     for (auto &kv : ctx->pool_live) (void)hipFree(kv.first);
+    for (auto &b : ctx->host_pool_free) (void)hipHostFree(b.first);
+    for (auto &kv : ctx->host_pool_live) (void)hipHostFree(kv.first);
     for (auto &s : ctx->scratch)
         if (s.p) (void)hipFree(s.p);
     if (ctx->tables) (void)hipFree(ctx->tables);

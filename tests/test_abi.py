@@ -176,3 +176,30 @@ def test_commit_cols_einval_never_consumes_the_set(eng):
     assert eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, 3, 2, 1, 0, None, None, None, ref.ctypes.data, None) == _lib.OK
     assert (cap == ref).all() and cap.any()
     eng.lib.p2hot_batch_free(out)
+
+
+def test_pinned_host_blocks_are_cached_per_context(eng, ora):
+    """p2hot_host_alloc / p2hot_host_free: the flat leaf matrix the Rust shim keeps behind MerkleTree::get lives in a pinned block
+    of the context's cache -- a commit writes it, a freed block is handed out again for the next request of that size,
+    p2hot_ctx_trim gives cached blocks back"""
+    from plonky2_amd import _lib
+    W, log_n, rb, cap = 5, 5, 3, 2
+    n, N = 1 << log_n, 1 << (log_n + rb)
+    cols = np.random.default_rng(11).integers(0, P_, size=(W, n), dtype=np.uint64)
+    ptrs = (C.c_void_p * W)(*[cols[c].ctypes.data for c in range(W)])
+    blk = C.c_void_p()
+    assert eng.lib.p2hot_host_alloc(eng.ctx, N * W * 8, C.byref(blk)) == _lib.OK and blk.value
+    capv = np.zeros((1 << cap, 4), dtype=np.uint64)
+    assert eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, 0, None, blk, None, capv.ctypes.data, None) == _lib.OK
+    leaves = np.ctypeslib.as_array(C.cast(blk, C.POINTER(C.c_uint64)), shape=(N * W,)).reshape(N, W).copy()
+    o = ora.commit(cols, rb, cap, True)
+    assert (leaves == o["leaves"]).all() and (capv == o["cap"]).all()
+    first = blk.value
+    eng.lib.p2hot_host_free(eng.ctx, blk)
+    eng.lib.p2hot_host_free(eng.ctx, blk)            # a second free of the same block is ignored
+    again = C.c_void_p()
+    assert eng.lib.p2hot_host_alloc(eng.ctx, N * W * 8 - 64, C.byref(again)) == _lib.OK
+    assert again.value == first, "the cached block was not reused"
+    eng.lib.p2hot_host_free(eng.ctx, again)
+    assert eng.lib.p2hot_ctx_trim(eng.ctx) == _lib.OK
+    assert eng.lib.p2hot_host_alloc(None, 8, C.byref(again)) == _lib.EINVAL

@@ -348,8 +348,9 @@ def test_leaf_matrix_is_one_flat_buffer_behind_get():
     assert "flat: flat_leaves" in body and "P2HOT_COEFFS_PER_COLUMN" in body
     assert not re.search(r"\.chunks_exact\([^)]*\)\s*\.map\(\|\w+\|\s*\w+\.to_vec\(\)\)", body), "a serial per-row / per-column copy is back"
     assert "if leaves_as_vecs() { device.leaves_as_vecs() } else { Vec::new() }" in body
-    assert re.search(r"fn row\(&self, i: usize\) -> &\[F\] \{\s*if !self\.flat\.is_empty\(\) \{\s*return &self\.flat\[i \* self\.width\.\.\(i \+ 1\) \* self\.width\]", s)
-    assert "self.flat.par_chunks_exact(" in s                                   # the Vec<Vec<F>> form, when asked for, is built in parallel
+    assert re.search(r"fn row\(&self, i: usize\) -> &\[F\] \{\s*let flat = self\.flat\.as_slice\(\);\s*if !flat\.is_empty\(\) \{\s*return &flat\[i \* self\.width\.\.\(i \+ 1\) \* self\.width\]", s)
+    assert "flat.par_chunks_exact(" in s                                        # the Vec<Vec<F>> form, when asked for, is built in parallel
+    assert "p2hot_host_alloc(ctx, len * core::mem::size_of::<F>(), &mut p)" in s and "p2hot_host_free(ctx, *ptr as *mut c_void)" in s  # pinned, cached
     for needle in ("+    pub fn num_leaves(&self) -> usize {", "+            merkle_tree_prove::<F, H>(leaf_index, self.num_leaves(), cap_height, &self.digests);",
                    "+        self.write_usize(tree.num_leaves())?;", "+            self.write_field_vec(tree.get(i))?;", "+                return device.num_leaves();"):
         assert needle in p, needle
