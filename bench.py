@@ -414,7 +414,7 @@ def other_configs(eng, torch, reps=3, only=None):
     from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, eval_openings, prove_openings
     from plonky2_amd.fri.prover import fri_committed_trees_device
     from plonky2_amd.iop.challenger import Challenger
-    from plonky2_amd.plonk.prover import all_wires_permutation_partial_products
+    from plonky2_amd.plonk.prover import all_wires_permutation_partial_products, compute_quotient_polys
     from plonky2_amd.util.synthetic import fibonacci_trace
     dev = eng.mem.device
     out = {}
@@ -440,26 +440,31 @@ def other_configs(eng, torch, reps=3, only=None):
         host_pointer_lines(eng, out, reps)
         host_tail_line(out)
         return out
-    commit_line("c2_wires", 135, 16, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 135, 1 << 16),
-                "C2: from_values W=135, 2^16 rows, rate 1/8, cap 4")
-    commit_line("c3_constants_sigmas", 84, 20, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 84, 1 << 20),
-                "C3: from_values W=84 (constants + sigmas: the commitment CircuitBuilder::build makes, circuit_builder.rs:1182-1191), "
-                "2^20 rows, rate 1/8, cap 4")
-    commit_line("c3_zs_partial_products", 20, 20, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 20, 1 << 20),
-                "C3: from_values W=20 (Zs + partial products), 2^20 rows, rate 1/8, cap 4")
-    commit_line("c3_quotient_chunks", 16, 20, 3, 4, False, splitmix_columns_torch(torch, dev, 0, 16, 1 << 20),
-                "C3: from_coeffs W=16 (quotient chunks), 2^20 rows, rate 1/8, cap 4")
-    commit_line("c4_fibonacci_trace", 2, 22, 1, 4, True, eng.dev(fibonacci_trace(22)),
-                "C4: from_values W=2 (Fibonacci trace), 2^22 rows, rate 1/2, cap 4 (hash_or_noop leaves)")
-    host_pointer_lines(eng, out, reps)
-    host_tail_line(out)
-    recursion_lines(eng, torch, out)
-    for name, log_n, rb in (("c3_fri_commit_phase", 20, 3), ("c4_fri_commit_phase", 22, 1)):
-        planes = splitmix_columns_torch(torch, dev, 500, 2, 1 << log_n)
-        ch = Challenger(eng)
-        ms = timed(lambda: fri_committed_trees_device(planes, log_n, ch, rb, 4, [4, 4, 4, 4], eng))
-        out[name] = {"workload": "fri_committed_trees, N=2^%d, arity 16 x4, cap 4 (final FFT + 4 round trees + folds, device resident)"
-                                 % (log_n + rb), "ms": ms}
+    if only == "path":  # tooling: the per-proof paths alone
+        _only_paths = True
+    else:
+        _only_paths = False
+    if not _only_paths:
+        commit_line("c2_wires", 135, 16, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 135, 1 << 16),
+                    "C2: from_values W=135, 2^16 rows, rate 1/8, cap 4")
+        commit_line("c3_constants_sigmas", 84, 20, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 84, 1 << 20),
+                    "C3: from_values W=84 (constants + sigmas: the commitment CircuitBuilder::build makes, circuit_builder.rs:1182-1191), "
+                    "2^20 rows, rate 1/8, cap 4")
+        commit_line("c3_zs_partial_products", 20, 20, 3, 4, True, splitmix_columns_torch(torch, dev, 0, 20, 1 << 20),
+                    "C3: from_values W=20 (Zs + partial products), 2^20 rows, rate 1/8, cap 4")
+        commit_line("c3_quotient_chunks", 16, 20, 3, 4, False, splitmix_columns_torch(torch, dev, 0, 16, 1 << 20),
+                    "C3: from_coeffs W=16 (quotient chunks), 2^20 rows, rate 1/8, cap 4")
+        commit_line("c4_fibonacci_trace", 2, 22, 1, 4, True, eng.dev(fibonacci_trace(22)),
+                    "C4: from_values W=2 (Fibonacci trace), 2^22 rows, rate 1/2, cap 4 (hash_or_noop leaves)")
+        host_pointer_lines(eng, out, reps)
+        host_tail_line(out)
+        recursion_lines(eng, torch, out)
+        for name, log_n, rb in (("c3_fri_commit_phase", 20, 3), ("c4_fri_commit_phase", 22, 1)):
+            planes = splitmix_columns_torch(torch, dev, 500, 2, 1 << log_n)
+            ch = Challenger(eng)
+            ms = timed(lambda: fri_committed_trees_device(planes, log_n, ch, rb, 4, [4, 4, 4, 4], eng))
+            out[name] = {"workload": "fri_committed_trees, N=2^%d, arity 16 x4, cap 4 (final FFT + 4 round trees + folds, device resident)"
+                                     % (log_n + rb), "ms": ms}
     # the per-proof path of a standard_recursion_config proof: every stage of SURVEY section 8 back to back, at the
     # headline size (2^20 gates) and at recursion size (2^12 gates: the two recursive proofs of bench_recursion's chain)
     def path_line(name, log_n, arity):
@@ -467,7 +472,6 @@ def other_configs(eng, torch, reps=3, only=None):
         wires = splitmix_columns_torch(torch, dev, 0, 135, n)
         cs = splitmix_columns_torch(torch, dev, 1000, 84, n)   # constants (4) + sigmas (80): prover_data, committed by build()
         sig = cs[4:84]
-        quo = splitmix_columns_torch(torch, dev, 2000, 16, n)
         k_is = [pow(14293326489335486720, j, P) for j in range(80)]
         # CircuitBuilder::build's commitment (circuit_builder.rs:1182-1191): part of the circuit, not of a proof -> outside the timed path
         b_cs = PolynomialBatch.from_values(cs, rb, False, cap, engine=eng)
@@ -492,7 +496,12 @@ def other_configs(eng, torch, reps=3, only=None):
             lap("partial products + Zs (80 routed wires, 2 challenges)")
             b_z = PolynomialBatch.from_values(zs, rb, False, cap, engine=eng)
             lap("Zs + partial products commit (W=20, from_values)")
-            b_q = PolynomialBatch.from_coeffs(quo, rb, False, cap, engine=eng)
+            # compute_quotient_polys without its gate evaluation (prover.rs:609-815; vanishing_poly.rs:167-330): the permutation
+            # argument's terms at the 2^(k+3) points of the quotient coset from the three device-resident LDE matrices, / Z_H,
+            # coset_ifft, 16 chunks -- the gate constraint terms are circuit specific and out of scope (gate_sums = None)
+            chunks = compute_quotient_polys(b_w, b_cs, 4, b_z, k_is, 8, [3, 5], [11, 13], [17, 19], engine=eng)
+            lap("quotient polynomials: permutation terms on the quotient coset + coset_ifft + chunks (gate terms excluded)")
+            b_q = PolynomialBatch.from_coeffs(chunks, rb, False, cap, engine=eng)
             lap("quotient chunks commit (W=16, from_coeffs)")
             oracles = [b_cs, b_w, b_z, b_q]
             ch = Challenger(eng)
@@ -508,16 +517,20 @@ def other_configs(eng, torch, reps=3, only=None):
             return stage
 
         path()
+        path()  # two warm-ups: the block cache alternates between two sets while the previous proof's commitments are still alive
         stages = [path() for _ in range(reps)]
         mean = {k: sum(s_[k] for s_ in stages) / reps for k in stages[0]}
         out[name] = {"workload": "the SURVEY section-8 stages of one 2^%d-gate standard_recursion_config proof back to back, on the reference's own "
                                  "FRI instance (get_fri_instance, plonk/circuit_data.rs:530-548: 4 oracles, 255 polynomials at zeta, the 2 Z at g*zeta); "
                                  "the constants_sigmas commitment (W=84) belongs to CircuitBuilder::build and is made outside the timed path; "
                                  "gate evaluation / witness generation excluded (out of scope)" % log_n,
-                     "ms": sum(mean.values()), "stage_ms": {k: round(v, 3) for k, v in mean.items()}}
+                     "ms": sum(mean.values()), "stage_ms": {k: round(v, 3) for k, v in mean.items()},
+                     "ms_per_repetition": [round(sum(s_.values()), 3) for s_ in stages]}
 
     path_line("per_proof_path_k20", 20, [4, 4, 4, 4])
     path_line("per_proof_path_k12", 12, [4, 4])
+    if _only_paths:
+        return out
 
     # C4: the starky per-proof path (StarkConfig::standard_fast_config: rate 1/2, cap 4, 84 queries, PoW 16 bits):
     # trace commit (from_values, W=2) + quotient commit (from_coeffs, W = quotient_degree_factor * 2 = 2) + the

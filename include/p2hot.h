@@ -242,7 +242,7 @@ int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bit
  * A context runs ONE host-pointer call at a time; a second thread entering gets P2HOT_EBUSY (plonky2 calls these
  * from the main thread, outside its rayon closures).  Serialised by the library (busy guard): p2hot_commit*, p2hot_cols_upload,
  * p2hot_batch_coeffs / _rows / _paths / _digests, p2hot_eval_openings, p2hot_prove_openings, p2hot_partial_products,
- * p2hot_quotient_chunks, p2hot_ctx_trim.  p2hot_batch_free / p2hot_cols_free may be called from any thread at any time (a
+ * p2hot_quotient_chunks, p2hot_quotient_polys, p2hot_ctx_trim.  p2hot_batch_free / p2hot_cols_free may be called from any thread at any time (a
  * Drop, a finaliser): the block cache has its own lock.  Everything else -- the *_dev building blocks, p2hot_fri_commit,
  * p2hot_fri_pow, p2hot_challenger_* -- enqueues on the context's stream without a guard: the CALLER serialises those with
  * each other and with the host-pointer calls of the same context (the Rust shim holds the context behind a Mutex). */
@@ -422,6 +422,28 @@ int p2hot_partial_products(p2hot_ctx *ctx, const p2hot_cols *wires, size_t wires
  * coefficients, ready for p2hot_commit_cols(is_values = 0). */
 int p2hot_quotient_chunks(p2hot_ctx *ctx, const uint64_t *const *quotient_values, unsigned num_challenges,
                           unsigned degree_bits, unsigned quotient_degree_factor, p2hot_cols **chunks_out);
+/* compute_quotient_polys (plonk/prover.rs:609-815) WITHOUT its gate evaluation: the permutation argument's share of
+ * eval_vanishing_poly_base_batch (plonk/vanishing_poly.rs:167-330) evaluated on the quotient coset from the device-resident LDE
+ * matrices of the three commitments -- for every x = g * w^i of the coset of size n << log2_ceil(quotient_degree_factor):
+ *   terms  L_0(x) (Z_c(x) - 1)  for every challenge c, then check_partial_products (util/partial_products.rs:52-79) per challenge:
+ *          prev_acc * prod(wire_j + beta_c k_j x + gamma_c) - next_acc * prod(wire_j + beta_c sigma_j(x) + gamma_c) per chunk of
+ *          quotient_degree_factor routed wires, accumulators Z_c(x), the partial products, Z_c(g x);
+ *   value_a(x) = (reduce_with_powers(terms, alpha_a) + alpha_a^K * gate_sums[a][i]) / Z_H(x),  K = the number of terms above
+ * -- the gate constraint terms (circuit specific, out of scope) are the CALLER's: gate_sums[a] = their own reduce_with_powers
+ * by alpha_a on the same coset (n << qbits words, natural order), or gate_sums = NULL for none --, followed by the tail of
+ * p2hot_quotient_chunks (coset_ifft, the divisibility check, chunks of n coefficients).
+ *   wires, constants_sigmas, zs_partial_products: commitments of THIS context with the same degree and rate; the routed wires are
+ *     columns 0 .. num_routed of `wires`, the sigma polynomials columns sigmas_first_col .. of `constants_sigmas`
+ *     (common_data.sigmas_range()), `zs_partial_products` holds Z_0 .. Z_{nc-1} then the partial products of challenge 0, 1, ...
+ *     (prover.rs:224-229: the order p2hot_partial_products emits)
+ *   k_is HOST [num_routed]; betas / gammas / alphas HOST [num_challenges], 1 <= num_challenges <= 4
+ *   values_out (optional) HOST [num_challenges][n << qbits]: the quotient VALUES on the coset (prover.rs:805: quotient_values)
+ *   chunks_out (optional): [num_challenges * quotient_degree_factor][n] coefficients for p2hot_commit_cols(is_values = 0)
+ * P2HOT_EINVAL "Quotient has failed ..." when the result is not a polynomial of the expected degree (the reference panics). */
+int p2hot_quotient_polys(p2hot_ctx *ctx, const p2hot_batch *wires, const p2hot_batch *constants_sigmas, size_t sigmas_first_col,
+                         const p2hot_batch *zs_partial_products, const uint64_t *k_is, unsigned num_routed,
+                         unsigned quotient_degree_factor, const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas,
+                         unsigned num_challenges, const uint64_t *const *gate_sums, uint64_t *values_out, p2hot_cols **chunks_out);
 
 /* ================================================================ multi-GPU: the coset-sharded commit
  * The rate-1/B LDE is B independent coset transforms and coset j is the contiguous row block bitrev(j) of the

@@ -302,6 +302,11 @@ extern "C" {
         ctx: *mut P2hotCtx, quotient_values: *const *const u64, num_challenges: c_uint, degree_bits: c_uint, quotient_degree_factor: c_uint,
         chunks_out: *mut *mut P2hotCols,
     ) -> c_int;
+    pub fn p2hot_quotient_polys(
+        ctx: *mut P2hotCtx, wires: *const P2hotBatch, constants_sigmas: *const P2hotBatch, sigmas_first_col: usize, zs_partial_products: *const P2hotBatch,
+        k_is: *const u64, num_routed: c_uint, quotient_degree_factor: c_uint, betas: *const u64, gammas: *const u64, alphas: *const u64,
+        num_challenges: c_uint, gate_sums: *const *const u64, values_out: *mut u64, chunks_out: *mut *mut P2hotCols,
+    ) -> c_int;
     // ---- multi-GPU
     pub fn p2hot_comm_unique_id(out: *mut u8) -> c_int;
     pub fn p2hot_comm_create_rccl(ctx: *mut P2hotCtx, rank: c_int, world: c_int, id: *const u8, out: *mut *mut P2hotComm) -> c_int;

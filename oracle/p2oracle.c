@@ -701,3 +701,73 @@ void ora_divide_by_linear(const uint64_t *poly, size_t n, const uint64_t z[2], u
     out[2 * (n - 1)] = 0;
     out[2 * (n - 1) + 1] = 0;
 }
+
+/* ---- the gate-independent part of compute_quotient_polys (plonk/prover.rs:609-815) with
+ * eval_vanishing_poly_base_batch (plonk/vanishing_poly.rs:167-330): the permutation argument's vanishing terms on the quotient
+ * coset, combined with the powers of alpha, divided by Z_H.  For every natural index i of the coset (size Nq = n << qbits,
+ * qbits = log2_ceil(quotient_degree_factor); x = g * w_Nq^i, prover.rs:707):
+ *   rows: get_lde_values(i, step) = leaves[reverse_bits(i * step, log_n + rate_bits)], step = 1 << (rate_bits - qbits)
+ *         (oracle.rs:142-147, prover.rs:640); the "next" row i_next = (i + next_step) % Nq, next_step = 1 << qbits (:643, :708)
+ *   terms, in the order of vanishing_poly.rs:326-330:
+ *     for c in challenges:  L_0(x) * (Z_c(x) - 1),   L_0 = ZeroPolyOnCoset::eval_l_0 (field/src/zero_poly_coset.rs:58-61)
+ *     for c in challenges:  check_partial_products(numerators, denominators, partials_c, Z_c(x), Z_c(g x), max_degree)
+ *                           (util/partial_products.rs:52-79): prev_acc * prod(num chunk) - next_acc * prod(den chunk),
+ *                           num_j = wire_j + beta_c * k_j * x + gamma_c, den_j = wire_j + beta_c * sigma_j(x) + gamma_c (:278-289)
+ *     then the gate constraint terms -- circuit specific, OUT OF SCOPE here: `gate_sums[a][i]` (nullable = none) is the caller's
+ *     reduce_with_powers of them alone, which enters as alpha_a^K * gate_sums (K = the number of permutation terms above)
+ *   out[a][i] = reduce_with_powers_multi(terms, alphas)[a] * Z_H(x_i)^-1   (plonk_common.rs:99-115, prover.rs:797-803)
+ * wires / cs / zs: the three commitments' leaf matrices, row-major [N][W_*], committed order; the sigma polynomials are columns
+ * sigmas_first .. + num_routed of `cs`; `zs` holds Z_0..Z_{nc-1} then the partial products of challenge 0, 1, ... (prover.rs:224-229).
+ * Returns -1 for an unsupported shape (quotient degree above the rate: the reference asserts, prover.rs:632-636). */
+int ora_quotient_permutation(const uint64_t *wires, size_t W_w, const uint64_t *cs, size_t W_cs, size_t sigmas_first, const uint64_t *zs,
+                             size_t W_z, unsigned log_n, unsigned rate_bits, const uint64_t *k_is, size_t num_routed, size_t qdf, unsigned nc,
+                             const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas, const uint64_t *gate_sums, uint64_t *out) {
+    unsigned qbits = 0;
+    while (((size_t)1 << qbits) < qdf) ++qbits; /* log2_ceil */
+    if (qbits > rate_bits || qdf < 2) return -1;
+    const size_t n = (size_t)1 << log_n, Nq = n << qbits, step = (size_t)1 << (rate_bits - qbits), next_step = (size_t)1 << qbits;
+    const unsigned log_N = log_n + rate_bits;
+    const size_t num_chunks = (num_routed + qdf - 1) / qdf, num_prods = num_chunks - 1;
+    if (W_z < nc * (1 + num_prods) || W_w < num_routed || W_cs < sigmas_first + num_routed) return -1;
+    /* ZeroPolyOnCoset::new(n_log, qbits) (zero_poly_coset.rs:21-34) */
+    const size_t rate = (size_t)1 << qbits;
+    uint64_t zh[64], zh_inv[64];
+    const uint64_t g_pow_n = ora_gl_pow(ORA_COSET_SHIFT, n), v = ora_gl_root_of_unity(qbits);
+    for (size_t j = 0; j < rate; ++j) {
+        zh[j] = ora_gl_sub(ora_gl_mul(g_pow_n, ora_gl_pow(v, j)), 1);
+        zh_inv[j] = ora_gl_inv(zh[j]);
+    }
+    const uint64_t w = ora_gl_root_of_unity(log_n + qbits), n_f = (uint64_t)n % P;
+    const size_t K = (size_t)nc + (size_t)nc * num_chunks;
+    uint64_t *terms = (uint64_t *)malloc(sizeof(uint64_t) * (K ? K : 1));
+    uint64_t xi = 1; /* points = two_adic_subgroup (prover.rs:645) */
+    for (size_t i = 0; i < Nq; ++i) {
+        const uint64_t x = ora_gl_mul(ORA_COSET_SHIFT, xi); /* shifted_x, prover.rs:707 */
+        const size_t row = reverse_bits(i * step, log_N), row_next = reverse_bits(((i + next_step) % Nq) * step, log_N);
+        const uint64_t *lw = wires + row * W_w, *lc = cs + row * W_cs, *lz = zs + row * W_z, *nz = zs + row_next * W_z;
+        const uint64_t l0 = ora_gl_mul(zh[i % rate], ora_gl_inv(ora_gl_mul(n_f, ora_gl_sub(x, 1)))); /* eval_l_0 */
+        size_t t = 0;
+        for (unsigned c = 0; c < nc; ++c) terms[t++] = ora_gl_mul(l0, ora_gl_sub(lz[c], 1));
+        for (unsigned c = 0; c < nc; ++c) {
+            const uint64_t *partials = lz + nc + (size_t)c * num_prods;
+            for (size_t ch = 0; ch < num_chunks; ++ch) {
+                uint64_t pn = 1, pd = 1;
+                for (size_t j = ch * qdf; j < (ch + 1) * qdf && j < num_routed; ++j) {
+                    const uint64_t s_id = ora_gl_mul(k_is[j], x);
+                    pn = ora_gl_mul(pn, ora_gl_add(ora_gl_add(lw[j], ora_gl_mul(betas[c], s_id)), gammas[c]));
+                    pd = ora_gl_mul(pd, ora_gl_add(ora_gl_add(lw[j], ora_gl_mul(betas[c], lc[sigmas_first + j])), gammas[c]));
+                }
+                const uint64_t prev = ch == 0 ? lz[c] : partials[ch - 1], next = ch == num_chunks - 1 ? nz[c] : partials[ch];
+                terms[t++] = ora_gl_sub(ora_gl_mul(prev, pn), ora_gl_mul(next, pd));
+            }
+        }
+        for (unsigned a = 0; a < nc; ++a) {
+            uint64_t cumul = gate_sums ? gate_sums[(size_t)a * Nq + i] : 0; /* the terms behind ours, already reduced */
+            for (size_t k = K; k-- > 0;) cumul = ora_gl_add(terms[k], ora_gl_mul(cumul, alphas[a])); /* multiply_accumulate */
+            out[(size_t)a * Nq + i] = ora_gl_canon(ora_gl_mul(cumul, zh_inv[i % rate]));
+        }
+        xi = ora_gl_mul(xi, w);
+    }
+    free(terms);
+    return 0;
+}

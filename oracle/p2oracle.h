@@ -133,6 +133,12 @@ void ora_divide_by_linear(const uint64_t *poly, size_t n, const uint64_t z[2], u
 int ora_partial_products(const uint64_t *wires, const uint64_t *sigmas, const uint64_t *k_is, size_t num_routed,
                          unsigned log_n, size_t degree, uint64_t beta, uint64_t gamma, uint64_t *out);
 
+/* ---- the gate-independent part of compute_quotient_polys (plonk/prover.rs:609-815) + the permutation terms of
+ * eval_vanishing_poly_base_batch (plonk/vanishing_poly.rs:167-330); see the definition for the layout.  out [nc][n << qbits]. */
+int ora_quotient_permutation(const uint64_t *wires, size_t W_w, const uint64_t *cs, size_t W_cs, size_t sigmas_first, const uint64_t *zs,
+                             size_t W_z, unsigned log_n, unsigned rate_bits, const uint64_t *k_is, size_t num_routed, size_t qdf, unsigned nc,
+                             const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas, const uint64_t *gate_sums, uint64_t *out);
+
 int ora_num_threads(void);
 void ora_set_num_threads(int n); /* e.g. the cgroup CPU quota of the job */
 

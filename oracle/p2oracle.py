@@ -322,3 +322,20 @@ def partial_products(wires, sigmas, k_is, degree, beta, gamma):
         raise ZeroDivisionError("Tried to invert zero")
     return out
 
+
+
+def quotient_permutation(wires_leaves, cs_leaves, sigmas_first, zs_leaves, log_n, rate_bits, k_is, qdf, betas, gammas, alphas, gate_sums=None):
+    """the permutation argument's share of compute_quotient_polys (plonk/prover.rs:609-815, plonk/vanishing_poly.rs:167-330):
+    quotient values [nc][n << log2_ceil(qdf)] in natural order, from the three commitments' leaf matrices (committed order)"""
+    ww, cc, zz, k = arr(wires_leaves), arr(cs_leaves), arr(zs_leaves), arr(k_is)
+    b, g, a = arr(betas), arr(gammas), arr(alphas)
+    nc = len(b)
+    qbits = (int(qdf) - 1).bit_length()
+    out = np.zeros((nc, (1 << log_n) << qbits), dtype=np.uint64)
+    gs = arr(gate_sums) if gate_sums is not None else None
+    rc = lib.ora_quotient_permutation(_p(ww), C.c_size_t(ww.shape[1]), _p(cc), C.c_size_t(cc.shape[1]), C.c_size_t(sigmas_first), _p(zz),
+                                      C.c_size_t(zz.shape[1]), C.c_uint(log_n), C.c_uint(rate_bits), _p(k), C.c_size_t(len(k)), C.c_size_t(qdf),
+                                      C.c_uint(nc), _p(b), _p(g), _p(a), _p(gs) if gs is not None else None, _p(out))
+    if rc:
+        raise ValueError("unsupported quotient shape")
+    return out

@@ -123,6 +123,7 @@ SIGNATURES = {
                                       C.POINTER(FriParams), C.POINTER(FriProof)]),
     "p2hot_partial_products": (i, [vp, vp, sz, vp, sz, vp, u, u, vp, vp, u, vp, C.POINTER(vp)]),
     "p2hot_quotient_chunks": (i, [vp, C.POINTER(vp), u, u, u, C.POINTER(vp)]),
+    "p2hot_quotient_polys": (i, [vp, vp, vp, sz, vp, vp, u, u, vp, vp, vp, u, C.POINTER(vp), vp, C.POINTER(vp)]),
     "p2hot_comm_unique_id": (i, [vp]),
     "p2hot_comm_create_rccl": (i, [vp, i, i, vp, C.POINTER(vp)]),
     "p2hot_comm_create_callback": (i, [vp, i, i, ALLGATHER_FN, vp, C.POINTER(vp)]),

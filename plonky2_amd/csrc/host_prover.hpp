@@ -1109,25 +1109,15 @@ extern "C" int p2hot_partial_products(p2hot_ctx *ctx, const p2hot_cols *wires, s
 }
 
 // ------------------------------------------------------------------ quotient polynomials -> chunks (plonk/prover.rs:274-289, :810-815)
-extern "C" int p2hot_quotient_chunks(p2hot_ctx *ctx, const uint64_t *const *quotient_values, unsigned num_challenges,
-                                     unsigned degree_bits, unsigned quotient_degree_factor, p2hot_cols **chunks_out) {
-    P2_ENTER(ctx);
-    if (!chunks_out) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_chunks: null output");
-    *chunks_out = nullptr;
-    if (quotient_degree_factor == 0 || (num_challenges && !quotient_values)) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_chunks: bad arguments");
-    unsigned qbits = 0;
-    while ((1u << qbits) < quotient_degree_factor) ++qbits;  // log2_ceil (circuit_data.rs quotient_degree_bits)
-    P2_TRY(check_log(ctx, degree_bits + qbits, "quotient_chunks"));
+// the tail both quotient entry points share: d_work holds num_challenges polynomials' VALUES on g*H of size m = n << qbits
+// (natural order, one flag word behind them); coset_ifft, trim_to_len with its divisibility check, chunks of n
+static int quotient_chunks_core(p2hot_ctx *ctx, PoolBuf &d_work, unsigned num_challenges, unsigned degree_bits, unsigned qbits,
+                                unsigned quotient_degree_factor, const char *what, p2hot_cols **chunks_out) {
     const size_t n = (size_t)1 << degree_bits, m = n << qbits, keep = n * quotient_degree_factor;
-    PoolBuf d_work(ctx), d_chunks(ctx);
-    P2_TRY(pool_alloc(ctx, (num_challenges ? num_challenges : 1) * m * 8 + 8, &d_work.p));
+    PoolBuf d_chunks(ctx);
     P2_TRY(pool_alloc(ctx, (num_challenges ? (size_t)num_challenges * quotient_degree_factor : 1) * n * 8, &d_chunks.p));
     unsigned nonzero = 0;
     auto body = [&]() -> int {
-        for (unsigned c = 0; c < num_challenges; ++c) {
-            if (!quotient_values[c]) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_chunks: polynomial %u is null", c);
-            P2_HIP(ctx, hipMemcpyAsync(d_work.u() + c * m, quotient_values[c], m * 8, hipMemcpyHostToDevice, ctx->stream));
-        }
         // values.coset_ifft(F::coset_shift()) (prover.rs:810-814)
         P2_TRY(p2hot_coset_ifft_dev(ctx, d_work.u(), num_challenges, m, degree_bits + qbits, gl::COSET_SHIFT));
         // trim_to_len(quotient_degree_factor * n) (polynomial/mod.rs:164-178) with its divisibility check, then
@@ -1150,10 +1140,109 @@ extern "C" int p2hot_quotient_chunks(p2hot_ctx *ctx, const uint64_t *const *quot
         P2_HIP(ctx, hipMemcpyAsync(&nonzero, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
         return P2HOT_OK;
     };
-    int rc = sync_checked(ctx, body(), "quotient_chunks");
+    int rc = sync_checked(ctx, body(), what);
     if (rc != P2HOT_OK) return rc;
     if (nonzero) P2_FAIL(ctx, P2HOT_EINVAL, "Quotient has failed, the vanishing polynomial is not divisible by Z_H");
     *chunks_out = new p2hot_cols{ctx, d_chunks.u(), (size_t)num_challenges * quotient_degree_factor, degree_bits, true};
     d_chunks.p = nullptr;
     return P2HOT_OK;
+}
+
+extern "C" int p2hot_quotient_chunks(p2hot_ctx *ctx, const uint64_t *const *quotient_values, unsigned num_challenges,
+                                     unsigned degree_bits, unsigned quotient_degree_factor, p2hot_cols **chunks_out) {
+    P2_ENTER(ctx);
+    if (!chunks_out) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_chunks: null output");
+    *chunks_out = nullptr;
+    if (quotient_degree_factor == 0 || (num_challenges && !quotient_values)) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_chunks: bad arguments");
+    unsigned qbits = 0;
+    while ((1u << qbits) < quotient_degree_factor) ++qbits;  // log2_ceil (circuit_data.rs quotient_degree_bits)
+    P2_TRY(check_log(ctx, degree_bits + qbits, "quotient_chunks"));
+    const size_t n = (size_t)1 << degree_bits, m = n << qbits;
+    PoolBuf d_work(ctx);
+    P2_TRY(pool_alloc(ctx, (num_challenges ? num_challenges : 1) * m * 8 + 8, &d_work.p));
+    for (unsigned c = 0; c < num_challenges; ++c) {
+        if (!quotient_values[c]) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_chunks: polynomial %u is null", c);
+        P2_HIP(ctx, hipMemcpyAsync(d_work.u() + c * m, quotient_values[c], m * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return quotient_chunks_core(ctx, d_work, num_challenges, degree_bits, qbits, quotient_degree_factor, "quotient_chunks", chunks_out);
+}
+
+// compute_quotient_polys (plonky2/src/plonk/prover.rs:609-815) without its gate evaluation: the permutation argument's vanishing
+// terms on the quotient coset (plonk/vanishing_poly.rs:167-330; kernel: plonk::quotient_perm_kernel) from the three commitments'
+// device-resident LDE matrices, plus the caller's reduced gate terms, over Z_H; then the same tail as p2hot_quotient_chunks.
+extern "C" int p2hot_quotient_polys(p2hot_ctx *ctx, const p2hot_batch *wires, const p2hot_batch *constants_sigmas, size_t sigmas_first_col,
+                                    const p2hot_batch *zs_partial_products, const uint64_t *k_is, unsigned num_routed,
+                                    unsigned quotient_degree_factor, const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas,
+                                    unsigned num_challenges, const uint64_t *const *gate_sums, uint64_t *values_out, p2hot_cols **chunks_out) {
+    P2_ENTER(ctx);
+    if (chunks_out) *chunks_out = nullptr;
+    if (!wires || !constants_sigmas || !zs_partial_products || !k_is || !betas || !gammas || !alphas) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_polys: null argument");
+    if (!chunks_out && !values_out) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_polys: nothing asked for");
+    const p2hot_batch *bs[3] = {wires, constants_sigmas, zs_partial_products};
+    for (const p2hot_batch *b : bs) {
+        if (b->ctx != ctx) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_polys: a commitment belongs to another context");
+        if (b->log_n != wires->log_n || b->rate_bits != wires->rate_bits) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_polys: the commitments differ in degree or rate");
+    }
+    if (num_challenges == 0 || num_challenges > 4) P2_FAIL(ctx, P2HOT_EUNSUPPORTED, "quotient_polys: %u challenges (1..4 supported; plonky2's configs use 2)", num_challenges);
+    if (quotient_degree_factor < 2 || num_routed == 0) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_polys: bad quotient degree factor or no routed wires");
+    unsigned qbits = 0;
+    while ((1u << qbits) < quotient_degree_factor) ++qbits;
+    // "Having constraints of degree higher than the rate is not supported yet." (prover.rs:632-636)
+    if (qbits > wires->rate_bits) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_polys: quotient degree 2^%u above the rate 2^%u (prover.rs:632-636)", qbits, wires->rate_bits);
+    const unsigned degree_bits = wires->log_n, log_nq = degree_bits + qbits;
+    const unsigned num_chunks = (num_routed + quotient_degree_factor - 1) / quotient_degree_factor, num_prods = num_chunks - 1;
+    if (wires->W < num_routed || constants_sigmas->W < sigmas_first_col + num_routed || zs_partial_products->W < (size_t)num_challenges * (1 + num_prods))
+        P2_FAIL(ctx, P2HOT_EINVAL, "quotient_polys: a commitment is narrower than the permutation argument needs");
+    const size_t n = (size_t)1 << degree_bits, m = n << qbits, rate = (size_t)1 << qbits;
+    for (unsigned c = 0; c < num_challenges && gate_sums; ++c)
+        if (!gate_sums[c]) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_polys: gate_sums[%u] is null", c);
+    PoolBuf d_work(ctx), d_small(ctx), d_gate(ctx);
+    P2_TRY(pool_alloc(ctx, (size_t)num_challenges * m * 8 + 8, &d_work.p));
+    P2_TRY(pool_alloc(ctx, ((size_t)num_routed + 2 * rate) * 8, &d_small.p));
+    if (gate_sums) P2_TRY(pool_alloc(ctx, (size_t)num_challenges * m * 8, &d_gate.p));
+    // ZeroPolyOnCoset::new(degree_bits, qbits) (field/src/zero_poly_coset.rs:21-34) and the k_is, on the host
+    std::vector<u64> small((size_t)num_routed + 2 * rate);
+    for (unsigned j = 0; j < num_routed; ++j) small[j] = k_is[j];
+    const u64 g_pow_n = gl::pow(gl::COSET_SHIFT, n), v = gl::root_of_unity(qbits);
+    for (size_t j = 0; j < rate; ++j) {
+        const u64 e = gl::canon(gl::sub(gl::mul(g_pow_n, gl::pow(v, j)), 1));
+        if (e == 0) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_polys: Z_H vanishes on the coset");
+        small[num_routed + j] = e;
+        small[num_routed + rate + j] = gl::inv(e);
+    }
+    plonk::QuotArgs q{};
+    q.wires = wires->d_lde, q.wires_stride = wires->col_stride_lde();
+    q.sigmas = constants_sigmas->d_lde + sigmas_first_col * constants_sigmas->col_stride_lde(), q.sigmas_stride = constants_sigmas->col_stride_lde();
+    q.zs = zs_partial_products->d_lde, q.zs_stride = zs_partial_products->col_stride_lde();
+    q.k_is = d_small.u(), q.zh = d_small.u() + num_routed;
+    q.gate_sums = gate_sums ? d_gate.u() : nullptr;
+    q.out = d_work.u();
+    q.num_routed = num_routed, q.degree = quotient_degree_factor, q.num_chunks = num_chunks, q.log_nq = log_nq, q.qbits = qbits;
+    q.n_field = (u64)n % gl::P;
+    const u64 K = (u64)num_challenges + (u64)num_challenges * num_chunks;
+    for (unsigned a = 0; a < num_challenges; ++a) {
+        q.betas[a] = betas[a], q.gammas[a] = gammas[a], q.alphas[a] = alphas[a];
+        q.alpha_k[a] = gl::pow(alphas[a], K);
+        for (unsigned c = 0; c < num_challenges; ++c) q.base[a][c] = gl::pow(alphas[a], (u64)num_challenges + (u64)c * num_chunks);
+    }
+    q.roots = ctx->fwd;
+    auto body = [&]() -> int {
+        P2_HIP(ctx, hipMemcpyAsync(d_small.p, small.data(), small.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        for (unsigned c = 0; c < num_challenges && gate_sums; ++c)
+            P2_HIP(ctx, hipMemcpyAsync(d_gate.u() + (size_t)c * m, gate_sums[c], m * 8, hipMemcpyHostToDevice, ctx->stream));
+        ProfScope prof(ctx, "quotient_perm");
+        const dim3 grid(cdiv(m, 256)), block(256);
+        switch (num_challenges) {
+            case 1: P2HOT_LAUNCH(plonk::quotient_perm_kernel<1>, grid, block, 0, ctx->stream, q); break;
+            case 2: P2HOT_LAUNCH(plonk::quotient_perm_kernel<2>, grid, block, 0, ctx->stream, q); break;
+            case 3: P2HOT_LAUNCH(plonk::quotient_perm_kernel<3>, grid, block, 0, ctx->stream, q); break;
+            default: P2HOT_LAUNCH(plonk::quotient_perm_kernel<4>, grid, block, 0, ctx->stream, q); break;
+        }
+        P2_LAUNCH_CHECK(ctx);
+        if (values_out) P2_HIP(ctx, hipMemcpyAsync(values_out, d_work.p, (size_t)num_challenges * m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        return P2HOT_OK;
+    };
+    int rc = body();
+    if (rc != P2HOT_OK || !chunks_out) return sync_checked(ctx, rc, "quotient_polys");
+    return quotient_chunks_core(ctx, d_work, num_challenges, degree_bits, qbits, quotient_degree_factor, "quotient_polys", chunks_out);
 }

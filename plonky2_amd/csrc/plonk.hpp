@@ -130,4 +130,104 @@ __global__ void any_nonzero_kernel(const u64 *v, size_t count, unsigned *flag) {
     if (i < count && gl::canon(v[i]) != 0) atomicOr(flag, 1u);
 }
 
+// ------------------------------------------------------------------ the permutation argument's share of the quotient
+// compute_quotient_polys (plonky2/src/plonk/prover.rs:609-815) evaluates, at every point x = g * w^i of the quotient coset
+// (size Nq = n << qbits, qbits = log2_ceil(quotient_degree_factor)), eval_vanishing_poly_base_batch
+// (plonk/vanishing_poly.rs:167-330): the terms  L_0(x) (Z_c(x) - 1)  and, per chunk of `degree` routed wires,
+//   prev_acc * prod(wire_j + beta_c k_j x + gamma_c) - next_acc * prod(wire_j + beta_c sigma_j(x) + gamma_c)
+// (check_partial_products, util/partial_products.rs:52-79: the accumulators run Z_c(x), the partial products, Z_c(g x)), then
+// the gate constraint terms; reduces them with the powers of every alpha (plonk_common.rs:99-115) and multiplies by 1 / Z_H(x)
+// (prover.rs:797-803).  Everything but the gate terms is circuit independent: this kernel computes it where the three
+// commitments' LDE matrices already are.  The gate terms stay the caller's (out of scope): their own reduce_with_powers,
+// `gate_sums[a][i]`, enters as alpha_a^K * gate_sums behind the K permutation terms.
+// lane = row L of the LDE matrices (committed order).  The reference reads get_lde_values(i, step) = leaves[reverse_bits(i * step)]
+// with step = 2^(rate_bits - qbits) (oracle.rs:142-147, prover.rs:640): those are exactly the rows L < Nq, i = bitrev_{log Nq}(L),
+// so the column-major matrices are read coalesced; the "next" row is bitrev(i + 2^qbits mod Nq) (prover.rs:643, :708).
+struct QuotArgs {
+    const u64 *wires, *sigmas, *zs;  // column-major LDE matrices, element (col, L) at col * stride + L; sigmas points at sigma_0
+    size_t wires_stride, sigmas_stride, zs_stride;
+    const u64 *k_is;       // device [num_routed]
+    const u64 *zh;         // device [2 << qbits]: Z_H(g w^i) for i mod 2^qbits, then their inverses (field/src/zero_poly_coset.rs:21-34)
+    const u64 *gate_sums;  // device [nc][Nq] natural order, or null
+    u64 *out;              // device [nc][Nq] natural order (prover.rs:805-807: transpose(&quotient_values))
+    unsigned num_routed, degree, num_chunks, log_nq, qbits;
+    u64 n_field;           // |H| as a field element
+    u64 betas[4], gammas[4], alphas[4];
+    u64 base[4][4];        // base[a][c] = alpha_a^(nc + c * num_chunks): where challenge c's chunk terms start in the term list
+    u64 alpha_k[4];        // alpha_a^K, K = nc + nc * num_chunks
+    ntt::RootTable roots;  // forward table: w_Nq^i
+};
+
+template <int NC>
+__global__ void __launch_bounds__(256) quotient_perm_kernel(QuotArgs q) {
+    const size_t L = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nq = (size_t)1 << q.log_nq;
+    if (L >= nq) return;
+    const size_t i = q.log_nq ? (size_t)(__brevll((unsigned long long)L) >> (64 - q.log_nq)) : 0;
+    const size_t i_next = (i + ((size_t)1 << q.qbits)) & (nq - 1);
+    const size_t L_next = q.log_nq ? (size_t)(__brevll((unsigned long long)i_next) >> (64 - q.log_nq)) : 0;
+    const u64 x = gl::mul(gl::COSET_SHIFT, q.log_nq ? ntt::root_pow(q.roots, (u32)(i << (32 - q.log_nq))) : (u64)1);
+    const size_t r = i & (((size_t)1 << q.qbits) - 1);
+    // L_0(x) = Z_H(x) / (n (x - 1))  (zero_poly_coset.rs:58-61)
+    const u64 l0 = gl::mul(q.zh[r], gl::inv(gl::mul(q.n_field, gl::sub(x, 1))));
+    const unsigned num_prods = q.num_chunks - 1;
+    u64 zx[NC], bx[NC], acc[NC][NC], pw[NC], res[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        zx[c] = q.zs[(size_t)c * q.zs_stride + L];
+        bx[c] = gl::mul(q.betas[c], x);
+#pragma unroll
+        for (int a = 0; a < NC; ++a) acc[a][c] = 0;
+        pw[c] = 1;  // alpha_c^chunk
+    }
+    // terms 0 .. NC-1: L_0(x) (Z_c(x) - 1)
+#pragma unroll
+    for (int a = 0; a < NC; ++a) {
+        u64 s = 0, p = 1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            s = gl::add(s, gl::mul(gl::mul(l0, gl::sub(zx[c], 1)), p));
+            p = gl::mul(p, q.alphas[a]);
+        }
+        res[a] = s;
+    }
+    u64 prev[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) prev[c] = zx[c];
+    for (unsigned ch = 0; ch < q.num_chunks; ++ch) {
+        u64 pn[NC], pd[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) pn[c] = pd[c] = 1;
+        const unsigned j_end = (ch + 1) * q.degree < q.num_routed ? (ch + 1) * q.degree : q.num_routed;
+        for (unsigned j = ch * q.degree; j < j_end; ++j) {
+            const u64 w = q.wires[(size_t)j * q.wires_stride + L], sg = q.sigmas[(size_t)j * q.sigmas_stride + L], kj = q.k_is[j];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                pn[c] = gl::mul(pn[c], gl::add(gl::add(w, gl::mul(bx[c], kj)), q.gammas[c]));
+                pd[c] = gl::mul(pd[c], gl::add(gl::add(w, gl::mul(q.betas[c], sg)), q.gammas[c]));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const u64 next = ch == num_prods ? q.zs[(size_t)c * q.zs_stride + L_next]
+                                             : q.zs[((size_t)NC + (size_t)c * num_prods + ch) * q.zs_stride + L];
+            const u64 term = gl::sub(gl::mul(prev[c], pn[c]), gl::mul(next, pd[c]));
+            prev[c] = next;
+#pragma unroll
+            for (int a = 0; a < NC; ++a) acc[a][c] = gl::add(acc[a][c], gl::mul(term, pw[a]));
+        }
+#pragma unroll
+        for (int a = 0; a < NC; ++a) pw[a] = gl::mul(pw[a], q.alphas[a]);
+    }
+    const u64 zinv = q.zh[((size_t)1 << q.qbits) + r];
+#pragma unroll
+    for (int a = 0; a < NC; ++a) {
+        u64 s = res[a];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) s = gl::add(s, gl::mul(acc[a][c], q.base[a][c]));
+        if (q.gate_sums) s = gl::add(s, gl::mul(q.alpha_k[a], q.gate_sums[(size_t)a * nq + i]));
+        q.out[(size_t)a * nq + i] = gl::canon(gl::mul(s, zinv));
+    }
+}
+
 }  // namespace plonk

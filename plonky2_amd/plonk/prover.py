@@ -101,3 +101,38 @@ def quotient_poly_chunks(quotient_values, degree_bits, quotient_degree_factor, e
         raise ValueError(eng.lib.p2hot_last_error(eng._ctx).decode())  # the reference panics (polynomial/mod.rs:164-178)
     eng.check(rc)
     return DeviceColumns(eng, h)
+
+
+def compute_quotient_polys(wires_commitment, constants_sigmas_commitment, sigmas_first_col, zs_partial_products_commitment, k_is,
+                           quotient_degree_factor, betas, gammas, alphas, gate_sums=None, want_values=False, engine=None):
+    """compute_quotient_polys (prover.rs:609-815) without its gate evaluation -- one p2hot_quotient_polys call: the permutation
+    argument's vanishing terms (vanishing_poly.rs:167-330) on the quotient coset from the three commitments' device-resident LDE
+    matrices, plus `gate_sums` (the caller's reduce_with_powers of the gate constraint terms, [num_challenges][n << qbits], or
+    None), over Z_H, then coset_ifft / trim / chunks.  Returns DeviceColumns [num_challenges * quotient_degree_factor][n] for
+    PolynomialBatch.from_coeffs (and the quotient values [num_challenges][n << qbits] when want_values)."""
+    from ..fri.oracle import DeviceColumns
+    eng = engine or wires_commitment.engine
+    k = np.ascontiguousarray(np.asarray(k_is, dtype=np.uint64))
+    b, g, a = (np.ascontiguousarray(np.asarray(v, dtype=np.uint64)) for v in (betas, gammas, alphas))
+    if not (b.shape == g.shape == a.shape and b.ndim == 1):
+        raise ValueError("betas, gammas and alphas must be equally long vectors")
+    nc = len(b)
+    qb = max(0, (quotient_degree_factor - 1).bit_length())
+    m = (1 << wires_commitment.degree_log) << qb
+    gs = None
+    if gate_sums is not None:
+        gs = np.ascontiguousarray(np.asarray(gate_sums, dtype=np.uint64))
+        if gs.shape != (nc, m):
+            raise ValueError("gate_sums must be [num_challenges][n << ceil(log2(quotient_degree_factor))]")
+    gptrs = (C.c_void_p * nc)(*[gs[c].ctypes.data for c in range(nc)]) if gs is not None else None
+    vals = np.zeros((nc, m), dtype=np.uint64) if want_values else None
+    h = C.c_void_p()
+    rc = eng.lib.p2hot_quotient_polys(eng.ctx, wires_commitment._h, constants_sigmas_commitment._h, sigmas_first_col,
+                                      zs_partial_products_commitment._h, k.ctypes.data_as(C.c_void_p), len(k), quotient_degree_factor,
+                                      b.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), nc, gptrs,
+                                      vals.ctypes.data_as(C.c_void_p) if want_values else None, C.byref(h))
+    if rc == 1 and b"Quotient has failed" in eng.lib.p2hot_last_error(eng._ctx):
+        raise ValueError(eng.lib.p2hot_last_error(eng._ctx).decode())  # the reference panics (polynomial/mod.rs:164-178)
+    eng.check(rc)
+    cols = DeviceColumns(eng, h)
+    return (cols, vals) if want_values else cols

@@ -146,3 +146,121 @@ def test_quotient_poly_chunks(eng, ora, degree_bits, factor, nc):
         bad = np.stack([ora.coset_fft(c.copy()) for c in coeffs])
         with pytest.raises(ValueError, match="Quotient has failed"):
             quotient_poly_chunks(bad, degree_bits, factor, eng)
+
+
+# ---------------------------------------------------------------- the permutation argument's share of the quotient
+def _quotient_instance(ora, rng, num_routed, degree, log_n, rate_bits, nc, extra_wires=3, num_constants=2, cap=2):
+    """a satisfied permutation argument as the prover holds it when compute_quotient_polys runs (plonk/prover.rs:231-260): the
+    wires commitment (routed wires first), the constants_sigmas commitment, the Zs + partial products commitment (Z first,
+    prover.rs:224-229), the challenges.  No gates: a circuit whose only constraints are its copy constraints"""
+    n = 1 << log_n
+    routed, sigmas, k = _permutation_instance(ora, rng, num_routed, log_n)
+    wires = np.concatenate([routed, rand_field(rng, extra_wires, n)]) if extra_wires else routed
+    cs = np.concatenate([rand_field(rng, num_constants, n), sigmas]) if num_constants else sigmas
+    betas, gammas, alphas = rand_field(rng, nc), rand_field(rng, nc), rand_field(rng, nc)
+    num_prods = -(-num_routed // degree) - 1
+    pps = [ora.partial_products(routed, sigmas, k, degree, betas[c], gammas[c]) for c in range(nc)]   # [num_prods + 1][n], Z last
+    zs = np.stack([pp[num_prods] for pp in pps] + [row for pp in pps for row in pp[:num_prods]])
+    return dict(wires=wires, cs=cs, zs=zs, k=k, betas=betas, gammas=gammas, alphas=alphas, sigmas_first=num_constants, num_prods=num_prods,
+                n=n, log_n=log_n, rate_bits=rate_bits, degree=degree, cap=cap, nc=nc)
+
+
+def _oracle_quotient(ora, q, gate_sums=None, mutate=None):
+    lv = {name: ora.commit(q[name], q["rate_bits"], q["cap"], True)["leaves"].copy() for name in ("wires", "cs", "zs")}
+    if mutate:
+        mutate(lv)
+    return ora.quotient_permutation(lv["wires"], lv["cs"], q["sigmas_first"], lv["zs"], q["log_n"], q["rate_bits"], q["k"], q["degree"],
+                                    q["betas"], q["gammas"], q["alphas"], gate_sums)
+
+
+@pytest.mark.parametrize("num_routed,degree,log_n,rate_bits,nc", [(12, 5, 5, 3, 2), (7, 3, 4, 2, 1), (20, 6, 3, 3, 2)])
+def test_oracle_quotient_of_a_satisfied_permutation_is_a_polynomial(ora, num_routed, degree, log_n, rate_bits, nc):
+    """pins the ORACLE's restatement of compute_quotient_polys' gate-independent part (plonk/prover.rs:609-815,
+    vanishing_poly.rs:167-330) by the property the reference itself asserts (`trim_to_len`: "Quotient has failed ..."): with a
+    quotient degree factor that is not a power of two the quotient coset is larger than the kept degree, and for a satisfied
+    permutation argument every coefficient beyond quotient_degree_factor * n vanishes -- row choice (get_lde_values + the next
+    row), L_0, the chunk products, the order of the alpha powers and the division by Z_H all have to be right for that; one
+    changed wire value breaks it"""
+    rng = np.random.default_rng(num_routed * 7 + degree)
+    q = _quotient_instance(ora, rng, num_routed, degree, log_n, rate_bits, nc)
+    keep = degree << log_n
+    vals = _oracle_quotient(ora, q)
+    assert vals.shape[1] > keep, "pick a degree whose log2_ceil leaves a tail to check"
+    for a in range(nc):
+        co = ora.coset_ifft(vals[a])
+        assert not co[keep:].any() and co[:keep].any()
+
+    def spoil(lv):
+        lv["wires"][3, 1] = (int(lv["wires"][3, 1]) + 1) % P
+    bad = _oracle_quotient(ora, q, mutate=spoil)
+    assert ora.coset_ifft(bad[0])[keep:].any()
+    # the gate terms enter behind the permutation terms: alpha^K * gate_sums, divided by Z_H like the rest
+    gs = rand_field(rng, nc, vals.shape[1])
+    with_g = _oracle_quotient(ora, q, gate_sums=gs)
+    K = nc + nc * (q["num_prods"] + 1)
+    g_n = pow(GEN, q["n"], P)
+    qbits = (degree - 1).bit_length()
+    v = ora.root_of_unity(qbits)
+    for a in range(nc):
+        for i in (0, 1, vals.shape[1] - 1):
+            zh = (g_n * pow(v, i % (1 << qbits), P) - 1) % P
+            extra = pow(int(q["alphas"][a]), K, P) * int(gs[a, i]) % P * pow(zh, P - 2, P) % P
+            assert int(with_g[a, i]) == (int(vals[a, i]) + extra) % P
+
+
+@pytest.mark.parametrize("num_routed,degree,log_n,rate_bits,nc,with_gates", [
+    (12, 5, 5, 3, 2, False), (7, 3, 4, 2, 1, True), (80, 8, 4, 3, 2, True),   # the last: standard_recursion_config's 80 routed wires, degree 8
+    (20, 6, 3, 3, 3, False), (10, 4, 6, 3, 2, False),                         # rate above the quotient degree: step = 2 (prover.rs:640)
+])
+def test_quotient_polys_vs_oracle(eng, ora, num_routed, degree, log_n, rate_bits, nc, with_gates):
+    """p2hot_quotient_polys: quotient values bit-exact against the oracle's restatement of the reference loop, the chunk polynomials
+    = the oracle's coset_ifft of them, the commit of the chunks = the oracle's commit; with a wrong witness the call reports the
+    reference's panic text"""
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    from plonky2_amd.plonk.prover import compute_quotient_polys
+    rng = np.random.default_rng(num_routed * 13 + degree + log_n)
+    q = _quotient_instance(ora, rng, num_routed, degree, log_n, rate_bits, nc)
+    n, qbits = q["n"], (degree - 1).bit_length()
+    m = n << qbits
+    gs = rand_field(rng, nc, m) if with_gates else None
+    b_w, b_cs, b_z = (PolynomialBatch.from_values(q[name], rate_bits, False, q["cap"], engine=eng) for name in ("wires", "cs", "zs"))
+    exp = _oracle_quotient(ora, q, gate_sums=gs)
+    if with_gates:   # random "gate terms" are not divisible: only the values can be compared (and only when nothing is trimmed)
+        if m == degree * n:
+            cols, vals = compute_quotient_polys(b_w, b_cs, q["sigmas_first"], b_z, q["k"], degree, q["betas"], q["gammas"], q["alphas"], gate_sums=gs,
+                                                want_values=True, engine=eng)
+            assert (vals == exp).all()
+            co = np.stack([ora.coset_ifft(exp[a]) for a in range(nc)]).reshape(nc * degree, n)
+            assert (cols.host() == co).all()
+        else:
+            with pytest.raises(ValueError, match="Quotient has failed"):
+                compute_quotient_polys(b_w, b_cs, q["sigmas_first"], b_z, q["k"], degree, q["betas"], q["gammas"], q["alphas"], gate_sums=gs, engine=eng)
+        return
+    cols, vals = compute_quotient_polys(b_w, b_cs, q["sigmas_first"], b_z, q["k"], degree, q["betas"], q["gammas"], q["alphas"], want_values=True, engine=eng)
+    assert (vals == exp).all() and (vals < np.uint64(P)).all()
+    co = np.stack([ora.coset_ifft(exp[a])[:degree * n] for a in range(nc)]).reshape(nc * degree, n)
+    got = cols.host()
+    assert got.shape == (nc * degree, n) and (got == co).all()
+    batch = PolynomialBatch.from_coeffs(cols, rate_bits, False, q["cap"], engine=eng)     # quotient_polys_commitment (prover.rs:293-305)
+    assert (batch.merkle_tree.cap.entries == ora.commit(co, rate_bits, q["cap"], False)["cap"]).all()
+    # a witness that violates a copy constraint: the reference panics in trim_to_len
+    if m > degree * n:
+        bad = dict(q)
+        bad["wires"] = q["wires"].copy()
+        bad["wires"][1, 2] = (int(bad["wires"][1, 2]) + 1) % P
+        b_bad = PolynomialBatch.from_values(bad["wires"], rate_bits, False, q["cap"], engine=eng)
+        with pytest.raises(ValueError, match="Quotient has failed"):
+            compute_quotient_polys(b_bad, b_cs, q["sigmas_first"], b_z, q["k"], degree, q["betas"], q["gammas"], q["alphas"], engine=eng)
+
+
+def test_quotient_polys_argument_errors(eng, ora):
+    from plonky2_amd import _lib
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    from plonky2_amd.plonk.prover import compute_quotient_polys
+    rng = np.random.default_rng(1)
+    q = _quotient_instance(ora, rng, 6, 3, 3, 1, 1)          # quotient degree 2^2 above the rate 2^1
+    b_w, b_cs, b_z = (PolynomialBatch.from_values(q[name], 1, False, 0, engine=eng) for name in ("wires", "cs", "zs"))
+    with pytest.raises(_lib.P2HotError, match="above the rate"):
+        compute_quotient_polys(b_w, b_cs, q["sigmas_first"], b_z, q["k"], 3, q["betas"], q["gammas"], q["alphas"], engine=eng)
+    with pytest.raises(_lib.P2HotError, match="narrower"):
+        compute_quotient_polys(b_w, b_cs, q["sigmas_first"] + 1, b_z, q["k"], 2, q["betas"], q["gammas"], q["alphas"], engine=eng)
