@@ -60,8 +60,13 @@ use crate::hash::merkle_proofs::MerkleProof;
 use crate::hash::merkle_tree::{MerkleCap, MerkleTree};
 use crate::hash::poseidon::PoseidonHash;
 use crate::iop::challenger::Challenger;
+use crate::plonk::circuit_data::{CommonCircuitData, ProverOnlyCircuitData};
 use crate::plonk::config::{GenericConfig, Hasher};
-use crate::util::log2_strict;
+use crate::plonk::plonk_common::reduce_with_powers_multi;
+use crate::plonk::vanishing_poly::evaluate_gate_constraints_base_batch;
+use crate::plonk::vars::EvaluationVarsBaseBatch;
+use crate::util::strided_view::PackedStridedView;
+use crate::util::{log2_ceil, log2_strict};
 
 // ------------------------------------------------------------------------------------------------
 // Raw bindings: one declaration per symbol of include/p2hot.h, same order.
@@ -917,6 +922,102 @@ pub fn prove_openings<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, 
         final_poly: PolynomialCoeffs::new(final_poly.chunks_exact(2).map(ext).collect()),
         pow_witness: f(proof.pow_witness),
     })
+}
+
+// ------------------------------------------------------------------------------------------------
+// compute_quotient_polys (plonk/prover.rs:609-815): the permutation argument's share on the GPU
+// ------------------------------------------------------------------------------------------------
+/// The vanishing polynomial's terms are `[L_0 (Z - 1) ..] ++ [partial product checks ..] ++ [gate constraint terms ..]`
+/// (plonk/vanishing_poly.rs:326-330) reduced with the powers of each alpha.  The gate terms are circuit specific: they are
+/// evaluated HERE by the reference's own `evaluate_gate_constraints_base_batch` on the reference's own point batches
+/// (prover.rs:684-779, BATCH_SIZE = 32) and reduced on their own; everything in front of them -- 80 routed wires x 2 challenges at
+/// 2^23 points for a 2^20-gate circuit -- and the division by Z_H, the coset_ifft and the trim run in ONE `p2hot_quotient_polys`
+/// call on the LDE matrices the three commitments already hold on the device.  Returns the reference's result (one polynomial of
+/// `quotient_degree_factor * n` coefficients per challenge); `None` sends the caller down the CPU body (lookups, a commitment
+/// without a device handle, more than 4 challenges).
+pub fn compute_quotient_polys<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(
+    common_data: &CommonCircuitData<F, D>,
+    prover_data: &ProverOnlyCircuitData<F, C, D>,
+    public_inputs_hash: &<<C as GenericConfig<D>>::InnerHasher as Hasher<F>>::Hash,
+    wires_commitment: &PolynomialBatch<F, C, D>,
+    zs_partial_products_commitment: &PolynomialBatch<F, C, D>,
+    betas: &[F],
+    gammas: &[F],
+    alphas: &[F],
+) -> Option<Vec<PolynomialCoeffs<F>>> {
+    if !applies::<F, C, D>(false) || common_data.num_lookup_polys != 0 {
+        return None;
+    }
+    let cs = &prover_data.constants_sigmas_commitment;
+    let h_wires = wires_commitment.merkle_tree.device.as_ref()?.raw();
+    let h_cs = cs.merkle_tree.device.as_ref()?.raw();
+    let h_zs = zs_partial_products_commitment.merkle_tree.device.as_ref()?.raw();
+    let nc = common_data.config.num_challenges;
+    let qdf = common_data.quotient_degree_factor;
+    let quotient_degree_bits = log2_ceil(qdf);
+    let rate_bits = common_data.config.fri_config.rate_bits;
+    if nc > 4 || quotient_degree_bits > rate_bits {
+        return None; // (the CPU body asserts on the second, prover.rs:632-636)
+    }
+    let n = 1usize << common_data.degree_bits();
+    let step = 1usize << (rate_bits - quotient_degree_bits); // prover.rs:640
+    let lde_size = n << quotient_degree_bits;
+    let num_constants = common_data.constants_range().len();
+    let num_wires = common_data.config.num_wires;
+    // gate_sums[a][i] = reduce_with_powers(gate constraint terms at point i, alpha_a)
+    const BATCH_SIZE: usize = 32; // prover.rs:607
+    let indices: Vec<usize> = (0..lde_size).collect();
+    let per_point: Vec<Vec<F>> = indices
+        .par_chunks(BATCH_SIZE)
+        .flat_map(|batch| {
+            let m = batch.len();
+            let mut local_constants_batch = vec![F::ZERO; m * num_constants];
+            let mut local_wires_batch = vec![F::ZERO; m * num_wires];
+            for (j, &i) in batch.iter().enumerate() {
+                let local_constants_sigmas = cs.get_lde_values(i, step);
+                let local_wires = wires_commitment.get_lde_values(i, step);
+                for (k, &v) in local_constants_sigmas[common_data.constants_range()].iter().enumerate() {
+                    local_constants_batch[k * m + j] = v; // the transposed layout of prover.rs:748-761
+                }
+                for (k, &v) in local_wires.iter().enumerate() {
+                    local_wires_batch[k * m + j] = v;
+                }
+            }
+            let vars_batch = EvaluationVarsBaseBatch::new(m, &local_constants_batch, &local_wires_batch, public_inputs_hash);
+            let constraint_terms_batch = evaluate_gate_constraints_base_batch::<F, D>(common_data, vars_batch);
+            (0..m)
+                .map(|j| {
+                    if constraint_terms_batch.is_empty() {
+                        vec![F::ZERO; alphas.len()]
+                    } else {
+                        reduce_with_powers_multi(PackedStridedView::<F>::new(&constraint_terms_batch, m, j), alphas)
+                    }
+                })
+                .collect::<Vec<_>>()
+        })
+        .collect();
+    let gate_sums: Vec<Vec<u64>> = (0..nc).map(|a| per_point.iter().map(|v| v[a].to_canonical_u64()).collect()).collect();
+    let gate_ptrs: Vec<*const u64> = gate_sums.iter().map(|v| v.as_ptr()).collect();
+    let num_routed = common_data.config.num_routed_wires;
+    let k_is: Vec<u64> = common_data.k_is[..num_routed].iter().map(|k| k.to_canonical_u64()).collect();
+    let to_u64 = |v: &[F]| -> Vec<u64> { v.iter().map(|x| x.to_canonical_u64()).collect() };
+    let (b, g, a) = (to_u64(betas), to_u64(gammas), to_u64(alphas));
+    let mut chunks: *mut P2hotCols = core::ptr::null_mut();
+    let coeffs: Vec<F> = vec_from_words(nc * qdf * n, |out| {
+        with_ctx(|ctx| {
+            let rc = unsafe {
+                p2hot_quotient_polys(
+                    ctx, h_wires, h_cs, common_data.sigmas_range().start, h_zs, k_is.as_ptr(), num_routed as c_uint, qdf as c_uint,
+                    b.as_ptr(), g.as_ptr(), a.as_ptr(), nc as c_uint, gate_ptrs.as_ptr(), core::ptr::null_mut(), &mut chunks,
+                )
+            };
+            check(ctx, rc, "p2hot_quotient_polys"); // "Quotient has failed ..." panics here as trim_to_len does on the CPU path
+            check(ctx, unsafe { p2hot_cols_download(chunks, 0, nc * qdf, out) }, "p2hot_cols_download");
+            unsafe { p2hot_cols_free(chunks) };
+        })
+    });
+    // challenge c's polynomial = its quotient_degree_factor chunks of n coefficients, back to back (prover.rs:810-814 + :279-287)
+    Some(coeffs.par_chunks_exact((qdf * n).max(1)).map(|c| PolynomialCoeffs::new(c.to_vec())).collect())
 }
 
 /// PolynomialValues -> column slices for `commit`

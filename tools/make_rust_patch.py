@@ -5,6 +5,7 @@ The patch is the Rust side of the drop-in boundary: Cargo feature `p
 `plonky2/src/p2hot.rs` (= integration/p2hot.rs, verbatim) and the feature-gated early returns in
   fri/oracle.rs        from_values / from_coeffs / get_lde_values / prove_openings
   fri/prover.rs        fri_committed_trees
+  plonk/prover.rs      compute_quotient_polys: the gate terms on the CPU, the permutation terms + coset_ifft on the GPU
   hash/merkle_tree.rs  `device` handle on MerkleTree, get / num_leaves / prove (the leaf matrix may be ONE flat buffer behind it)
   iop/challenger.rs    accessor for the transcript state
   util/serialization   the one other MerkleTree struct literal; write_merkle_tree reads rows through get / num_leaves
@@ -25,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("P2_REFERENCE", "/root/reference")
 OUT = os.path.join(ROOT, "integration", "plonky2_p2hot.patch")
 
-FILES = ["plonky2/Cargo.toml", "plonky2/src/lib.rs", "plonky2/src/fri/oracle.rs", "plonky2/src/fri/prover.rs",
+FILES = ["plonky2/Cargo.toml", "plonky2/src/lib.rs", "plonky2/src/fri/oracle.rs", "plonky2/src/fri/prover.rs", "plonky2/src/plonk/prover.rs",
          "plonky2/src/hash/merkle_tree.rs", "plonky2/src/iop/challenger.rs", "plonky2/src/util/serialization/mod.rs"]
 
 
@@ -123,6 +124,33 @@ fn main() {
             return proof;
         }
         let alpha = challenger.get_extension_challenge::<D>();
+''')])
+    # ---- the quotient: the permutation argument's share of compute_quotient_polys on the GPU
+    edit(os.path.join(b, "plonky2/src/plonk/prover.rs"), [
+        ('''    alphas: &[F],
+) -> Vec<PolynomialCoeffs<F>> {
+    let num_challenges = common_data.config.num_challenges;
+
+    let has_lookup = common_data.num_lookup_polys != 0;
+''', '''    alphas: &[F],
+) -> Vec<PolynomialCoeffs<F>> {
+    #[cfg(feature = "p2hot")]
+    if let Some(quotient_polys) = crate::p2hot::compute_quotient_polys::<F, C, D>(
+        common_data,
+        prover_data,
+        public_inputs_hash,
+        wires_commitment,
+        zs_partial_products_and_lookup_commitment,
+        betas,
+        gammas,
+        alphas,
+    ) {
+        // the permutation terms of the vanishing polynomial, / Z_H, coset_ifft ran on the GPU; the gate terms on the CPU
+        return quotient_polys;
+    }
+    let num_challenges = common_data.config.num_challenges;
+
+    let has_lookup = common_data.num_lookup_polys != 0;
 ''')])
     # ---- FRI commit phase
     edit(os.path.join(b, "plonky2/src/fri/prover.rs"), [
