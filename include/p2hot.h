@@ -241,7 +241,7 @@ int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bit
  *   p2hot_challenger  the Fiat-Shamir transcript (above)
  * A context runs ONE host-pointer call at a time; a second thread entering gets P2HOT_EBUSY (plonky2 calls these
  * from the main thread, outside its rayon closures).  Serialised by the library (busy guard): p2hot_commit*, p2hot_cols_upload,
- * p2hot_batch_coeffs / _rows / _paths / _digests, p2hot_eval_openings, p2hot_prove_openings, p2hot_partial_products,
+ * p2hot_batch_coeffs / _rows / _paths / _digests / _subgroup_values, p2hot_eval_openings, p2hot_prove_openings, p2hot_partial_products,
  * p2hot_quotient_chunks, p2hot_quotient_polys, p2hot_ctx_trim.  p2hot_batch_free / p2hot_cols_free may be called from any thread at any time (a
  * Drop, a finaliser): the block cache has its own lock.  Everything else -- the *_dev building blocks, p2hot_fri_commit,
  * p2hot_fri_pow, p2hot_challenger_* -- enqueues on the context's stream without a guard: the CALLER serialises those with
@@ -320,6 +320,11 @@ int p2hot_batch_digests(p2hot_batch *batch, uint64_t *out);
 /* the kept input values (P2HOT_KEEP_VALUES) as a BORROWED column set: valid while the batch lives; p2hot_cols_free on
  * the view leaves the batch's memory alone */
 int p2hot_batch_values(p2hot_batch *batch, p2hot_cols **out);
+/* polynomials [first, first + count) of the batch as values on the subgroup H_n, as an OWNED column set (free with
+ * p2hot_cols_free): a forward NTT (field/src/fft.rs:53-65) of a copy of their device-resident coefficients.  For the sigma range
+ * of the constants_sigmas commitment this is `prover_data.sigmas` (plonk/prover.rs:413) column-major: the `sigmas` input of
+ * p2hot_partial_products, with no host transpose and no upload.  count == 0 or a range beyond the batch is EINVAL. */
+int p2hot_batch_subgroup_values(p2hot_batch *batch, size_t first, size_t count, p2hot_cols **out);
 /* returns the batch's device blocks to its context's block cache; call it BEFORE p2hot_ctx_destroy of that context
  * (the host-pointer entry points keep their device blocks in a per-context cache: a fresh allocation of the 9 GB LDE
  * matrix costs up to a second; p2hot_ctx_trim gives the cached free blocks back to the driver) */

@@ -60,6 +60,7 @@ use crate::hash::merkle_proofs::MerkleProof;
 use crate::hash::merkle_tree::{MerkleCap, MerkleTree};
 use crate::hash::poseidon::PoseidonHash;
 use crate::iop::challenger::Challenger;
+use crate::iop::witness::MatrixWitness;
 use crate::plonk::circuit_data::{CommonCircuitData, ProverOnlyCircuitData};
 use crate::plonk::config::{GenericConfig, Hasher};
 use crate::plonk::plonk_common::reduce_with_powers_multi;
@@ -275,6 +276,7 @@ extern "C" {
     pub fn p2hot_batch_paths(batch: *mut P2hotBatch, leaf_idx: *const u64, m: usize, out: *mut u64) -> c_int;
     pub fn p2hot_batch_digests(batch: *mut P2hotBatch, out: *mut u64) -> c_int;
     pub fn p2hot_batch_values(batch: *mut P2hotBatch, out: *mut *mut P2hotCols) -> c_int;
+    pub fn p2hot_batch_subgroup_values(batch: *mut P2hotBatch, first: usize, count: usize, out: *mut *mut P2hotCols) -> c_int;
     pub fn p2hot_batch_free(batch: *mut P2hotBatch);
     pub fn p2hot_ctx_trim(ctx: *mut P2hotCtx) -> c_int;
     pub fn p2hot_host_alloc(ctx: *mut P2hotCtx, bytes: usize, out: *mut *mut c_void) -> c_int;
@@ -925,6 +927,93 @@ pub fn prove_openings<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// all_wires_permutation_partial_products (plonk/prover.rs:356-449) on the GPU
+// ------------------------------------------------------------------------------------------------
+struct ColsGuard(*mut P2hotCols);
+impl Drop for ColsGuard {
+    fn drop(&mut self) {
+        if !self.0.is_null() {
+            unsafe { p2hot_cols_free(self.0) };
+        }
+    }
+}
+
+/// The permutation argument's Z and partial-product polynomials for every (beta, gamma): the routed wire columns go up as they
+/// lie in the witness (`wire_values[col][row]`, iop/witness.rs:283-291), the sigma values come from the constants_sigmas
+/// commitment's device-resident coefficients (`p2hot_batch_subgroup_values`: no host transpose of `prover_data.sigmas`), one
+/// `p2hot_partial_products` call (lane = row, one inversion per row, the sequential row walk as a prefix-product scan).
+/// Returns the reference's shape -- per challenge the `num_partial_products` polynomials followed by Z (prover.rs:437-447) --
+/// or `None` for the CPU body.
+pub fn all_wires_permutation_partial_products<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(
+    witness: &MatrixWitness<F>,
+    betas: &[F],
+    gammas: &[F],
+    prover_data: &ProverOnlyCircuitData<F, C, D>,
+    common_data: &CommonCircuitData<F, D>,
+) -> Option<Vec<Vec<PolynomialValues<F>>>> {
+    if !applies::<F, C, D>(false) {
+        return None;
+    }
+    let h_cs = prover_data.constants_sigmas_commitment.merkle_tree.device.as_ref()?.raw();
+    let nc = common_data.config.num_challenges;
+    let num_routed = common_data.config.num_routed_wires;
+    let degree = common_data.quotient_degree_factor;
+    let num_prods = common_data.num_partial_products;
+    let n = 1usize << common_data.degree_bits();
+    let wire_ptrs: Vec<*const u64> = witness.wire_values[..num_routed].iter().map(|c| words(c)).collect();
+    assert!(witness.wire_values[..num_routed].iter().all(|c| c.len() == n));
+    let k_is: Vec<u64> = common_data.k_is[..num_routed].iter().map(|k| k.to_canonical_u64()).collect();
+    let b: Vec<u64> = betas.iter().map(|x| x.to_canonical_u64()).collect();
+    let g: Vec<u64> = gammas.iter().map(|x| x.to_canonical_u64()).collect();
+    let flat: Vec<F> = vec_from_words(nc * (num_prods + 1) * n, |out| {
+        with_ctx(|ctx| {
+            let (mut wires, mut sigmas) = (ColsGuard(core::ptr::null_mut()), ColsGuard(core::ptr::null_mut()));
+            check(ctx, unsafe { p2hot_cols_upload(ctx, wire_ptrs.as_ptr(), num_routed, log2_strict(n) as c_uint, &mut wires.0) }, "p2hot_cols_upload");
+            check(
+                ctx,
+                unsafe { p2hot_batch_subgroup_values(h_cs as *mut P2hotBatch, common_data.sigmas_range().start, num_routed, &mut sigmas.0) },
+                "p2hot_batch_subgroup_values",
+            );
+            let rc = unsafe {
+                p2hot_partial_products(
+                    ctx, wires.0, 0, sigmas.0, 0, k_is.as_ptr(), num_routed as c_uint, degree as c_uint, b.as_ptr(), g.as_ptr(), nc as c_uint, out,
+                    core::ptr::null_mut(),
+                )
+            };
+            check(ctx, rc, "p2hot_partial_products"); // a zero denominator: the reference panics with "Tried to invert zero"
+        })
+    });
+    // the library's order is the batch order (Z_0 .. Z_{nc-1}, then the partial products of challenge 0, 1, ...: prover.rs:224-229);
+    // the function's own result has, per challenge, the partial products and THEN Z (the caller pops it, prover.rs:226-229)
+    let col = |r: usize| PolynomialValues::new(flat[r * n..(r + 1) * n].to_vec());
+    Some((0..nc).map(|c| (0..num_prods).map(|p| col(nc + c * num_prods + p)).chain(core::iter::once(col(c))).collect()).collect())
+}
+
+// ------------------------------------------------------------------------------------------------
+// OpeningSet::new (plonk/proof.rs:314-351): `eval_commitment` on the GPU
+// ------------------------------------------------------------------------------------------------
+/// `c.polynomials.par_iter().map(|p| p.to_extension().eval(z))` (proof.rs:323-328) as ONE `p2hot_eval_openings` call on the
+/// coefficients the commitment already holds on the device: W Horner evaluations of degree n in F^2.  `None` (no device handle,
+/// another field / hasher, the path switched off) sends the caller down the CPU closure.
+pub fn eval_commitment<F: RichField + Extendable<D>, C: GenericConfig<D, F = F>, const D: usize>(
+    z: F::Extension,
+    c: &PolynomialBatch<F, C, D>,
+) -> Option<Vec<F::Extension>> {
+    if !applies::<F, C, D>(false) {
+        return None;
+    }
+    let handle = c.merkle_tree.device.as_ref()?.raw();
+    let w = c.polynomials.len();
+    let zb = z.to_basefield_array();
+    let point = [zb[0].to_canonical_u64(), zb[1].to_canonical_u64()];
+    let handles = [handle];
+    // out: [n_points = 1][W][2] words = W extension elements ([a0, a1], field/src/extension/quadratic.rs:13)
+    Some(vec_from_words::<F::Extension>(w, |out| {
+        with_ctx(|ctx| check(ctx, unsafe { p2hot_eval_openings(ctx, handles.as_ptr(), 1, point.as_ptr(), 1, out) }, "p2hot_eval_openings"));
+    }))
+}
+
+// ------------------------------------------------------------------------------------------------
 // compute_quotient_polys (plonk/prover.rs:609-815): the permutation argument's share on the GPU
 // ------------------------------------------------------------------------------------------------
 /// The vanishing polynomial's terms are `[L_0 (Z - 1) ..] ++ [partial product checks ..] ++ [gate constraint terms ..]`
@@ -1137,6 +1226,18 @@ mod tests {
                 assert_eq!(dev.path::<H>(i), cpu.merkle_tree.prove(i).siblings);
             }
         }
+    }
+
+    /// OpeningSet::new's eval_commitment (plonk/proof.rs:323-328) on the device vs the CPU closure
+    #[test]
+    fn eval_commitment_matches_the_cpu_horner() {
+        let values: Vec<PolynomialValues<F>> = (0..7).map(|_| PolynomialValues::new(F::rand_vec(1 << 9))).collect();
+        let batch = Batch::from_values(values, 3, false, 4, &mut TimingTree::default(), None);
+        let z = <F as Extendable<D>>::Extension::rand();
+        let gpu = eval_commitment::<F, C, D>(z, &batch).expect("the p2hot body did not run");
+        let cpu: Vec<_> = batch.polynomials.iter().map(|p| p.to_extension::<D>().eval(z)).collect();
+        assert_eq!(cpu, gpu);
+        assert!(on_cpu(|| eval_commitment::<F, C, D>(z, &batch)).is_none());
     }
 
     /// blinding = true with the SAME salts on both sides: the CPU tree is assembled exactly as from_coeffs does it

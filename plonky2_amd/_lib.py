@@ -106,6 +106,7 @@ SIGNATURES = {
     "p2hot_batch_paths": (i, [vp, vp, sz, vp]),
     "p2hot_batch_digests": (i, [vp, vp]),
     "p2hot_batch_values": (i, [vp, C.POINTER(vp)]),
+    "p2hot_batch_subgroup_values": (i, [vp, sz, sz, C.POINTER(vp)]),
     "p2hot_batch_free": (None, [vp]),
     "p2hot_ctx_trim": (i, [vp]),
     "p2hot_cols_upload": (i, [vp, C.POINTER(vp), sz, u, C.POINTER(vp)]),

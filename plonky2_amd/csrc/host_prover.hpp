@@ -517,6 +517,33 @@ extern "C" int p2hot_batch_values(p2hot_batch *b, p2hot_cols **out) {
     return P2HOT_OK;
 }
 
+// polynomials [first, first + count) of the batch as VALUES on the subgroup H_n (an owned column set): a forward NTT of a copy of
+// their device-resident coefficients.  What plonk/prover.rs reads as `prover_data.sigmas` (the sigma polynomials' values, row
+// by row: prover.rs:413) is this for the sigma range of the constants_sigmas commitment -- the input of p2hot_partial_products.
+extern "C" int p2hot_batch_subgroup_values(p2hot_batch *b, size_t first, size_t count, p2hot_cols **out) {
+    if (!b || !out) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = b->ctx;
+    P2_ENTER(ctx);
+    *out = nullptr;
+    if (first > b->W || count > b->W - first || count == 0) P2_FAIL(ctx, P2HOT_EINVAL, "batch_subgroup_values: polynomials [%zu,+%zu) of %zu", first, count, b->W);
+    const size_t n = (size_t)1 << b->log_n;
+    PoolBuf d(ctx);
+    P2_TRY(pool_alloc(ctx, count * n * 8, &d.p));
+    auto body = [&]() -> int {
+        P2_HIP(ctx, hipMemcpy2DAsync(d.p, n * 8, b->d_coef + first * b->col_stride_coef(), b->col_stride_coef() * 8, n * 8, count,
+                                     hipMemcpyDeviceToDevice, ctx->stream));
+        P2_TRY(p2hot_fft_dev(ctx, d.u(), count, n, b->log_n));
+        P2HOT_LAUNCH(ntt::canon_kernel, dim3(cdiv(count * n, 256)), dim3(256), 0, ctx->stream, d.u(), count * n);
+        P2_LAUNCH_CHECK(ctx);
+        return P2HOT_OK;
+    };
+    int rc = sync_checked(ctx, body(), "batch_subgroup_values");
+    if (rc != P2HOT_OK) return rc;
+    *out = new p2hot_cols{ctx, d.u(), count, b->log_n, true};
+    d.p = nullptr;
+    return P2HOT_OK;
+}
+
 extern "C" int p2hot_batch_coeffs(p2hot_batch *b, size_t first, size_t count, uint64_t *out) {
     if (!b) return P2HOT_EINVAL;
     p2hot_ctx *ctx = b->ctx;

@@ -188,6 +188,14 @@ class PolynomialBatch:
         self.engine.check(self.engine.lib.p2hot_batch_values(self._h, C.byref(h)))
         return DeviceColumns(self.engine, h, owner=self)
 
+    def subgroup_values(self, first, count):
+        """values on H_n of polynomials [first, first+count) of the batch, from the device-resident coefficients
+        (p2hot_batch_subgroup_values) -- how plonk.prover reads the sigma values off the constants_sigmas commitment
+        instead of ProverOnlyCircuitData.sigmas (circuit_data.rs:455-456) -- as owned DeviceColumns"""
+        h = C.c_void_p()
+        self.engine.check(self.engine.lib.p2hot_batch_subgroup_values(self._h, first, count, C.byref(h)))
+        return DeviceColumns(self.engine, h)
+
     def get_lde_values(self, index, step=1):
         """oracle.rs:142-147: row reverse_bits(index*step, degree_log + rate_bits) of the leaf matrix"""
         bits = self.degree_log + self.rate_bits

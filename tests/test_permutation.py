@@ -264,3 +264,53 @@ def test_quotient_polys_argument_errors(eng, ora):
         compute_quotient_polys(b_w, b_cs, q["sigmas_first"], b_z, q["k"], 3, q["betas"], q["gammas"], q["alphas"], engine=eng)
     with pytest.raises(_lib.P2HotError, match="narrower"):
         compute_quotient_polys(b_w, b_cs, q["sigmas_first"] + 1, b_z, q["k"], 2, q["betas"], q["gammas"], q["alphas"], engine=eng)
+
+
+@pytest.mark.parametrize("log_n,rate_bits,first,count,from_values", [(5, 3, 2, 7, True), (0, 1, 0, 3, False), (9, 1, 0, 12, False),
+                                                                       (6, 2, 11, 1, True)])
+def test_batch_subgroup_values_vs_oracle(eng, ora, log_n, rate_bits, first, count, from_values):
+    """the sigma values the Rust shim feeds p2hot_partial_products: values on H of a committed batch's polynomials, recomputed from
+    the device-resident coefficients (the reference keeps them in ProverOnlyCircuitData.sigmas, circuit_builder.rs:1177-1179)"""
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    rng = np.random.default_rng(log_n * 13 + first)
+    W, n = 12, 1 << log_n
+    cols = rand_field(rng, W, n, noncanonical=True)
+    build = PolynomialBatch.from_values if from_values else PolynomialBatch.from_coeffs
+    batch = build(cols, rate_bits, False, 0, engine=eng)
+    got = batch.subgroup_values(first, count)
+    assert (got.width, got.degree_log) == (count, log_n)
+    vals = got.host()
+    exp = cols % np.uint64(P) if from_values else np.stack([ora.fft(c) for c in cols]) % np.uint64(P)
+    assert (vals == exp[first:first + count]).all()
+    assert (batch.polynomials == (np.stack([ora.ifft(c) for c in cols]) if from_values else cols % np.uint64(P))).all()   # untouched
+
+
+def test_partial_products_from_a_committed_sigma_batch(eng, ora):
+    """the shim's composition (integration/p2hot.rs all_wires_permutation_partial_products): wires uploaded, sigmas read off the
+    constants_sigmas commitment at sigmas_range().start -- the same polynomials the CPU body computes from prover_data.sigmas"""
+    from plonky2_amd.fri.oracle import DeviceColumns, PolynomialBatch
+    from plonky2_amd.plonk.prover import all_wires_permutation_partial_products, num_partial_products
+    rng = np.random.default_rng(4242)
+    num_routed, degree, log_n, nc, num_constants = 10, 4, 6, 2, 3
+    wires, sigmas, k = _permutation_instance(ora, rng, num_routed, log_n)
+    constants = rand_field(rng, num_constants, 1 << log_n)
+    cs = PolynomialBatch.from_values(np.concatenate([constants, sigmas]), 3, False, 1, engine=eng)
+    betas, gammas = rand_field(rng, nc), rand_field(rng, nc)
+    got = all_wires_permutation_partial_products(DeviceColumns.upload(wires, eng), cs.subgroup_values(num_constants, num_routed), k,
+                                                 degree, betas, gammas, eng).host()
+    num_prods = num_partial_products(num_routed, degree)
+    for ch in range(nc):
+        exp = ora.partial_products(wires, sigmas, k, degree, betas[ch], gammas[ch])
+        assert (got[ch] == exp[num_prods]).all()
+        assert (got[nc + ch * num_prods: nc + (ch + 1) * num_prods] == exp[:num_prods]).all()
+
+
+def test_batch_subgroup_values_argument_errors(eng):
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    batch = PolynomialBatch.from_coeffs(np.ones((3, 8), dtype=np.uint64), 1, False, 0, engine=eng)
+    with pytest.raises(Exception, match="range|polynomial"):
+        batch.subgroup_values(2, 2)
+    with pytest.raises(Exception, match="range|polynomial"):
+        batch.subgroup_values(4, 0)
+    with pytest.raises(Exception, match="range|polynomial"):
+        batch.subgroup_values(1, 0)   # an empty column set is refused, like a commit without polynomials

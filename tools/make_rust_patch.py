@@ -5,7 +5,9 @@ The patch is the Rust side of the drop-in boundary: Cargo feature `p
 `plonky2/src/p2hot.rs` (= integration/p2hot.rs, verbatim) and the feature-gated early returns in
   fri/oracle.rs        from_values / from_coeffs / get_lde_values / prove_openings
   fri/prover.rs        fri_committed_trees
-  plonk/prover.rs      compute_quotient_polys: the gate terms on the CPU, the permutation terms + coset_ifft on the GPU
+  plonk/proof.rs       OpeningSet::new: eval_commitment through p2hot_eval_openings
+  plonk/prover.rs      all_wires_permutation_partial_products through p2hot_partial_products;
+                       compute_quotient_polys: the gate terms on the CPU, the permutation terms + coset_ifft on the GPU
   hash/merkle_tree.rs  `device` handle on MerkleTree, get / num_leaves / prove (the leaf matrix may be ONE flat buffer behind it)
   iop/challenger.rs    accessor for the transcript state
   util/serialization   the one other MerkleTree struct literal; write_merkle_tree reads rows through get / num_leaves
@@ -27,6 +29,7 @@ REF = os.environ.get("P2_REFERENCE", "/root/reference")
 OUT = os.path.join(ROOT, "integration", "plonky2_p2hot.patch")
 
 FILES = ["plonky2/Cargo.toml", "plonky2/src/lib.rs", "plonky2/src/fri/oracle.rs", "plonky2/src/fri/prover.rs", "plonky2/src/plonk/prover.rs",
+         "plonky2/src/plonk/proof.rs",
          "plonky2/src/hash/merkle_tree.rs", "plonky2/src/iop/challenger.rs", "plonky2/src/util/serialization/mod.rs"]
 
 
@@ -125,8 +128,37 @@ fn main() {
         }
         let alpha = challenger.get_extension_challenge::<D>();
 ''')])
+    # ---- OpeningSet::new: the W Horner evaluations of a commitment at one point, on the coefficients the device already holds
+    edit(os.path.join(b, "plonky2/src/plonk/proof.rs"), [
+        ('''        let eval_commitment = |z: F::Extension, c: &PolynomialBatch<F, C, D>| {
+            c.polynomials
+''', '''        let eval_commitment = |z: F::Extension, c: &PolynomialBatch<F, C, D>| {
+            #[cfg(feature = "p2hot")]
+            if let Some(evals) = crate::p2hot::eval_commitment::<F, C, D>(z, c) {
+                return evals;
+            }
+            c.polynomials
+''')])
     # ---- the quotient: the permutation argument's share of compute_quotient_polys on the GPU
     edit(os.path.join(b, "plonky2/src/plonk/prover.rs"), [
+        ('''    common_data: &CommonCircuitData<F, D>,
+) -> Vec<Vec<PolynomialValues<F>>> {
+    (0..common_data.config.num_challenges)
+''', '''    common_data: &CommonCircuitData<F, D>,
+) -> Vec<Vec<PolynomialValues<F>>> {
+    #[cfg(feature = "p2hot")]
+    if let Some(polys) = crate::p2hot::all_wires_permutation_partial_products::<F, C, D>(
+        witness,
+        betas,
+        gammas,
+        prover_data,
+        common_data,
+    ) {
+        // the row walk as a prefix-product scan on the GPU, for every (beta, gamma) at once
+        return polys;
+    }
+    (0..common_data.config.num_challenges)
+'''),
         ('''    alphas: &[F],
 ) -> Vec<PolynomialCoeffs<F>> {
     let num_challenges = common_data.config.num_challenges;
