@@ -455,7 +455,9 @@ int p2hot_quotient_polys(p2hot_ctx *ctx, const p2hot_batch *wires, const p2hot_b
  * committed order, so rank r of G owns rows [r*N/G, (r+1)*N/G) = whole cosets = whole cap subtrees: it runs the LDE,
  * the leaf sponge and the Merkle levels of its rows with no data-path exchange.  Exchanges: the coefficients after the
  * column-sharded iNTT (W*n*8 bytes, pipelined in column chunks beside the transforms), the 2^cap_height cap entries,
- * and -- on request -- the digest slices.  G <= 2^rate_bits and G <= 2^cap_height, G a power of two.
+ * and -- on request -- the digest slices.  G <= 2^cap_height, G a power of two.  G > 2^rate_bits (starky's rate-1/2 traces on 4 or
+ * 8 GPUs): the cosets are split into sub-cosets of H_n -- rank r folds every polynomial mod x^n' - c_r (n' = N/G rows, c_r = the
+ * n'-th power of its block's coset shift) and runs the same LDE at (log n', log(N/n')); same exchange, same results.
  * Two ways to run it:
  *   one process per GPU   p2hot_comm_create_rccl (RCCL over xGMI; the launcher distributes the unique id) or
  *                         p2hot_comm_create_callback (the host application's own all-gather), then p2hot_commit_sharded_dev
@@ -516,8 +518,8 @@ int p2hot_group_commit(p2hot_group *group, const uint64_t *const *cols, size_t W
 /* shard_mode: P2HOT_SHARD_COSETS (default design, above) or P2HOT_SHARD_COLUMNS -- the fallback of SURVEY 8e's last row:
  * each rank runs the iNTT and the WHOLE LDE of its ceil(W/G) columns, then the LDE matrix is re-partitioned to row blocks
  * by an all-to-all of strided peer copies (the leaf sponge chains across the columns of a row) before hashing.  It moves
- * W*N*8 bytes instead of W*n*8 (2^rate_bits times more) but needs no G <= 2^rate_bits: starky's rate-1/2 traces can use
- * 4 or 8 GPUs.  Same results bit for bit. */
+ * W*N*8 bytes instead of W*n*8 (2^rate_bits times more); kept as a second, independently derived partition (the coset mode
+ * serves G > 2^rate_bits by sub-cosets).  Same results bit for bit. */
 #define P2HOT_SHARD_COSETS 0
 #define P2HOT_SHARD_COLUMNS 1
 /* MerkleTree::get + merkle_tree_prove (merkle_tree.rs:227, :151-190) for m leaves, each answered by the rank that owns

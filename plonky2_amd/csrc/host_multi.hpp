@@ -346,7 +346,9 @@ static int shard_plan(p2hot_ctx *ctx, size_t W, unsigned log_n, unsigned rate_bi
     p->N = p->n << rate_bits;
     p->world = world;
     if (cap_height > p->log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: cap_height > log2(N) (merkle_tree.rs:195-200)");
-    if (!by_columns && (size_t)world > ((size_t)1 << rate_bits)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: world size %d exceeds the %u LDE cosets", world, 1u << rate_bits);
+    // more ranks than LDE cosets (starky's rate-1/2 traces on 4 or 8 GPUs): the cosets are split into sub-cosets of H_n (sub_bits > 0
+    // in sharded_commit_core); what is left as a bound is one row block per rank and whole cap subtrees
+    if (!by_columns && (size_t)world > p->N) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: world size %d exceeds the %zu LDE rows", world, p->N);
     if ((size_t)world > ((size_t)1 << cap_height)) P2_FAIL(ctx, P2HOT_EINVAL, "commit_sharded: world size %d exceeds the %u cap subtrees", world, 1u << cap_height);
     p->rows_per_rank = p->N / world;
     p->cols_per_rank = W ? (W + world - 1) / world : 0;
@@ -410,7 +412,16 @@ static int sharded_commit_core(std::vector<p2hot_comm *> &cs, std::vector<ShardA
         P2_TRY(gather_start(cs, base, offs, (hi - lo) * n * 8, spans.size()));
         spans.emplace_back(lo, hi);
     }
-    // 3. LDE of every gathered chunk for this rank's coset rows
+    // 3. LDE of every gathered chunk for this rank's coset rows.  world > 2^rate_bits: rows_per_rank = n' < n, one sub-coset per rank
+    unsigned sub_bits = 0;
+    while ((p.rows_per_rank << sub_bits) < n) ++sub_bits;
+    const size_t np = n >> sub_bits;
+    std::vector<u64> sub_c(L, 1);
+    if (sub_bits)
+        for (size_t s = 0; s < L; ++s) {  // block b of the committed order is the coset j = bitrev(b); c_j = (g * w_N^j)^n'
+            const u64 shift = gl::mul(gl::COSET_SHIFT, gl::pow(gl::root_of_unity(p.log_N), bitrev_sz((size_t)cs[s]->rank, p.rate_bits + sub_bits)));
+            sub_c[s] = gl::canon(gl::pow(shift, np));
+        }
     for (size_t k = 0; k < spans.size(); ++k) {
         P2_TRY(gather_wait(cs, k));
         const size_t lo = spans[k].first, hi = spans[k].second;
@@ -420,8 +431,24 @@ static int sharded_commit_core(std::vector<p2hot_comm *> &cs, std::vector<ShardA
             for (int r = 0; r < world; ++r) {
                 const size_t cb = (size_t)r * cpr + lo, ce = std::min(std::min((size_t)r * cpr + hi, W), ((size_t)r + 1) * cpr);
                 if (ce <= cb) continue;
-                P2_TRY(p2hot_coset_lde_dev(cs[s]->ctx, slice_at(s, (size_t)r, lo, hi), ce - cb, n, p.log_n, p.rate_bits, gl::COSET_SHIFT, row_begin,
-                                           p.rows_per_rank, as[s].lde + cb * as[s].lde_stride, as[s].lde_stride));
+                if (sub_bits == 0) {
+                    P2_TRY(p2hot_coset_lde_dev(cs[s]->ctx, slice_at(s, (size_t)r, lo, hi), ce - cb, n, p.log_n, p.rate_bits, gl::COSET_SHIFT, row_begin,
+                                               p.rows_per_rank, as[s].lde + cb * as[s].lde_stride, as[s].lde_stride));
+                    continue;
+                }
+                // sub-coset mode: this rank's one row block is the coset (g * w_N^j) * H_{n'}; fold the polynomials mod x^n' - c_j, then
+                // the same LDE kernels at (log_n - sub_bits, rate_bits + sub_bits) place it (same N, same shift formula, same block order)
+                p2hot_ctx *ctx = cs[s]->ctx;
+                u64 *folded;
+                P2_TRY(scratch_get(ctx, 0, (ce - cb) * np * 8, (void **)&folded));
+                for (size_t c = 0; c < ce - cb; c += 65535) {
+                    const size_t cnt = std::min<size_t>(65535, ce - cb - c);
+                    P2HOT_LAUNCH(ntt::fold_mod_kernel, dim3((unsigned)cdiv(np, 256), (unsigned)cnt), dim3(256), 0, ctx->stream,
+                                 slice_at(s, (size_t)r, lo, hi) + c * n, n, folded + c * np, np, p.log_n - sub_bits, 1u << sub_bits, sub_c[s]);
+                    P2_LAUNCH_CHECK(ctx);
+                }
+                P2_TRY(p2hot_coset_lde_dev(ctx, folded, ce - cb, np, p.log_n - sub_bits, p.rate_bits + sub_bits, gl::COSET_SHIFT, row_begin, p.rows_per_rank,
+                                           as[s].lde + cb * as[s].lde_stride, as[s].lde_stride));
             }
             if (staged)  // the chunk's `world` slices -> rows r*cpr + lo .. of coeffs_all: one strided copy
                 P2_HIP(cs[s]->ctx, hipMemcpy2DAsync(as[s].coeffs_all + lo * n, cpr * n * 8, stage[s] + (size_t)world * lo * n, (hi - lo) * n * 8,

@@ -459,6 +459,18 @@ __global__ void scale_by_powers_kernel(u64 *data, size_t poly_stride, unsigned l
     *p = gl::canon(gl::mul(*p, s));
 }
 
+// Sub-coset sharding (more GPUs than LDE cosets).  On the coset s*H_{n'} of size n' = n / m every point has x^n' = c =
+// s^n', so p(x) = (p mod (x^n' - c))(x): out[col][t] = sum_u in[col][t + u*n'] * c^u, Horner from the top block.  The size-n' coset
+// NTT of `out` with shift s is then that block of the LDE (field/src/polynomial/mod.rs:280-293 evaluated on a sub-coset).
+__global__ void fold_mod_kernel(const u64 *in, size_t in_stride, u64 *out, size_t out_stride, unsigned log_np, unsigned m, u64 c) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, np = (size_t)1 << log_np;
+    if (t >= np) return;
+    const u64 *p = in + (size_t)blockIdx.y * in_stride;
+    u64 acc = p[t + (size_t)(m - 1) * np];
+    for (unsigned u = m - 1; u-- > 0;) acc = gl::add(gl::mul(acc, c), p[t + (size_t)u * np]);
+    out[(size_t)blockIdx.y * out_stride + t] = acc;
+}
+
 __global__ void canon_kernel(u64 *data, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) data[i] = gl::canon(data[i]);

@@ -40,8 +40,10 @@ class ShardPlan:
             raise ValueError("cap_height > log2(N) (merkle_tree.rs:195-200)")
         self.rows_per_rank = self.N // world
         sub_leaves = self.N >> cap_height
-        if world > (1 << rate_bits) or self.rows_per_rank % self.n:
-            raise ValueError("world size %d exceeds the %d LDE cosets" % (world, 1 << rate_bits))
+        if world > self.N:
+            raise ValueError("world size %d exceeds the %d LDE rows" % (world, self.N))
+        # more ranks than LDE cosets: every coset is split into 2^sub_bits sub-cosets of H_n, one per rank (csrc/host_multi.hpp)
+        self.sub_bits = max(0, log_n - (self.rows_per_rank.bit_length() - 1))
         if world > (1 << cap_height) or self.rows_per_rank % sub_leaves:
             raise ValueError("world size %d exceeds the %d cap subtrees" % (world, 1 << cap_height))
         self.cols_per_rank = -(-W // world) if W else 0
@@ -57,10 +59,12 @@ class ShardPlan:
         return c0, min(self.W, c0 + self.cols_per_rank)
 
     def cosets(self, rank):
-        """natural coset indices j (points g * w_N^(B*q + j)) whose rows this rank owns"""
-        b0 = rank * self.rows_per_rank // self.n
-        nb = self.rows_per_rank // self.n
-        rb = self.rate_bits
+        """natural coset indices j (points g * w_N^(B'*q + j), B' = 2^(rate_bits + sub_bits) cosets of size n >> sub_bits) whose
+        rows this rank owns"""
+        np_ = self.n >> self.sub_bits
+        b0 = rank * self.rows_per_rank // np_
+        nb = self.rows_per_rank // np_
+        rb = self.rate_bits + self.sub_bits
         return [int(format(b, "0%db" % rb)[::-1], 2) if rb else 0 for b in range(b0, b0 + nb)]
 
 
@@ -290,8 +294,8 @@ class GroupCommit:
     def commit(self, cols, rate_bits, cap_height, is_values=True, want_leaves=False, want_digests=True, pipeline_chunks=8,
                by_columns=False):
         """cols: host [W][n].  Returns dict(coeffs, leaves, digests, cap) host arrays + an opener for rows / paths.
-        by_columns: the column-sharded fallback (P2HOT_SHARD_COLUMNS: whole-column LDEs + an all-to-all of the LDE matrix;
-        no world <= 2^rate_bits constraint)."""
+        by_columns: the column-sharded mode (P2HOT_SHARD_COLUMNS: whole-column LDEs + an all-to-all of the LDE matrix), a second
+        partition with 2^rate_bits times the traffic; the default coset mode covers world > 2^rate_bits by sub-cosets."""
         cols = np.ascontiguousarray(np.asarray(cols, dtype=np.uint64))
         W, n = cols.shape
         log_n = int(n).bit_length() - 1

@@ -50,7 +50,9 @@ def _worker(rank, world, port, W, log_n, rb, cap, is_values, chunks, q):
 @pytest.mark.parametrize("world,W,log_n,rb,cap,is_values,chunks", [
     (2, 5, 5, 3, 4, True, 1), (4, 7, 4, 3, 4, True, 1), (2, 3, 6, 1, 2, False, 1),
     # pipelined coefficient exchange: async chunked all-gathers overlapped with the iNTT / LDE of the other chunks
-    (2, 11, 5, 3, 4, True, 4), (4, 135, 3, 3, 4, True, 4), (2, 7, 6, 1, 2, False, 3), (8, 20, 3, 3, 4, True, 2)])
+    (2, 11, 5, 3, 4, True, 4), (4, 135, 3, 3, 4, True, 4), (2, 7, 6, 1, 2, False, 3), (8, 20, 3, 3, 4, True, 2),
+    # more ranks than LDE cosets (starky's rate 1/2, C4's shape): one sub-coset of H_n per rank
+    (4, 2, 6, 1, 4, True, 1), (8, 3, 5, 1, 3, False, 2)])
 def test_sharded_commit_gloo(world, W, log_n, rb, cap, is_values, chunks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -180,15 +182,17 @@ def test_shard_plan():
     assert sorted(sum((p.cosets(r) for r in range(8)), [])) == list(range(8))
     assert p.cosets(1) == [4]  # row block 1 is coset bitrev_3(1) = 4
     assert p.digests_per_rank * 8 == p.num_digests and p.cap_per_rank == 2
-    with pytest.raises(ValueError):
-        ShardPlan(2, 22, 1, 4, 4)  # starky rate 1/2: only two cosets
+    q = ShardPlan(2, 22, 1, 4, 8)  # starky rate 1/2 (C4) on 8 GPUs: two cosets, each split into four sub-cosets of H_n
+    assert q.sub_bits == 2 and q.rows_per_rank == 1 << 20 and q.cosets(1) == [4] and q.cosets(6) == [3]
+    assert sorted(sum((q.cosets(r) for r in range(8)), [])) == list(range(8))
     with pytest.raises(ValueError):
         ShardPlan(2, 10, 3, 1, 4)  # fewer cap subtrees than ranks
 
 
 @pytest.mark.parametrize("world,W,log_n,rb,cap,is_values,chunks", [
     (2, 5, 5, 3, 4, True, 1), (4, 135, 3, 3, 4, True, 4), (8, 20, 4, 3, 4, True, 2), (2, 3, 6, 1, 2, False, 3),
-    (8, 9, 3, 3, 3, False, 8), (1, 6, 4, 2, 1, True, 2)])
+    (8, 9, 3, 3, 3, False, 8), (1, 6, 4, 2, 1, True, 2),
+    (4, 2, 6, 1, 4, True, 1), (8, 2, 5, 1, 3, False, 2), (8, 5, 4, 0, 3, True, 3), (4, 135, 2, 1, 2, True, 4)])   # more ranks than cosets: sub-cosets
 def test_group_commit_single_process(ora, world, W, log_n, rb, cap, is_values, chunks):
     """p2hot_group_commit -- ONE process driving `world` ranks (a patched plonky2's mode), host pointers in and out:
     coefficients, leaves, the full digest array and the cap equal the oracle's; rows / paths are served by the owning
@@ -229,8 +233,10 @@ def test_group_and_comm_argument_errors():
     g = GroupCommit(lib, 4, [0] * 4)
     assert lib.p2hot_group_size(g._h) == 4 and lib.p2hot_group_size(None) == 0
     cols = np.ones((2, 16), dtype=np.uint64)
-    with pytest.raises(_lib.P2HotError, match="LDE cosets"):
-        g.commit(cols, 1, 4)                                # starky rate 1/2: only two cosets
+    r = g.commit(cols, 1, 4)                                # starky rate 1/2: two cosets on four ranks = sub-cosets, not an error
+    r["free"]()
+    with pytest.raises(_lib.P2HotError, match="LDE rows|cap subtrees"):
+        g.commit(cols[:, :1], 0, 0)                         # one row: nothing to shard
     with pytest.raises(_lib.P2HotError, match="cap subtrees"):
         g.commit(cols, 3, 1)
     g.close()
@@ -282,7 +288,8 @@ def test_group_commit_column_sharded_fallback(ora, world, W, log_n, rb, cap, is_
     g.close()
 
 
-@pytest.mark.parametrize("world,widths,log_n,rb,cap,arity", [(2, [5, 3], 6, 3, 4, [2, 1]), (4, [7, 2, 2], 5, 3, 3, [2]), (8, [3], 4, 3, 3, [])])
+@pytest.mark.parametrize("world,widths,log_n,rb,cap,arity", [(2, [5, 3], 6, 3, 4, [2, 1]), (4, [7, 2, 2], 5, 3, 3, [2]), (8, [3], 4, 3, 3, []),
+                                                               (4, [2, 2], 7, 1, 4, [2, 1])])   # starky's shape on sub-cosets
 def test_group_prove_openings_equals_single_context_proof(ora, world, widths, log_n, rb, cap, arity):
     from tests.emu_backend import emu_engine, emu_lib
     _group_proof_equals_single_context(emu_lib(), emu_engine(), world, widths, log_n, rb, cap, arity)

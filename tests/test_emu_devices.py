@@ -40,7 +40,8 @@ def delta(lib, before):
 
 
 @pytest.mark.parametrize("exchange", ["allgather", "broadcast", None])
-@pytest.mark.parametrize("world,W,log_n,rb,cap,is_values", [(8, 20, 5, 3, 4, True), (4, 7, 6, 3, 2, False), (2, 135, 4, 1, 4, True)])
+@pytest.mark.parametrize("world,W,log_n,rb,cap,is_values", [(8, 20, 5, 3, 4, True), (4, 7, 6, 3, 2, False), (2, 135, 4, 1, 4, True),
+                                                                 (8, 2, 6, 1, 4, True)])   # C4's shape: 2 cosets on 8 GPUs = sub-cosets
 def test_group_commit_on_distinct_devices_over_rccl(ora, monkeypatch, world, W, log_n, rb, cap, is_values, exchange):
     """p2hot_group_create(G, [0..G-1]) -> ncclCommInitAll; the coset-sharded commit over G emulated GPUs: same bytes as the oracle,
     every exchange through the collectives library (no raw peer copy), not one device / stream / buffer violation, and the calling

@@ -255,15 +255,17 @@ def test_fri_commit_phase_full_size_vs_oracle(gpu, ora, log_n, rb, arity):
     assert c.get_n_challenges(2) == oc.get_n_challenges(2)
 
 
-@pytest.mark.parametrize("world,W,log_n,chunks,by_columns", [(2, 9, 12, 3, False), (4, 20, 14, 8, False), (8, 135, 12, 4, False),
-                                                             (4, 20, 13, 1, True), (8, 135, 11, 1, True)])
-def test_group_commit_ranks_on_one_gpu(gpu, ora, world, W, log_n, chunks, by_columns):
+@pytest.mark.parametrize("world,W,log_n,chunks,by_columns,rb", [(2, 9, 12, 3, False, 3), (4, 20, 14, 8, False, 3), (8, 135, 12, 4, False, 3),
+                                                                (4, 20, 13, 1, True, 3), (8, 135, 11, 1, True, 3),
+                                                                # more ranks than cosets (starky's rate 1/2): sub-cosets of H_n
+                                                                (8, 2, 16, 1, False, 1), (4, 135, 13, 4, False, 1), (8, 20, 12, 2, False, 0)])
+def test_group_commit_ranks_on_one_gpu(gpu, ora, world, W, log_n, chunks, by_columns, rb):
     """p2hot_group_commit on the real GPU: `world` ranks of ONE process, all on device 0 (the box has one GPU), exchanging
     by copies on their communicator streams; coefficients, leaves, the whole digest array and the cap equal the oracle's,
     and the owner of a row serves its Merkle path"""
     from plonky2_amd.distributed import GroupCommit
     rng = np.random.default_rng(9 + world)
-    rb, cap = 3, 4
+    cap = 4
     cols = rand_field(rng, W, 1 << log_n, noncanonical=True)
     o = ora.commit(cols, rb, cap, True)
     g = GroupCommit(gpu.lib, world, [0] * world)
