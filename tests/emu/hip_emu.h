@@ -88,7 +88,10 @@ static inline unsigned atomicOr(unsigned *p, unsigned v) {
 //   message (hipGetErrorString); so does recording an event on a stream of another device, or using a destroyed handle.
 // * Copies BETWEEN devices go through hipMemcpyAsync / hipMemcpy2DAsync only (explicit peer copies: counted, see emu::stats).
 // * A fake RCCL (ncclCommInitAll / ncclCommInitRank / grouped ncclBroadcast / ncclAllGather, rccl_emu.h) enforces per-rank
-//   device, stream and buffer identity and refuses collectives that would hang on the real library.
+//   device, stream and buffer identity and refuses collectives that would hang on the real library.  ncclCommInitRank with
+//   nranks > 1 joins PROCESSES (one per rank, device ids node-global) through a shared-memory segment named by the unique id;
+//   every collective is announced to all ranks before data moves, and a rank that never arrives is a timeout
+//   (P2HOT_EMU_RCCL_TIMEOUT_MS, default 20 s), not a hang.
 // Work executes synchronously in program order: ordering bugs (a missing event wait) are NOT modelled.
 typedef int hipError_t;
 typedef void *hipStream_t;

@@ -1,10 +1,15 @@
 // hip_emu_rt.cpp -- TEST INFRASTRUCTURE ONLY (see hip_emu.h): the emulated HIP runtime -- devices, device-tagged allocations
 // behind page protection, streams and events with device identity -- and a fake RCCL.  None of this is linked into the product.
+#include <fcntl.h>
 #include <signal.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <chrono>
 #include <cstdarg>
 #include <map>
 #include <memory>
@@ -382,9 +387,13 @@ hipError_t hipMemGetInfo(size_t *f, size_t *t) {
 // ncclGroupStart / ncclGroupEnd, and every rank of the communicator must post the same sequence of collectives.
 namespace {
 struct Clique;
+struct Shared;
 struct Comm {
     int rank, nranks, device;
     std::shared_ptr<Clique> clique;
+    Shared *shm = nullptr;  // a communicator whose ranks are PROCESSES (ncclCommInitRank with nranks > 1): see below
+    std::string shm_name;
+    unsigned seq = 0;
 };
 struct Clique {
     std::vector<Comm *> members;
@@ -440,7 +449,126 @@ int validate(const char *what, Comm *c, const void *send, void *recv, hipStream_
     return 0;
 }
 
+// ---- one process per rank (bench.py --gpus N, plonky2_amd.distributed.Communicator(transport="rccl")): the ranks meet in a POSIX
+// shared-memory segment named by the unique id.  Every collective is announced (sequence number, kind, bytes, root) and checked
+// against every other rank's announcement before a byte moves; data travels through a staging area in pieces.  A rank that
+// never arrives -- a rank that posted fewer collectives, took another branch, or died -- is a TIMEOUT with a message, where
+// the real library hangs.  Device ids are node-global: two ranks on one device are refused as RCCL refuses them.
+constexpr size_t kStagePerRank = 1 << 20;
+constexpr int kMaxRanks = 16;
+struct Announce {
+    unsigned seq, kind, root;
+    unsigned long long bytes;
+};
+struct Shared {
+    std::atomic<unsigned> magic, arrived, generation, dead, joined;
+    int nranks;
+    int device[kMaxRanks];
+    Announce ann[kMaxRanks];
+    alignas(64) unsigned char stage[1];  // nranks * kStagePerRank
+};
+constexpr unsigned kMagic = 0x70326874;
+
+long timeout_ms() {
+    const char *e = getenv("P2HOT_EMU_RCCL_TIMEOUT_MS");
+    return e ? atol(e) : 20000;
+}
+
+// sense-reversing barrier over the segment; 0 = everybody arrived, else an error code with nccl_error set
+int shared_barrier(Comm *c, const char *what) {
+    Shared *sh = c->shm;
+    if (sh->dead.load()) return nccl_fail(6, "%s: another rank of the communicator already failed (rank %d gives up instead of waiting for ever)", what, c->rank);
+    const unsigned gen = sh->generation.load();
+    if (sh->arrived.fetch_add(1) + 1 == (unsigned)sh->nranks) {
+        sh->arrived.store(0);
+        sh->generation.fetch_add(1);
+        return 0;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const long limit = timeout_ms();
+    while (sh->generation.load() == gen) {
+        if (sh->dead.load()) return nccl_fail(6, "%s: another rank of the communicator failed while rank %d waited for it", what, c->rank);
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            sh->dead.store(1);
+            return nccl_fail(6, "%s: rank %d waited %ld ms for the other ranks of the communicator: they posted fewer collectives, took another "
+                                "path or died -- the real library hangs here", what, c->rank, limit);
+        }
+        usleep(50);
+    }
+    return 0;
+}
+
+int run_shared(Comm *c, std::vector<Op> &ops) {
+    Shared *sh = c->shm;
+    const size_t R = (size_t)c->nranks;
+    for (auto &o : ops) {
+        sh->ann[c->rank] = Announce{++c->seq, (unsigned)o.kind, (unsigned)o.root, (unsigned long long)o.bytes};
+        int rc = shared_barrier(c, o.kind ? "ncclAllGather" : "ncclBroadcast");
+        if (rc) return rc;
+        const Announce a0 = sh->ann[0];
+        int bad = -1;
+        for (size_t r = 0; r < R; ++r)
+            if (sh->ann[r].seq != a0.seq || sh->ann[r].kind != a0.kind || sh->ann[r].root != a0.root || sh->ann[r].bytes != a0.bytes) bad = (int)r;
+        if (a0.kind == 0 && a0.root >= R) bad = 0;
+        if (bad >= 0) {  // every rank sees the same table and fails the same way
+            const Announce b = sh->ann[bad];
+            rc = nccl_fail(5, "collective %u differs between ranks (rank 0: kind %u, %llu bytes, root %u; rank %d: #%u kind %u, %llu bytes, root %u): mismatched "
+                              "collectives corrupt or hang on the real library", a0.seq, a0.kind, a0.bytes, a0.root, bad, b.seq, b.kind, b.bytes, b.root);
+            (void)shared_barrier(c, "mismatch");
+            return rc;
+        }
+        for (size_t off = 0; off < o.bytes || off == 0; off += kStagePerRank) {
+            const size_t len = std::min(kStagePerRank, o.bytes - off);
+            if (o.kind == 0) {
+                if (c->rank == o.root && len) {
+                    Access acc{o.send};
+                    memcpy(sh->stage, (const char *)o.send + off, len);
+                }
+                if ((rc = shared_barrier(c, "ncclBroadcast"))) return rc;
+                if (len && !(c->rank == o.root && o.send == o.recv)) {
+                    Access acc{o.recv};
+                    memcpy((char *)o.recv + off, sh->stage, len);
+                }
+            } else {
+                if (len) {
+                    Access acc{o.send};
+                    memcpy(sh->stage + (size_t)c->rank * kStagePerRank, (const char *)o.send + off, len);
+                }
+                if ((rc = shared_barrier(c, "ncclAllGather"))) return rc;
+                for (size_t q = 0; q < R && len; ++q) {
+                    Access acc{o.recv};
+                    memcpy((char *)o.recv + q * o.bytes + off, sh->stage + q * kStagePerRank, len);
+                }
+            }
+            stats.nccl_bytes += len;
+            if ((rc = shared_barrier(c, "collective")))  return rc;  // the staging area is free again
+            if (o.bytes == 0) break;
+        }
+        ++(o.kind ? stats.nccl_allgathers : stats.nccl_broadcasts);
+    }
+    return 0;
+}
+
 int run_group(std::vector<Op> &ops) {
+    {  // communicators whose ranks are processes: this process posts for ONE rank of each; in posting order
+        std::map<Comm *, std::vector<Op>> shared;
+        std::vector<Comm *> order;
+        std::vector<Op> local;
+        for (auto &o : ops) {
+            if (!o.comm->shm) {
+                local.push_back(o);
+                continue;
+            }
+            if (!shared.count(o.comm)) order.push_back(o.comm);
+            shared[o.comm].push_back(o);
+        }
+        for (Comm *c : order) {
+            int rc = run_shared(c, shared[c]);
+            if (rc) return rc;
+        }
+        ops.swap(local);
+        if (ops.empty()) return 0;
+    }
     std::map<Clique *, std::map<int, std::vector<Op>>> by;  // clique -> rank -> ops in posting order
     for (auto &o : ops) by[o.comm->clique.get()][o.comm->rank].push_back(o);
     for (auto &kv : by) {
@@ -489,7 +617,7 @@ int post(Op o) {
         queued.push_back(o);
         return 0;
     }
-    if (o.comm->nranks > 1)
+    if (o.comm->nranks > 1 && !o.comm->shm)
         return nccl_fail(5, "a collective on a %d-rank communicator outside ncclGroupStart / ncclGroupEnd from the one thread that drives every rank: "
                             "the real library blocks here for ever", o.comm->nranks);
     std::vector<Op> one{o};
@@ -501,15 +629,91 @@ extern "C" {
 int emu_ncclGetUniqueId(char *id128) {
     memset(id128, 0, 128);
     const unsigned long long c = ++uid_counter;
-    memcpy(id128, &c, sizeof c);
+    snprintf(id128, 128, "/p2hot_emu_rccl_%d_%llu_%llx", (int)getpid(), c,
+             (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
     return 0;
 }
-int emu_ncclCommInitRank(void **comm, int nranks, const char *, int rank) {
-    if (nranks != 1 || rank != 0)
-        return nccl_fail(3, "ncclCommInitRank with %d ranks: the emulator runs one process; multi-rank communicators come from ncclCommInitAll "
-                            "(the process-per-GPU path is covered by the gloo tests through the caller-supplied transport)", nranks);
-    Comm *c = new Comm{0, 1, tls_device, std::make_shared<Clique>()};
-    c->clique->members.push_back(c);
+int emu_ncclCommInitRank(void **comm, int nranks, const char *id128, int rank) {
+    if (nranks < 1 || rank < 0 || rank >= nranks) return nccl_fail(4, "ncclCommInitRank: rank %d of %d", rank, nranks);
+    if (nranks == 1) {
+        Comm *c = new Comm{0, 1, tls_device, std::make_shared<Clique>()};
+        c->clique->members.push_back(c);
+        std::lock_guard<std::mutex> l(mu);
+        live_comms.insert(c);
+        *comm = c;
+        return 0;
+    }
+    if (nranks > kMaxRanks) return nccl_fail(4, "ncclCommInitRank: the emulated node has at most %d ranks", kMaxRanks);
+    if (!id128 || id128[0] != '/' || memchr(id128, 0, 128) == nullptr)
+        return nccl_fail(4, "ncclCommInitRank: rank %d was handed a unique id that no ncclGetUniqueId produced (was rank 0's id distributed?)", rank);
+    const size_t bytes = sizeof(Shared) + (size_t)nranks * kStagePerRank;
+    int fd = shm_open(id128, O_CREAT | O_EXCL | O_RDWR, 0600);
+    const bool creator = fd >= 0;
+    if (!creator) fd = shm_open(id128, O_RDWR, 0600);
+    if (fd < 0) return nccl_fail(2, "ncclCommInitRank: shm_open(%s): %s", id128, strerror(errno));
+    if (creator && ftruncate(fd, (off_t)bytes) != 0) {
+        close(fd);
+        shm_unlink(id128);
+        return nccl_fail(2, "ncclCommInitRank: ftruncate: %s", strerror(errno));
+    }
+    if (!creator) {  // the creator sizes the segment before anybody may map it
+        struct stat st;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (fstat(fd, &st) == 0 && (size_t)st.st_size < bytes) {
+            if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms()) {
+                close(fd);
+                return nccl_fail(6, "ncclCommInitRank: rank %d found the segment of another world size (ranks disagree on nranks?)", rank);
+            }
+            usleep(50);
+        }
+    }
+    void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return nccl_fail(2, "ncclCommInitRank: mmap: %s", strerror(errno));
+    Shared *sh = (Shared *)m;
+    if (creator) {
+        sh->nranks = nranks;
+        for (int r = 0; r < kMaxRanks; ++r) sh->device[r] = -1;
+        sh->magic.store(kMagic);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (sh->magic.load() != kMagic) {
+            if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms()) {
+                munmap(m, bytes);
+                return nccl_fail(6, "ncclCommInitRank: rank %d never saw the segment initialised", rank);
+            }
+            usleep(50);
+        }
+    }
+    Comm *c = new Comm{rank, nranks, tls_device, std::make_shared<Clique>()};
+    c->shm = sh;
+    c->shm_name = id128;
+    auto bail = [&](int rc) {
+        munmap(m, bytes);
+        if (rank == 0) shm_unlink(id128);
+        delete c;
+        return rc;
+    };
+    if (sh->nranks != nranks) {
+        sh->dead.store(1);
+        return bail(nccl_fail(5, "ncclCommInitRank: rank %d says %d ranks, the communicator has %d", rank, nranks, sh->nranks));
+    }
+    if (sh->device[rank] != -1) {
+        sh->dead.store(1);
+        return bail(nccl_fail(5, "ncclCommInitRank: two processes claim rank %d", rank));
+    }
+    sh->device[rank] = tls_device;
+    int rc = shared_barrier(c, "ncclCommInitRank");  // the real call returns when every rank has joined
+    if (rc) return bail(rc);
+    for (int r = 0; r < nranks; ++r)
+        for (int q = 0; q < r; ++q)
+            if (sh->device[r] == sh->device[q]) {
+                rc = nccl_fail(5, "ncclCommInitRank: Duplicate GPU detected: rank %d and rank %d both on device %d", q, r, sh->device[r]);
+                (void)shared_barrier(c, "ncclCommInitRank");
+                return bail(rc);
+            }
+    if ((rc = shared_barrier(c, "ncclCommInitRank"))) return bail(rc);
+    if (rank == 0) shm_unlink(id128);  // every rank has mapped it: the name can go, the memory lives until the last unmap
     std::lock_guard<std::mutex> l(mu);
     live_comms.insert(c);
     *comm = c;
@@ -536,7 +740,9 @@ int emu_ncclCommInitAll(void **comms, int ndev, const int *devlist) {
 int emu_ncclCommDestroy(void *comm) {
     std::lock_guard<std::mutex> l(mu);
     if (!live_comms.erase(comm)) return nccl_fail(4, "ncclCommDestroy(%p): not a live communicator", comm);
-    delete (Comm *)comm;
+    Comm *c = (Comm *)comm;
+    if (c->shm) munmap(c->shm, sizeof(Shared) + (size_t)c->nranks * kStagePerRank);
+    delete c;
     return 0;
 }
 int emu_ncclBroadcast(const void *send, void *recv, size_t count, int dtype, int root, void *comm, void *stream) {

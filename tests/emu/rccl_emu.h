@@ -2,7 +2,7 @@
 // plonky2_amd/csrc/host_multi.hpp binds these where the product dlopen()s librccl: ncclCommInitAll / ncclCommInitRank /
 // grouped ncclBroadcast / ncclAllGather with per-rank device, stream and buffer identity enforced, and the call patterns
 // that hang the real library (a multi-rank collective outside a group from one thread, ranks posting different sequences)
-// reported as errors.
+// reported as errors.  Multi-rank ncclCommInitRank = one PROCESS per rank over POSIX shared memory (tests/test_emu_rccl_ranks.py).
 #pragma once
 #include <stddef.h>
 extern "C" {

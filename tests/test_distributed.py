@@ -243,10 +243,16 @@ def test_group_and_comm_argument_errors():
     eng = emu_engine()
     h = C.c_void_p()
     # the emulator's fake RCCL makes one-rank communicators (as the GPU tier does on the real library); a multi-rank
-    # ncclCommInitRank needs one process per rank, which the emulated node does not have: refused, not hung
+    # ncclCommInitRank waits for the other ranks' processes (tests/test_emu_rccl_ranks.py) -- alone it times out, not hangs
     uid = np.zeros(128, dtype=np.uint8)
     assert lib.p2hot_comm_unique_id(uid.ctypes.data) == 0 and uid.any()
-    assert lib.p2hot_comm_create_rccl(eng.ctx, 0, 2, uid.ctypes.data, C.byref(h)) == _lib.ECOMM
+    os.environ["P2HOT_EMU_RCCL_TIMEOUT_MS"] = "300"
+    try:
+        assert lib.p2hot_comm_create_rccl(eng.ctx, 0, 2, uid.ctypes.data, C.byref(h)) == _lib.ECOMM
+        assert b"hangs here" in lib.p2hot_last_error(eng.ctx)
+    finally:
+        del os.environ["P2HOT_EMU_RCCL_TIMEOUT_MS"]
+    assert lib.p2hot_comm_unique_id(uid.ctypes.data) == 0
     assert lib.p2hot_comm_create_rccl(eng.ctx, 0, 1, uid.ctypes.data, C.byref(h)) == 0
     assert lib.p2hot_comm_selftest(h, 4096) == 0
     lib.p2hot_comm_destroy(h)
