@@ -8,6 +8,9 @@
 //!   `PolynomialBatch::prove_openings`                 (fri/oracle.rs:176-237)
 //!   `fri_committed_trees`                             (fri/prover.rs:84-150)
 //!   `MerkleTree::get` / `::prove`                     (hash/merkle_tree.rs:227, :231-237)
+//!   `all_wires_permutation_partial_products`          (plonk/prover.rs:356-390)
+//!   `compute_quotient_polys` (its permutation terms, the division by Z_H and the coset_ifft; plonk/prover.rs:609-815)
+//!   `OpeningSet::new`'s `eval_commitment`             (plonk/proof.rs:323-328)
 //! call into the library; every other instantiation takes the unchanged CPU path.  Signatures, struct fields
 //! and results are unchanged, so `CircuitBuilder::build`, `prove`, starky's `prove`, serialization and the
 //! verifier are untouched.
