@@ -40,7 +40,7 @@ def strip(src):
 
 def patched_tree(ref, patch):
     top = tempfile.mkdtemp(prefix="p2hot_lint_")
-    for d in ("plonky2", "field", "util", "maybe_rayon"):
+    for d in ("plonky2", "field", "util", "maybe_rayon", "starky"):
         shutil.copytree(os.path.join(ref, d), os.path.join(top, d), ignore=shutil.ignore_patterns("target", "*.md"))
     subprocess.check_call(["git", "init", "-q", top])
     subprocess.check_call(["git", "apply", patch], cwd=top)

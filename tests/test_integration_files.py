@@ -356,3 +356,46 @@ def test_leaf_matrix_is_one_flat_buffer_behind_get():
         assert needle in p, needle
     h = open(HDR).read()
     assert "#define P2HOT_COEFFS_PER_COLUMN 2u" in h and "pub const P2HOT_COEFFS_PER_COLUMN: c_uint = 2;" in s
+
+
+def test_every_hooked_reference_function_calls_a_shim_function_that_exists(patched_reference):
+    """every `crate::p2hot::name` / `plonky2::p2hot::name` the patch writes into a reference file (plonky2 and starky) is a `pub fn`
+    of the shim, is called with as many arguments as it declares, and sits behind the feature gate; the starky crate forwards the
+    feature to plonky2"""
+    from tests import rust_lint as rl
+    s = open(RS).read()
+    hooks = 0
+    patched_reference = patched_reference.top
+    for crate_dir, prefix in (("plonky2/src", "crate::p2hot::"), ("starky/src", "plonky2::p2hot::")):
+        for dirpath, _, files in os.walk(os.path.join(patched_reference, crate_dir)):
+            for f in files:
+                path = os.path.join(dirpath, f)
+                if not f.endswith(".rs") or path.endswith("src/p2hot.rs"):
+                    continue
+                src = open(path).read()
+                for m in re.finditer(re.escape(prefix) + r"(\w+)", src):
+                    name = m.group(1)
+                    if name in ("DeviceTree", "tests"):
+                        continue
+                    d = re.search(r"pub(?:\(crate\))? fn %s\b" % name, s)
+                    assert d, "%s calls p2hot::%s, which the shim does not define" % (path, name)
+                    hooks += 1
+                    call = src[m.end():]
+                    call = call[call.index("("):] if re.match(r"\s*(::<[^>]*>)?\s*\(", call) else None
+                    if call is None:
+                        continue
+                    n_args = len(rl.split_top(call[1:rl.matching(call, 0, "(", ")")]))
+                    decl = s[d.end():]
+                    decl = decl[decl.index("("):]
+                    # parameters = `name:` at the start or after a comma (types such as &<<C as GenericConfig<D>>::InnerHasher as ..>::Hash
+                    # defeat a bracket-aware split; no type on this boundary contains `, name:`)
+                    n_params = len(re.findall(r"(?:^|,)\s*(?:mut\s+)?[a-z_]\w*\s*:(?!:)", decl[1:rl.matching(decl, 0, "(", ")")]))
+                    assert n_args == n_params, "%s: p2hot::%s called with %d arguments, declared with %d" % (path, name, n_args, n_params)
+                    # the call sits in a statement gated by the feature: the nearest preceding attribute / cfg! within a dozen lines
+                    head = src[:m.start()].rsplit("\n", 14)[1:]
+                    assert any('feature = "p2hot"' in line for line in head), "%s: p2hot::%s is not behind the feature gate" % (path, name)
+    assert hooks >= 10
+    cargo = open(os.path.join(patched_reference, "starky/Cargo.toml")).read()
+    assert 'p2hot = ["std", "plonky2/p2hot"]' in cargo
+    proof = open(os.path.join(patched_reference, "starky/src/proof.rs")).read()
+    assert "plonky2::p2hot::eval_commitment::<F, C, D>(z, c)" in proof

@@ -12,6 +12,7 @@ The patch is the Rust side of the drop-in boundary: Cargo feature `p
   iop/challenger.rs    accessor for the transcript state
   util/serialization   the one other MerkleTree struct literal; write_merkle_tree reads rows through get / num_leaves
   fri/prover.rs        also: the grind takes the smallest witness under the feature; a test hook for the harness
+  starky/Cargo.toml, starky/src/proof.rs   feature forwarding; StarkOpeningSet::new: eval_commitment through p2hot_eval_openings
 plus plonky2/examples/p2hot_dump_goldens.rs (= integration/p2hot_dump_goldens.rs, verbatim): the golden dumper.
 It is built by anchored edits of a scratch copy, so this script holds only the NEW lines and short
 anchors -- no reference source is stored in the repository beyond the diff context of the patch itself.
@@ -30,7 +31,8 @@ OUT = os.path.join(ROOT, "integration", "plonky2_p2hot.patch")
 
 FILES = ["plonky2/Cargo.toml", "plonky2/src/lib.rs", "plonky2/src/fri/oracle.rs", "plonky2/src/fri/prover.rs", "plonky2/src/plonk/prover.rs",
          "plonky2/src/plonk/proof.rs",
-         "plonky2/src/hash/merkle_tree.rs", "plonky2/src/iop/challenger.rs", "plonky2/src/util/serialization/mod.rs"]
+         "plonky2/src/hash/merkle_tree.rs", "plonky2/src/iop/challenger.rs", "plonky2/src/util/serialization/mod.rs",
+         "starky/Cargo.toml", "starky/src/proof.rs"]
 
 
 def edit(path, pairs):
@@ -135,6 +137,23 @@ fn main() {
 ''', '''        let eval_commitment = |z: F::Extension, c: &PolynomialBatch<F, C, D>| {
             #[cfg(feature = "p2hot")]
             if let Some(evals) = crate::p2hot::eval_commitment::<F, C, D>(z, c) {
+                return evals;
+            }
+            c.polynomials
+''')])
+    # ---- starky: the feature is forwarded, and StarkOpeningSet::new (starky/src/proof.rs:237-242) evaluates its commitments the same
+    # way (the trace and quotient commitments come from plonky2's PolynomialBatch::from_values / from_coeffs, so they carry handles)
+    edit(os.path.join(b, "starky/Cargo.toml"), [
+        ('timing = ["plonky2/timing"]\n',
+         'timing = ["plonky2/timing"]\n'
+         '# the MI355X hot path of the plonky2 crate (commitments, FRI, openings); see plonky2/src/p2hot.rs\n'
+         'p2hot = ["std", "plonky2/p2hot"]\n')])
+    edit(os.path.join(b, "starky/src/proof.rs"), [
+        ('''        let eval_commitment = |z: F::Extension, c: &PolynomialBatch<F, C, D>| {
+            c.polynomials
+''', '''        let eval_commitment = |z: F::Extension, c: &PolynomialBatch<F, C, D>| {
+            #[cfg(feature = "p2hot")]
+            if let Some(evals) = plonky2::p2hot::eval_commitment::<F, C, D>(z, c) {
                 return evals;
             }
             c.polynomials
