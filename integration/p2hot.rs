@@ -1051,6 +1051,7 @@ pub fn compute_quotient_polys<F: RichField + Extendable<D>, C: GenericConfig<D, 
     if nc > 4 || quotient_degree_bits > rate_bits {
         return None; // (the CPU body asserts on the second, prover.rs:632-636)
     }
+    assert!(betas.len() == nc && gammas.len() == nc && alphas.len() == nc);
     let n = 1usize << common_data.degree_bits();
     let step = 1usize << (rate_bits - quotient_degree_bits); // prover.rs:640
     let lde_size = n << quotient_degree_bits;
@@ -1059,7 +1060,7 @@ pub fn compute_quotient_polys<F: RichField + Extendable<D>, C: GenericConfig<D, 
     // gate_sums[a][i] = reduce_with_powers(gate constraint terms at point i, alpha_a)
     const BATCH_SIZE: usize = 32; // prover.rs:607
     let indices: Vec<usize> = (0..lde_size).collect();
-    let per_point: Vec<Vec<F>> = indices
+    let per_point: Vec<F> = indices // point-major: [lde_size][nc]
         .par_chunks(BATCH_SIZE)
         .flat_map(|batch| {
             let m = batch.len();
@@ -1077,18 +1078,17 @@ pub fn compute_quotient_polys<F: RichField + Extendable<D>, C: GenericConfig<D, 
             }
             let vars_batch = EvaluationVarsBaseBatch::new(m, &local_constants_batch, &local_wires_batch, public_inputs_hash);
             let constraint_terms_batch = evaluate_gate_constraints_base_batch::<F, D>(common_data, vars_batch);
-            (0..m)
-                .map(|j| {
-                    if constraint_terms_batch.is_empty() {
-                        vec![F::ZERO; alphas.len()]
-                    } else {
-                        reduce_with_powers_multi(PackedStridedView::<F>::new(&constraint_terms_batch, m, j), alphas)
-                    }
-                })
-                .collect::<Vec<_>>()
+            let mut sums = vec![F::ZERO; m * nc];
+            if !constraint_terms_batch.is_empty() {
+                for j in 0..m {
+                    let r = reduce_with_powers_multi(PackedStridedView::<F>::new(&constraint_terms_batch, m, j), alphas);
+                    sums[j * nc..(j + 1) * nc].copy_from_slice(&r);
+                }
+            }
+            sums
         })
         .collect();
-    let gate_sums: Vec<Vec<u64>> = (0..nc).map(|a| per_point.iter().map(|v| v[a].to_canonical_u64()).collect()).collect();
+    let gate_sums: Vec<Vec<u64>> = (0..nc).map(|a| per_point.iter().skip(a).step_by(nc).map(|v| v.to_canonical_u64()).collect()).collect();
     let gate_ptrs: Vec<*const u64> = gate_sums.iter().map(|v| v.as_ptr()).collect();
     let num_routed = common_data.config.num_routed_wires;
     let k_is: Vec<u64> = common_data.k_is[..num_routed].iter().map(|k| k.to_canonical_u64()).collect();
