@@ -87,8 +87,9 @@ class MerkleTree:
         if self._digests_dev is not None and self._digests is None:
             eng = self._engine
             out = eng.mem.zeros(len(idx), max(num_layers, 1), 4)
+            d_idx = eng.dev(idx)  # named: the buffer must outlive the (asynchronous) call that reads it
             eng.check(eng.lib.p2hot_merkle_paths_dev(eng.ctx, eng.ptr(self._digests_dev), log_n, self.cap_height,
-                                                     eng.ptr(eng.dev(idx)), len(idx), eng.ptr(out)))
+                                                     eng.ptr(d_idx), len(idx), eng.ptr(out)))
             return eng.host(out)[:, :num_layers]
         digests = np.asarray(self.digests, dtype=np.uint64).reshape(-1, 4)
         tree_len = digests.shape[0] >> self.cap_height

@@ -82,7 +82,9 @@ static inline unsigned atomicOr(unsigned *p, unsigned v) {
 // * hipMalloc returns page-aligned memory tagged with the device that was current; while another device is current the
 //   pages are PROT_NONE, so a kernel, a host loop or a memcpy that touches another GPU's memory faults, and the fault handler
 //   names the allocation, its device and the current device before aborting (an access from a thread whose OWN current device
-//   owns the pages is let through: protection is process-wide, the current device is per thread).
+//   owns the pages is let through: protection is process-wide, the current device is per thread).  Every allocation ENDS (to 16
+//   bytes) at a guard page that is never accessible: an index that runs off the end of a device buffer is a named fault
+//   ("DEVICE MEMORY OVERRUN: ... N bytes past the end of a B-byte allocation") at the first word, in any kernel, copy or host loop.
 // * Streams and events belong to the device that was current when they were created.  A launch, copy, memset, event record
 //   or stream wait issued on a stream of another device than the current one fails with hipErrorInvalidResourceHandle and a
 //   message (hipGetErrorString); so does recording an event on a stream of another device, or using a destroyed handle.

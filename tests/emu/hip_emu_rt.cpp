@@ -26,9 +26,10 @@ bool fault_no_device_guard = false;
 
 namespace {
 struct Alloc {
-    size_t bytes = 0, mapped = 0;
-    int device = -1;   // -1: host (pinned) memory
-    bool open = true;  // pages currently readable / writable
+    size_t bytes = 0, mapped = 0;  // mapped: the accessible pages; ONE more page behind them is a guard that is never accessible
+    uintptr_t user = 0;            // what hipMalloc returned: the allocation ENDS (to 16 bytes) where the guard page begins
+    int device = -1;               // -1: host (pinned) memory
+    bool open = true;              // pages currently readable / writable
 };
 std::mutex mu;                        // registry lock; never held while user memory is touched
 std::map<uintptr_t, Alloc> allocs;    // base address -> allocation
@@ -78,7 +79,7 @@ std::map<uintptr_t, Alloc>::iterator find_alloc(const void *p) {  // caller hold
     auto it = allocs.upper_bound(a);
     if (it == allocs.begin()) return allocs.end();
     --it;
-    return a < it->first + std::max(it->second.bytes, it->second.mapped) ? it : allocs.end();
+    return a < it->first + std::max(it->second.bytes, it->second.mapped + (it->second.device >= 0 ? page() : 0)) ? it : allocs.end();
 }
 
 void set_open(std::map<uintptr_t, Alloc>::iterator it, bool open) {  // caller holds mu
@@ -117,9 +118,15 @@ void on_segv(int sig, siginfo_t *info, void *uctx) {
     int dev = -1;
     size_t bytes = 0;
     uintptr_t base = 0;
+    bool overrun = false;
     if (mu.try_lock()) {
         auto it = find_alloc(addr);
-        if (it != allocs.end() && it->second.device >= 0 && !it->second.open) {
+        if (it != allocs.end() && it->second.device >= 0 && (uintptr_t)addr >= it->first + it->second.mapped) {
+            overrun = true;
+            dev = it->second.device;
+            bytes = it->second.bytes;
+            base = it->second.user;
+        } else if (it != allocs.end() && it->second.device >= 0 && !it->second.open) {
             ours = true;
             dev = it->second.device;
             bytes = it->second.bytes;
@@ -132,6 +139,14 @@ void on_segv(int sig, siginfo_t *info, void *uctx) {
         mu.unlock();
     }
     if (let_through) return;
+    if (overrun) {
+        fprintf(stderr,
+                "hip_emu: DEVICE MEMORY OVERRUN: address %p is %zu bytes past the end of a %zu-byte allocation of device %d (hipMalloc returned %p) "
+                "-- an index ran off the end of a device buffer\n",
+                addr, (size_t)((uintptr_t)addr - (base + bytes)), bytes, dev, (void *)base);
+        fflush(stderr);
+        abort();
+    }
     if (ours) {
         fprintf(stderr,
                 "hip_emu: DEVICE MEMORY FAULT: address %p lies in a %zu-byte allocation of device %d (base %p) but device %d is current "
@@ -220,29 +235,35 @@ hipError_t hipDeviceEnablePeerAccess(int peer, unsigned) {
 
 hipError_t hipMalloc(void **p, size_t n) {
     install_handler();
-    const size_t mapped = ((n ? n : 1) + page() - 1) / page() * page();
-    void *m = mmap(nullptr, mapped, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    // the allocation is placed so that it ENDS (rounded up to 16 bytes) at a guard page: an index that runs off the end of a device
+    // buffer faults on the spot, in every kernel, copy and host loop of the tier (what AddressSanitizer did while device memory was malloc'ed)
+    const size_t want = ((n ? n : 1) + 15) / 16 * 16;
+    const size_t mapped = (want + page() - 1) / page() * page();
+    void *m = mmap(nullptr, mapped + page(), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (m == MAP_FAILED) {
         *p = nullptr;
         return hipErrorOutOfMemory;
     }
+    mprotect((char *)m + mapped, page(), PROT_NONE);
     std::lock_guard<std::mutex> l(mu);
     Alloc a;
     a.bytes = n;
     a.mapped = mapped;
+    a.user = (uintptr_t)m + (mapped - want);
     a.device = tls_device;
     a.open = true;
     auto it = allocs.emplace((uintptr_t)m, a).first;
     if (tls_device != open_device) set_open(it, false);  // (another thread's device holds the window; this thread's first touch reopens it)
-    *p = m;
+    *p = (void *)a.user;
     return hipSuccess;
 }
 hipError_t hipFree(void *p) {
     if (!p) return hipSuccess;
     std::lock_guard<std::mutex> l(mu);
-    auto it = allocs.find((uintptr_t)p);
-    if (it == allocs.end() || it->second.device < 0) return violation(hipErrorInvalidValue, "hipFree(%p): not the base of a live device allocation", p);
-    munmap(p, it->second.mapped);
+    auto it = find_alloc(p);
+    if (it == allocs.end() || it->second.device < 0 || it->second.user != (uintptr_t)p)
+        return violation(hipErrorInvalidValue, "hipFree(%p): not the base of a live device allocation", p);
+    munmap((void *)it->first, it->second.mapped + page());
     allocs.erase(it);
     return hipSuccess;
 }

@@ -5,8 +5,10 @@ model of the HIP grid/block/__syncthreads semantics, so `pytest -m "not gpu"` ca
 arithmetic, the host orchestration and the multi-rank sharding logic against the oracle in the
 GPU-less build container.  "Device" buffers are numpy arrays.  Never imported by plonky2_amd.
 """
+import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -22,15 +24,57 @@ class DevArray(np.ndarray):
     """marks an ndarray as an emulated *device* buffer, so host arrays are always copied in (as on the GPU)"""
 
 
+def _hip(lib, name, argtypes):
+    """a C++ entry point of the emulated HIP runtime (tests/emu/hip_emu_rt.cpp), found by its mangled name"""
+    import re
+    global _syms
+    if _syms is None:
+        _syms = subprocess.run(["nm", "-D", "--defined-only", _SO], capture_output=True, text=True).stdout
+    m = re.search(r"\b(_Z%d%s\w*)\b" % (len(name), name), _syms)
+    f = getattr(lib, m.group(1))
+    f.argtypes, f.restype = argtypes, C.c_int
+    return f
+
+
+_syms = None
+
+
 class HostMemory:
+    """"Device" buffers of the test tier.  They come from the emulated hipMalloc, so they carry the device that was current when
+    they were made (the fake RCCL and the peer-copy rules see them), sit behind that device's page protection, and END at a guard
+    page: a kernel of a *_dev entry point that indexes past the end of a caller's buffer faults with a named message instead of
+    scribbling over numpy's heap.  Each block is returned to the emulated runtime when its last numpy view dies."""
+
+    def __init__(self):
+        lib = emu_lib()
+        self._malloc = _hip(lib, "hipMalloc", [C.POINTER(C.c_void_p), C.c_size_t])
+        self._free = _hip(lib, "hipFree", [C.c_void_p])
+
+    def _block(self, shape, zero):
+        words = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+        if words == 0:
+            return np.zeros(shape, dtype=np.uint64).view(DevArray)
+        p = C.c_void_p()
+        if self._malloc(C.byref(p), words * 8) != 0:
+            raise MemoryError("emulated hipMalloc(%d)" % (words * 8))
+        buf = (C.c_uint64 * words).from_address(p.value)
+        weakref.finalize(buf, self._free, p.value)   # every numpy view keeps `buf` alive through its base chain
+        a = np.frombuffer(buf, dtype=np.uint64).reshape(shape)
+        if zero:
+            a[...] = 0   # (mmap'ed pages are zero, but a recycled block need not be)
+        return a.view(DevArray)
+
     def empty(self, *shape):
-        return np.empty(shape, dtype=np.uint64).view(DevArray)
+        return self._block(shape, False)
 
     def zeros(self, *shape):
-        return np.zeros(shape, dtype=np.uint64).view(DevArray)
+        return self._block(shape, True)
 
     def from_host(self, a):
-        return np.array(a, dtype=np.uint64, order="C", copy=True).view(DevArray)
+        a = np.asarray(a, dtype=np.uint64)
+        d = self._block(a.shape, False)
+        d[...] = a
+        return d
 
     def to_host(self, t):
         return np.array(t, dtype=np.uint64, copy=True).view(np.ndarray)

@@ -314,3 +314,33 @@ def test_runtime_refuses_cross_device_handles():
     lib.p2hot_emu_set_device(7)
     assert sdestroy(s7) == 0 and edestroy(e7) == 0
     lib.p2hot_emu_set_device(0)
+
+
+def test_index_past_the_end_of_a_device_buffer_is_a_named_fault():
+    """emulated device allocations END at a guard page: a kernel whose index runs off the end of a buffer (here: a batch NTT told
+    about one polynomial more than the buffer holds) faults on the first word past the end, and the handler says how far past the end
+    of which allocation -- in every kernel, copy and host loop of the CPU tier; in-bounds work on the same buffer passes"""
+    code = r"""
+import ctypes as C, re, subprocess, sys, os
+sys.path.insert(0, %r)
+from tests.emu_backend import emu_lib
+lib = emu_lib()
+syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(%r, "tests", "emu", "libp2hot_emu.so")], capture_output=True, text=True).stdout
+hip_malloc = getattr(lib, re.search(r"\b(_Z9hipMalloc\w*)\b", syms).group(1))
+hip_malloc.argtypes, hip_malloc.restype = [C.POINTER(C.c_void_p), C.c_size_t], C.c_int
+ctx = C.c_void_p()
+assert lib.p2hot_ctx_create(0, None, C.byref(ctx)) == 0
+n, batch = 64, 3
+buf = C.c_void_p()
+assert hip_malloc(C.byref(buf), batch * n * 8) == 0
+C.memset(buf, 0, batch * n * 8)
+lib.p2hot_fft_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint]
+print("in bounds", lib.p2hot_fft_dev(ctx, buf, batch, n, 6), lib.p2hot_ctx_sync(ctx) if hasattr(lib, "p2hot_ctx_sync") else 0, flush=True)
+rc = lib.p2hot_fft_dev(ctx, buf, batch + 1, n, 6)
+print("survived", rc, flush=True)
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env={**os.environ, "PYTHONFAULTHANDLER": "0"})
+    assert "in bounds 0" in r.stdout, r.stdout + r.stderr
+    assert "survived" not in r.stdout and r.returncode != 0, r.stdout + r.stderr
+    assert "DEVICE MEMORY OVERRUN" in r.stderr and "past the end of a 1536-byte allocation of device 0" in r.stderr, r.stderr

@@ -148,7 +148,8 @@ def test_merkle_paths_device(eng, ora):
         idx = rng.integers(0, n, size=7).astype(np.uint64)
         layers = log_n - cap
         out = eng.mem.zeros(7, max(layers, 1), 4)
-        eng.check(eng.lib.p2hot_merkle_paths_dev(eng.ctx, eng.ptr(digests), log_n, cap, eng.ptr(eng.dev(idx)), 7, eng.ptr(out)))
+        d_idx = eng.dev(idx)
+        eng.check(eng.lib.p2hot_merkle_paths_dev(eng.ctx, eng.ptr(digests), log_n, cap, eng.ptr(d_idx), 7, eng.ptr(out)))
         got = eng.host(out)
         od, _ = ora.merkle_tree(leaves, cap)
         for q, i in enumerate(idx):
