@@ -7,7 +7,7 @@
 #ifdef P2HOT_EMU
 #include "hip_emu.h"
 #define P2HOT_LAUNCH(kernel, grid, block, shmem, stream, ...) \
-    emu::launch_on((stream), (grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })
+    emu::launch_on((stream), (grid), (block), (shmem), emu::bind_kernel(kernel, __VA_ARGS__))
 #define P2HOT_DYN_SHARED(type, name) type *name = reinterpret_cast<type *>(emu::dyn_shared)
 #else
 #include <hip/hip_runtime.h>

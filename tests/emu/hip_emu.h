@@ -94,7 +94,14 @@ static inline unsigned atomicOr(unsigned *p, unsigned v) {
 //   nranks > 1 joins PROCESSES (one per rank, device ids node-global) through a shared-memory segment named by the unique id;
 //   every collective is announced to all ranks before data moves, and a rank that never arrives is a timeout
 //   (P2HOT_EMU_RCCL_TIMEOUT_MS, default 20 s), not a hang.
-// Work executes synchronously in program order: ordering bugs (a missing event wait) are NOT modelled.
+// * Streams are QUEUES.  Launches, asynchronous copies, memsets, event records, stream waits and collectives are appended to
+//   their stream and run only when somebody needs the result (a synchronisation, a synchronous copy, hipFree, another stream's
+//   wait on an event recorded behind them): the as-late-as-legal schedule.  A consumer that forgot its hipStreamWaitEvent runs
+//   before its producer; a host read before the synchronisation sees old bytes; kernel arguments are captured by value at
+//   launch.  P2HOT_EMU_ASYNC=random:<seed> adds random legal steps (other schedules), =0 restores immediate execution.
+//   Copies follow the runtime's documented rules (pageable source captured at the call, pageable destination synchronous,
+//   pinned / device memory in stream order).  A collective of an in-process communicator executes when EVERY rank's stream has
+//   reached it.  One adversarial schedule plus random ones, not an exhaustive exploration.
 typedef int hipError_t;
 typedef void *hipStream_t;
 typedef void *hipEvent_t;
@@ -109,11 +116,17 @@ struct Stats {
     unsigned long long device_switches = 0, violations = 0;    // violations: API calls refused for a device / handle mismatch
 };
 extern Stats stats;
+extern bool fault_drop_waits;        // test hook (p2hot_emu_fault "drop_stream_waits"): hipStreamWaitEvent does nothing
 extern bool fault_no_device_guard;  // test hook (p2hot_emu_fault): DeviceGuard becomes a no-op, so a mis-guarded entry point is visible
 int current_device();
 int device_of(const void *p);       // device owning the allocation that contains p, -1: host / unknown memory
 // kernel launch on `stream`: refused (sticky error for hipGetLastError) unless the stream belongs to the current device
-void launch_on(hipStream_t stream, dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
+void launch_on(hipStream_t stream, dim3 grid, dim3 block, size_t shmem, std::function<void()> body);
+// the kernel with its arguments captured BY VALUE at launch time (as a real launch marshals them): the call itself is queued
+template <class K, class... A>
+std::function<void()> bind_kernel(K k, A... a) {
+    return [=]() { k(a...); };
+}
 }  // namespace emu
 
 hipError_t hipSetDevice(int d);

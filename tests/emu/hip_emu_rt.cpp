@@ -11,9 +11,11 @@
 #include <cerrno>
 #include <chrono>
 #include <cstdarg>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <random>
 #include <set>
 #include <string>
 
@@ -23,6 +25,7 @@
 namespace emu {
 Stats stats;
 bool fault_no_device_guard = false;
+bool fault_drop_waits = false;
 
 namespace {
 struct Alloc {
@@ -40,14 +43,41 @@ thread_local std::string tls_error;
 thread_local hipError_t tls_sticky = hipSuccess;
 std::set<std::pair<int, int>> peer_enabled;
 
+// ---- streams are QUEUES (P2HOT_EMU_ASYNC=0 switches back to immediate execution).  A launch, an asynchronous copy, a memset, an
+// event record, a stream wait and a collective are appended to their stream and run only when somebody NEEDS the result: a
+// hipStreamSynchronize / hipEventSynchronize / hipDeviceSynchronize, a synchronous copy, a hipFree -- or another stream's wait on
+// an event recorded behind them.  Work nobody waits for stays undone, so a consumer that forgot its hipStreamWaitEvent runs BEFORE
+// its producer and reads stale memory, and a host read of a result before the synchronisation reads stale memory: the missing
+// dependency of an asynchronous program shows as a wrong answer in the CPU tier.  (One adversarial schedule -- as late as legal --
+// not all of them.)  The copy rules follow the runtime's documentation: from pageable host memory the source is captured when the
+// call returns; into pageable host memory the call is synchronous; pinned and device memory are read and written in stream order.
+struct EventState {
+    int device;
+    unsigned long long enqueued = 0, done = 0;  // hipEventRecord calls so far / records that have executed
+};
+struct Stream;
+struct Coll;
+struct Task {
+    enum Kind { RUN, WAIT, RECORD, COLL } kind = RUN;
+    std::function<void()> fn;
+    std::shared_ptr<EventState> ev;
+    unsigned long long ver = 0;
+    Stream *src = nullptr;  // WAIT: the stream the awaited record sits on
+    std::shared_ptr<Coll> coll;
+};
 struct Stream {
     int device;
+    std::deque<Task> q;
+    bool busy = false;  // being advanced further up the call stack (blocked on a wait): reaching it again is a circular wait
 };
 struct Event {
     int device;
-    bool recorded = false;
+    std::shared_ptr<EventState> st;
+    Stream *rec = nullptr;  // where the latest record was enqueued
 };
 std::set<void *> live_streams, live_events;
+std::recursive_mutex sched_mu;        // the scheduler: held while queued work executes (kernels are emulated one at a time)
+std::map<int, Stream *> null_streams;  // the default stream of every device
 
 size_t page() {
     static const size_t p = (size_t)sysconf(_SC_PAGESIZE);
@@ -194,13 +224,202 @@ int device_of(const void *p) {
     return it == allocs.end() ? -1 : it->second.device;
 }
 
-void launch_on(hipStream_t stream, dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body) {
+namespace {
+// P2HOT_EMU_ASYNC: unset / "1" = as late as legal; "0" = immediate execution (the old model); "random:<seed>" = as late as legal
+// plus, at every enqueue and before every synchronisation, a random number of steps on randomly chosen streams -- other LEGAL
+// schedules between the two extremes (every step honours its stream's order and its waits), e.g. an overwrite running before a
+// lagging reader that nothing orders it against
+bool async_mode() {
+    static const bool on = !(getenv("P2HOT_EMU_ASYNC") && !strcmp(getenv("P2HOT_EMU_ASYNC"), "0"));
+    return on;
+}
+std::mt19937_64 *chaos_rng() {
+    static std::mt19937_64 *rng = []() -> std::mt19937_64 * {
+        const char *e = getenv("P2HOT_EMU_ASYNC");
+        return e && !strncmp(e, "random:", 7) ? new std::mt19937_64(strtoull(e + 7, nullptr, 10)) : nullptr;
+    }();
+    return rng;
+}
+Stream *resolve(hipStream_t s) {  // caller holds sched_mu
+    if (s) return (Stream *)s;
+    auto it = null_streams.find(tls_device);
+    if (it == null_streams.end()) it = null_streams.emplace(tls_device, new Stream{tls_device}).first;
+    return it->second;
+}
+
+// queued work of device d runs with d current and its pages open, whatever the calling thread's device is
+struct ExecScope {
+    int saved;
+    static void switch_to(int d) {
+        tls_device = d;
+        std::lock_guard<std::mutex> l(mu);
+        if (d != open_device) {
+            for (auto it = allocs.begin(); it != allocs.end(); ++it)
+                if (it->second.device >= 0) set_open(it, it->second.device == d);
+            open_device = d;
+        }
+    }
+    explicit ExecScope(int d) : saved(tls_device) {
+        if (d != saved) switch_to(d);
+    }
+    ~ExecScope() {
+        if (tls_device != saved) switch_to(saved);
+    }
+};
+
+struct Coll {  // one collective of a communicator whose ranks live in this process: executes when EVERY rank's stream has reached it
+    int kind;  // 0 broadcast, 1 all-gather
+    size_t bytes;
+    int root;
+    struct Part {
+        Stream *st;
+        int rank;
+        const void *send;
+        void *recv;
+    };
+    std::vector<Part> parts;
+};
+void run_collective(const Coll &c);  // (fake RCCL section)
+
+hipError_t deadlock(const char *what, Stream *s) {
+    return violation((hipError_t)999, "%s: circular wait -- a stream of device %d waits (directly or through other streams) for work queued behind its own wait: "
+                                      "the real runtime hangs here", what, s->device);
+}
+
+hipError_t step(Stream *s);
+hipError_t drive_event(Stream *src, EventState *ev, unsigned long long ver, const char *what) {
+    while (ev->done < ver) {
+        if (!src || src->busy) return deadlock(what, src ? src : resolve(nullptr));
+        if (src->q.empty()) return violation((hipError_t)999, "%s: the awaited event record is not queued anywhere (the recording stream was reset?)", what);
+        hipError_t rc = step(src);
+        if (rc != hipSuccess) return rc;
+    }
+    return hipSuccess;
+}
+hipError_t step(Stream *s) {  // executes the head of s (caller holds sched_mu, s->q is not empty)
+    Task &t = s->q.front();
+    static const bool trace = getenv("P2HOT_EMU_TRACE_SCHED") != nullptr;
+    if (trace) fprintf(stderr, "hip_emu: stream %p (device %d) runs %s, %zu queued behind it\n", (void *)s, s->device,
+                       t.kind == Task::RUN ? "work" : t.kind == Task::WAIT ? "a wait" : t.kind == Task::RECORD ? "an event record" : "a collective", s->q.size() - 1);
+    hipError_t rc = hipSuccess;
+    switch (t.kind) {
+        case Task::WAIT: {
+            s->busy = true;
+            std::shared_ptr<EventState> ev = t.ev;
+            rc = drive_event(t.src, ev.get(), t.ver, "hipStreamWaitEvent");
+            s->busy = false;
+            if (rc == hipSuccess) s->q.pop_front();
+            return rc;
+        }
+        case Task::RECORD:
+            t.ev->done = std::max(t.ev->done, t.ver);
+            s->q.pop_front();
+            return hipSuccess;
+        case Task::COLL: {
+            std::shared_ptr<Coll> c = t.coll;
+            s->busy = true;
+            for (auto &p : c->parts) {
+                while (rc == hipSuccess && !(!p.st->q.empty() && p.st->q.front().kind == Task::COLL && p.st->q.front().coll == c)) {
+                    if (p.st->busy || p.st->q.empty()) {
+                        rc = deadlock("collective", p.st);
+                        break;
+                    }
+                    rc = step(p.st);
+                }
+                if (rc != hipSuccess) break;
+            }
+            s->busy = false;
+            if (rc != hipSuccess) return rc;
+            run_collective(*c);
+            for (auto &p : c->parts) p.st->q.pop_front();
+            return hipSuccess;
+        }
+        default: {
+            std::function<void()> fn = std::move(t.fn);
+            s->q.pop_front();
+            s->busy = true;
+            {
+                ExecScope scope(s->device);
+                fn();
+            }
+            s->busy = false;
+            return hipSuccess;
+        }
+    }
+}
+void chaos() {  // caller holds sched_mu
+    std::mt19937_64 *rng = chaos_rng();
+    if (!rng) return;
+    static bool inside = false;
+    if (inside) return;
+    inside = true;
+    for (unsigned n = (unsigned)((*rng)() % 4); n > 0; --n) {
+        std::vector<Stream *> ready;
+        {
+            std::lock_guard<std::mutex> l(mu);
+            for (void *p : live_streams)
+                if (!((Stream *)p)->q.empty() && !((Stream *)p)->busy) ready.push_back((Stream *)p);
+        }
+        for (auto &kv : null_streams)
+            if (!kv.second->q.empty() && !kv.second->busy) ready.push_back(kv.second);
+        if (ready.empty()) break;
+        (void)step(ready[(size_t)((*rng)() % ready.size())]);  // (an error here resurfaces at the synchronisation that needs the work)
+    }
+    inside = false;
+}
+hipError_t drain(Stream *s) {
+    chaos();
+    while (!s->q.empty()) {
+        if (s->busy) return deadlock("synchronisation", s);
+        hipError_t rc = step(s);
+        if (rc != hipSuccess) return rc;
+    }
+    return hipSuccess;
+}
+hipError_t drain_device(int d) {
+    std::vector<Stream *> all;
+    {
+        std::lock_guard<std::mutex> l(mu);
+        for (void *p : live_streams)
+            if (((Stream *)p)->device == d) all.push_back((Stream *)p);
+    }
+    auto it = null_streams.find(d);
+    if (it != null_streams.end()) all.push_back(it->second);
+    for (Stream *st : all) {
+        hipError_t rc = drain(st);
+        if (rc != hipSuccess) return rc;
+    }
+    return hipSuccess;
+}
+// appends work to a stream, or runs it now in the immediate mode
+hipError_t enqueue(hipStream_t stream, std::function<void()> fn) {
+    if (!async_mode()) {
+        fn();
+        return hipSuccess;
+    }
+    std::lock_guard<std::recursive_mutex> g(sched_mu);
+    Task t;
+    t.kind = Task::RUN;
+    t.fn = std::move(fn);
+    resolve(stream)->q.push_back(std::move(t));
+    chaos();
+    return hipSuccess;
+}
+enum MemKind { PAGEABLE, PINNED, DEVICE };
+MemKind mem_kind(const void *p) {
+    std::lock_guard<std::mutex> l(mu);
+    auto it = find_alloc(p);
+    return it == allocs.end() ? PAGEABLE : it->second.device < 0 ? PINNED : DEVICE;
+}
+}  // namespace
+
+void launch_on(hipStream_t stream, dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
     hipError_t e = check_stream(stream, "kernel launch");
     if (e != hipSuccess) {
         tls_sticky = e;  // reported by the hipGetLastError that follows every launch
         return;
     }
-    launch(grid, block, shmem, body);
+    (void)enqueue(stream, [grid, block, shmem, body]() { launch(grid, block, shmem, body); });
 }
 }  // namespace emu
 
@@ -259,6 +478,12 @@ hipError_t hipMalloc(void **p, size_t n) {
 }
 hipError_t hipFree(void *p) {
     if (!p) return hipSuccess;
+    if (async_mode()) {  // hipFree waits for the device's outstanding work (it may still use the block)
+        const int d = device_of(p);
+        std::lock_guard<std::recursive_mutex> g(sched_mu);
+        hipError_t rc = drain_device(d >= 0 ? d : tls_device);
+        if (rc != hipSuccess) return rc;
+    }
     std::lock_guard<std::mutex> l(mu);
     auto it = find_alloc(p);
     if (it == allocs.end() || it->second.device < 0 || it->second.user != (uintptr_t)p)
@@ -279,6 +504,11 @@ hipError_t hipHostMalloc(void **p, size_t n, unsigned) {
 }
 hipError_t hipHostFree(void *p) {
     if (!p) return hipSuccess;
+    if (async_mode()) {
+        std::lock_guard<std::recursive_mutex> g(sched_mu);
+        hipError_t rc = drain_device(tls_device);
+        if (rc != hipSuccess) return rc;
+    }
     {
         std::lock_guard<std::mutex> l(mu);
         auto it = allocs.find((uintptr_t)p);
@@ -296,32 +526,50 @@ static void count_peer(const void *d, const void *s, size_t n) {
         stats.peer_bytes += n;
     }
 }
-hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t stream) {
-    hipError_t e = check_stream(stream, "hipMemcpyAsync");
-    if (e != hipSuccess) return e;
-    if (n == 0) return hipSuccess;
-    count_peer(d, s, n);
-    Access acc{d, s};
-    memmove(d, s, n);
-    return hipSuccess;
-}
-hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind k) { return hipMemcpyAsync(d, s, n, k, nullptr); }
 hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t stream) {
-    hipError_t e = check_stream(stream, "hipMemcpy2DAsync");
+    hipError_t e = check_stream(stream, "hipMemcpyAsync");
     if (e != hipSuccess) return e;
     if (width == 0 || height == 0) return hipSuccess;
     count_peer(d, s, width * height);
-    Access acc{d, s};
-    for (size_t r = 0; r < height; ++r) memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width);
-    return hipSuccess;
+    auto copy = [=](const void *from, size_t from_pitch) {
+        Access acc{d, from};
+        for (size_t r = 0; r < height; ++r) memmove((char *)d + r * dpitch, (const char *)from + r * from_pitch, width);
+    };
+    if (!async_mode()) {
+        copy(s, spitch);
+        return hipSuccess;
+    }
+    const MemKind dk = mem_kind(d), sk = mem_kind(s);
+    if (dk == PAGEABLE) {  // "the function will return only once the copy has completed": everything queued before it runs now
+        std::lock_guard<std::recursive_mutex> g(sched_mu);
+        hipError_t rc = drain(resolve(stream));
+        if (rc != hipSuccess) return rc;
+        copy(s, spitch);
+        return hipSuccess;
+    }
+    if (sk == PAGEABLE) {  // the source is staged before the call returns (the caller may reuse it); the device side is stream ordered
+        auto staged = std::make_shared<std::vector<unsigned char>>(width * height);
+        for (size_t r = 0; r < height; ++r) memcpy(staged->data() + r * width, (const char *)s + r * spitch, width);
+        return enqueue(stream, [=]() {
+            (void)staged;
+            copy(staged->data(), width);
+        });
+    }
+    return enqueue(stream, [=]() { copy(s, spitch); });
+}
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t stream) {
+    return hipMemcpy2DAsync(d, n, s, n, n, n ? 1 : 0, k, stream);
+}
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind k) {
+    hipError_t rc = hipMemcpyAsync(d, s, n, k, nullptr);
+    return rc != hipSuccess ? rc : hipStreamSynchronize(nullptr);
 }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t stream) {
     hipError_t e = check_stream(stream, "hipMemsetAsync");
     if (e != hipSuccess) return e;
     const int dd = device_of(d);
     if (dd >= 0 && dd != tls_device) return violation(hipErrorInvalidValue, "hipMemsetAsync on memory of device %d while device %d is current", dd, tls_device);
-    memset(d, v, n);
-    return hipSuccess;
+    return enqueue(stream, [=]() { memset(d, v, n); });
 }
 
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
@@ -332,19 +580,28 @@ hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
     return hipSuccess;
 }
 hipError_t hipStreamDestroy(hipStream_t s) {
+    std::lock_guard<std::recursive_mutex> g(sched_mu);
+    {
+        std::lock_guard<std::mutex> l(mu);
+        if (!s || !live_streams.count(s)) return violation(hipErrorInvalidResourceHandle, "hipStreamDestroy(%p): not a live stream", s);
+    }
+    hipError_t rc = drain((Stream *)s);  // the queued work still completes
     std::lock_guard<std::mutex> l(mu);
-    if (!s || !live_streams.erase(s)) return violation(hipErrorInvalidResourceHandle, "hipStreamDestroy(%p): not a live stream", s);
+    live_streams.erase(s);
     delete (Stream *)s;
-    return hipSuccess;
+    return rc;
 }
 hipError_t hipStreamSynchronize(hipStream_t s) {  // any device's stream may be synchronised from any thread
-    if (!s) return hipSuccess;
-    std::lock_guard<std::mutex> l(mu);
-    if (!live_streams.count(s)) return violation(hipErrorInvalidResourceHandle, "hipStreamSynchronize(%p): the stream was destroyed or never created", s);
-    return hipSuccess;
+    std::lock_guard<std::recursive_mutex> g(sched_mu);
+    if (s) {
+        std::lock_guard<std::mutex> l(mu);
+        if (!live_streams.count(s)) return violation(hipErrorInvalidResourceHandle, "hipStreamSynchronize(%p): the stream was destroyed or never created", s);
+    }
+    return drain(resolve(s));
 }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) {
-    Event *ev = new Event{tls_device};
+    Event *ev = new Event{tls_device, std::make_shared<EventState>()};
+    ev->st->device = tls_device;
     std::lock_guard<std::mutex> l(mu);
     live_events.insert(ev);
     *e = ev;
@@ -354,39 +611,72 @@ hipError_t hipEventCreate(hipEvent_t *e) { return hipEventCreateWithFlags(e, 0);
 hipError_t hipEventDestroy(hipEvent_t e) {
     std::lock_guard<std::mutex> l(mu);
     if (!e || !live_events.erase(e)) return violation(hipErrorInvalidResourceHandle, "hipEventDestroy(%p): not a live event", e);
-    delete (Event *)e;
+    delete (Event *)e;  // queued records / waits keep the shared state alive: destroying an event with pending work is legal
     return hipSuccess;
 }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
     hipError_t rc = check_stream(s, "hipEventRecord");
     if (rc != hipSuccess) return rc;
+    std::lock_guard<std::recursive_mutex> g(sched_mu);
     std::lock_guard<std::mutex> l(mu);
     if (!live_events.count(e)) return violation(hipErrorInvalidResourceHandle, "hipEventRecord: the event %p was destroyed or never created", e);
     Event *ev = (Event *)e;
     if (ev->device != stream_device(s))
         return violation(hipErrorInvalidResourceHandle, "hipEventRecord: an event of device %d recorded on a stream of device %d", ev->device, stream_device(s));
-    ev->recorded = true;
+    const unsigned long long ver = ++ev->st->enqueued;
+    if (!async_mode()) {
+        ev->st->done = ver;
+        return hipSuccess;
+    }
+    Task t;
+    t.kind = Task::RECORD;
+    t.ev = ev->st;
+    t.ver = ver;
+    ev->rec = resolve(s);
+    ev->rec->q.push_back(std::move(t));
     return hipSuccess;
 }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
     hipError_t rc = check_stream(s, "hipStreamWaitEvent");
     if (rc != hipSuccess) return rc;
+    std::lock_guard<std::recursive_mutex> g(sched_mu);
     std::lock_guard<std::mutex> l(mu);
     if (!live_events.count(e)) return violation(hipErrorInvalidResourceHandle, "hipStreamWaitEvent: the event %p was destroyed or never created", e);
-    return hipSuccess;  // (an event of ANOTHER device is fine: that is how the ranks' streams are ordered against each other)
-}
-hipError_t hipEventSynchronize(hipEvent_t e) {
-    std::lock_guard<std::mutex> l(mu);
-    if (!live_events.count(e)) return violation(hipErrorInvalidResourceHandle, "hipEventSynchronize: the event %p was destroyed or never created", e);
+    // (an event of ANOTHER device is fine: that is how the ranks' streams are ordered against each other)
+    Event *ev = (Event *)e;
+    if (fault_drop_waits) return hipSuccess;  // test hook: every stream dependency of the program is "forgotten"
+    if (ev->st->enqueued == 0 || ev->st->done >= ev->st->enqueued) return hipSuccess;  // never recorded / already complete: no wait
+    Task t;
+    t.kind = Task::WAIT;
+    t.ev = ev->st;
+    t.ver = ev->st->enqueued;  // the record the event holds NOW; a later re-record does not move this wait
+    t.src = ev->rec;
+    resolve(s)->q.push_back(std::move(t));
     return hipSuccess;
 }
+hipError_t hipEventSynchronize(hipEvent_t e) {
+    std::lock_guard<std::recursive_mutex> g(sched_mu);
+    Event *ev = (Event *)e;
+    {
+        std::lock_guard<std::mutex> l(mu);
+        if (!live_events.count(e)) return violation(hipErrorInvalidResourceHandle, "hipEventSynchronize: the event %p was destroyed or never created", e);
+    }
+    return drive_event(ev->rec, ev->st.get(), ev->st->enqueued, "hipEventSynchronize");
+}
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    std::lock_guard<std::recursive_mutex> g(sched_mu);
     std::lock_guard<std::mutex> l(mu);
     if (!live_events.count(a) || !live_events.count(b)) return violation(hipErrorInvalidResourceHandle, "hipEventElapsedTime: dead event");
+    for (hipEvent_t e : {a, b})
+        if (((Event *)e)->st->done < ((Event *)e)->st->enqueued)
+            return violation((hipError_t)600, "hipEventElapsedTime: an event has not completed yet (hipErrorNotReady): synchronise first");
     *ms = 0.f;  // the emulator has no clock
     return hipSuccess;
 }
-hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipDeviceSynchronize() {
+    std::lock_guard<std::recursive_mutex> g(sched_mu);
+    return drain_device(tls_device);
+}
 hipError_t hipGetLastError() {
     hipError_t e = tls_sticky;
     tls_sticky = hipSuccess;
@@ -426,7 +716,14 @@ struct Op {
     void *recv;
     size_t bytes;
     int root;
+    void *stream;
 };
+Stream *stream_of(void *stream, int device) {  // caller holds sched_mu
+    if (stream) return (Stream *)stream;
+    auto it = null_streams.find(device);
+    if (it == null_streams.end()) it = null_streams.emplace(device, new Stream{device}).first;
+    return it->second;
+}
 std::set<void *> live_comms;
 thread_local int group_depth = 0;
 thread_local std::vector<Op> queued;
@@ -452,6 +749,37 @@ void move(void *d, const void *s, size_t n) {
     memmove(d, s, n);
     stats.nccl_bytes += n;
 }
+
+}  // namespace
+namespace emu {
+namespace {
+void run_collective(const Coll &c) {
+    if (c.kind == 0) {
+        const void *src = nullptr;
+        for (auto &p : c.parts)
+            if (p.rank == c.root) src = p.send;
+        for (auto &p : c.parts) move(p.recv, src, c.bytes);
+        ++stats.nccl_broadcasts;
+    } else {
+        // every rank's contribution is staged first: an in-place all-gather reads a slot another rank's copy may overwrite
+        std::vector<std::vector<unsigned char>> stage(c.parts.size());
+        for (auto &p : c.parts) {
+            stage[(size_t)p.rank].resize(c.bytes);
+            Access acc{p.send};
+            memcpy(stage[(size_t)p.rank].data(), p.send, c.bytes);
+        }
+        for (auto &p : c.parts)
+            for (size_t q = 0; q < stage.size(); ++q) {
+                Access acc{p.recv};
+                memcpy((char *)p.recv + q * c.bytes, stage[q].data(), c.bytes);
+                stats.nccl_bytes += c.bytes;
+            }
+        ++stats.nccl_allgathers;
+    }
+}
+}  // namespace
+}  // namespace emu
+namespace {
 
 int validate(const char *what, Comm *c, const void *send, void *recv, hipStream_t stream) {
     {
@@ -523,6 +851,10 @@ int run_shared(Comm *c, std::vector<Op> &ops) {
     Shared *sh = c->shm;
     const size_t R = (size_t)c->nranks;
     for (auto &o : ops) {
+        if (async_mode()) {  // a collective between PROCESSES runs when it is posted (the other ranks' hosts are not ours to schedule):
+            std::lock_guard<std::recursive_mutex> g(sched_mu);  // everything queued in front of it on its stream runs first
+            if (drain(stream_of(o.stream, c->device)) != hipSuccess) return nccl_fail(6, "a collective's stream could not be advanced: %s", tls_error.c_str());
+        }
         sh->ann[c->rank] = Announce{++c->seq, (unsigned)o.kind, (unsigned)o.root, (unsigned long long)o.bytes};
         int rc = shared_barrier(c, o.kind ? "ncclAllGather" : "ncclBroadcast");
         if (rc) return rc;
@@ -607,26 +939,20 @@ int run_group(std::vector<Op> &ops) {
                 if (o.kind != o0.kind || o.bytes != o0.bytes || o.root != o0.root)
                     return nccl_fail(5, "collective %zu differs between ranks (kind %d/%d, bytes %zu/%zu, root %d/%d): mismatched collectives", k, o.kind, o0.kind, o.bytes, o0.bytes, o.root, o0.root);
             }
-            if (o0.kind == 0) {
-                if (o0.root < 0 || o0.root >= (int)cl->members.size()) return nccl_fail(4, "ncclBroadcast: root %d out of range", o0.root);
-                const void *src = ranks[o0.root][k].send;
-                for (auto &r : ranks) move(r.second[k].recv, src, o0.bytes);
-                ++stats.nccl_broadcasts;
-            } else {
-                // every rank's contribution is staged first: an in-place all-gather reads a slot another rank's copy may overwrite
-                std::vector<std::vector<unsigned char>> stage(ranks.size());
-                for (auto &r : ranks) {
-                    stage[(size_t)r.first].resize(o0.bytes);
-                    Access acc{r.second[k].send};
-                    memcpy(stage[(size_t)r.first].data(), r.second[k].send, o0.bytes);
-                }
-                for (auto &r : ranks)
-                    for (size_t q = 0; q < stage.size(); ++q) {
-                        Access acc{r.second[k].recv};
-                        memcpy((char *)r.second[k].recv + q * o0.bytes, stage[q].data(), o0.bytes);
-                        stats.nccl_bytes += o0.bytes;
-                    }
-                ++stats.nccl_allgathers;
+            if (o0.kind == 0 && (o0.root < 0 || o0.root >= (int)cl->members.size())) return nccl_fail(4, "ncclBroadcast: root %d out of range", o0.root);
+            auto c = std::make_shared<Coll>();
+            c->kind = o0.kind, c->bytes = o0.bytes, c->root = o0.root;
+            std::lock_guard<std::recursive_mutex> g(sched_mu);
+            for (auto &r : ranks) c->parts.push_back(Coll::Part{stream_of(r.second[k].stream, r.second[k].comm->device), r.first, r.second[k].send, r.second[k].recv});
+            if (!async_mode()) {
+                run_collective(*c);
+                continue;
+            }
+            for (auto &p : c->parts) {  // it executes when every rank's stream has reached it
+                Task t;
+                t.kind = Task::COLL;
+                t.coll = c;
+                p.st->q.push_back(std::move(t));
             }
         }
     }
@@ -771,14 +1097,14 @@ int emu_ncclBroadcast(const void *send, void *recv, size_t count, int dtype, int
     int rc = validate("ncclBroadcast", c, send, recv, stream);
     if (rc) return rc;
     if (!dtype_bytes(dtype)) return nccl_fail(4, "ncclBroadcast: unknown datatype %d", dtype);
-    return post(Op{0, c, send, recv, count * dtype_bytes(dtype), root});
+    return post(Op{0, c, send, recv, count * dtype_bytes(dtype), root, stream});
 }
 int emu_ncclAllGather(const void *send, void *recv, size_t sendcount, int dtype, void *comm, void *stream) {
     Comm *c = (Comm *)comm;
     int rc = validate("ncclAllGather", c, send, recv, stream);
     if (rc) return rc;
     if (!dtype_bytes(dtype)) return nccl_fail(4, "ncclAllGather: unknown datatype %d", dtype);
-    return post(Op{1, c, send, recv, sendcount * dtype_bytes(dtype), 0});
+    return post(Op{1, c, send, recv, sendcount * dtype_bytes(dtype), 0, stream});
 }
 int emu_ncclGroupStart() {
     ++group_depth;
@@ -801,6 +1127,10 @@ void p2hot_emu_stats(unsigned long long out[8]) {
 int p2hot_emu_fault(const char *what, int on) {
     if (!strcmp(what, "no_device_guard")) {
         fault_no_device_guard = on != 0;
+        return 0;
+    }
+    if (!strcmp(what, "drop_stream_waits")) {  // hipStreamWaitEvent becomes a no-op: what a program that forgot its waits does
+        fault_drop_waits = on != 0;
         return 0;
     }
     return 1;

@@ -49,6 +49,16 @@ class HostMemory:
         lib = emu_lib()
         self._malloc = _hip(lib, "hipMalloc", [C.POINTER(C.c_void_p), C.c_size_t])
         self._free = _hip(lib, "hipFree", [C.c_void_p])
+        self._sync = _hip(lib, "hipStreamSynchronize", [C.c_void_p])
+        self._errstr = _hip(lib, "hipGetErrorString", [C.c_int])
+        self._errstr.restype = C.c_char_p
+
+    def _synchronize(self):
+        """the emulated streams are queues (tests/emu/hip_emu_rt.cpp): work runs when somebody waits for it.  The engines of this
+        tier sit on the null stream, so this is torch's `.cpu()` / current-stream synchronisation of the GPU tier"""
+        rc = self._sync(None)
+        if rc != 0:
+            raise RuntimeError("emulated hipStreamSynchronize: %s" % self._errstr(rc).decode())
 
     def _block(self, shape, zero):
         words = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
@@ -77,6 +87,7 @@ class HostMemory:
         return d
 
     def to_host(self, t):
+        self._synchronize()
         return np.array(t, dtype=np.uint64, copy=True).view(np.ndarray)
 
     def is_buffer(self, x):
@@ -92,10 +103,11 @@ class HostMemory:
     def as_torch(self, t):
         import torch
         assert t.flags["C_CONTIGUOUS"]
+        self._synchronize()
         return torch.from_numpy(t.view(np.ndarray).view(np.int64))  # shares memory
 
     def collective_fence(self):
-        pass
+        self._synchronize()
 
 
 _lib_cache = None

@@ -251,7 +251,10 @@ def test_fake_rccl_refuses_what_hangs_or_corrupts_the_real_library():
     assert lib.emu_ncclBroadcast(a.ctypes.data, a.ctypes.data, 64, 1, 0, comms[0], None) == 0
     lib.p2hot_emu_set_device(2)
     assert lib.emu_ncclBroadcast(a.ctypes.data, b.ctypes.data, 64, 1, 0, comms[1], None) == 0
-    assert lib.emu_ncclGroupEnd() == 0 and (b == a).all()
+    assert lib.emu_ncclGroupEnd() == 0
+    assert os.environ.get("P2HOT_EMU_ASYNC", "1") != "1" or not (b == a).all()   # posted, not run: a collective is stream work like any other ...
+    ssync = _runtime(lib)("hipStreamSynchronize", [C.c_void_p])
+    assert ssync(None) == 0 and (b == a).all()  # ... waiting for ONE rank's stream pulls every rank's stream up to the collective
     # in-place all-gather of two 32-byte slices
     x, y = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
     x[:4], y[4:] = 7, 9
@@ -260,7 +263,7 @@ def test_fake_rccl_refuses_what_hangs_or_corrupts_the_real_library():
     assert lib.emu_ncclAllGather(x.ctypes.data, x.ctypes.data, 32, 1, comms[0], None) == 0
     lib.p2hot_emu_set_device(2)
     assert lib.emu_ncclAllGather(y.ctypes.data + 32, y.ctypes.data, 32, 1, comms[1], None) == 0
-    assert lib.emu_ncclGroupEnd() == 0
+    assert lib.emu_ncclGroupEnd() == 0 and ssync(None) == 0
     assert (x == y).all() and (x[:4] == 7).all() and (x[4:] == 9).all()
     # mismatched sequences
     lib.emu_ncclGroupStart()
@@ -335,12 +338,144 @@ buf = C.c_void_p()
 assert hip_malloc(C.byref(buf), batch * n * 8) == 0
 C.memset(buf, 0, batch * n * 8)
 lib.p2hot_fft_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint]
-print("in bounds", lib.p2hot_fft_dev(ctx, buf, batch, n, 6), lib.p2hot_ctx_sync(ctx) if hasattr(lib, "p2hot_ctx_sync") else 0, flush=True)
-rc = lib.p2hot_fft_dev(ctx, buf, batch + 1, n, 6)
+print("in bounds", lib.p2hot_fft_dev(ctx, buf, batch, n, 6), flush=True)
+hip_sync = getattr(lib, re.search(r"\b(_Z20hipStreamSynchronize\w*)\b", syms).group(1))
+hip_sync.argtypes, hip_sync.restype = [C.c_void_p], C.c_int
+rc = lib.p2hot_fft_dev(ctx, buf, batch + 1, n, 6)     # queued ...
+print("queued", rc, flush=True)
+rc = hip_sync(None)                                   # ... runs when somebody waits for it
 print("survived", rc, flush=True)
 """ % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT,
-                       env={**os.environ, "PYTHONFAULTHANDLER": "0"})
-    assert "in bounds 0" in r.stdout, r.stdout + r.stderr
+                       env={**os.environ, "PYTHONFAULTHANDLER": "0", "P2HOT_EMU_ASYNC": "1"})
+    assert "in bounds 0" in r.stdout and "queued 0" in r.stdout, r.stdout + r.stderr
     assert "survived" not in r.stdout and r.returncode != 0, r.stdout + r.stderr
     assert "DEVICE MEMORY OVERRUN" in r.stderr and "past the end of a 1536-byte allocation of device 0" in r.stderr, r.stderr
+
+
+def _runtime(lib):
+    import re
+    syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "tests", "emu", "libp2hot_emu.so")], capture_output=True, text=True).stdout
+
+    def fn(name, argtypes, restype=C.c_int):
+        m = re.search(r"\b(_Z%d%s\w*)\b" % (len(name), name), syms)
+        assert m, name
+        f = getattr(lib, m.group(1))
+        f.argtypes, f.restype = argtypes, restype
+        return f
+    return fn
+
+
+def test_streams_are_queues_a_missing_wait_reads_stale_memory():
+    """the emulated streams execute as late as is legal: work runs when somebody waits for it.  A consumer stream WITHOUT a
+    hipStreamWaitEvent on its producer's event runs before the producer and copies stale bytes; with the wait it copies the
+    produced bytes; a host read of pinned memory before the synchronisation is stale; a copy into pageable memory is synchronous;
+    a pageable source is captured when the call returns; a wait placed before its record does not wait"""
+    if os.environ.get("P2HOT_EMU_ASYNC", "1") != "1":
+        pytest.skip("this test pins the as-late-as-legal schedule")
+    lib = _lib_emu()
+    fn = _runtime(lib)
+    vp, sz = C.c_void_p, C.c_size_t
+    malloc_, free_ = fn("hipMalloc", [C.POINTER(vp), sz]), fn("hipFree", [vp])
+    hmalloc, hfree = fn("hipHostMalloc", [C.POINTER(vp), sz, C.c_uint]), fn("hipHostFree", [vp])
+    memset_, memcpy_ = fn("hipMemsetAsync", [vp, C.c_int, sz, vp]), fn("hipMemcpyAsync", [vp, vp, sz, C.c_int, vp])
+    screate, sdestroy, ssync = fn("hipStreamCreateWithFlags", [C.POINTER(vp), C.c_uint]), fn("hipStreamDestroy", [vp]), fn("hipStreamSynchronize", [vp])
+    ecreate, edestroy = fn("hipEventCreateWithFlags", [C.POINTER(vp), C.c_uint]), fn("hipEventDestroy", [vp])
+    erecord, swait, esync = fn("hipEventRecord", [vp, vp]), fn("hipStreamWaitEvent", [vp, vp, C.c_uint]), fn("hipEventSynchronize", [vp])
+    errstr = fn("hipGetErrorString", [C.c_int], C.c_char_p)
+    lib.p2hot_emu_set_device(0)
+    a, b, pin = vp(), vp(), vp()
+    assert malloc_(C.byref(a), 64) == 0 and malloc_(C.byref(b), 64) == 0 and hmalloc(C.byref(pin), 64, 0) == 0
+    prod, cons, ev = vp(), vp(), vp()
+    assert screate(C.byref(prod), 1) == 0 and screate(C.byref(cons), 1) == 0 and ecreate(C.byref(ev), 2) == 0
+    pinned = (C.c_ubyte * 64).from_address(pin.value)
+
+    def round_trip(with_wait):
+        C.memset(pin, 0xEE, 64)
+        assert memset_(a, 0x11, 64, None) == 0 and ssync(None) == 0               # a = 0x11 everywhere, done
+        assert memset_(a, 0x77, 64, prod) == 0 and erecord(ev, prod) == 0           # the producer overwrites a ...
+        if with_wait:
+            assert swait(cons, ev, 0) == 0
+        assert memcpy_(pin, a, 64, 2, cons) == 0                                    # ... the consumer copies a into pinned host memory
+        assert pinned[0] == 0xEE                                                    # nothing has run: the host sees the old bytes
+        assert ssync(cons) == 0
+        got = pinned[0]
+        assert ssync(prod) == 0
+        return got
+    assert round_trip(False) == 0x11      # no wait: the consumer ran first and saw the value from before the producer
+    assert round_trip(True) == 0x77       # with the wait the producer was pulled in front of it
+    # pageable destination: synchronous (and everything queued before it on that stream has run)
+    host = (C.c_ubyte * 64)()
+    assert memset_(b, 0x42, 64, prod) == 0 and memcpy_(host, b, 64, 2, prod) == 0 and host[63] == 0x42
+    # pageable source: captured when the call returns
+    src = (C.c_ubyte * 64)(*([9] * 64))
+    assert memcpy_(b, src, 64, 1, prod) == 0
+    C.memset(src, 0, 64)
+    assert memcpy_(host, b, 64, 2, prod) == 0 and host[0] == 9
+    # a wait placed BEFORE the record it is meant for does not wait (the event's state at the time of the call counts)
+    fresh = vp()
+    assert ecreate(C.byref(fresh), 2) == 0
+    assert memset_(a, 0x55, 64, None) == 0 and ssync(None) == 0
+    assert swait(cons, fresh, 0) == 0                                               # never recorded: no-op
+    assert memset_(a, 0x66, 64, prod) == 0 and erecord(fresh, prod) == 0
+    C.memset(pin, 0, 64)
+    assert memcpy_(pin, a, 64, 2, cons) == 0 and ssync(cons) == 0 and pinned[0] == 0x55
+    assert esync(fresh) == 0 and memcpy_(pin, a, 64, 2, cons) == 0 and ssync(cons) == 0 and pinned[0] == 0x66
+    for h in (prod, cons):
+        assert sdestroy(h) == 0
+    for h in (ev, fresh):
+        assert edestroy(h) == 0
+    assert free_(a) == 0 and free_(b) == 0 and hfree(pin) == 0
+
+
+def test_forgotten_stream_waits_are_visible_as_wrong_results(ora, monkeypatch):
+    """what the queue model is for: with every hipStreamWaitEvent of the program dropped (the emulator build's test hook) the
+    pipelined host-pointer commit -- uploads on a side stream, leaf copies beside the sponge -- and the group commit -- exchange on
+    the communication streams -- no longer produce the oracle's trees under the as-late-as-legal schedule; with the waits in
+    place they do (every other test of the tier)"""
+    if os.environ.get("P2HOT_EMU_ASYNC", "1") != "1":
+        pytest.skip("this test pins the as-late-as-legal schedule")
+    from plonky2_amd import _lib
+    from plonky2_amd.distributed import GroupCommit
+    lib = _lib_emu()
+    lib.p2hot_emu_set_device(0)
+    rng = np.random.default_rng(3)
+    W, log_n, rb, cap = 70, 5, 2, 2
+    monkeypatch.setenv("P2HOT_HOST_BLOCK_COLS", "16")   # column blocks as at 2^20 rows: uploads on the side stream, the sponge absorbing beside them
+    cols = rand_field(rng, W, 1 << log_n)
+    o = ora.commit(cols, rb, cap, True)
+    ptrs = (C.c_void_p * W)(*[cols[c].ctypes.data for c in range(W)])
+    N = 1 << (log_n + rb)
+
+    def host_commit():
+        ctx = C.c_void_p()
+        assert lib.p2hot_ctx_create(0, None, C.byref(ctx)) == 0
+        capv, leaves, coeffs = np.zeros((1 << cap, 4), dtype=np.uint64), np.zeros((N, W), dtype=np.uint64), np.zeros((W, 1 << log_n), dtype=np.uint64)
+        digests = np.zeros((max(1, 2 * (N - (1 << cap))), 4), dtype=np.uint64)
+        rc = lib.p2hot_commit(ctx, ptrs, W, log_n, rb, cap, 1, 0, coeffs.ctypes.data, leaves.ctypes.data, digests.ctypes.data, capv.ctypes.data, None)
+        lib.p2hot_ctx_destroy(ctx)
+        return rc == _lib.OK and (capv == o["cap"]).all() and (leaves == o["leaves"]).all() and (coeffs == o["coeffs"]).all()
+
+    def group_commit():
+        try:
+            g = GroupCommit(lib, 4, [0, 1, 2, 3])
+        except _lib.P2HotError:
+            return False          # the group's own preflight (a pattern exchange checked on every rank) already notices
+        try:
+            r = g.commit(cols, rb, cap, want_leaves=True, pipeline_chunks=3)
+            ok = bool((r["cap"] == o["cap"]).all() and (r["leaves"] == o["leaves"]).all())
+            r["free"]()
+            return ok
+        except _lib.P2HotError:
+            return False
+        finally:
+            g.close()
+    assert host_commit() and group_commit()
+    assert lib.p2hot_emu_fault(b"drop_stream_waits", 1) == 0
+    try:
+        broken = (host_commit(), group_commit())
+    finally:
+        assert lib.p2hot_emu_fault(b"drop_stream_waits", 0) == 0
+        lib.p2hot_emu_set_device(0)
+    assert broken == (False, False), broken
+    assert host_commit() and group_commit()
