@@ -130,9 +130,16 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &bo
     blockDim_ = block;
     gridDim_ = grid;
     current_body = &body;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
+    // P2HOT_EMU_THREADS=reverse: blocks and the threads of a block are visited in DESCENDING order.  Between two barriers the
+    // fibers run one after the other, so a read of shared or global memory that another thread writes in the same interval sees
+    // "written" in one visiting order and "not yet written" in the other: a missing __syncthreads shows in at least one of them
+    static const bool reverse = getenv("P2HOT_EMU_THREADS") && !strcmp(getenv("P2HOT_EMU_THREADS"), "reverse");
+    std::vector<size_t> order(nthreads);
+    for (size_t i = 0; i < nthreads; ++i) order[i] = reverse ? nthreads - 1 - i : i;
+    for (unsigned bz_ = 0; bz_ < grid.z; ++bz_)
+        for (unsigned by_ = 0; by_ < grid.y; ++by_)
+            for (unsigned bx_ = 0; bx_ < grid.x; ++bx_) {
+                const unsigned bx = reverse ? grid.x - 1 - bx_ : bx_, by = reverse ? grid.y - 1 - by_ : by_, bz = reverse ? grid.z - 1 - bz_ : bz_;
                 blockIdx_ = {bx, by, bz};
                 size_t t = 0;
                 for (unsigned tz = 0; tz < block.z; ++tz)
@@ -146,19 +153,21 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &bo
                 size_t live = nthreads;
                 bool first_pass = true;
                 while (live) {
-                    for (size_t i = 0; i < nthreads; ++i) {
+                    for (size_t k = 0; k < nthreads; ++k) {
+                        const size_t i = order[k];
                         Fiber &f = fibers[i];
                         if (f.done) continue;
                         current = &f;
                         threadIdx_ = f.tid;
-                        if (first_pass && i == 0) fiber_yielded = false;
+                        if (first_pass && k == 0) fiber_yielded = false;
                         start_or_resume(f);
                         if (f.done) --live;
-                        if (first_pass && i == 0 && f.done && !fiber_yielded) {
-                            // thread 0 ran to completion without a barrier: the block is barrier-free (a barrier that only
+                        if (first_pass && k == 0 && f.done && !fiber_yielded) {
+                            // the first thread ran to completion without a barrier: the block is barrier-free (a barrier that only
                             // other threads reach aborts loudly), so its other threads run as plain calls -- no context switches
                             direct_mode = true;
-                            for (size_t j = 1; j < nthreads; ++j) {
+                            for (size_t kk = 1; kk < nthreads; ++kk) {
+                                const size_t j = order[kk];
                                 threadIdx_ = fibers[j].tid;
                                 body();
                                 fibers[j].done = true;

@@ -6,7 +6,9 @@
 // tests/emu/libp2hot_emu.so and their index arithmetic checked against the oracle in the
 // GPU-less build container (`pytest -m "not gpu"`).  It is never built into, linked with or
 // loaded by the product library (libp2hot.so is hipcc/gfx950 only and fails loudly without a GPU).
-// No wave intrinsics are emulated beyond 64-lane __shfl/__shfl_xor/__shfl_down within a block.
+// No wave intrinsics are emulated beyond 64-lane __shfl/__shfl_xor/__shfl_down within a block.  Between two barriers a block's
+// threads run one after the other, ascending; P2HOT_EMU_THREADS=reverse visits threads and blocks in descending order, so that a
+// dependency on another thread's write inside a barrier interval (a missing __syncthreads) fails in at least one of the two orders.
 #pragma once
 #include <ucontext.h>
 

@@ -24,3 +24,15 @@ def test_stream_heavy_paths_under_another_schedule(mode):
                        capture_output=True, text=True, timeout=1500, cwd=ROOT, env={**os.environ, "P2HOT_EMU_ASYNC": mode})
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]
     assert r.returncode == 0 and " passed" in tail and "failed" not in tail, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_kernels_with_threads_and_blocks_visited_in_reverse():
+    """between two barriers the emulator runs a block's threads one after the other: ascending by default, DESCENDING here
+    (P2HOT_EMU_THREADS=reverse, blocks too).  A read of shared or global memory that another thread writes in the same
+    barrier interval sees the write in one order and not in the other, so a missing __syncthreads fails one of the two runs.
+    (The whole tier was run this way when the switch was added; this keeps the kernels' own parity tests under it.)"""
+    sel = ["tests/test_parity.py", "-k", "emu and (fft_ifft or coset_lde or merkle_tree_vs or polynomial_batch_vs or fri_committed or transpose or reverse_index)"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + sel,
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT, env={**os.environ, "P2HOT_EMU_THREADS": "reverse"})
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, r.stdout[-3000:] + r.stderr[-2000:]
