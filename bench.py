@@ -111,7 +111,7 @@ def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=45.0, golden_cap=None
     dt = time.perf_counter() - t0
     fe = W * (1 << (kk + rate_bits))
     whole = kk == log_n
-    out = {"value": fe / dt / 1e9, "unit": "GFE/s", "cores": cores, "kind": "port-tuned", "variant": "a port (oracle/p2fast.c), tuned: AVX-512 + OpenMP", "seconds": dt,
+    out = {"value": fe / dt / 1e9, "unit": "GFE/s", "cores": cores, "kind": "port", "variant": "a port (oracle/p2fast.c), tuned: AVX-512 + OpenMP", "seconds": dt,
            "sample": ("the whole step" if whole else "1/%d of the GPU step's rows" % (1 << (log_n - kk)))
                      + ": from_values W=%d, 2^%d rows, rate 1/%d, cap %d, %.2f s on %d cores; oracle/p2fast.c (tuned C + OpenMP + AVX-512 "
                        "restatement of the reference algorithm), not the Rust prover (no cargo in the image)" % (W, kk, 1 << rate_bits, cap_height, dt, cores),
