@@ -18,7 +18,7 @@ SELECTION = ["tests/test_parity.py", "tests/test_prove_openings.py", "tests/test
              "group_commit_on_distinct_devices or group_prove_openings_on_distinct or peer_copy_transports"]
 
 
-@pytest.mark.parametrize("mode", ["random:11", "random:12"])   # (the whole tier was run under random:1, random:2 and 0 when the model was built)
+@pytest.mark.parametrize("mode", ["random:11"])   # (the whole tier was run under random:1, random:2 and 0 when the model was built)
 def test_stream_heavy_paths_under_another_schedule(mode):
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + SELECTION,
                        capture_output=True, text=True, timeout=1500, cwd=ROOT, env={**os.environ, "P2HOT_EMU_ASYNC": mode})
