@@ -95,7 +95,7 @@ static inline unsigned atomicOr(unsigned *p, unsigned v) {
 //   device, stream and buffer identity and refuses collectives that would hang on the real library.  ncclCommInitRank with
 //   nranks > 1 joins PROCESSES (one per rank, device ids node-global) through a shared-memory segment named by the unique id;
 //   every collective is announced to all ranks before data moves, and a rank that never arrives is a timeout
-//   (P2HOT_EMU_RCCL_TIMEOUT_MS, default 20 s), not a hang.
+//   (P2HOT_EMU_RCCL_TIMEOUT_MS, default 60 s), not a hang.
 // * Streams are QUEUES.  Launches, asynchronous copies, memsets, event records, stream waits and collectives are appended to
 //   their stream and run only when somebody needs the result (a synchronisation, a synchronous copy, hipFree, another stream's
 //   wait on an event recorded behind them): the as-late-as-legal schedule.  A consumer that forgot its hipStreamWaitEvent runs

@@ -820,7 +820,7 @@ constexpr unsigned kMagic = 0x70326874;
 
 long timeout_ms() {
     const char *e = getenv("P2HOT_EMU_RCCL_TIMEOUT_MS");
-    return e ? atol(e) : 20000;
+    return e ? atol(e) : 60000;
 }
 
 // sense-reversing barrier over the segment; 0 = everybody arrived, else an error code with nccl_error set
