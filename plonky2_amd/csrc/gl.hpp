@@ -109,6 +109,17 @@ __host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
     return reduce128(lo, hi);
 }
 
+// a * b + c (mod P), c any 64-bit word: the two halves of c ride the multiply-add chain of mul128 (p00 + c.lo and
+// p01 + (p00 >> 32) + c.hi still fit in 64 bits), so the addition costs two instructions instead of a modular add
+__host__ __device__ __forceinline__ u64 mul_add(u64 a, u64 b, u64 c) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0 + (u32)c;                          // <= (2^32-1)^2 + 2^32 - 1
+    u64 p01 = (u64)a0 * b1 + ((p00 >> 32) + (c >> 32));      // <= (2^32-1)^2 + 2 (2^32-1) = 2^64 - 1
+    u64 p10 = (u64)a1 * b0 + (u32)p01;
+    u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    return reduce128((p10 << 32) | (u32)p00, p11);
+}
+
 __host__ __device__ __forceinline__ u64 sqr(u64 a) {
     u64 lo, hi;
     sqr128(a, lo, hi);

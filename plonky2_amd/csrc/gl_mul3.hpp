@@ -72,6 +72,42 @@ __device__ __forceinline__ void mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
     r[2] = rc;
 }
 
+// ---- mad3 / mad2: r[k] = a[k] * b[k] + c[k] (mod P) with c ANY 64-bit word, at the price of the plain product.  The halves of c
+// ride the first two multiply-adds of a stream: P = a0*b0 + c.lo and M = a1*b0 + c.hi still fit in 64 bits ((2^32-1)^2 + 2^32 - 1),
+// M + a0*b1 carries out once as before, and the 128-bit value a*b + c <= 2^128 - 2^64 reduces like any product.  The callers
+// pass the halves as 64-bit operands (high word zero): v_mad_u64_u32's addend is a register pair.
+#define P2_MADROW1                                                       \
+    "v_mad_u64_u32 v[70:71], s[40:41], %[xa0], %[ya0], %[ca0]\n\t"       \
+    "v_mad_u64_u32 v[76:77], s[44:45], %[xb0], %[yb0], %[cb0]\n\t"       \
+    "v_mad_u64_u32 v[82:83], s[48:49], %[xc0], %[yc0], %[cc0]\n\t"
+#define P2_MADROW2                                                       \
+    "v_mad_u64_u32 v[72:73], s[40:41], %[xa1], %[ya0], %[ca1]\n\t"       \
+    "v_mad_u64_u32 v[78:79], s[44:45], %[xb1], %[yb0], %[cb1]\n\t"       \
+    "v_mad_u64_u32 v[84:85], s[48:49], %[xc1], %[yc0], %[cc1]\n\t"
+__host__ __device__ __forceinline__ u64 mul_add(u64 a, u64 b, u64 c);
+__device__ __forceinline__ void mad3(const u64 a[3], const u64 b[3], const u64 c[3], u64 r[3]) {
+    if (!P2_ASM_INTERPRETED()) {
+        for (int k = 0; k < 3; ++k) r[k] = mul_add(a[k], b[k], c[k]);
+        return;
+    }
+    u64 ra, rb, rc;
+    P2_ASM(P2_MADROW1 P2_MADROW2 P2_ROW(P2_ST3) P2_ROW(P2_ST4) P2_ROW(P2_ST5) P2_ROW(P2_ST6) P2_ROW(P2_ST7)
+               P2_ROW(P2_ST8) P2_ROW(P2_ST9) P2_ROW(P2_ST10) P2_ROW(P2_ST11) P2_ROW(P2_ST12) P2_ROW(P2_ST13)
+                   P2_ROW(P2_ST14),
+           (P2_O([ra0], "=&v", ra), P2_O([rb0], "=&v", rb), P2_O([rc0], "=&v", rc)),
+           (P2_I([xa0], "v", (u32)a[0]), P2_I([xa1], "v", (u32)(a[0] >> 32)), P2_I([ya0], "v", (u32)b[0]),
+            P2_I([ya1], "v", (u32)(b[0] >> 32)), P2_I([xb0], "v", (u32)a[1]), P2_I([xb1], "v", (u32)(a[1] >> 32)),
+            P2_I([yb0], "v", (u32)b[1]), P2_I([yb1], "v", (u32)(b[1] >> 32)), P2_I([xc0], "v", (u32)a[2]),
+            P2_I([xc1], "v", (u32)(a[2] >> 32)), P2_I([yc0], "v", (u32)b[2]), P2_I([yc1], "v", (u32)(b[2] >> 32)),
+            P2_I([ca0], "v", (u64)(u32)c[0]), P2_I([ca1], "v", c[0] >> 32), P2_I([cb0], "v", (u64)(u32)c[1]), P2_I([cb1], "v", c[1] >> 32),
+            P2_I([cc0], "v", (u64)(u32)c[2]), P2_I([cc1], "v", c[2] >> 32)),
+           ("v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85",
+            "v86", "v87", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51"));
+    r[0] = ra;
+    r[1] = rb;
+    r[2] = rc;
+}
+
 // ---- mul2: two interleaved streams (what is left of a group of independent products after the threes) ----
 // One foreign instruction sits between a carry producer and its consumer, so the four adjacent producer/consumer rows
 // (5->6, 6->7, 8->9, 10->11) are followed by one more wait state each (`s_nop 0`): 28 instructions + 4 single wait states

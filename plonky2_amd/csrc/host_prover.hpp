@@ -1225,30 +1225,45 @@ extern "C" int p2hot_quotient_polys(p2hot_ctx *ctx, const p2hot_batch *wires, co
         if (!gate_sums[c]) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_polys: gate_sums[%u] is null", c);
     PoolBuf d_work(ctx), d_small(ctx), d_gate(ctx);
     P2_TRY(pool_alloc(ctx, (size_t)num_challenges * m * 8 + 8, &d_work.p));
-    P2_TRY(pool_alloc(ctx, ((size_t)num_routed + 2 * rate) * 8, &d_small.p));
+    const size_t nbk = (size_t)num_challenges * num_routed;
+    P2_TRY(pool_alloc(ctx, (nbk + 2 * rate) * 8, &d_small.p));
     if (gate_sums) P2_TRY(pool_alloc(ctx, (size_t)num_challenges * m * 8, &d_gate.p));
-    // ZeroPolyOnCoset::new(degree_bits, qbits) (field/src/zero_poly_coset.rs:21-34) and the k_is, on the host
-    std::vector<u64> small((size_t)num_routed + 2 * rate);
-    for (unsigned j = 0; j < num_routed; ++j) small[j] = k_is[j];
+    // ZeroPolyOnCoset::new(degree_bits, qbits) (field/src/zero_poly_coset.rs:21-34) and beta_c * k_j, on the host
+    std::vector<u64> small(nbk + 2 * rate);
+    for (unsigned c = 0; c < num_challenges; ++c)
+        for (unsigned j = 0; j < num_routed; ++j) small[(size_t)c * num_routed + j] = gl::canon(gl::mul(betas[c], k_is[j]));
+    const size_t num_routed_ = nbk;  // (offset of the Z_H table behind the beta * k table)
     const u64 g_pow_n = gl::pow(gl::COSET_SHIFT, n), v = gl::root_of_unity(qbits);
     for (size_t j = 0; j < rate; ++j) {
         const u64 e = gl::canon(gl::sub(gl::mul(g_pow_n, gl::pow(v, j)), 1));
         if (e == 0) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_polys: Z_H vanishes on the coset");
-        small[num_routed + j] = e;
-        small[num_routed + rate + j] = gl::inv(e);
+        small[num_routed_ + j] = e;
+        small[num_routed_ + rate + j] = gl::inv(e);
+    }
+    // 1 / (n (x - 1)) for every point of the quotient coset: sizes only, kept by the context
+    const auto inv_key = std::make_tuple(100, log_nq, qbits);
+    auto inv_it = ctx->twid_cache.find(inv_key);
+    if (inv_it == ctx->twid_cache.end()) {
+        u64 *t = nullptr;
+        P2_HIP(ctx, hipMalloc((void **)&t, m * 8));
+        P2HOT_LAUNCH(plonk::quot_inv_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, t, log_nq, (u64)n % gl::P, ctx->fwd);
+        if (hipGetLastError() != hipSuccess) {
+            (void)hipFree(t);
+            P2_FAIL(ctx, P2HOT_EHIP, "quotient_polys: the L_0 denominator table could not be launched");
+        }
+        inv_it = ctx->twid_cache.emplace(inv_key, t).first;
     }
     plonk::QuotArgs q{};
     q.wires = wires->d_lde, q.wires_stride = wires->col_stride_lde();
     q.sigmas = constants_sigmas->d_lde + sigmas_first_col * constants_sigmas->col_stride_lde(), q.sigmas_stride = constants_sigmas->col_stride_lde();
     q.zs = zs_partial_products->d_lde, q.zs_stride = zs_partial_products->col_stride_lde();
-    q.k_is = d_small.u(), q.zh = d_small.u() + num_routed;
+    q.bk = d_small.u(), q.zh = d_small.u() + nbk, q.inv_nx1 = inv_it->second;
     q.gate_sums = gate_sums ? d_gate.u() : nullptr;
     q.out = d_work.u();
     q.num_routed = num_routed, q.degree = quotient_degree_factor, q.num_chunks = num_chunks, q.log_nq = log_nq, q.qbits = qbits;
-    q.n_field = (u64)n % gl::P;
     const u64 K = (u64)num_challenges + (u64)num_challenges * num_chunks;
     for (unsigned a = 0; a < num_challenges; ++a) {
-        q.betas[a] = betas[a], q.gammas[a] = gammas[a], q.alphas[a] = alphas[a];
+        q.betas[a] = betas[a], q.gammas[a] = gl::canon(gammas[a]), q.alphas[a] = alphas[a];
         q.alpha_k[a] = gl::pow(alphas[a], K);
         for (unsigned c = 0; c < num_challenges; ++c) q.base[a][c] = gl::pow(alphas[a], (u64)num_challenges + (u64)c * num_chunks);
     }
@@ -1259,11 +1274,15 @@ extern "C" int p2hot_quotient_polys(p2hot_ctx *ctx, const p2hot_batch *wires, co
             P2_HIP(ctx, hipMemcpyAsync(d_gate.u() + (size_t)c * m, gate_sums[c], m * 8, hipMemcpyHostToDevice, ctx->stream));
         ProfScope prof(ctx, "quotient_perm");
         const dim3 grid(cdiv(m, 256)), block(256);
-        switch (num_challenges) {
-            case 1: P2HOT_LAUNCH(plonk::quotient_perm_kernel<1>, grid, block, 0, ctx->stream, q); break;
-            case 2: P2HOT_LAUNCH(plonk::quotient_perm_kernel<2>, grid, block, 0, ctx->stream, q); break;
-            case 3: P2HOT_LAUNCH(plonk::quotient_perm_kernel<3>, grid, block, 0, ctx->stream, q); break;
-            default: P2HOT_LAUNCH(plonk::quotient_perm_kernel<4>, grid, block, 0, ctx->stream, q); break;
+        if (num_challenges == 2 && quotient_degree_factor == 8) {  // every plonky2 config (circuit_data.rs:101-119): the pipelined instantiation
+            P2HOT_LAUNCH((plonk::quotient_perm_kernel<2, 8>), grid, block, 0, ctx->stream, q);
+        } else {
+            switch (num_challenges) {
+                case 1: P2HOT_LAUNCH((plonk::quotient_perm_kernel<1, 0>), grid, block, 0, ctx->stream, q); break;
+                case 2: P2HOT_LAUNCH((plonk::quotient_perm_kernel<2, 0>), grid, block, 0, ctx->stream, q); break;
+                case 3: P2HOT_LAUNCH((plonk::quotient_perm_kernel<3, 0>), grid, block, 0, ctx->stream, q); break;
+                default: P2HOT_LAUNCH((plonk::quotient_perm_kernel<4, 0>), grid, block, 0, ctx->stream, q); break;
+            }
         }
         P2_LAUNCH_CHECK(ctx);
         if (values_out) P2_HIP(ctx, hipMemcpyAsync(values_out, d_work.p, (size_t)num_challenges * m * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -270,7 +270,7 @@ __global__ void field_selftest_kernel(const u64 *a, const u64 *b, size_t count, 
     u64 ok = (gl::canon(rr[1]) == gl::canon(rr[0])) && (gl::canon(rr[2]) == gl::canon(gl::mul(x, x))) ? 0 : 1;
     // the other hand-written streams against the compiler's arithmetic, one flag bit each:
     // 2 = the low-register single stream, 4 = the power-of-two twiddle multiplies of the radix-8 butterflies (ntt.hpp),
-    // 8 / 16 = the MDS row recombinations fold1 / fold3 on accumulators below 2^63, 32 / 64 = the two-stream mul2 / fold2
+    // 8 / 16 = the MDS row recombinations fold1 / fold3 on accumulators below 2^63, 32 / 64 = the two-stream mul2 / fold2, 128 = gl::mul_add, 256 = gl::mad3
     if (gl::canon(gl::mul1_lowregs(x, y)) != gl::canon(gl::mul(x, y))) ok |= 2;
 #define P2_CHK_POW2(S)                                                                                              \
     if (gl::canon(ntt::mul_pow2_asm<S>(x)) != gl::canon(gl::mul(x, (S) < 64 ? 1ull << ((S) & 63) : 0xFFFFFFFFull << (((S) - 64) & 31)))) \
@@ -298,6 +298,17 @@ __global__ void field_selftest_kernel(const u64 *a, const u64 *b, size_t count, 
         gl::fold2(l2, h2, f2);
         for (int k = 0; k < 2; ++k)
             if (gl::canon(f2[k]) != gl::canon(gl::add(l2[k], gl::mul(h2[k], 1ull << 32)))) ok |= 64;
+    }
+    // 128 = the fused multiply-add (gl::mul_add: the addend rides the multiply-add chain), with addends up to 2^64 - 1
+    if (gl::canon(gl::mul_add(x, y, x ^ y)) != gl::canon(gl::add(gl::mul(x, y), x ^ y)) || gl::canon(gl::mul_add(y, x, ~0ull)) != gl::canon(gl::add(gl::mul(x, y), ~0ull)) ||
+        gl::canon(gl::mul_add(x, x, y)) != gl::canon(gl::add(gl::mul(x, x), y)))
+        ok |= 128;
+    {  // 256 = the fused multiply-add streams (gl::mad3), addends up to 2^64 - 1
+        const u64 a3[3] = {x, y, x}, b3[3] = {y, x, x}, c3[3] = {x ^ y, ~0ull, y};
+        u64 r3[3];
+        gl::mad3(a3, b3, c3, r3);
+        for (int k = 0; k < 3; ++k)
+            if (gl::canon(r3[k]) != gl::canon(gl::add(gl::mul(a3[k], b3[k]), c3[k]))) ok |= 256;
     }
     out[2 * count + t] = gl::canon(rr[0]);
     out[5 * count + t] = ok;

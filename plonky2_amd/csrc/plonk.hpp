@@ -13,6 +13,7 @@
 // reference's element-wise batch_multiplicative_inverse route (field/src/types.rs:133) bit for bit once canonical.
 // A zero denominator makes the reference panic ("Tried to invert zero"); here it raises a flag -> P2HOT_EINVAL.
 #pragma once
+#include "gl_mul3.hpp"
 #include "gl.hpp"
 #include "ntt.hpp"
 
@@ -146,19 +147,32 @@ __global__ void any_nonzero_kernel(const u64 *v, size_t count, unsigned *flag) {
 struct QuotArgs {
     const u64 *wires, *sigmas, *zs;  // column-major LDE matrices, element (col, L) at col * stride + L; sigmas points at sigma_0
     size_t wires_stride, sigmas_stride, zs_stride;
-    const u64 *k_is;       // device [num_routed]
+    const u64 *bk;         // device [nc][num_routed]: beta_c * k_j (wave-uniform)
     const u64 *zh;         // device [2 << qbits]: Z_H(g w^i) for i mod 2^qbits, then their inverses (field/src/zero_poly_coset.rs:21-34)
+    const u64 *inv_nx1;    // device [Nq], committed order: 1 / (n (x_L - 1)), x_L = g w^bitrev(L)  (quot_inv_kernel; cached per size)
     const u64 *gate_sums;  // device [nc][Nq] natural order, or null
     u64 *out;              // device [nc][Nq] natural order (prover.rs:805-807: transpose(&quotient_values))
     unsigned num_routed, degree, num_chunks, log_nq, qbits;
-    u64 n_field;           // |H| as a field element
     u64 betas[4], gammas[4], alphas[4];
     u64 base[4][4];        // base[a][c] = alpha_a^(nc + c * num_chunks): where challenge c's chunk terms start in the term list
     u64 alpha_k[4];        // alpha_a^K, K = nc + nc * num_chunks
     ntt::RootTable roots;  // forward table: w_Nq^i
 };
 
-template <int NC>
+// 1 / (n (x - 1)) on the quotient coset, in the committed (bit-reversed) order: the denominator of L_0 (zero_poly_coset.rs:58-61).
+// Depends on the sizes only, so it is computed once per (log_nq, qbits) and kept by the context.
+__global__ void __launch_bounds__(256) quot_inv_kernel(u64 *out, unsigned log_nq, u64 n_field, ntt::RootTable roots) {
+    const size_t L = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >> log_nq) return;
+    const size_t i = log_nq ? (size_t)(__brevll((unsigned long long)L) >> (64 - log_nq)) : 0;
+    const u64 x = gl::mul(gl::COSET_SHIFT, log_nq ? ntt::root_pow(roots, (u32)(i << (32 - log_nq))) : (u64)1);
+    out[L] = gl::canon(gl::inv(gl::mul(n_field, gl::sub(x, 1))));
+}
+
+// DEG > 0: quotient_degree_factor known at compile time (8 in every plonky2 config): the 2 * DEG loads of the NEXT chunk of routed
+// wires are issued before the current chunk's 4 * NC * DEG multiplications, so the kernel streams its 13 GB instead of waiting
+// for each pair of loads.  DEG == 0: any degree, plain loop.
+template <int NC, int DEG>
 __global__ void __launch_bounds__(256) quotient_perm_kernel(QuotArgs q) {
     const size_t L = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nq = (size_t)1 << q.log_nq;
@@ -169,13 +183,13 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(QuotArgs q) {
     const u64 x = gl::mul(gl::COSET_SHIFT, q.log_nq ? ntt::root_pow(q.roots, (u32)(i << (32 - q.log_nq))) : (u64)1);
     const size_t r = i & (((size_t)1 << q.qbits) - 1);
     // L_0(x) = Z_H(x) / (n (x - 1))  (zero_poly_coset.rs:58-61)
-    const u64 l0 = gl::mul(q.zh[r], gl::inv(gl::mul(q.n_field, gl::sub(x, 1))));
+    const u64 l0 = gl::mul(q.zh[r], q.inv_nx1[L]);
     const unsigned num_prods = q.num_chunks - 1;
-    u64 zx[NC], bx[NC], acc[NC][NC], pw[NC], res[NC];
+    const unsigned degree = DEG ? (unsigned)DEG : q.degree;
+    u64 zx[NC], acc[NC][NC], pw[NC], res[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         zx[c] = q.zs[(size_t)c * q.zs_stride + L];
-        bx[c] = gl::mul(q.betas[c], x);
 #pragma unroll
         for (int a = 0; a < NC; ++a) acc[a][c] = 0;
         pw[c] = 1;  // alpha_c^chunk
@@ -186,7 +200,7 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(QuotArgs q) {
         u64 s = 0, p = 1;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            s = gl::add(s, gl::mul(gl::mul(l0, gl::sub(zx[c], 1)), p));
+            s = gl::mul_add(gl::mul(l0, gl::sub(zx[c], 1)), p, s);
             p = gl::mul(p, q.alphas[a]);
         }
         res[a] = s;
@@ -194,38 +208,119 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(QuotArgs q) {
     u64 prev[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) prev[c] = zx[c];
+    constexpr int BUF = DEG ? DEG : 1;
+    u64 wb[BUF], sb[BUF];  // the chunk in flight (DEG > 0)
+    if (DEG) {
+#pragma unroll
+        for (int t = 0; t < BUF; ++t) {
+            const unsigned j = (unsigned)t < q.num_routed ? (unsigned)t : q.num_routed - 1;
+            wb[t] = q.wires[(size_t)j * q.wires_stride + L];
+            sb[t] = q.sigmas[(size_t)j * q.sigmas_stride + L];
+        }
+    }
     for (unsigned ch = 0; ch < q.num_chunks; ++ch) {
         u64 pn[NC], pd[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) pn[c] = pd[c] = 1;
-        const unsigned j_end = (ch + 1) * q.degree < q.num_routed ? (ch + 1) * q.degree : q.num_routed;
-        for (unsigned j = ch * q.degree; j < j_end; ++j) {
-            const u64 w = q.wires[(size_t)j * q.wires_stride + L], sg = q.sigmas[(size_t)j * q.sigmas_stride + L], kj = q.k_is[j];
+        const unsigned j0 = ch * degree, j_end = j0 + degree < q.num_routed ? j0 + degree : q.num_routed;
+        // the "next" value of this chunk's check (a partial product of x, or Z(g x) for the last chunk): loaded early too
+        u64 nextv[NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                pn[c] = gl::mul(pn[c], gl::add(gl::add(w, gl::mul(bx[c], kj)), q.gammas[c]));
-                pd[c] = gl::mul(pd[c], gl::add(gl::add(w, gl::mul(q.betas[c], sg)), q.gammas[c]));
+        for (int c = 0; c < NC; ++c)
+            nextv[c] = ch == num_prods ? q.zs[(size_t)c * q.zs_stride + L_next] : q.zs[((size_t)NC + (size_t)c * num_prods + ch) * q.zs_stride + L];
+        if (DEG) {
+            u64 wc[BUF], sc[BUF];
+#pragma unroll
+            for (int t = 0; t < BUF; ++t) wc[t] = wb[t], sc[t] = sb[t];
+            if (ch + 1 < q.num_chunks) {  // the next chunk's loads go out before this chunk's arithmetic
+#pragma unroll
+                for (int t = 0; t < BUF; ++t) {
+                    const unsigned jn = j0 + degree + (unsigned)t, j = jn < q.num_routed ? jn : q.num_routed - 1;
+                    wb[t] = q.wires[(size_t)j * q.wires_stride + L];
+                    sb[t] = q.sigmas[(size_t)j * q.sigmas_stride + L];
+                }
+            }
+            if constexpr (NC == 2) {
+                // eight multiplications per routed wire as hand-scheduled streams (gl_mul3.hpp: 14 instructions each, where the
+                // compiler's 64-bit code spends ~34 per multiply-reduce here): {bk0 x + wg0, bk1 x + wg1, beta0 sigma + wg0}, then
+                // {beta1 sigma + wg1, pn0 n0, pn1 n1}, then {pd0 d0, pd1 d1}
+#pragma unroll
+                for (int t = 0; t < BUF; ++t) {
+                    if (j0 + (unsigned)t < j_end) {
+                        const u64 wg0 = gl::add_canon(wc[t], q.gammas[0]), wg1 = gl::add_canon(wc[t], q.gammas[1]);
+                        // (the additions ride the streams' multiply-adds: gl::mad3)
+                        const u64 a1[3] = {q.bk[j0 + t], q.bk[(size_t)q.num_routed + j0 + t], q.betas[0]}, b1[3] = {x, x, sc[t]}, c1[3] = {wg0, wg1, wg0};
+                        u64 r1[3];
+                        gl::mad3(a1, b1, c1, r1);  // n0, n1, d0
+                        const u64 a2[3] = {q.betas[1], pn[0], pn[1]}, b2[3] = {sc[t], r1[0], r1[1]}, c2[3] = {wg1, 0, 0};
+                        u64 r2[3];
+                        gl::mad3(a2, b2, c2, r2);  // d1, pn0 n0, pn1 n1
+                        pn[0] = r2[1], pn[1] = r2[2];
+                        const u64 d0 = r1[2], d1 = r2[0];
+                        const u64 a3[2] = {pd[0], pd[1]}, b3[2] = {d0, d1};
+                        u64 r3[2];
+                        gl::mul2(a3, b3, r3);
+                        pd[0] = r3[0], pd[1] = r3[1];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < BUF; ++t) {
+                    if (j0 + (unsigned)t < j_end) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const u64 wg = gl::add(wc[t], q.gammas[c]);
+                            pn[c] = gl::mul(pn[c], gl::mul_add(q.bk[(size_t)c * q.num_routed + j0 + t], x, wg));
+                            pd[c] = gl::mul(pd[c], gl::mul_add(q.betas[c], sc[t], wg));
+                        }
+                    }
+                }
+            }
+        } else {
+            for (unsigned j = j0; j < j_end; ++j) {
+                const u64 w = q.wires[(size_t)j * q.wires_stride + L], sg = q.sigmas[(size_t)j * q.sigmas_stride + L];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const u64 wg = gl::add(w, q.gammas[c]);
+                    pn[c] = gl::mul(pn[c], gl::mul_add(q.bk[(size_t)c * q.num_routed + j], x, wg));
+                    pd[c] = gl::mul(pd[c], gl::mul_add(q.betas[c], sg, wg));
+                }
             }
         }
+        if constexpr (NC == 2 && DEG != 0) {  // the chunk's check and its place in the alpha sums, as streams too
+            const u64 a1[3] = {prev[0], prev[1], nextv[0]}, b1[3] = {pn[0], pn[1], pd[0]};
+            u64 r1[3];
+            gl::mul3(a1, b1, r1);
+            const u64 a2[3] = {nextv[1], pw[0], pw[1]}, b2[3] = {pd[1], q.alphas[0], q.alphas[1]}, z3[3] = {0, 0, 0};
+            u64 r2[3];
+            gl::mad3(a2, b2, z3, r2);
+            const u64 term0 = gl::sub(r1[0], r1[2]), term1 = gl::sub(r1[1], r2[0]);
+            const u64 a3[3] = {term0, term0, term1}, b3[3] = {pw[0], pw[1], pw[0]}, c3[3] = {acc[0][0], acc[1][0], acc[0][1]};
+            u64 r3[3];
+            gl::mad3(a3, b3, c3, r3);
+            acc[0][0] = r3[0], acc[1][0] = r3[1], acc[0][1] = r3[2];
+            acc[1][1] = gl::mul_add(term1, pw[1], acc[1][1]);
+            pw[0] = r2[1], pw[1] = r2[2];
+            prev[0] = nextv[0], prev[1] = nextv[1];
+        } else {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const u64 next = ch == num_prods ? q.zs[(size_t)c * q.zs_stride + L_next]
-                                             : q.zs[((size_t)NC + (size_t)c * num_prods + ch) * q.zs_stride + L];
-            const u64 term = gl::sub(gl::mul(prev[c], pn[c]), gl::mul(next, pd[c]));
-            prev[c] = next;
+            for (int c = 0; c < NC; ++c) {
+                const u64 term = gl::sub(gl::mul(prev[c], pn[c]), gl::mul(nextv[c], pd[c]));
+                prev[c] = nextv[c];
 #pragma unroll
-            for (int a = 0; a < NC; ++a) acc[a][c] = gl::add(acc[a][c], gl::mul(term, pw[a]));
+                for (int a = 0; a < NC; ++a) acc[a][c] = gl::mul_add(term, pw[a], acc[a][c]);
+            }
+#pragma unroll
+            for (int a = 0; a < NC; ++a) pw[a] = gl::mul(pw[a], q.alphas[a]);
         }
-#pragma unroll
-        for (int a = 0; a < NC; ++a) pw[a] = gl::mul(pw[a], q.alphas[a]);
     }
     const u64 zinv = q.zh[((size_t)1 << q.qbits) + r];
 #pragma unroll
     for (int a = 0; a < NC; ++a) {
         u64 s = res[a];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) s = gl::add(s, gl::mul(acc[a][c], q.base[a][c]));
-        if (q.gate_sums) s = gl::add(s, gl::mul(q.alpha_k[a], q.gate_sums[(size_t)a * nq + i]));
+        for (int c = 0; c < NC; ++c) s = gl::mul_add(acc[a][c], q.base[a][c], s);
+        if (q.gate_sums) s = gl::mul_add(q.alpha_k[a], q.gate_sums[(size_t)a * nq + i], s);
         q.out[(size_t)a * nq + i] = gl::canon(gl::mul(s, zinv));
     }
 }

@@ -211,6 +211,7 @@ def test_oracle_quotient_of_a_satisfied_permutation_is_a_polynomial(ora, num_rou
 @pytest.mark.parametrize("num_routed,degree,log_n,rate_bits,nc,with_gates", [
     (12, 5, 5, 3, 2, False), (7, 3, 4, 2, 1, True), (80, 8, 4, 3, 2, True),   # the last: standard_recursion_config's 80 routed wires, degree 8
     (20, 6, 3, 3, 3, False), (10, 4, 6, 3, 2, False),                         # rate above the quotient degree: step = 2 (prover.rs:640)
+    (19, 8, 5, 3, 2, True), (9, 8, 3, 3, 2, False),                           # the pipelined <2, 8> instantiation with a partial last chunk
 ])
 def test_quotient_polys_vs_oracle(eng, ora, num_routed, degree, log_n, rate_bits, nc, with_gates):
     """p2hot_quotient_polys: quotient values bit-exact against the oracle's restatement of the reference loop, the chunk polynomials
