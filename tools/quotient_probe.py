@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from plonky2_amd import Engine                                                   # noqa: E402
 from plonky2_amd.fri.oracle import PolynomialBatch                                # noqa: E402
 from plonky2_amd.plonk.prover import all_wires_permutation_partial_products, compute_quotient_polys   # noqa: E402
