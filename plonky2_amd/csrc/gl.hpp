@@ -136,7 +136,18 @@ __host__ __device__ inline u64 pow(u64 a, u64 e) {
     return r;
 }
 
-__host__ __device__ inline u64 inv(u64 a) { return pow(a, P - 2); }
+// a^(P-2).  P - 2 = (2^31 - 1) * 2^33 + (2^32 - 1): an addition chain of 64 squarings and 9 multiplications through
+// a^(2^k - 1), k = 2, 3, 6, 12, 24, 30, 31, 32 (square-and-multiply needs 63 + 62); inv(0) = 0 like pow(0, P - 2)
+__host__ __device__ inline u64 inv(u64 a) {
+    auto sqn = [](u64 v, int k) {
+        for (int t = 0; t < k; ++t) v = sqr(v);
+        return v;
+    };
+    const u64 t2 = mul(sqr(a), a), t3 = mul(sqr(t2), a), t6 = mul(sqn(t3, 3), t3), t12 = mul(sqn(t6, 6), t6), t24 = mul(sqn(t12, 12), t12);
+    const u64 t31 = mul(sqr(mul(sqn(t24, 6), t6)), a);  // a^(2^31 - 1)
+    const u64 t32 = mul(sqr(t31), a);                   // a^(2^32 - 1)
+    return mul(sqn(t31, 33), t32);
+}
 
 // primitive 2^log_n-th root of unity (field/src/types.rs:268-272)
 __host__ __device__ inline u64 root_of_unity(unsigned log_n) {

@@ -47,6 +47,7 @@ struct p2hot_ctx {
     size_t host_tail_min_leaves = (size_t)1 << 18;  // ... and the tail per group of cap subtrees of at least this many leaves (P2HOT_HOST_TAIL_MIN_LEAVES)
     bool host_leaves_first = true;  // p2hot_commit with leaves_out: transforms, then the leaf matrix's copy beside the sponge (P2HOT_HOST_LEAVES_FIRST)
     bool host_chunked_hash = true;  // p2hot_commit: the leaf sponge absorbs each block's columns as soon as they are extended
+    bool pp_streams = true;       // partial products: pairs of challenges through pp_quotients2_kernel (P2HOT_PP_STREAMS=0: one kernel per challenge)
     unsigned limb_tiles_log = 4;  // contiguous limb passes: a workgroup stages its tables once for 2^this tiles (P2HOT_LIMB_TILES_LOG)
     // second stream: the VALU-bound leaf sponge of coset block b runs beside the wait-bound NTT of block b+1
     hipStream_t side = nullptr;
@@ -422,6 +423,7 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     if (const char *e = getenv("P2HOT_NTT_ZLOOP_MIN")) ctx->zloop_min_groups = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HORNER_2L_MIN")) ctx->horner_two_level_min = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HOST_BLOCK_COLS")) ctx->host_block_cols = (size_t)strtoull(e, nullptr, 10);
+    if (const char *e = getenv("P2HOT_PP_STREAMS")) ctx->pp_streams = atoi(e) != 0;
     if (const char *e = getenv("P2HOT_HOST_CHUNKED_HASH")) ctx->host_chunked_hash = atoi(e) != 0;
     if (const char *e = getenv("P2HOT_HOST_LEAVES_FIRST")) ctx->host_leaves_first = atoi(e) != 0;
     if (const char *e = getenv("P2HOT_HOST_TAIL_MIN_LEAVES")) ctx->host_tail_min_leaves = (size_t)strtoull(e, nullptr, 10);
@@ -1658,20 +1660,23 @@ extern "C" int p2hot_partial_products_dev(p2hot_ctx *ctx, const uint64_t *d_wire
     const unsigned num_chunks = (num_routed + degree - 1) / degree, num_prods = num_chunks - 1;
     const unsigned chunk_log = log_n < 6 ? log_n : 6;  // rows per scan chunk
     const size_t n_chunks = n >> chunk_log, per = (n_chunks + 1023) / 1024;
-    // scratch: k_is | chunk denominators [num_chunks][n] | row totals [n] | chunk products | carries | flag
-    const size_t words = num_routed + (size_t)num_chunks * n + n + 2 * n_chunks + 1;
+    // scratch: k_is | 2 x (chunk denominators [num_chunks][n] | row totals [n]) | chunk products | carries | flag
+    // (two sets: a pair of challenges goes through pp_quotients2_kernel in one pass)
+    const size_t set_words = (size_t)num_chunks * n + n;
+    const size_t words = num_routed + 2 * set_words + 2 * n_chunks + 1;
     u64 *base = nullptr;
     P2_TRY(scratch_get(ctx, 0, words * 8, (void **)&base));
-    u64 *d_k = base, *dchunk = d_k + num_routed, *total = dchunk + (size_t)num_chunks * n, *prod = total + n,
-        *carry = prod + n_chunks;
+    u64 *d_k = base, *sets = d_k + num_routed, *prod = sets + 2 * set_words, *carry = prod + n_chunks;
     unsigned *flag = (unsigned *)(carry + n_chunks);
     std::vector<u64> kc(num_routed);
     for (unsigned j = 0; j < num_routed; ++j) kc[j] = gl::canon(k_is[j]);
     P2_HIP(ctx, hipMemcpyAsync(d_k, kc.data(), (size_t)num_routed * 8, hipMemcpyHostToDevice, ctx->stream));
     P2_HIP(ctx, hipMemsetAsync(flag, 0, 8, ctx->stream));
     ProfScope ps(ctx, "partial_products");
+    std::vector<plonk::PPArgs> args(num_challenges);
     for (unsigned ch = 0; ch < num_challenges; ++ch) {
-        plonk::PPArgs a{};
+        plonk::PPArgs &a = args[ch];
+        u64 *dchunk = sets + (size_t)(ch & 1) * set_words, *total = dchunk + (size_t)num_chunks * n;
         a.wires = d_wires;
         a.sigmas = d_sigmas;
         a.wires_stride = wires_stride;
@@ -1689,8 +1694,17 @@ extern "C" int p2hot_partial_products_dev(p2hot_ctx *ctx, const uint64_t *d_wire
         a.dchunk = dchunk;
         a.total = total;
         a.zero_flag = flag;
+    }
+    for (unsigned ch = 0; ch < num_challenges; ++ch) {
+        const plonk::PPArgs &a = args[ch];
+        const u64 *total = a.total;
         u64 *z = d_out + (size_t)ch * out_stride;
-        P2HOT_LAUNCH(plonk::pp_quotients_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, a);
+        if (ctx->pp_streams && (ch & 1) == 0 && ch + 1 < num_challenges) {  // a pair of challenges: one pass over the wires and sigmas
+            plonk::PPArgs2 two{{args[ch], args[ch + 1]}};
+            P2HOT_LAUNCH(plonk::pp_quotients2_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, two);
+        } else if (!(ctx->pp_streams && (ch & 1))) {
+            P2HOT_LAUNCH(plonk::pp_quotients_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, a);
+        }
         P2HOT_LAUNCH(plonk::pp_chunk_totals_kernel, dim3(cdiv(n_chunks, 256)), dim3(256), 0, ctx->stream, (const u64 *)total,
                      chunk_log, n_chunks, prod);
         P2HOT_LAUNCH(plonk::pp_carries_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u64 *)prod, n_chunks, per, carry);

@@ -69,6 +69,91 @@ __global__ void __launch_bounds__(256) pp_quotients_kernel(PPArgs a) {
     }
 }
 
+// Both challenges of a plonky2 config in ONE pass over the wires and sigmas, all multiplications as gl_mul3.hpp streams (the
+// additions ride the multiply-adds), the two Fermat inversions as two interleaved streams: the same results as two
+// pp_quotients_kernel launches at less than half their instructions (the compiler's 64-bit multiply-reduce costs ~34 here).
+struct PPArgs2 {
+    PPArgs c[2];  // wires / sigmas / k_is / sizes / roots are taken from c[0]
+};
+__global__ void __launch_bounds__(256) pp_quotients2_kernel(PPArgs2 aa) {
+    const PPArgs &a = aa.c[0], &b = aa.c[1];
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)1 << a.log_n;
+    if (i >= n) return;
+    const u64 x = a.log_n ? ntt::root_pow(a.roots, (u32)(i << (32 - a.log_n))) : 1;
+    const u64 beta[2] = {a.beta, b.beta}, gamma[2] = {a.gamma, b.gamma};  // canonical (the host canonicalises)
+    u64 bx[2];
+    {
+        const u64 xx[2] = {x, x};
+        gl::mul2(beta, xx, bx);
+    }
+    u64 pn[2] = {1, 1}, pd[2] = {1, 1};
+    for (unsigned c = 0; c < a.num_chunks; ++c) {
+        u64 d[2] = {1, 1};
+        const unsigned j_end = (c + 1) * a.degree < a.num_routed ? (c + 1) * a.degree : a.num_routed;
+        for (unsigned j = c * a.degree; j < j_end; ++j) {
+            const u64 w = a.wires[(size_t)j * a.wires_stride + i], sg = a.sigmas[(size_t)j * a.sigmas_stride + i], kj = a.k_is[j];
+            const u64 wg0 = gl::add_canon(w, gamma[0]), wg1 = gl::add_canon(w, gamma[1]);
+            const u64 a1[3] = {bx[0], bx[1], beta[0]}, b1[3] = {kj, kj, sg}, c1[3] = {wg0, wg1, wg0};
+            u64 r1[3];
+            gl::mad3(a1, b1, c1, r1);  // num0, num1, den0
+            const u64 a2[3] = {beta[1], pn[0], pn[1]}, b2[3] = {sg, r1[0], r1[1]}, c2[3] = {wg1, 0, 0};
+            u64 r2[3];
+            gl::mad3(a2, b2, c2, r2);  // den1, pn0 num0, pn1 num1
+            pn[0] = r2[1], pn[1] = r2[2];
+            const u64 b3[2] = {r1[2], r2[0]};
+            u64 r3[2];
+            gl::mul2(d, b3, r3);
+            d[0] = r3[0], d[1] = r3[1];
+        }
+        gl::mul2(pd, d, pd);
+        a.dchunk[(size_t)c * n + i] = d[0];
+        b.dchunk[(size_t)c * n + i] = d[1];
+        if (c + 1 < a.num_chunks) {
+            a.pp[(size_t)c * a.pp_stride + i] = pn[0];
+            b.pp[(size_t)c * b.pp_stride + i] = pn[1];
+        }
+    }
+    if (gl::canon(pd[0]) == 0 || gl::canon(pd[1]) == 0) atomicOr(a.zero_flag, 1u);
+    // pd^(P-2) for both challenges at once.  P - 2 = (2^31 - 1) * 2^33 + (2^32 - 1): an addition chain of 64 squarings and 9
+    // multiplications (x^(2^k - 1) for k = 2, 3, 6, 12, 24, 30, 31, 32) instead of square-and-multiply's 63 + 62
+    u64 inv[2];
+    {
+        auto sqn = [](u64 v[2], int k) {
+            for (int t = 0; t < k; ++t) gl::mul2(v, v, v);
+        };
+        u64 t2[2] = {pd[0], pd[1]}, t3[2], t6[2], t12[2], t24[2], t[2];
+        sqn(t2, 1), gl::mul2(t2, pd, t2);                                   // 2^2 - 1
+        t3[0] = t2[0], t3[1] = t2[1], sqn(t3, 1), gl::mul2(t3, pd, t3);     // 2^3 - 1
+        t6[0] = t3[0], t6[1] = t3[1], sqn(t6, 3), gl::mul2(t6, t3, t6);     // 2^6 - 1
+        t12[0] = t6[0], t12[1] = t6[1], sqn(t12, 6), gl::mul2(t12, t6, t12);
+        t24[0] = t12[0], t24[1] = t12[1], sqn(t24, 12), gl::mul2(t24, t12, t24);
+        t[0] = t24[0], t[1] = t24[1], sqn(t, 6), gl::mul2(t, t6, t);        // 2^30 - 1
+        sqn(t, 1), gl::mul2(t, pd, t);                                      // a = x^(2^31 - 1)
+        u64 b[2] = {t[0], t[1]};
+        sqn(b, 1), gl::mul2(b, pd, b);                                      // b = x^(2^32 - 1)
+        sqn(t, 33);
+        gl::mul2(t, b, inv);
+    }
+    {
+        u64 t[2];
+        gl::mul2(pn, inv, t);
+        a.total[i] = t[0];
+        b.total[i] = t[1];
+    }
+    for (unsigned c = a.num_chunks; c-- > 0;) {
+        if (c + 1 < a.num_chunks) {
+            u64 *q0 = a.pp + (size_t)c * a.pp_stride + i, *q1 = b.pp + (size_t)c * b.pp_stride + i;
+            const u64 qq[2] = {*q0, *q1};
+            u64 t[2];
+            gl::mul2(qq, inv, t);
+            *q0 = t[0], *q1 = t[1];
+        }
+        const u64 dd[2] = {a.dchunk[(size_t)c * n + i], b.dchunk[(size_t)c * n + i]};
+        gl::mul2(inv, dd, inv);
+    }
+}
+
 // lane = chunk of 2^chunk_log rows: its product
 __global__ void pp_chunk_totals_kernel(const u64 *total, unsigned chunk_log, size_t n_chunks, u64 *prod) {
     const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
