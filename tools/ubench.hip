@@ -130,6 +130,32 @@
     "v_add_co_u32 %5, vcc, %5, %16\n\tv_mad_u64_u32 %11, vcc, %16, %17, %11\n\tv_add_u32 %6, %6, %16\n\tv_addc_co_u32 %7, vcc, %7, %16, vcc\n\t" \
     "v_mad_u64_u32 %12, vcc, %16, %17, %12\n\tv_sub_u32 %0, %0, %17\n\tv_alignbit_b32 %1, %1, %16, 24\n\tv_lshl_add_u64 %13, %13, 3, %13"
 
+// ---- round 4: would the full-round MDS on the matrix pipe pay?  (north_star says no MFMA -- this prices the
+// question instead of arguing it.)  One full-round MDS layer today is 338 VALU instructions (288 v_mad_u64_u32 + 12 x the
+// 4-instruction row fold + 2).  On byte limbs with v_mfma_i32_4x4x4_16b_i8 it is 72 MFMAs + 48 v_perm_b32 + 24 v_xor_b32 +
+// ~190 recombination instructions (carry-aware: multiply-adds and carry adds).  Both as dependency-free streams, HALF a layer per
+// loop trip: MIX_MDS_VALU = 144 multiply-adds + 6 folds (169 slots); MIX_MDS_MFMA = 36 MFMAs + 24 perms + 12 xors + 48 multiply-adds
+// + 24 v_add_co + 23 v_addc (167 slots).  %19..%22 are four 4-register accumulators of the MFMAs.
+#define MFMA4(i, j) "v_mfma_i32_4x4x4_16b_i8 %" #i ", %16, %17, %" #i "\n\tv_mfma_i32_4x4x4_16b_i8 %" #j ", %17, %16, %" #j "\n\t"
+#define MAD6 "v_mad_u64_u32 %8, s[22:23], %16, %17, %8\n\tv_mad_u64_u32 %9, s[22:23], %17, %16, %9\n\tv_mad_u64_u32 %10, s[22:23], %16, %16, %10\n\t" \
+             "v_mad_u64_u32 %11, s[22:23], %16, %17, %11\n\tv_mad_u64_u32 %12, s[22:23], %17, %16, %12\n\tv_mad_u64_u32 %13, s[22:23], %16, %16, %13\n\t"
+#define FOLD1 "v_mad_u64_u32 %14, s[22:23], %16, -1, %14\n\tv_add_co_u32 %0, vcc, %0, %16\n\tv_mov_b32 %2, %17\n\tv_cndmask_b32 %1, %1, %17, vcc\n\tv_mad_u64_u32 %15, s[22:23], %17, 1, %15\n\t"
+#define MAD24 MAD6 MAD6 MAD6 MAD6
+#define MIX_MDS_VALU MAD24 FOLD1 MAD24 FOLD1 MAD24 FOLD1 MAD24 FOLD1 MAD24 FOLD1 MAD24 "v_mad_u64_u32 %14, s[22:23], %16, -1, %14\n\tv_add_co_u32 %0, vcc, %0, %16\n\tv_cndmask_b32 %1, %1, %17, vcc\n\tv_mad_u64_u32 %15, s[22:23], %17, 1, %15"
+#define PERM4 "v_perm_b32 %0, %0, %16, %17\n\tv_perm_b32 %1, %1, %17, %16\n\tv_perm_b32 %2, %2, %16, %17\n\tv_perm_b32 %3, %3, %17, %16\n\t"
+#define XOR2 "v_xor_b32 %4, %4, %16\n\tv_xor_b32 %5, %5, %17\n\t"
+#define CARRY4 "v_add_co_u32 %6, vcc, %6, %16\n\tv_mad_u64_u32 %8, s[22:23], %16, %17, %8\n\tv_addc_co_u32 %7, vcc, %7, %16, vcc\n\tv_mad_u64_u32 %9, s[22:23], %17, %16, %9\n\t"
+// one sixth of the half layer: 6 MFMAs, 4 perms, 2 xors, 8 multiply-adds, 4 add_co, 4 addc (28 slots; x6 = 168, minus one v_addc)
+#define MFMA_SIXTH MFMA4(19, 20) PERM4 MFMA4(21, 22) XOR2 CARRY4 MFMA4(19, 21) CARRY4 CARRY4 CARRY4
+#define MIX_MDS_MFMA MFMA_SIXTH MFMA_SIXTH MFMA_SIXTH MFMA_SIXTH MFMA_SIXTH MFMA_SIXTH "v_mov_b32 %2, %17"
+#define MFMA8 MFMA4(19, 20) MFMA4(21, 22) MFMA4(19, 20) MFMA4(21, 22) "v_mov_b32 %2, %17"
+typedef int v4i __attribute__((ext_vector_type(4)));
+#define OPS_M                                                                                       \
+    : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), \
+      "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])  \
+    : "v"(c), "v"(d), "v"(e), "v"(m0), "v"(m1), "v"(m2), "v"(m3)                                     \
+    : "vcc", "s20", "s21", "s22", "s23"
+
 #define R8B(INS) INS(8) "\n\t" INS(9) "\n\t" INS(10) "\n\t" INS(11) "\n\t" INS(12) "\n\t" INS(13) "\n\t" INS(14) "\n\t" INS(15)
 
 template <int OP>
@@ -144,6 +170,7 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t 
         a[i] = (uint64_t)t * 0x9E3779B97F4A7C15ull + i + seed;
         b[i] = t * 2246822519u + i * 7 + seed;
     }
+    v4i m0 = {(int)c, (int)d, 1, 2}, m1 = m0 + 1, m2 = m0 + 2, m3 = m0 + 3;  // MFMA accumulators (read-write through "v": the asm names them %19..%22)
     uint64_t t0 = __builtin_readcyclecounter();  // s_memtime: shader-clock ticks
 #pragma unroll 1
     for (int it = 0; it < ITERS; ++it) {
@@ -197,11 +224,15 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t 
         if (OP == 48) asm volatile(MIX_HASH OPS);
         if (OP == 49) asm volatile(MIX_NTT OPS);
         if (OP == 50) asm volatile(MIX_HASH "\n\t" MIX_HASH "\n\t" MIX_HASH "\n\t" MIX_HASH OPS);  // 128 slots per loop trip: the loop's own SALU is < 3 %
+        if (OP == 51) asm volatile(MFMA8 OPS_M);
+        if (OP == 52) asm volatile(MIX_MDS_VALU OPS_M);
+        if (OP == 53) asm volatile(MIX_MDS_MFMA OPS_M);
     }
     uint64_t t1 = __builtin_readcyclecounter();
     uint64_t s = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += a[i] + b[i];
+    s += (uint64_t)(m0.x + m1.y + m2.z + m3.w);
     out[t] = s;
     if ((threadIdx.x & 63) == 0) ticks[t >> 6] = t1 - t0;
 }
@@ -309,6 +340,9 @@ int main(int argc, char **argv) {
     run<47>("chain v_mad_u64");
     run<48>("mix hash_leaves", 32);
     run<50>("mix hash_leaves x4", 128);
+    run<51>("v_mfma_i32_4x4x4_16b_i8", 9);   // 8 MFMAs + 1 v_mov per trip
+    run<52>("mix mds valu (half layer)", 173);
+    run<53>("mix mds mfma (half layer)", 169);
     run<49>("mix limb_ntt", 16);
     return 0;
 }
