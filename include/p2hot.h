@@ -329,6 +329,8 @@ int p2hot_batch_subgroup_values(p2hot_batch *batch, size_t first, size_t count, 
  * (the host-pointer entry points keep their device blocks in a per-context cache: a fresh allocation of the 9 GB LDE
  * matrix costs up to a second; p2hot_ctx_trim gives the cached free blocks back to the driver) */
 void p2hot_batch_free(p2hot_batch *batch);
+/* frees what the context only keeps for speed: the cached free device and pinned blocks (its helpers' too) and the per-size
+ * L_0 denominator tables of p2hot_quotient_polys (8 bytes per point of the quotient coset; rebuilt on demand) */
 int p2hot_ctx_trim(p2hot_ctx *ctx);
 /* PINNED host memory from a grow-only cache of the context, for output buffers that live as long as a commitment -- above all the
  * flat leaf matrix (`leaves_out`, 9 GB at the C3 shape) the Rust shim keeps behind MerkleTree::get (hash/merkle_tree.rs:227).

@@ -646,6 +646,16 @@ extern "C" int p2hot_ctx_trim(p2hot_ctx *ctx) {
         for (auto &blk : ctx->host_pool_free) (void)hipHostFree(blk.first);
         ctx->host_pool_free.clear();
     }
+    // the per-size L_0 denominator tables of p2hot_quotient_polys (8 bytes per point of the quotient coset: 64 MB at 2^20 gates);
+    // rebuilt in 0.35 ms by the next call that needs one
+    for (auto it = ctx->twid_cache.begin(); it != ctx->twid_cache.end();) {
+        if (std::get<0>(it->first) == 100) {
+            (void)hipFree(it->second);
+            it = ctx->twid_cache.erase(it);
+        } else {
+            ++it;
+        }
+    }
     for (p2hot_ctx *h : ctx->helpers) {  // the sibling contexts of p2hot_prove_openings_many keep their own block caches
         P2_HIP(ctx, stream_sync(h));
         std::lock_guard<std::mutex> pool_lock_(h->pool_mu);
