@@ -27,7 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 P = 0xFFFFFFFF00000001
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable float4 copy)
+from plonky2_amd.util.chip import HBM_PEAK_GBS, NUM_SIMDS, VALU_NOMINAL_GWAVE_INST_PER_S, box_report  # noqa: E402  (constants cite the guide)
 
 
 from plonky2_amd.util.synthetic import splitmix_columns_numpy, splitmix_columns_torch  # noqa: E402,F401
@@ -128,8 +128,10 @@ def cpu_baseline(W, log_n, rate_bits, cap_height, budget_s=45.0, golden_cap=None
 
 
 def golden(name):
+    """the oracle's record of a commit shape (tools/gen_golden_caps.py).  P2HOT_BENCH_GOLDEN_CAPS: another file (the test of the
+    check itself, tests/test_bench_launch.py)"""
     try:
-        return json.load(open(os.path.join(ROOT, "tests", "golden", "commit_caps.json")))[name]
+        return json.load(open(os.environ.get("P2HOT_BENCH_GOLDEN_CAPS") or os.path.join(ROOT, "tests", "golden", "commit_caps.json")))[name]
     except Exception:
         return None
 
@@ -411,10 +413,8 @@ def recursion_lines(eng, torch, out):
 def other_configs(eng, torch, reps=3, only=None):
     """Driver-timed lines for the other BASELINE shapes (extra keys of the JSON line; the headline is unchanged):
     each is `reps` timed repetitions after one warm-up, inputs resident in HBM, synchronised wall time."""
-    from plonky2_amd.fri.oracle import FriBatchInfo, PolynomialBatch, eval_openings, prove_openings
     from plonky2_amd.fri.prover import fri_committed_trees_device
     from plonky2_amd.iop.challenger import Challenger
-    from plonky2_amd.plonk.prover import all_wires_permutation_partial_products, compute_quotient_polys
     from plonky2_amd.util.synthetic import fibonacci_trace
     dev = eng.mem.device
     out = {}
@@ -466,112 +466,55 @@ def other_configs(eng, torch, reps=3, only=None):
             out[name] = {"workload": "fri_committed_trees, N=2^%d, arity 16 x4, cap 4 (final FFT + 4 round trees + folds, device resident)"
                                      % (log_n + rb), "ms": ms}
     # the per-proof path of a standard_recursion_config proof: every stage of SURVEY section 8 back to back, at the
-    # headline size (2^20 gates) and at recursion size (2^12 gates: the two recursive proofs of bench_recursion's chain)
-    def path_line(name, log_n, arity):
-        n, rb, cap, nq = 1 << log_n, 3, 4, 28
-        wires = splitmix_columns_torch(torch, dev, 0, 135, n)
-        cs = splitmix_columns_torch(torch, dev, 1000, 84, n)   # constants (4) + sigmas (80): prover_data, committed by build()
-        sig = cs[4:84]
-        k_is = [pow(14293326489335486720, j, P) for j in range(80)]
-        # CircuitBuilder::build's commitment (circuit_builder.rs:1182-1191): part of the circuit, not of a proof -> outside the timed path
-        b_cs = PolynomialBatch.from_values(cs, rb, False, cap, engine=eng)
-        # get_fri_instance (plonk/circuit_data.rs:530-548, :578-664): oracles [constants_sigmas, wires, Zs + partial products,
-        # quotient]; every polynomial (84 + 135 + 20 + 16 = 255) at zeta; the num_challenges = 2 Z polynomials at g * zeta
-        widths = (84, 135, 20, 16)
-        allp = [(oi, pi) for oi, W in enumerate(widths) for pi in range(W)]
-        nxt = [(2, pi) for pi in range(2)]
+    # headline size (2^20 gates) and at recursion size (2^12 gates: the two recursive proofs of bench_recursion's chain), and C4's
+    # starky path (StarkConfig::standard_fast_config: rate 1/2, cap 4, 84 queries, PoW 16 bits).  The stages live in
+    # plonky2_amd/util/proof_path.py (shared with tests/test_gpu_fullsize.py); the instances in plonky2_amd/util/synthetic.py.
+    # WHAT IS TIMED IS CHECKED: after the timed repetitions the same path runs once more keeping every stage's output, and each
+    # is compared with the CPU oracle's bytes for the same instance (tests/golden/path_goldens.json, tools/gen_golden_path.py):
+    # the four caps, SHA-256 of the Zs / partial-products matrix, of the quotient values at all 2^(k+3) points and of the 16 chunk
+    # polynomials, every opening value, alpha (through final_poly), the commit-phase caps, final_poly, the PoW witness, the query
+    # indices and SHA-256 of the whole FriProof in the reference's wire format.  A mismatch ends the bench with a non-zero exit.
+    from plonky2_amd.util import proof_path as pp
+    from plonky2_amd.util.synthetic import path_instance
 
-        def path():
-            stage = {}
-            t = [time.perf_counter()]
-
-            def lap(label):
-                torch.cuda.synchronize()
-                now = time.perf_counter()
-                stage[label] = (now - t[0]) * 1e3
-                t[0] = now
-            b_w = PolynomialBatch.from_values(wires, rb, False, cap, engine=eng)
-            lap("wires commit (W=135, from_values)")
-            zs = all_wires_permutation_partial_products(wires[:80], sig, k_is, 8, [3, 5], [11, 13], eng)
-            lap("partial products + Zs (80 routed wires, 2 challenges)")
-            b_z = PolynomialBatch.from_values(zs, rb, False, cap, engine=eng)
-            lap("Zs + partial products commit (W=20, from_values)")
-            # compute_quotient_polys without its gate evaluation (prover.rs:609-815; vanishing_poly.rs:167-330): the permutation
-            # argument's terms at the 2^(k+3) points of the quotient coset from the three device-resident LDE matrices, / Z_H,
-            # coset_ifft, 16 chunks -- the gate constraint terms are circuit specific and out of scope (gate_sums = None)
-            chunks = compute_quotient_polys(b_w, b_cs, 4, b_z, k_is, 8, [3, 5], [11, 13], [17, 19], engine=eng)
-            lap("quotient polynomials: permutation terms on the quotient coset + coset_ifft + chunks (gate terms excluded)")
-            b_q = PolynomialBatch.from_coeffs(chunks, rb, False, cap, engine=eng)
-            lap("quotient chunks commit (W=16, from_coeffs)")
-            oracles = [b_cs, b_w, b_z, b_q]
-            ch = Challenger(eng)
-            ch.observe_elements(np.arange(8, dtype=np.uint64))
-            zeta = ch.get_extension_challenge()
-            gz = [(zeta[0] * 7) % P, zeta[1]]
-            # OpeningSet::new (plonk/proof.rs:314-345): the four commitments at zeta, the Zs commitment again at g * zeta
-            eval_openings(oracles, [zeta], eng)
-            eval_openings([b_z], [gz], eng)
-            lap("OpeningSet (255 polynomials at zeta; the 20 of the Zs oracle at g*zeta, of which the proof keeps the 2 Z)")
-            prove_openings([FriBatchInfo(zeta, allp), FriBatchInfo(gz, nxt)], oracles, ch, rb, cap, arity, 16, nq, engine=eng)
-            lap("prove_openings (4 oracles: 255 polynomials at zeta + 2 at g*zeta; final_poly, FRI commit, PoW 16 bits, 28 queries x 4 initial trees)")
-            return stage
-
-        path()
-        path()  # two warm-ups: the block cache alternates between two sets while the previous proof's commitments are still alive
-        stages = [path() for _ in range(reps)]
+    def path_line(name, what, warmups):
+        inst = path_instance(name)
+        inp = pp.PathInputs(eng, inst)
+        for _ in range(warmups):  # the block cache alternates between two sets while the previous proof's commitments are still alive
+            pp.run_path(eng, inp, sync=torch.cuda.synchronize)
+        stages = [pp.run_path(eng, inp, sync=torch.cuda.synchronize)["stage_ms"] for _ in range(reps)]
         mean = {k: sum(s_[k] for s_ in stages) / reps for k in stages[0]}
-        out[name] = {"workload": "the SURVEY section-8 stages of one 2^%d-gate standard_recursion_config proof back to back, on the reference's own "
-                                 "FRI instance (get_fri_instance, plonk/circuit_data.rs:530-548: 4 oracles, 255 polynomials at zeta, the 2 Z at g*zeta); "
-                                 "the constants_sigmas commitment (W=84) belongs to CircuitBuilder::build and is made outside the timed path; "
-                                 "gate evaluation / witness generation excluded (out of scope)" % log_n,
-                     "ms": sum(mean.values()), "stage_ms": {k: round(v, 3) for k, v in mean.items()},
-                     "ms_per_repetition": [round(sum(s_.values()), 3) for s_ in stages]}
+        rec = {"workload": what, "ms": sum(mean.values()), "stage_ms": {k: round(v, 3) for k, v in mean.items()},
+               "ms_per_repetition": [round(sum(s_.values()), 3) for s_ in stages]}
+        g = pp.golden(name)
+        if g is not None:
+            res = pp.run_path(eng, inp, sync=torch.cuda.synchronize, keep=True)
+            bad = pp.compare_with_golden(res, g)
+            if bad:
+                raise SystemExit("bench: %s differs from the oracle's record in: %s" % (name, "; ".join(bad)))
+            rec["checked"] = True
+            rec["checked_against"] = ("tests/golden/path_goldens.json (oracle/p2oracle.c on the same instance): caps, Zs + partial products, quotient "
+                                      "values, chunk polynomials, openings, FRI caps, final_poly, PoW witness, query indices, FriProof bytes"
+                                      if inst["kind"] == "plonk" else
+                                      "tests/golden/path_goldens.json (oracle/p2oracle.c on the same instance): caps, openings, FRI caps, final_poly, "
+                                      "PoW witness, query indices, FriProof bytes")
+            del res
+        else:
+            rec["checked"] = False
+        out[name] = rec
+        del inp
+        torch.cuda.empty_cache()
 
-    path_line("per_proof_path_k20", 20, [4, 4, 4, 4])
-    path_line("per_proof_path_k12", 12, [4, 4])
+    plonk_what = ("the SURVEY section-8 stages of one 2^%d-gate standard_recursion_config proof back to back, on the reference's own "
+                  "FRI instance (get_fri_instance, plonk/circuit_data.rs:530-548: 4 oracles, 255 polynomials at zeta, the 2 Z at g*zeta); "
+                  "the constants_sigmas commitment (W=84) belongs to CircuitBuilder::build and is made outside the timed path; "
+                  "gate evaluation / witness generation excluded (out of scope)")
+    path_line("per_proof_path_k20", plonk_what % 20, 2)
+    path_line("per_proof_path_k12", plonk_what % 12, 2)
     if _only_paths:
         return out
-
-    # C4: the starky per-proof path (StarkConfig::standard_fast_config: rate 1/2, cap 4, 84 queries, PoW 16 bits):
-    # trace commit (from_values, W=2) + quotient commit (from_coeffs, W = quotient_degree_factor * 2 = 2) + the
-    # StarkOpeningSet evaluations (trace + quotient at zeta, trace at g * zeta, starky/src/stark.rs:101-156) + prove_openings
-    def starky_line(name, log_n):
-        n, rb, cap, nq, arity = 1 << log_n, 1, 4, 84, [4, 4, 4, 4]
-        trace = eng.dev(fibonacci_trace(log_n))
-        quo = splitmix_columns_torch(torch, dev, 3000, 2, n)
-
-        def path():
-            stage = {}
-            t = [time.perf_counter()]
-
-            def lap(label):
-                torch.cuda.synchronize()
-                now = time.perf_counter()
-                stage[label] = (now - t[0]) * 1e3
-                t[0] = now
-            b_t = PolynomialBatch.from_values(trace, rb, False, cap, engine=eng)
-            lap("trace commit (W=2, from_values)")
-            b_q = PolynomialBatch.from_coeffs(quo, rb, False, cap, engine=eng)
-            lap("quotient commit (W=2, from_coeffs)")
-            ch = Challenger(eng)
-            ch.observe_elements(np.arange(8, dtype=np.uint64))
-            zeta = ch.get_extension_challenge()
-            gz = [(zeta[0] * 7) % P, zeta[1]]
-            eval_openings([b_t, b_q], [zeta, gz], eng)
-            lap("StarkOpeningSet (4 polynomials at 2 points)")
-            prove_openings([FriBatchInfo(zeta, [(0, 0), (0, 1), (1, 0), (1, 1)]), FriBatchInfo(gz, [(0, 0), (0, 1)])], [b_t, b_q], ch,
-                           rb, cap, arity, 16, nq, engine=eng)
-            lap("prove_openings (final_poly, FRI commit, PoW 16 bits, 84 queries)")
-            return stage
-
-        path()
-        stages = [path() for _ in range(reps)]
-        mean = {k: sum(s_[k] for s_ in stages) / reps for k in stages[0]}
-        out[name] = {"workload": "C4: every section-8 stage of one starky proof of a 2-column, 2^%d-row trace (Fibonacci), rate 1/2, back to "
-                                 "back (constraint evaluation excluded: out of scope)" % log_n,
-                     "ms": sum(mean.values()), "stage_ms": {k: round(v, 3) for k, v in mean.items()}}
-
-    starky_line("per_proof_path_starky_k22", 22)
+    path_line("per_proof_path_starky_k22", "C4: every section-8 stage of one starky proof of a 2-column, 2^22-row trace (Fibonacci), rate 1/2, back to "
+              "back (constraint evaluation excluded: out of scope)", 1)
 
     # C5 (2^23 rows, W = 135: the 8-GPU configuration, 72.5 GB of LDE values) as ONE MI355X's commit: HBM holds it whole
     torch.cuda.empty_cache()
@@ -583,63 +526,71 @@ def other_configs(eng, torch, reps=3, only=None):
 
 
 def valu_line(e, launches_per_step, h):
-    """Issue-rate view of the dominant kernel, everything in shader CYCLES (no assumed clock):
-      achieved   cycles per wave64 VALU instruction per SIMD of the kernel = GRBM_GUI_ACTIVE / 8 * 1024 / SQ_INSTS_VALU
-                 (committed PMC pass, profiles/pmc_traffic.json)
-      ceiling    the same quantity for the kernel's OWN instruction mix issued as dependency-free streams
-                 (tools/ubench.hip `mix hash_leaves`: 59 % multiply-adds, 25 % carry adds / subtracts, 6 % selects, 10 % moves and
-                 plain adds -- the static histogram of the kernel's loops, tools/isa_stats.py), measured the same way; the better of
-                 4 and 8 resident waves per SIMD (the kernel runs 4)
-      frac       ceiling / achieved: 1 = the SIMDs issue this mix as fast as they can issue it at all; the remainder is waits.
-    `classes` prices the single instruction classes the same way (why the NTT passes' cheap 32-bit adds pay)."""
-    if not e or not e.get("sq_insts_valu_per_launch") or not e.get("clock_ghz") or not e.get("ms_per_launch_under_pmc"):
+    """Issue-rate view of the dominant kernel, MEASURED IN THIS RUN: achieved = (wave64 VALU instructions one launch retires) /
+    (the kernel's average duration in this run's timed region, HIP events on its launch stream).  The instruction count is a
+    property of the kernel binary and the shape (SQ_INSTS_VALU of the committed PMC pass, profiles/pmc_traffic.json: it does not
+    vary from run to run); the time is this run's.  Priced against two ceilings, neither capped:
+      valu_nominal    1024 SIMDs x 2.4 GHz / 4 cycles per single-issue wave64 instruction = 614.4 Gwave-inst/s
+                      (plonky2_amd/util/chip.py; spec clock, so a chip that clocks to its power budget shows below 1)
+      valu_empirical  the kernel's OWN instruction mix issued as dependency-free streams (tools/ubench.hip `mix hash_leaves`:
+                      59 % multiply-adds, 25 % carry adds / subtracts, 6 % selects, 10 % moves and plain adds), as measured on an
+                      MI355X under rocprofv3 --pmc (profiles/ubench.json): 1024 x probe clock / probe cycles per instruction;
+                      `frac_raw` only -- a self-measured ceiling that a kernel can tie or beat by scatter, so it is never clamped
+    The committed PMC pass's own cycles per instruction (true shader cycles, clock-free) stay under `pmc_pass`."""
+    if not e or not e.get("sq_insts_valu_per_launch") or not h.get("ms_per_launch") or h["ms_per_launch"] != h["ms_per_launch"]:
         return None
-    ub = ubench_json()
     n = e["sq_insts_valu_per_launch"] / launches_per_step
-    clock = e["clock_ghz"]
-    cyc = e["ms_per_launch_under_pmc"] * 1e-3 * clock * 1e9 * 1024 / e["sq_insts_valu_per_launch"]
-    out = {"kernel": "hash_leaves", "bound": "valu-issue", "wave_insts_per_launch": n, "clock_ghz_under_pmc": clock,
-           "cycles_per_inst": cyc, "live_Gwave_inst_per_s": n / (h["ms_per_launch"] * 1e-3) / 1e9,
-           "valu_busy_frac_pmc": e.get("valu_busy_frac"),
-           "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE, kernel duration under rocprofv3 --pmc)"}
+    live = n / (h["ms_per_launch"] * 1e-3) / 1e9
+    out = {"kernel": "hash_leaves", "bound": "valu-issue", "wave_insts_per_launch": n, "live_ms_per_launch": h["ms_per_launch"],
+           "achieved_Gwave_inst_per_s": live,
+           "valu_nominal": {"peak": VALU_NOMINAL_GWAVE_INST_PER_S, "unit": "Gwave-inst/s", "frac": live / VALU_NOMINAL_GWAVE_INST_PER_S,
+                            "peak_source": "plonky2_amd/util/chip.py: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"},
+           "source": "instruction count: profiles/pmc_traffic.json (SQ_INSTS_VALU per launch, committed PMC pass); time: this run's HIP events"}
+    if e.get("clock_ghz") and e.get("ms_per_launch_under_pmc"):
+        clock = e["clock_ghz"]
+        cyc = e["ms_per_launch_under_pmc"] * 1e-3 * clock * 1e9 * NUM_SIMDS / e["sq_insts_valu_per_launch"]
+        out["pmc_pass"] = {"clock_ghz": clock, "ms_per_launch": e["ms_per_launch_under_pmc"], "cycles_per_inst": cyc,
+                           "valu_busy_frac": e.get("valu_busy_frac"),
+                           # the clock this run's kernel time implies if it retired its instructions at the PMC pass's cycles each
+                           "implied_live_clock_ghz": live * cyc / NUM_SIMDS}
+    ub = ubench_json()
     if ub:
         occ = ub.get("occupancy", {})
         probes = {w + ("" if nm == "mix hash_leaves" else " x4"): o["probes"].get(nm, {}) for w, o in occ.items() for nm in ("mix hash_leaves", "mix hash_leaves x4")}
-        best = min((p_["cyc_per_inst"], w) for w, p_ in probes.items() if p_.get("cyc_per_inst")) if any(p_.get("cyc_per_inst") for p_ in probes.values()) else None
-        if best:
-            raw = best[0] / cyc
-            out.update({"ceiling_cycles_per_inst": best[0], "ceiling_probe": "tools/ubench.hip `mix hash_leaves` (%s: waves per SIMD, x4 = 128 instructions per loop trip), %.2f GHz"
-                        % (best[1][1:], probes[best[1]]["clock_ghz"]),
-                        # the probe is an EMPIRICAL ceiling (the fastest dependency-free arrangement of the mix that was measured), so a
-                        # kernel that is itself such an arrangement can tie it within the +-1 % scatter of two PMC runs: capped, raw kept
-                        "frac": min(1.0, raw), "frac_raw": raw,
-                        "ceiling_by_occupancy": {w: round(p_["cyc_per_inst"], 3) for w, p_ in probes.items() if p_.get("cyc_per_inst")},
-                        "peak_Gwave_inst_per_s": 1024 * clock / best[0], "achieved_Gwave_inst_per_s": 1024 * clock / cyc})
+        rated = [(NUM_SIMDS * p_["clock_ghz"] / p_["cyc_per_inst"], w) for w, p_ in probes.items() if p_.get("cyc_per_inst") and p_.get("clock_ghz")]
+        if rated:
+            peak, w = max(rated)
+            out["valu_empirical"] = {"peak": peak, "unit": "Gwave-inst/s", "frac_raw": live / peak,
+                                     "probe": "tools/ubench.hip `mix hash_leaves` (%s: waves per SIMD, x4 = 128 instructions per loop trip): %.3f cycles per "
+                                              "instruction at %.2f GHz" % (w[1:], probes[w]["cyc_per_inst"], probes[w]["clock_ghz"]),
+                                     "cycles_per_inst_by_occupancy": {w_: round(p_["cyc_per_inst"], 3) for w_, p_ in probes.items() if p_.get("cyc_per_inst")},
+                                     "peak_source": "profiles/ubench.json (tools/ubench_pmc.sh: every probe under rocprofv3 --pmc, true cycles)"}
         out["classes_cycles_per_inst"] = {w: {c: round(v["cyc_per_inst_median"], 2) for c, v in o.get("classes", {}).items()} for w, o in occ.items()}
-        out["ubench_source"] = "profiles/ubench.json (tools/ubench_pmc.sh: every probe under rocprofv3 --pmc, true cycles)"
     return out
 
 
 def roofline_line(vl, hbm_achieved, hash_bytes, perms, h, launches_per_step, e):
-    """The dominant kernel (the Poseidon leaf sponge) against the resource that bounds it.  It is integer-VALU-issue bound
-    (PMC traffic = 1.000 x its algorithmic bytes, 2-3 % of HBM peak), so `bound` is "valu": achieved / peak are wave64 VALU
-    instructions per second at the clock the kernel ran at (valu_line), and the HBM view the contract names is the
-    secondary figure under `hbm`."""
+    """The dominant kernel (the Poseidon leaf sponge), every figure from THIS run's kernel time.  Three fractions side by side,
+    none capped: `hbm` (the contract's view: algorithmic bytes per launch / live duration / 8 TB/s; also the scalar `hbm_frac`),
+    `valu_nominal` and `valu_empirical` (valu_line).  The kernel is integer-VALU-issue bound (PMC traffic = 1.000 x its
+    algorithmic bytes, 2-3 % of HBM peak), so the top-level bound / achieved / peak / frac are the nominal VALU view."""
     hbm = {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
-           "algorithmic_bytes_per_launch": hash_bytes}
+           "algorithmic_bytes_per_launch": hash_bytes, "peak_source": "plonky2_amd/util/chip.py (the guide: 8.0 TB/s HBM3E)"}
     common = {"kernel": "hash_leaves_kernel<ColMajorReader> (Poseidon leaf sponge)",
               "traffic": e["hbm_bytes_per_launch"] / launches_per_step if e else None, "traffic_stale": pmc_stale(),
-              "launches_per_step": launches_per_step,
+              "launches_per_step": launches_per_step, "live_ms_per_launch": h["ms_per_launch"],
               "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                                 "traffic_stale = the kernel sources changed since they were collected)",
               **({"overlap": "launched on a second stream beside the next coset block's LDE; durations are wall "
                              "time while sharing the GPU"} if launches_per_step > 1 else {}),
               "note": "integer-VALU-issue bound (%.3g permutations per launch, %.2f Gperm/s, 13.2 k VALU instructions each); "
-                      "algorithmic bytes per launch = 8*W*rows + 32*rows = %d" % (perms, perms / (h["ms_per_launch"] * 1e-3) / 1e9, hash_bytes)}
-    if vl and vl.get("frac"):
-        return {**common, "bound": "valu", "achieved": vl["achieved_Gwave_inst_per_s"], "peak": vl["peak_Gwave_inst_per_s"],
-                "unit": "Gwave-inst/s", "frac": vl["frac"], "hbm": hbm}
-    return {**common, **hbm}  # no committed counters for this shape: the HBM view alone
+                      "algorithmic bytes per launch = 8*W*rows + 32*rows = %d" % (perms, perms / (h["ms_per_launch"] * 1e-3) / 1e9, hash_bytes),
+              "hbm_frac": hbm["frac"], "hbm": hbm}
+    if vl:
+        nom = vl["valu_nominal"]
+        return {**common, "bound": "valu", "achieved": vl["achieved_Gwave_inst_per_s"], "peak": nom["peak"], "unit": "Gwave-inst/s",
+                "frac": nom["frac"], "valu_nominal": nom, "valu_empirical": vl.get("valu_empirical")}
+    return {**common, **{k: hbm[k] for k in ("bound", "achieved", "peak", "unit", "frac")}}  # no committed counters for this shape
 
 
 def ntt_roofline(kern, W, n_local, rows_local, steps, entry):
@@ -672,6 +623,24 @@ def ntt_roofline(kern, W, n_local, rows_local, steps, entry):
                     % ("%.0f" % big["valu_insts_per_element"] if big.get("valu_insts_per_element") else "~30")}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` outside a launcher: re-run this file as N ranks (one process per GPU) under
+    torch.distributed.run on 127.0.0.1 and a free port; the ranks inherit stdout / stderr, so rank 0's JSON line is this
+    process's JSON line, and the launcher's exit code is returned."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -687,21 +656,30 @@ def main():
     ap.add_argument("--extra-only", default=None, help="tooling: only this group of extra lines (host)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU under
+    # torch.distributed.run, rendezvous on 127.0.0.1), pass the child's JSON line and exit code through
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
+    # P2HOT_BENCH_EMU=1 (CPU TEST TIER ONLY, tests/test_bench_launch.py): the same main() over the kernel-source emulator and its
+    # fake RCCL (tests/emu) -- launcher, rank plumbing, preflight, sharded commit, cap check and the JSON line run where there is
+    # no GPU; the line says "emulated": true and its timings mean nothing.  Without it, no GPU = no bench.
+    emu = os.environ.get("P2HOT_BENCH_EMU") == "1"
     import torch
-    if not torch.cuda.is_available():
+    if not emu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's world size and --gpus must agree" % (args.gpus, world))
     # P2HOT_BENCH_BACKEND=gloo (tooling): the ranks may share a GPU and exchange through the host -- the whole multi-process
     # flow, cap check included, on a one-GPU box; the numbers of such a run are not scaling numbers
-    backend = os.environ.get("P2HOT_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+    backend = "gloo" if emu else os.environ.get("P2HOT_BENCH_BACKEND", "nccl")
+    if not emu:
+        if backend != "nccl":
+            local_rank %= torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -712,15 +690,25 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build_product()
-    if dist:
-        dist.barrier()
-    from plonky2_amd import Engine
     from plonky2_amd.distributed import ShardedCommit
-
-    eng = Engine(local_rank)
+    if emu:
+        import ctypes as C
+        from plonky2_amd.engine import Engine
+        from tests.emu_backend import HostMemory, emu_lib
+        lib = emu_lib()
+        lib.p2hot_emu_set_device.argtypes = [C.c_int]
+        lib.p2hot_emu_set_device(local_rank)
+        eng = Engine(local_rank, lib=lib, memory=HostMemory())
+        device_sync = eng.sync
+    else:
+        import __graft_entry__ as ge
+        if rank == 0:
+            ge.build_product()
+        if dist:
+            dist.barrier()
+        from plonky2_amd import Engine
+        eng = Engine(local_rank)
+        device_sync = torch.cuda.synchronize
     W, rb, cap = args.width, args.rate_bits, args.cap_height
     log_g = (world - 1).bit_length()
     if world != 1 << log_g:
@@ -731,11 +719,16 @@ def main():
     # digests stay with the rank that owns the rows (its Merkle paths never leave its cap subtrees); only the cap is
     # all-gathered (SURVEY 8e collective 2).  P2HOT_GATHER_DIGESTS=1 also reassembles the full digest array everywhere.
     gather_digests = os.environ.get("P2HOT_GATHER_DIGESTS") == "1"
-    job = ShardedCommit(eng, W, log_n, rb, cap, is_values=True, rank=rank, world=world, dist=dist,
-                        gather_digests=gather_digests)
-    # synthetic trace: each rank generates the columns it owns for the iNTT stage, on its device
-    c0, c1 = job.column_range
-    cols = splitmix_columns_torch(torch, eng.mem.device, c0, c1 - c0, n)
+    def make_job(log_rows, comm=None):
+        """the sharded commit of 2^log_rows rows in total + this rank's synthetic columns (generated on its device)"""
+        j = ShardedCommit(eng, W, log_rows, rb, cap, is_values=True, rank=rank, world=world, dist=dist, gather_digests=gather_digests,
+                          transport="rccl" if (emu and world > 1) else None, comm=comm)
+        a, b = j.column_range
+        if emu:
+            return j, eng.dev(splitmix_columns_numpy(a, b - a, 1 << log_rows))
+        return j, splitmix_columns_torch(torch, eng.mem.device, a, b - a, 1 << log_rows)
+
+    job, cols = make_job(log_n)
 
     # preflight (before anything is timed): peer access between the node's GPUs, the transport that was bound, and a 1 MB
     # all-gather through the library's own exchange path checked on every rank -- a broken fabric fails here, by name
@@ -743,7 +736,7 @@ def main():
     if world > 1:
         preflight = {"transport": job.comm.transport}
         try:
-            nd_ = torch.cuda.device_count()
+            nd_ = torch.cuda.device_count() if not emu else 0
             preflight["peer_access"] = [bool(torch.cuda.can_device_access_peer(local_rank, j)) for j in range(nd_) if j != local_rank] if backend == "nccl" else None
         except Exception as ex:  # noqa: BLE001
             preflight["peer_access"] = "query failed: %r" % (ex,)
@@ -756,57 +749,86 @@ def main():
         preflight["selftest_ms"] = (time.perf_counter() - t_pf) * 1e3
         preflight["exchange"] = job.comm.exchange  # "allgather" / "broadcast": what the selftest's micro-timing of both kept
 
-    # the cap of EVERY timed step is kept (512 bytes each, an asynchronous device copy) and compared after the timed region
-    cap_log = eng.mem.zeros(max(args.steps, 1), (1 << cap) * 4)
+    gnames = {(135, 16, 3, 4): "c2_wires", (135, 20, 3, 4): "c3_wires", (135, 21, 3, 4): "scale2_wires", (135, 22, 3, 4): "scale4_wires",
+              (135, 23, 3, 4): "c5_wires", (135, 7, 3, 4): "tiny_wires", (135, 6, 3, 4): "tiny_strong_wires"}
 
-    def step(i=None):
-        job.run(cols)
-        if i is not None:
-            cap_log[i].copy_(job.cap.reshape(-1))
+    def timed_steps(job, cols, log_rows):
+        """W untimed warm-up steps, then exactly K steps between barrier + device synchronisation on both sides; the cap of EVERY
+        timed step is kept (512 bytes each, an asynchronous device copy) and compared, after the timed region, with the oracle's
+        golden cap of the same synthetic columns (tests/golden/commit_caps.json: the headline shape and the 2 / 4 / 8-GPU
+        weak-scaling shapes, C5 at 8).  Returns (seconds, kernel profile, cap_checked, golden record)."""
+        cap_log = eng.mem.zeros(max(args.steps, 1), (1 << cap) * 4)
 
-    for _ in range(args.warmup):
-        step()
-    eng.profile(True)
-    eng.profile_results(reset=True)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof = eng.profile_results(reset=True)
-    eng.profile(False)
-    # what was timed is checked: the cap of EVERY timed step against the oracle's golden cap of the same synthetic
-    # columns (tests/golden/commit_caps.json: the headline shape and the 2 / 4 / 8-GPU weak-scaling shapes, C5 at 8)
-    gname = {(135, 16, 3, 4): "c2_wires", (135, 20, 3, 4): "c3_wires", (135, 21, 3, 4): "scale2_wires", (135, 22, 3, 4): "scale4_wires",
-             (135, 23, 3, 4): "c5_wires"}.get((W, log_n, rb, cap))
-    g = golden(gname) if gname else None
-    cap_checked = None
-    if g is not None:
-        caps_host = eng.host(cap_log).reshape(args.steps, 1 << cap, 4).tolist()
-        bad = [i for i, c in enumerate(caps_host) if c != g["cap"]]
-        cap_checked = not bad and args.steps > 0
-        if bad:
-            raise SystemExit("bench: the Merkle cap of timed step(s) %s differs from the oracle's golden cap" % bad[:8])
-    rank_rows = None
-    if dist:
+        def step(i=None):
+            job.run(cols)
+            if i is not None:
+                if emu:
+                    cap_log[i][...] = eng.host(job.cap).reshape(-1)
+                else:
+                    cap_log[i].copy_(job.cap.reshape(-1))
+
+        for _ in range(args.warmup):
+            step()
+        eng.profile(True)
+        eng.profile_results(reset=True)
+        if dist:
+            dist.barrier()
+        device_sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        device_sync()
+        if dist:
+            dist.barrier()
+        device_sync()
+        dt = time.perf_counter() - t0
+        prof = eng.profile_results(reset=True)
+        eng.profile(False)
+        gname = gnames.get((W, log_rows, rb, cap))
+        g = golden(gname) if gname else None
+        cap_checked = None
+        if g is not None:
+            caps_host = eng.host(cap_log).reshape(args.steps, 1 << cap, 4).tolist()
+            bad = [i for i, c in enumerate(caps_host) if c != g["cap"]]
+            cap_checked = not bad and args.steps > 0
+            if bad:
+                raise SystemExit("bench: the Merkle cap of timed step(s) %s differs from the oracle's golden cap" % bad[:8])
+        return dt, prof, cap_checked, g
+
+    def max_over_ranks(dt):
+        if not dist:
+            return dt
         t = torch.tensor([dt], dtype=torch.float64, device=eng.mem.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_local, dt = dt, float(t.item())
+        return float(t.item())
+
+    dt, prof, cap_checked, g = timed_steps(job, cols, log_n)
+    rank_rows = None
+    if dist:
+        dt_local, dt = dt, max_over_ranks(dt)
         # one row per rank: its own wall time, the span of its exchanges on the communication stream, the sum of its compute
         # kernels and the kernel table -- a slow curve is diagnosed from ONE driver run
         ex_ms = prof.get("exchange", {"ms": 0.0})["ms"] / args.steps
         comp_ms = sum(v["ms"] for k, v in prof.items() if k != "exchange") / args.steps
-        mine = {"rank": rank, "device": torch.cuda.get_device_name(local_rank), "transport": job.comm.transport, "ms_per_step": dt_local / args.steps * 1e3,
+        mine = {"rank": rank, "device": "emulated device %d" % local_rank if emu else torch.cuda.get_device_name(local_rank), "transport": job.comm.transport, "ms_per_step": dt_local / args.steps * 1e3,
                 "exchange_ms": ex_ms, "compute_ms": comp_ms, "preflight": preflight,
                 "kernels": {k: round(v["ms"] / max(v["launches"], 1), 4) for k, v in prof.items()}}
         rank_rows = [None] * world
         dist.all_gather_object(rank_rows, mine)
+
+    # the strong-scaling companion of a weak-scaling run: the SAME total size at every --gpus (2^log_n rows in all: the C3 wires
+    # commit split over the ranks), timed and cap-checked the same way on the same communicator, reported under "strong_scaling"
+    strong = None
+    if world > 1 and not args.strong and os.environ.get("P2HOT_BENCH_NO_STRONG") != "1":
+        del cols
+        job2, cols2 = make_job(args.log_n, comm=job.comm)
+        dt2, _prof2, cap2, _g2 = timed_steps(job2, cols2, args.log_n)
+        dt2 = max_over_ranks(dt2)
+        strong = {"scaling": "strong", "workload": "PolynomialBatch::from_values, W=%d, 2^%d rows IN TOTAL split over %d ranks, rate 1/%d, cap_height %d"
+                                                   % (W, args.log_n, world, 1 << rb, cap),
+                  "ms_per_step": dt2 / args.steps * 1e3, "value": W * (1 << (args.log_n + rb)) / (dt2 / args.steps) / 1e9, "unit": "GFE/s",
+                  "steps": args.steps, "cap_checked": cap2, "caps_checked": args.steps if cap2 else 0}
+        del job2, cols2
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -814,7 +836,8 @@ def main():
         # dominant kernel: the Poseidon leaf sponge over this rank's rows
         rows_local = N // world
         ab = algorithmic_bytes(W, log_n, rb)
-        kern = {k: {"ms_per_launch": v["ms"] / max(v["launches"], 1), "launches": v["launches"]} for k, v in prof.items()}
+        # (the emulated runtime's events carry no time: a floor keeps the emulated line's arithmetic finite)
+        kern = {k: {"ms_per_launch": max(v["ms"] / max(v["launches"], 1), 1e-9 if emu else 0.0), "launches": v["launches"]} for k, v in prof.items()}
         for agg in ("strided", "contig"):  # the aggregated keys of rounds 1-2: all passes of that kind in a step
             parts = [v for k, v in kern.items() if k.startswith("ntt_") and k.endswith("_" + agg)]
             if parts:
@@ -832,7 +855,8 @@ def main():
             "metric": "LDE+Poseidon-commit GFE/s", "value": fe / (dt / args.steps) / 1e9, "unit": "GFE/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks)",
-            "data": "synthetic (splitmix64 columns generated on device)",
+            "data": "synthetic (splitmix64 columns generated on device)" if not emu else "synthetic; EMULATED devices (CPU test tier): timings mean nothing",
+            **({"emulated": True} if emu else {}),
             "config": {"workload": "PolynomialBatch::from_values, W=%d, 2^%d rows, rate 1/%d (N=2^%d), cap_height %d, "
                                    "PoseidonGoldilocksConfig (%s)"
                                    % (W, log_n, 1 << rb, log_n + rb, cap, "--strong: the same total size at every --gpus" if args.strong else
@@ -851,16 +875,18 @@ def main():
                                          lambda *needles: pmc_entry(W, log_n, rb, cap, world, *needles)),
             "cap_checked": cap_checked,
             "caps_checked": args.steps if cap_checked else 0,
+            "box": None if emu else box_report(torch, local_rank),
             **({"ranks": rank_rows} if rank_rows else {}),
+            **({"strong_scaling": strong} if strong else {}),
             "kernels": kern,
             "algorithmic_bytes_per_step": ab,
             "commit_hbm_frac": ab["total"] / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         }
-        if world == 1 and not args.no_extra:
+        if world == 1 and not args.no_extra and not emu:
             del job, cols
             torch.cuda.empty_cache()
             out["other_configs"] = other_configs(eng, torch, only=args.extra_only)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not emu:
             out["cpu_baseline"] = cpu_baseline(W, log_n, rb, cap, golden_cap=g["cap"] if g else None)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))

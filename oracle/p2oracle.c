@@ -702,6 +702,23 @@ void ora_divide_by_linear(const uint64_t *poly, size_t n, const uint64_t z[2], u
     out[2 * (n - 1) + 1] = 0;
 }
 
+/* OpeningSet::new's eval_commitment (plonk/proof.rs:314-327): p.to_extension().eval(z) for every polynomial of a batch,
+ * eval = coeffs.iter().rev().fold(ZERO, |acc, c| acc * x + c) (field/src/polynomial/mod.rs:155-160, :295-300).
+ * polys: n_polys pointers to n base-field coefficients; out[n_polys][2], canonical. */
+void ora_eval_polys_ext(const uint64_t *const *polys, size_t n_polys, size_t n, const uint64_t z[2], uint64_t *out) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t j = 0; j < n_polys; ++j) {
+        uint64_t acc[2] = {0, 0}, t[2];
+        for (size_t k = n; k-- > 0;) {
+            ora_ext2_mul(acc, z, t);
+            acc[0] = ora_gl_add(t[0], polys[j][k]);
+            acc[1] = t[1];
+        }
+        out[2 * j] = ora_gl_canon(acc[0]);
+        out[2 * j + 1] = ora_gl_canon(acc[1]);
+    }
+}
+
 /* ---- the gate-independent part of compute_quotient_polys (plonk/prover.rs:609-815) with
  * eval_vanishing_poly_base_batch (plonk/vanishing_poly.rs:167-330): the permutation argument's vanishing terms on the quotient
  * coset, combined with the powers of alpha, divided by Z_H.  For every natural index i of the coset (size Nq = n << qbits,

@@ -126,6 +126,8 @@ void ora_reduce_polys_base(const uint64_t *const *polys, size_t n_polys, size_t 
 /* divide_by_linear (field/src/polynomial/division.rs:79-92) on an extension polynomial of n coeffs:
  * quotient has n-1 coeffs; out[n][2] gets them plus a trailing zero ("pad back to power of two"). */
 void ora_divide_by_linear(const uint64_t *poly, size_t n, const uint64_t z[2], uint64_t *out);
+/* plonk/proof.rs:314-327 eval_commitment: every polynomial (n base coefficients) at the extension point z; out[n_polys][2] */
+void ora_eval_polys_ext(const uint64_t *const *polys, size_t n_polys, size_t n, const uint64_t z[2], uint64_t *out);
 
 /* ---- wires_permutation_partial_products_and_zs (plonk/prover.rs:392-449) for one (beta, gamma).
  * wires / sigmas: [num_routed][n] column-major (sigmas = the sigma polynomials' values on the subgroup);

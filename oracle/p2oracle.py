@@ -310,6 +310,17 @@ def divide_by_linear(poly, z):
     return out
 
 
+def eval_polys_ext(polys, z):
+    """OpeningSet::new's eval_commitment (plonk/proof.rs:314-327): [n_polys][2] = every polynomial at the extension point z"""
+    polys = arr(polys)
+    k, n = polys.shape
+    ptrs = (u64p * k)(*[polys[i].ctypes.data_as(u64p) for i in range(k)])
+    out = np.zeros((k, 2), dtype=np.uint64)
+    zz = arr(z)
+    lib.ora_eval_polys_ext(ptrs, C.c_size_t(k), C.c_size_t(n), _p(zz), _p(out))
+    return out
+
+
 def partial_products(wires, sigmas, k_is, degree, beta, gamma):
     """wires_permutation_partial_products_and_zs (plonk/prover.rs:392-449): [num_prods + 1][n], Z last"""
     wires, sigmas, k = arr(wires), arr(sigmas), arr(k_is)

@@ -209,7 +209,8 @@ class ShardedCommit:
     """from_values / from_coeffs over `world` ranks, one process per GPU.  Buffers are allocated once and reused."""
 
     def __init__(self, engine, W, log_n, rate_bits, cap_height, is_values=True, rank=0, world=1, dist=None,
-                 want_leaves=False, pipeline_chunks=None, gather_digests=True, transport=None):
+                 want_leaves=False, pipeline_chunks=None, gather_digests=True, transport=None, comm=None):
+        """comm: an existing Communicator of the same (engine, rank, world) to reuse (one RCCL communicator serves every shape)"""
         self.eng, self.dist, self.rank, self.world = engine, dist, rank, world
         if pipeline_chunks is None:
             pipeline_chunks = 1 if os.environ.get("P2HOT_SYNC_COLLECTIVES") == "1" else 8
@@ -220,7 +221,7 @@ class ShardedCommit:
         mem = engine.mem
         self.column_range = p.columns(rank)
         self.row_begin, self.row_count = p.rows(rank)
-        self.comm = Communicator(engine, rank, world, dist, transport)
+        self.comm = comm if comm is not None else Communicator(engine, rank, world, dist, transport)
         # coefficient buffer, padded to world * cols_per_rank columns so every rank's slot has the same size
         self.coeffs_all = mem.empty(max(1, world * p.cols_per_rank), p.n)
         self.lde = mem.empty(max(W, 1), self.row_count)

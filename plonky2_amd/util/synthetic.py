@@ -66,3 +66,47 @@ def fibonacci_trace(log_n):
         a, b = (a * fm1 + b * a) % P, (a * a + b * b) % P
         m *= 2
     return np.stack([f0.astype(np.uint64), f1.astype(np.uint64)])
+
+
+# ------------------------------------------------------------------ the per-proof paths of bench.py (`per_proof_path_*` lines)
+# One definition shared by bench.py, tools/gen_golden_path.py (the CPU oracle's bytes for exactly these inputs,
+# tests/golden/path_goldens.json) and tests/test_gpu_fullsize.py, so that all three prove the same instance.
+GENERATOR = 14293326489335486720  # MULTIPLICATIVE_GROUP_GENERATOR, field/src/goldilocks_field.rs:80
+
+
+def plonk_path_instance(log_n):
+    """One standard_recursion_config proof of 2^log_n gates on the reference's FRI instance (get_fri_instance,
+    plonk/circuit_data.rs:530-548, :578-664): oracles [constants_sigmas (4 + 80), wires (135), Zs + partial products (20),
+    quotient chunks (16)], every polynomial at zeta, the num_challenges = 2 Z polynomials at the second point."""
+    widths = (84, 135, 20, 16)
+    return {
+        "kind": "plonk", "log_n": log_n, "rate_bits": 3, "cap_height": 4, "num_queries": 28, "pow_bits": 16,
+        "arity": {20: [4, 4, 4, 4], 16: [4, 4, 4], 12: [4, 4]}[log_n],      # reduction_strategies.rs:41-52 (SURVEY 8)
+        "wires_seed": 0, "wires_width": 135, "cs_seed": 1000, "cs_width": 84, "num_constants": 4, "num_routed": 80,
+        "k_is": [pow(GENERATOR, j, P) for j in range(80)],                 # get_unique_coset_shifts, field/src/cosets.rs:9-24
+        "quotient_degree_factor": 8, "betas": [3, 5], "gammas": [11, 13], "alphas": [17, 19],
+        "widths": widths, "transcript_seed": list(range(8)),
+        "batch_zeta": [(oi, pi) for oi, W in enumerate(widths) for pi in range(W)],
+        "batch_next": [(2, pi) for pi in range(2)],
+    }
+
+
+def starky_path_instance(log_n):
+    """C4: one starky proof of the 2-column Fibonacci trace (StarkConfig::standard_fast_config: rate 1/2, cap 4, 84 queries,
+    PoW 16 bits): trace + quotient at zeta, trace at the second point (starky/src/stark.rs:101-156)."""
+    return {
+        "kind": "starky", "log_n": log_n, "rate_bits": 1, "cap_height": 4, "num_queries": 84, "pow_bits": 16, "arity": [4, 4, 4, 4],
+        "quotient_seed": 3000, "widths": (2, 2), "transcript_seed": list(range(8)),
+        "batch_zeta": [(0, 0), (0, 1), (1, 0), (1, 1)], "batch_next": [(0, 0), (0, 1)],
+    }
+
+
+def path_instance(name):
+    return {"per_proof_path_k20": lambda: plonk_path_instance(20), "per_proof_path_k12": lambda: plonk_path_instance(12),
+            "per_proof_path_starky_k22": lambda: starky_path_instance(22)}[name]()
+
+
+def second_point(zeta):
+    """the bench's stand-in for g * zeta: a second extension point derived from the first (any point != zeta exercises the
+    same code; the FRI instance only needs the two points to differ)"""
+    return [(int(zeta[0]) * 7) % P, int(zeta[1])]

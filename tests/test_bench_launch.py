@@ -1,0 +1,71 @@
+"""`python bench.py --gpus N` as the driver may run it: no launcher, no WORLD_SIZE / RANK / MASTER_* in the environment.
+bench.py starts its own ranks (torch.distributed.run on 127.0.0.1), forwards rank 0's JSON line and the exit code.  Here the
+ranks sit on the kernel-source emulator and its fake RCCL (P2HOT_BENCH_EMU=1: the test tier's switch, refused nowhere else),
+so the whole front door -- launcher, rank plumbing, in-library RCCL communicator, preflight, sharded commit, the cap check
+against the oracle's golden of the 2-rank shape, the strong-scaling companion, the JSON contract -- runs in the CPU tier."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.conftest import ROOT
+
+
+def _bench(*args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "P2HOT_EXCHANGE", "P2HOT_TRANSPORT")}
+    env["P2HOT_BENCH_EMU"] = "1"
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, capture_output=True, text=True,
+                          timeout=timeout, cwd="/tmp")
+
+
+def _one_json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    r = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "6")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["emulated"] is True
+    assert d["metric"] == "LDE+Poseidon-commit GFE/s" and d["unit"] == "GFE/s" and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["cap_checked"] is True and d["caps_checked"] == 2          # the 2-rank weak shape: 2^7 rows, golden "tiny_wires"
+    assert [row["rank"] for row in d["ranks"]] == [0, 1]
+    assert all(row["transport"] == "rccl" and row["preflight"]["selftest"] == "ok" for row in d["ranks"])
+    assert "RCCL inside libp2hot" in d["config"]["transport"] and d["config"]["exchange"] in ("allgather", "broadcast")
+    assert "2^7 rows" in d["config"]["workload"]
+    s = d["strong_scaling"]                                             # the same total size split over the ranks: 2^6 rows
+    assert s["scaling"] == "strong" and s["cap_checked"] is True and s["caps_checked"] == 2 and s["value"] > 0
+    for key in ("value", "ms_per_step", "roofline", "kernels", "algorithmic_bytes_per_step"):
+        assert key in d
+
+
+def test_bench_gpus_1_needs_no_launcher_either():
+    r = _bench("--gpus", "1", "--steps", "1", "--warmup", "0", "--log-n", "7", "--no-extra", "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["cap_checked"] is True and "ranks" not in d and "strong_scaling" not in d
+
+
+def test_a_launcher_and_gpus_that_disagree_is_an_error_not_a_hang():
+    r = _bench("--gpus", "2", "--steps", "1", "--log-n", "6", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_a_wrong_cap_fails_the_bench(tmp_path):
+    """what is timed is checked: with the golden of the shape replaced by another cap the run exits non-zero"""
+    import shutil
+    gold = os.path.join(ROOT, "tests", "golden", "commit_caps.json")
+    d = json.load(open(gold))
+    d["tiny_wires"]["cap"][3][1] += 1
+    alt = tmp_path / "caps.json"
+    alt.write_text(json.dumps(d))
+    r = _bench("--gpus", "1", "--steps", "1", "--warmup", "0", "--log-n", "7", "--no-extra", "--no-cpu-baseline",
+               env_extra={"P2HOT_BENCH_GOLDEN_CAPS": str(alt)})
+    assert r.returncode != 0 and "differs from the oracle's golden cap" in (r.stderr + r.stdout)
+    shutil.rmtree(tmp_path, ignore_errors=True)

@@ -390,3 +390,57 @@ def test_commit_many_upload_in_staging_slices(gpu):
         for m in range(k, M, 3):
             assert (caps[m] == c1).all() and (coeffs[m] == co1).all(), (k, m)
     assert (caps[0] != caps[1]).any() and (caps[1] != caps[2]).any()
+
+
+# ------------------------------------------------------------------ the widened rows at the sizes bench.py times them
+@pytest.mark.parametrize("name", ["per_proof_path_k20", "per_proof_path_starky_k22"])
+def test_proof_path_full_size_vs_oracle_records_and_verifier(gpu, ora, name):
+    """bench.py's per_proof_path_k20 (2^20 rows, 80 routed wires, degree 8, 2 challenges; 4 oracles, 255 polynomials at zeta, 2 at
+    the second point, arity [4,4,4,4], 28 queries) and per_proof_path_starky_k22 (C4: 2^22 rows, rate 1/2, 84 queries), every stage
+    against the CPU oracle's bytes for the same instance (tests/golden/path_goldens.json, tools/gen_golden_path.py):
+      p2hot_partial_products     SHA-256 of the whole [20][2^20] Zs + partial-products matrix   (plonk/prover.rs:392-449)
+      p2hot_quotient_polys       SHA-256 of the quotient values at all 2^23 points and of the 16 chunk polynomials
+                                 (plonk/prover.rs:609-815, vanishing_poly.rs:167-330)
+      p2hot_eval_openings        every opening value (255 at zeta, 20 at the second point)      (plonk/proof.rs:314-345)
+      p2hot_prove_openings       commit-phase caps, final_poly, PoW witness, query indices, SHA-256 of the FriProof's wire bytes
+                                 (fri/oracle.rs:176-237, fri/prover.rs:24-258)
+    and the device-made proof VERIFIES under the restated reference verifier (oracle/fri_verifier.py) and fails under six kinds of
+    tampering.  For k20 the gate-sum input of the quotient is exercised at full size as well: see below."""
+    import torch
+    from tests.test_proof_path import check_path
+    inst, inp, res, g = check_path(gpu, ora, name, sync=torch.cuda.synchronize)
+    if inst["kind"] != "plonk":
+        return
+    # with gate sums (the caller's reduce_with_powers of the gate constraint terms): the values are the golden-checked permutation
+    # quotient plus alpha^K * gate_sums / Z_H (vanishing_poly.rs:326-330, prover.rs:733-754) -- on 4096 sampled points in python
+    # integers --, and the chunk polynomials follow by linearity: chunks(with) - chunks(without) = coset_ifft(values(with) - values(without))
+    from plonky2_amd.plonk.prover import compute_quotient_polys
+    from plonky2_amd.util.synthetic import GENERATOR, splitmix_columns_numpy
+    n, qdf, nc = 1 << inst["log_n"], inst["quotient_degree_factor"], len(inst["alphas"])
+    qbits = (qdf - 1).bit_length()
+    m = n << qbits
+    gs = splitmix_columns_numpy(7000, nc, m)
+    b_cs, b_w, b_z, _ = res["oracles"]
+    cols_g, vals_g = compute_quotient_polys(b_w, b_cs, inst["num_constants"], b_z, inst["k_is"], qdf, inst["betas"], inst["gammas"],
+                                            inst["alphas"], gate_sums=gs, want_values=True, engine=gpu)
+    vals = res["quotient_values"]
+    K = nc + nc * (-(-inst["num_routed"] // qdf))        # L_0 terms + (num_prods + 1) partial-product terms per challenge
+    g_n, v = pow(GENERATOR, n, P), ora.root_of_unity(qbits)
+    rng = np.random.default_rng(20)
+    pts = np.unique(np.concatenate([[0, 1, m - 1], rng.integers(0, m, 4096)]))
+    for a in range(nc):
+        aK = pow(int(inst["alphas"][a]), K, P)
+        for i in pts:
+            zh = (g_n * pow(v, int(i) % (1 << qbits), P) - 1) % P
+            extra = aK * int(gs[a, i]) % P * pow(zh, P - 2, P) % P
+            assert int(vals_g[a, i]) == (int(vals[a, i]) + extra) % P, (a, int(i))
+    got = cols_g.host()
+    pp_ = np.uint64(P)
+    for a in range(nc):
+        d = np.where(vals_g[a] >= vals[a], vals_g[a] - vals[a], vals_g[a] + (pp_ - vals[a]))
+        co = ora.coset_ifft(d) % pp_
+        want = res["chunks"][a * qdf:(a + 1) * qdf].reshape(-1)
+        s = want + co[:qdf * n]                                  # mod-P addition on u64s: wrapped sums are below P - 2^32 + ... ; redo in two steps
+        s = np.where(s < want, s + np.uint64(0xFFFFFFFF), s)     # 2^64 = 2^32 - 1 (mod P)
+        s = np.where(s >= pp_, s - pp_, s)
+        assert (got[a * qdf:(a + 1) * qdf].reshape(-1) == s).all(), a

@@ -47,6 +47,9 @@ SHAPES = {
     "c3_zs_partial_products": (20, 20, 3, 4, True, "splitmix"),
     "c3_quotient_chunks": (16, 20, 3, 4, False, "splitmix"),
     "c4_fibonacci_trace": (2, 22, 1, 4, True, "fibonacci"),
+    # the CPU tier's `bench.py --gpus 2 --log-n 6` on the kernel emulator (tests/test_bench_launch.py): the weak shape and the strong one
+    "tiny_wires": (135, 7, 3, 4, True, "splitmix"),
+    "tiny_strong_wires": (135, 6, 3, 4, True, "splitmix"),
 }
 
 
