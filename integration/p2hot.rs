@@ -394,8 +394,20 @@ fn with_ctx<R>(f: impl FnOnce(*mut P2hotCtx) -> R) -> R {
         }
         Mutex::new(CtxPtr(ctx))
     });
-    let guard = m.lock().expect("p2hot context poisoned");
-    f(guard.0)
+    // The reference's own failure panics surface inside these closures ("Quotient has failed ...", "Tried to invert zero", shape
+    // violations).  A panic must not unwind THROUGH the guard: that would poison the process-wide mutex, and the `Drop` impls of the
+    // batches that unwind next (DeviceTree, FlatLeaves) lock it again -- a panic inside a panic, i.e. an abort where the CPU prover
+    // gives `#[should_panic]` tests and `catch_unwind` callers an ordinary panic.  So the payload is caught, the guard released, the
+    // panic resumed; and a mutex poisoned some other way is taken over (the library keeps its own state consistent: every failure is
+    // a return code).  Nothing inside a closure re-enters `with_ctx` (ColsGuard / DeviceChallenger free without the lock).
+    let guard = m.lock().unwrap_or_else(|e| e.into_inner());
+    let ctx = guard.0;
+    let r = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| f(ctx)));
+    drop(guard);
+    match r {
+        Ok(v) => v,
+        Err(payload) => std::panic::resume_unwind(payload),
+    }
 }
 
 fn error_text(ctx: *const P2hotCtx) -> String {
@@ -1094,18 +1106,17 @@ pub fn compute_quotient_polys<F: RichField + Extendable<D>, C: GenericConfig<D, 
     let k_is: Vec<u64> = common_data.k_is[..num_routed].iter().map(|k| k.to_canonical_u64()).collect();
     let to_u64 = |v: &[F]| -> Vec<u64> { v.iter().map(|x| x.to_canonical_u64()).collect() };
     let (b, g, a) = (to_u64(betas), to_u64(gammas), to_u64(alphas));
-    let mut chunks: *mut P2hotCols = core::ptr::null_mut();
     let coeffs: Vec<F> = vec_from_words(nc * qdf * n, |out| {
         with_ctx(|ctx| {
+            let mut chunks = ColsGuard(core::ptr::null_mut()); // freed on every path, the panicking ones included
             let rc = unsafe {
                 p2hot_quotient_polys(
                     ctx, h_wires, h_cs, common_data.sigmas_range().start, h_zs, k_is.as_ptr(), num_routed as c_uint, qdf as c_uint,
-                    b.as_ptr(), g.as_ptr(), a.as_ptr(), nc as c_uint, gate_ptrs.as_ptr(), core::ptr::null_mut(), &mut chunks,
+                    b.as_ptr(), g.as_ptr(), a.as_ptr(), nc as c_uint, gate_ptrs.as_ptr(), core::ptr::null_mut(), &mut chunks.0,
                 )
             };
             check(ctx, rc, "p2hot_quotient_polys"); // "Quotient has failed ..." panics here as trim_to_len does on the CPU path
-            check(ctx, unsafe { p2hot_cols_download(chunks, 0, nc * qdf, out) }, "p2hot_cols_download");
-            unsafe { p2hot_cols_free(chunks) };
+            check(ctx, unsafe { p2hot_cols_download(chunks.0, 0, nc * qdf, out) }, "p2hot_cols_download");
         })
     });
     // challenge c's polynomial = its quotient_degree_factor chunks of n coefficients, back to back (prover.rs:810-814 + :279-287)
@@ -1120,19 +1131,34 @@ pub fn coeff_slices<F: Field>(polys: &[PolynomialCoeffs<F>]) -> Vec<&[F]> {
     polys.iter().map(|p| p.coeffs.as_slice()).collect()
 }
 
-// MerkleTree derives Clone / Debug / Eq / PartialEq (hash/merkle_tree.rs:45); the device copy is a cache of the same
-// tree, not part of its value: two trees are equal when leaves, digests and cap are.
+// MerkleTree's value is (leaves, digests, cap) (hash/merkle_tree.rs:45-61); the device copy is a cache of the same tree, not part
+// of its value.
 impl<F: RichField> core::fmt::Debug for DeviceTree<F> {
     fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
         write!(f, "DeviceTree({:p}, {} leaves of {}, {} layers, {} host words)", self.batch, self.num_leaves, self.width, self.num_layers, self.flat.as_slice().len())
     }
 }
 impl<F: RichField> PartialEq for DeviceTree<F> {
+    /// the device copy is a cache of the tree it hangs off: it never decides an equality on its own.  The VALUE comparison of two
+    /// trees is `MerkleTree::eq`, written by hand under the feature (hash/merkle_tree.rs): rows through `get`, digests through
+    /// `digests_or_device`, cap -- so a GPU-built tree (`leaves` empty, the matrix behind `device`) equals its serialise /
+    /// deserialise round trip (`leaves` populated, `device: None`), as `examples/square_root.rs:152` asserts of CircuitData
     fn eq(&self, _other: &Self) -> bool {
         true
     }
 }
 impl<F: RichField> Eq for DeviceTree<F> {}
+
+impl<F: RichField> DeviceTree<F> {
+    /// `MerkleTree::digests` (reference layout) fetched from the device: what the field holds in the default mode, and what it
+    /// would hold in P2HOT_LEAVES=device, where it is left empty
+    pub fn digests<H: Hasher<F>>(&self) -> Vec<H::Hash> {
+        let cap_len = self.num_leaves >> self.num_layers;
+        vec_from_words(2 * (self.num_leaves - cap_len), |p| {
+            with_ctx(|c| check(c, unsafe { p2hot_batch_digests(self.batch, p) }, "p2hot_batch_digests"));
+        })
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Bit-exact harness (SURVEY 8c "Parity status" / "Bit-exact vs CPU prover protocol"): every replaced body, CPU vs GPU, in one
@@ -1205,7 +1231,45 @@ mod tests {
             gpu.merkle_tree.leaves = gpu.merkle_tree.device.as_ref().unwrap().leaves_as_vecs();
         }
         assert_eq!(cpu.merkle_tree.leaves, gpu.merkle_tree.leaves, "merkle_tree.leaves (LDE values, transposed, bit-reversed)");
-        assert_eq!(cpu, &*gpu); // the derived PartialEq (oracle.rs:29) over all of the above
+        assert_eq!(cpu, &*gpu); // PartialEq (oracle.rs:29) over all of the above
+    }
+
+    /// a GPU-built batch (default mode: `leaves` empty, the matrix behind `device`) equals its own serialise / deserialise round
+    /// trip (`leaves` populated, `device: None`) and the CPU-built batch, in both argument orders: `MerkleTree::eq` compares rows
+    /// through `get` (what `examples/square_root.rs:152` `assert_eq!(data, data_from_bytes)` relies on for CircuitData)
+    #[test]
+    fn gpu_built_batch_equals_its_round_trip() {
+        use crate::util::serialization::Buffer;
+        use crate::util::serialization::Read;
+        let (w, log_n, rate_bits, cap_height) = (7usize, 6usize, 3usize, 2usize);
+        let values: Vec<PolynomialValues<F>> = (0..w).map(|_| PolynomialValues::new(F::rand_vec(1 << log_n))).collect();
+        let cpu = on_cpu(|| Batch::from_values(values.clone(), rate_bits, false, cap_height, &mut TimingTree::default(), None));
+        let gpu = Batch::from_values(values.clone(), rate_bits, false, cap_height, &mut TimingTree::default(), None);
+        assert!(gpu.merkle_tree.device.is_some() && (leaves_as_vecs() || gpu.merkle_tree.leaves.is_empty()));
+        let mut bytes = Vec::<u8>::new();
+        bytes.write_polynomial_batch(&gpu).unwrap();
+        let back: Batch = Buffer::new(&bytes).read_polynomial_batch().unwrap();
+        assert!(back.merkle_tree.device.is_none() && !back.merkle_tree.leaves.is_empty());
+        assert_eq!(gpu, back);
+        assert_eq!(back, gpu);
+        assert_eq!(cpu, gpu);
+        assert_eq!(gpu, cpu);
+        // and the comparison still tells two different GPU-built trees apart
+        let mut other = values;
+        other[0].values[1] += F::ONE;
+        let gpu2 = Batch::from_values(other, rate_bits, false, cap_height, &mut TimingTree::default(), None);
+        assert_ne!(gpu, gpu2);
+    }
+
+    /// the reference's failure panics stay panics under the feature (no abort through a poisoned context mutex): a zero
+    /// denominator in the partial products panics with the reference's text, and the context works afterwards
+    #[test]
+    fn a_failure_panic_does_not_poison_the_context() {
+        let r = std::panic::catch_unwind(|| with_ctx(|_| panic!("Tried to invert zero")));
+        assert!(r.is_err());
+        let values: Vec<PolynomialValues<F>> = (0..3).map(|_| PolynomialValues::new(F::rand_vec(8))).collect();
+        let gpu = Batch::from_values(values, 1, false, 0, &mut TimingTree::default(), None); // locks the same mutex
+        assert!(gpu.merkle_tree.device.is_some());
     }
 
     /// from_values and from_coeffs at the widths of a proof's four commitments (constants_sigmas ~84, wires 135, Zs 20, quotient 16)

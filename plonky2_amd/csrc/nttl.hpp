@@ -52,6 +52,26 @@ constexpr bool LIMB_MUL3 = P2HOT_LIMB_MUL3 != 0;    // independent general multi
 constexpr bool LIMB_DIRECT_CONTIG = P2HOT_LIMB_DIRECT_CONTIG != 0;  // contiguous pass: store the last round's outputs from registers
 constexpr int LIMB_MIN_WAVES = P2HOT_LIMB_MIN_WAVES;  // waves per SIMD the register allocation must allow (4: <= 128 VGPRs)
 
+// The tile's place in LDS.  ntt.hpp pads one word per 16 (pad_idx); under the per-instruction banking of gfx950 -- ds_read_b64: two
+// groups of 32 lanes over 32 eight-byte banks, ds_write_b64: four groups of 16 lanes over 16 -- that padding itself costs a second
+// LDS cycle whenever 32 consecutive words straddle a pad (the contiguous pass ran 17.7 % of its LDS-active cycles in conflicts,
+// profiles/r04_x_pmc_sq.txt).  The limb passes use an XOR swizzle instead: word i lives at
+//     swz(i) = i ^ (((i >> 2) ^ (i >> 3)) & 31)        (bit k ^= bit k+2 ^ bit k+3, k < 5: GF(2)-linear, unit upper triangular)
+// which is conflict-free for every access pattern of every tile shape but one (2^10 x 2^2: 1.11 cycles per group), no padding
+// words, and -- being linear -- lets a unit's 2^P addresses be ONE swizzled base XOR compile-time constants: the base and the
+// q-offsets occupy disjoint bits, so swz(base + off_q) = swz(base) ^ swz(off_q).  (tools/lds_conflicts.py is the model.)
+#ifndef P2HOT_LIMB_SWZ
+#define P2HOT_LIMB_SWZ 1
+#endif
+constexpr bool LIMB_SWZ = P2HOT_LIMB_SWZ != 0;
+__host__ __device__ constexpr unsigned swz(unsigned i) { return LIMB_SWZ ? i ^ (((i >> 2) ^ (i >> 3)) & 31u) : i + (i >> 4); }
+// the tile word of base + off for DISJOINT bit sets base / off (off a compile-time constant at every call site)
+__device__ __forceinline__ unsigned tix(unsigned sbase, unsigned base, unsigned off) {
+    if constexpr (LIMB_SWZ) return sbase ^ swz(off);
+    return swz(base + off);
+}
+constexpr unsigned TILE_WORDS = LIMB_SWZ ? (1u << TILE_LOG) : ntt::TILE_WORDS_PADDED;
+
 struct L4 {
     u32 l[4];  // signed limbs, two's complement
 };
@@ -292,7 +312,7 @@ constexpr int limb_tables_w2(int log_r) { return round_table_off(log_r, n_rounds
 constexpr int UFAC_WORDS = 64;  // u[a * 8 + k], a < 8, k < 8 (only round 0 ever borrows)
 constexpr bool uses_ufac(int log_r) { return round_borrows(log_r, 0) && !defers(log_r); }
 constexpr size_t limb_shmem_bytes(int log_r) {
-    return (size_t)8 * ntt::TILE_WORDS_PADDED + (size_t)16 * limb_tables_w2(log_r) + (uses_ufac(log_r) ? 8 * UFAC_WORDS : 0);
+    return (size_t)8 * TILE_WORDS + (size_t)16 * limb_tables_w2(log_r) + (uses_ufac(log_r) ? 8 * UFAC_WORDS : 0);
 }
 
 __device__ __forceinline__ u64 limb_mul(u64 a, u64 b) { return gl::mul1(a, b); }
@@ -410,13 +430,14 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
         const unsigned c = u & (C - 1), rest = u >> LOG_C;
         const unsigned lo = rest & ((1u << S_LOG) - 1), hi = rest >> S_LOG;
         const unsigned i0 = (hi << LOG_RB) + lo;
+        const unsigned eb = (i0 << LOG_C) + c, seb = swz(eb);  // the unit's element q is tile word tix(seb, eb, q << (S_LOG + LOG_C))
         u64 v[1 << P];
         if constexpr (FIRST) {
 #pragma unroll
             for (int q = 0; q < (1 << P); ++q) v[q] = raw[(uu << P) + q];
         } else {
 #pragma unroll
-            for (int q = 0; q < (1 << P); ++q) v[q] = tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)];
+            for (int q = 0; q < (1 << P); ++q) v[q] = tile[tix(seb, eb, (unsigned)q << (S_LOG + LOG_C))];
         }
         if constexpr (FIRST && SCALE == ntt::SCALE_CONST) {
 #pragma unroll
@@ -460,7 +481,7 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
                     },
                     y);
 #pragma unroll
-                for (int q = 0; q < (1 << P); ++q) tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = y[q];
+                for (int q = 0; q < (1 << P); ++q) tile[tix(seb, eb, (unsigned)q << (S_LOG + LOG_C))] = y[q];
             } else if constexpr (ABSORB) {
                 // this round's twiddle times the factor round 0 deferred: slab k0 = the frequency whose first-round block
                 // this unit lies in (position bits LOG_R-P0 .. LOG_R-1, bit-reversed), every output converts through the table
@@ -471,12 +492,12 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
                 for (int q = 0; q < (1 << P); ++q) {
                     const unsigned k = q ? (unsigned)(__brev((unsigned)q) >> (32 - P)) : 0u;
                     const W2 wa = tw[(k * 2) << T_LOG], wb = tw[(k * 2 + 1) << T_LOG];
-                    tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = convmul(x[q], wa.a, wa.b, wb.a, wb.b);
+                    tile[tix(seb, eb, (unsigned)q << (S_LOG + LOG_C))] = convmul(x[q], wa.a, wa.b, wb.a, wb.b);
                 }
             } else {
                 const W2 *tw = ltw + T_OFF + (BORROW ? lo >> P : lo);
                 [[maybe_unused]] const u64 *uf = lu + (lo & ((1u << P) - 1)) * 8;
-                tile[ntt::pad_idx((i0 << LOG_C) + c)] = conv_unit(x[0]);
+                tile[seb] = conv_unit(x[0]);
                 [[maybe_unused]] u64 yb[(1 << P) - 1], ub[(1 << P) - 1];
 #pragma unroll
                 for (int q = 1; q < (1 << P); ++q) {
@@ -487,13 +508,13 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
                     if constexpr (BORROW && !defers(LOG_R) && LIMB_MUL3) {
                         yb[q - 1] = y, ub[q - 1] = uf[k];
                     } else {
-                        tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = y;
+                        tile[tix(seb, eb, (unsigned)q << (S_LOG + LOG_C))] = y;
                     }
                 }
                 if constexpr (BORROW && !defers(LOG_R) && LIMB_MUL3) {  // the second factors of the unit's outputs, three streams at a time
                     limb_mul_n<(1 << P) - 1>(yb, ub);
 #pragma unroll
-                    for (int q = 1; q < (1 << P); ++q) tile[ntt::pad_idx(((i0 + ((unsigned)q << S_LOG)) << LOG_C) + c)] = yb[q - 1];
+                    for (int q = 1; q < (1 << P); ++q) tile[tix(seb, eb, (unsigned)q << (S_LOG + LOG_C))] = yb[q - 1];
                 }
             }
         } else {
@@ -558,7 +579,7 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
                 u64 y[1 << P];
                 conv_last_all(y);
 #pragma unroll
-                for (int q = 0; q < (1 << P); ++q) tile[ntt::pad_idx(((i0 + (unsigned)q) << LOG_C) + c)] = y[q];
+                for (int q = 0; q < (1 << P); ++q) tile[tix(seb, eb, (unsigned)q << LOG_C)] = y[q];
             }
         }
     }
@@ -580,7 +601,7 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
     P2HOT_DYN_SHARED(u64, tile);
     const ntt::PassArgs &a = ra.a;
     const unsigned tid = threadIdx.x;
-    W2 *ltw = reinterpret_cast<W2 *>(tile + ntt::TILE_WORDS_PADDED);
+    W2 *ltw = reinterpret_cast<W2 *>(tile + TILE_WORDS);
     u64 *lu = reinterpret_cast<u64 *>(ltw + limb_tables_w2(LOG_R));
     for (unsigned e = tid; e < (unsigned)limb_tables_w2(LOG_R); e += NT) ltw[e] = ra.tw_all[e];
     if constexpr (uses_ufac(LOG_R))
@@ -592,6 +613,7 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
     const size_t z_begin = ra.zloop ? 0 : blockIdx.z, z_end = ra.zloop ? ra.zloop : blockIdx.z + 1;
     const bool same_input = a.in_z_stride == 0;  // every z slice transforms the same polynomials (coset LDE): fetch them once
     const unsigned e0 = (tid >> 6) * 512u + (tid & 63u);  // store phase: wave w moves tile elements [512 w, 512 w + 512)
+    const unsigned se0 = swz(e0);
     const size_t n_tiles = (size_t)1 << ra.tiles_log;
     auto tile_in = [&](size_t t, size_t z) {
         const size_t tau = (wg << ra.tiles_log) + t;
@@ -622,7 +644,7 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
             if constexpr (LOG_C == 0 && !(LAST_P == 3 && LIMB_DIRECT_CONTIG)) {
 #pragma unroll
                 for (unsigned j = 0; j < 8; ++j) {
-                    const u64 v = tile[ntt::pad_idx(e0 + 64 * j)];
+                    const u64 v = tile[tix(se0, e0, 64 * j)];
                     out[e0 + 64 * j] = a.canon_out ? gl::canon(v) : v;
                 }
             } else if constexpr (LOG_C > 0 && LAST_P == 3) {
@@ -639,7 +661,7 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
                         const unsigned U = U0 + 64 * j;
                         const size_t step = ((size_t)(U >> LOG_C) << log_stride) + (U & (C - 1));
                         w8[j] = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ra.twid + base0 + step) + off0);
-                        v8[j] = tile[ntt::pad_idx(e0 + 64 * j)];
+                        v8[j] = tile[tix(se0, e0, 64 * j)];
                     }
                     limb_mul_n<8>(v8, w8);
 #pragma unroll
@@ -654,7 +676,7 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
                         const unsigned U = U0 + 64 * j;
                         const size_t step = ((size_t)(U >> LOG_C) << log_stride) + (U & (C - 1));
                         const u64 w = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ra.twid + base0 + step) + off0);
-                        u64 v = limb_mul(tile[ntt::pad_idx(e0 + 64 * j)], w);
+                        u64 v = limb_mul(tile[tix(se0, e0, 64 * j)], w);
                         *reinterpret_cast<u64 *>(reinterpret_cast<char *>(out + step) + off0) = a.canon_out ? gl::canon(v) : v;
                     }
                 }

@@ -44,10 +44,10 @@ def _tamperings():
         pf["final_poly"][0][0] = (int(pf["final_poly"][0][0]) + 1) % P
 
     def opening(pf, op):
-        op[0][5][1] = (int(op[0][5][1]) + 1) % P
+        op[0][-2][1] = (int(op[0][-2][1]) + 1) % P
 
     def next_opening(pf, op):
-        op[1][1][0] = (int(op[1][1][0]) + 1) % P
+        op[1][-1][0] = (int(op[1][-1][0]) + 1) % P
 
     def leaf(pf, op):
         q = pf["query_round_proofs"][3]

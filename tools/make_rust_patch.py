@@ -269,6 +269,36 @@ fn fri_prover_query_rounds<
 ''')])
     # ---- MerkleTree
     edit(os.path.join(b, "plonky2/src/hash/merkle_tree.rs"), [
+        # equality is the VALUE (leaf rows, digests, cap).  Under the feature the leaf matrix / digests of a GPU-built tree live behind
+        # `device` with the fields empty, so the derived field-by-field comparison would call such a tree unequal to its own
+        # serialise / deserialise round trip (examples/square_root.rs:152 asserts that equality of CircuitData): written by hand
+        ('''#[derive(Clone, Debug, Eq, PartialEq)]
+pub struct MerkleTree<F: RichField, H: Hasher<F>> {
+''', '''#[derive(Clone, Debug)]
+#[cfg_attr(not(feature = "p2hot"), derive(Eq, PartialEq))]
+pub struct MerkleTree<F: RichField, H: Hasher<F>> {
+'''),
+        ('''impl<F: RichField, H: Hasher<F>> Default for MerkleTree<F, H> {
+''', '''/// Value equality with the `p2hot` feature: the leaf rows (through `get`: `leaves`, or the flat buffer / the GPU behind `device`),
+/// the digests (the field, or the device's copy when the field was left empty) and the cap.
+#[cfg(feature = "p2hot")]
+impl<F: RichField, H: Hasher<F>> PartialEq for MerkleTree<F, H> {
+    fn eq(&self, other: &Self) -> bool {
+        if self.cap != other.cap || self.num_leaves() != other.num_leaves() {
+            return false;
+        }
+        let digests_eq = match (self.digests.is_empty(), other.digests.is_empty()) {
+            (false, false) => self.digests == other.digests,
+            _ => self.digests_or_device() == other.digests_or_device(),
+        };
+        digests_eq && (0..self.num_leaves()).all(|i| self.get(i) == other.get(i))
+    }
+}
+#[cfg(feature = "p2hot")]
+impl<F: RichField, H: Hasher<F>> Eq for MerkleTree<F, H> {}
+
+impl<F: RichField, H: Hasher<F>> Default for MerkleTree<F, H> {
+'''),
         ('''    /// The Merkle cap.
     pub cap: MerkleCap<F, H>,
 }
@@ -346,6 +376,18 @@ fn fri_prover_query_rounds<
             }
         }
         self.leaves.len()
+    }
+
+    /// `digests`, or -- when the field was left empty because the digests stayed on the GPU (P2HOT_LEAVES=device) -- the
+    /// device's copy of them, in the same (reference) layout
+    #[cfg(feature = "p2hot")]
+    pub fn digests_or_device(&self) -> alloc::borrow::Cow<'_, [H::Hash]> {
+        if self.digests.is_empty() {
+            if let Some(device) = &self.device {
+                return alloc::borrow::Cow::Owned(device.digests::<H>());
+            }
+        }
+        alloc::borrow::Cow::Borrowed(&self.digests)
     }
 
     pub fn new(leaves: Vec<Vec<F>>, cap_height: usize) -> Self {
