@@ -205,6 +205,47 @@ def host_pointer_lines(eng, out, reps):
         "buffer every call (what a fresh Vec is: a page fault per 4 KiB while the copy runs)", True, True, True, "c3_wires", reps=2, per_column=True, leaves_mem="fresh")
     run("host_c3_wires_leaves_back_pinned", 135, 20, base + "as host_c3_wires_leaves_back, but the leaf matrix lands in a block of the context's PINNED "
         "cache (p2hot_host_alloc / _free around every call: the Rust shim's flat leaf store)", True, True, True, "c3_wires", reps=2, per_column=True, leaves_mem="pinned")
+    # P2HOT_LEAVES_ASYNC | P2HOT_LEAVES_NATURAL (the shim's mode from round 5 on): the call returns with cap + coefficients + digests,
+    # the leaf matrix keeps travelling into the pinned block in 64 row blocks behind fences (p2hot_batch_leaves_wait)
+    def run_async(name, W, log_n, what, gname, reps=2):
+        n, N = 1 << log_n, 1 << (log_n + rb)
+        cols = [np.ascontiguousarray(c) for c in splitmix_columns_numpy(0, W, n)]
+        ptrs = (C.c_void_p * W)(*[c.ctypes.data for c in cols])
+        coeffs = np.zeros((W, n), dtype=np.uint64)
+        table = (C.c_void_p * W)(*[coeffs[c].ctypes.data for c in range(W)])
+        digests = np.zeros((eng.num_digests(log_n + rb, cap), 4), dtype=np.uint64)
+        capv = np.zeros((1 << cap, 4), dtype=np.uint64)
+        t_call, t_first, t_last = [], [], []
+
+        def once(timed):
+            h, blk = C.c_void_p(), C.c_void_p()
+            eng.check(eng.lib.p2hot_host_alloc(eng.ctx, N * W * 8, C.byref(blk)))
+            t0 = time.perf_counter()
+            eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1, 2 | 4 | 8, C.cast(table, C.c_void_p), blk, digests.ctypes.data,
+                                           capv.ctypes.data, C.byref(h)))
+            t1 = time.perf_counter()
+            eng.check(eng.lib.p2hot_batch_leaves_wait(h, 0, 1))
+            t2 = time.perf_counter()
+            eng.check(eng.lib.p2hot_batch_leaves_wait(h, 0, N))
+            t3 = time.perf_counter()
+            if timed:
+                t_call.append((t1 - t0) * 1e3), t_first.append((t2 - t0) * 1e3), t_last.append((t3 - t0) * 1e3)
+            # the natural-order buffer: row 1 is committed row N / 2 (reverse_bits(1)), served by the handle in the committed indexing
+            row = np.frombuffer((C.c_uint64 * W).from_address(blk.value + 8 * W), dtype=np.uint64).copy()
+            idx = np.array([N // 2], dtype=np.uint64)
+            got = np.zeros((1, W), dtype=np.uint64)
+            eng.check(eng.lib.p2hot_batch_rows(h, idx.ctypes.data, 1, got.ctypes.data))
+            eng.lib.p2hot_batch_free(h)
+            eng.lib.p2hot_host_free(eng.ctx, blk)
+            return bool((row == got[0]).all())
+        once(False)
+        rows_ok = all([once(True) for _ in range(reps)])
+        g = golden(gname) if gname else None
+        out[name] = {"workload": what, "ms": sum(t_call) / reps, "ms_first_block": sum(t_first) / reps, "ms_last_row": sum(t_last) / reps,
+                     "pcie_inclusive": True, "natural_order_row_checked": rows_ok, **({"cap_checked": capv.tolist() == g["cap"]} if g else {})}
+
+    run_async("host_c3_wires_leaves_async", 135, 20, base + "as host_c3_wires_leaves_back_pinned with P2HOT_LEAVES_ASYNC | P2HOT_LEAVES_NATURAL: `ms` = the call "
+              "(cap + coefficients + digests back), `ms_first_block` = the first 1/64 of the rows fenced, `ms_last_row` = the whole 9.1 GB matrix landed", "c3_wires")
     # the other two commitments of a proof in the shim's default mode (leaves back): one column block each
     run("host_c3_zs_leaves_back", 20, 20, "p2hot_commit (host pointers, pageable memory) C3 Zs + partial products: from_values W=20, 2^20 rows; "
         "coefficients + digests + cap + the 1.3 GB leaf matrix out", True, True, True, "c3_zs_partial_products", reps=3)

@@ -253,6 +253,19 @@ int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bit
  * n coefficients go to table[c] -- the caller's `polynomials: Vec<PolynomialCoeffs<F>>` (fri/oracle.rs:32) is W separate
  * vectors, and with this flag each is filled in place instead of being split out of one flat block afterwards */
 #define P2HOT_COEFFS_PER_COLUMN 2u
+/* p2hot_commit / _salted with leaves_out AND handle_out: the call returns when the cap, the coefficients and the digests are back;
+ * the row-major leaf matrix (9.1 GB at the C3 wires shape: 3 x the rest of the call over PCIe) keeps travelling into leaves_out on
+ * the context's leaf-copy stream, in 64 consecutive row blocks, first block first.  A row may be READ only after
+ * p2hot_batch_leaves_wait(handle, row_lo, row_hi) covered it; the buffer may be FREED only after p2hot_batch_free(handle) (which
+ * waits for the copy) or a wait over all rows.  leaves_out should be pinned (p2hot_host_alloc): a pageable destination makes the
+ * copy a synchronous one.  The next commitments, the partial products and the quotient run beside the copy. */
+#define P2HOT_LEAVES_ASYNC 4u
+/* leaves_out in NATURAL LDE order instead of the committed order: leaves_out[i] = merkle_tree.leaves[reverse_bits(i, log2 N)], i.e.
+ * `transpose(lde_values)` without the `reverse_index_bits_in_place` of fri/oracle.rs:97-98.  get_lde_values(i, step) (oracle.rs:142-147)
+ * is then row i * step of the buffer, so the quotient loop of plonk/prover.rs:712-722 walks the buffer FORWARD -- the order the
+ * P2HOT_LEAVES_ASYNC blocks arrive in -- and MerkleTree::get(r) is row reverse_bits(r).  p2hot_batch_rows / _paths and the proofs keep
+ * the committed indexing: only the host copy's row order changes. */
+#define P2HOT_LEAVES_NATURAL 8u
 
 typedef struct p2hot_batch p2hot_batch;
 typedef struct p2hot_cols p2hot_cols;
@@ -262,7 +275,8 @@ typedef struct p2hot_cols p2hot_cols;
  * coeffs_out [W][n], leaves_out [N][W], digests_out, cap_out: caller-allocated or NULL (anything not asked for is not
  * copied back: the leaf matrix is 9 GB at the C3 shape, and the query phase needs only a few dozen rows and paths).
  * handle_out (optional): the device-resident batch for p2hot_batch_rows / _paths / _coeffs, p2hot_eval_openings and
- * p2hot_prove_openings; free with p2hot_batch_free.  flags: P2HOT_KEEP_VALUES, P2HOT_COEFFS_PER_COLUMN.
+ * p2hot_prove_openings; free with p2hot_batch_free.  flags: P2HOT_KEEP_VALUES, P2HOT_COEFFS_PER_COLUMN, P2HOT_LEAVES_ASYNC,
+ * P2HOT_LEAVES_NATURAL.
  * W = 0 is P2HOT_EINVAL for every commit entry point (the reference panics on polynomials[0], fri/oracle.rs:90). */
 int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
                  unsigned cap_height, int is_values, unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out,
@@ -317,6 +331,10 @@ int p2hot_batch_rows(p2hot_batch *batch, const uint64_t *row_idx, size_t m, uint
 int p2hot_batch_paths(p2hot_batch *batch, const uint64_t *leaf_idx, size_t m, uint64_t *out);
 /* merkle_tree.digests (reference layout, hash/merkle_tree.rs:50-57): out [p2hot_num_digests(log2 N, cap_height)][4] */
 int p2hot_batch_digests(p2hot_batch *batch, uint64_t *out);
+/* P2HOT_LEAVES_ASYNC: blocks until rows [row_lo, row_hi) of the caller's leaves_out (in ITS row order: natural with
+ * P2HOT_LEAVES_NATURAL, committed otherwise) have landed.  A batch without a pending copy returns at once; row_hi beyond the
+ * leaf count or row_lo > row_hi is EINVAL.  This is the fence behind MerkleTree::get (hash/merkle_tree.rs:227) in the Rust shim. */
+int p2hot_batch_leaves_wait(p2hot_batch *batch, size_t row_lo, size_t row_hi);
 /* the kept input values (P2HOT_KEEP_VALUES) as a BORROWED column set: valid while the batch lives; p2hot_cols_free on
  * the view leaves the batch's memory alone */
 int p2hot_batch_values(p2hot_batch *batch, p2hot_cols **out);

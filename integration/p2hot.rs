@@ -43,7 +43,7 @@
 
 use core::any::type_name;
 use core::ffi::{c_char, c_int, c_uint, c_void};
-use core::sync::atomic::{AtomicBool, Ordering};
+use core::sync::atomic::{AtomicBool, AtomicUsize, Ordering};
 use std::collections::HashMap;
 use std::sync::{Mutex, OnceLock};
 
@@ -70,7 +70,7 @@ use crate::plonk::plonk_common::reduce_with_powers_multi;
 use crate::plonk::vanishing_poly::evaluate_gate_constraints_base_batch;
 use crate::plonk::vars::EvaluationVarsBaseBatch;
 use crate::util::strided_view::PackedStridedView;
-use crate::util::{log2_ceil, log2_strict};
+use crate::util::{log2_ceil, log2_strict, reverse_bits};
 
 // ------------------------------------------------------------------------------------------------
 // Raw bindings: one declaration per symbol of include/p2hot.h, same order.
@@ -170,6 +170,8 @@ pub type P2hotAllgatherFn = Option<
 pub const P2HOT_OK: c_int = 0;
 pub const P2HOT_KEEP_VALUES: c_uint = 1;
 pub const P2HOT_COEFFS_PER_COLUMN: c_uint = 2;
+pub const P2HOT_LEAVES_ASYNC: c_uint = 4;
+pub const P2HOT_LEAVES_NATURAL: c_uint = 8;
 
 #[link(name = "p2hot")]
 extern "C" {
@@ -278,6 +280,7 @@ extern "C" {
     pub fn p2hot_batch_rows(batch: *mut P2hotBatch, row_idx: *const u64, m: usize, out: *mut u64) -> c_int;
     pub fn p2hot_batch_paths(batch: *mut P2hotBatch, leaf_idx: *const u64, m: usize, out: *mut u64) -> c_int;
     pub fn p2hot_batch_digests(batch: *mut P2hotBatch, out: *mut u64) -> c_int;
+    pub fn p2hot_batch_leaves_wait(batch: *mut P2hotBatch, row_lo: usize, row_hi: usize) -> c_int;
     pub fn p2hot_batch_values(batch: *mut P2hotBatch, out: *mut *mut P2hotCols) -> c_int;
     pub fn p2hot_batch_subgroup_values(batch: *mut P2hotBatch, first: usize, count: usize, out: *mut *mut P2hotCols) -> c_int;
     pub fn p2hot_batch_free(batch: *mut P2hotBatch);
@@ -553,8 +556,13 @@ pub struct DeviceTree<F: RichField> {
     num_leaves: usize,
     num_layers: usize,
     /// P2HOT_LEAVES=host (default): the whole leaf matrix, row-major [num_leaves][width], exactly the buffer the library
-    /// filled (`leaves_out`) -- ONE allocation; empty when the matrix stayed on the GPU
+    /// filled (`leaves_out`) -- ONE allocation; empty when the matrix stayed on the GPU.  Rows in NATURAL LDE order
+    /// (P2HOT_LEAVES_NATURAL): buffer row i is `leaves[reverse_bits(i)]`, so `get_lde_values(i, step)` reads row i * step and
+    /// the quotient loop (plonk/prover.rs:712-722) walks the buffer forward
     flat: FlatLeaves<F>,
+    /// P2HOT_LEAVES_ASYNC: the buffer rows [0, landed) are known to have arrived (the copy delivers row blocks in order, first
+    /// block first); `num_leaves` once everything has.  A reader of a row at or beyond it asks `p2hot_batch_leaves_wait` first
+    landed: AtomicUsize,
     /// rows fetched so far in the device mode: `get` hands out `&[F]`, so fetched rows are kept (never moved) for the tree's lifetime
     rows: Mutex<HashMap<usize, Box<[F]>>>,
 }
@@ -580,7 +588,10 @@ impl<F: RichField> DeviceTree<F> {
     pub fn row(&self, i: usize) -> &[F] {
         let flat = self.flat.as_slice();
         if !flat.is_empty() {
-            return &flat[i * self.width..(i + 1) * self.width]; // panics on i >= num_leaves like `&self.leaves[i]`
+            assert!(i < self.num_leaves, "index out of bounds: the len is {} but the index is {}", self.num_leaves, i); // as `&self.leaves[i]`
+            let r = reverse_bits(i, self.num_leaves.trailing_zeros() as usize); // committed index -> buffer (natural) row
+            self.fence(r);
+            return &flat[r * self.width..(r + 1) * self.width];
         }
         let mut cache = self.rows.lock().unwrap();
         if !cache.contains_key(&i) {
@@ -595,14 +606,33 @@ impl<F: RichField> DeviceTree<F> {
         unsafe { core::slice::from_raw_parts(r.as_ptr(), r.len()) }
     }
 
+    /// The fence of the asynchronous leaf copy: returns once buffer row `r` has landed.  The copy delivers the buffer front to
+    /// back, so one atomic load serves every row below the mark; beyond it the library waits on the row block's event
+    /// (`p2hot_batch_leaves_wait` takes no context lock: rayon workers of the quotient loop call it side by side).
+    fn fence(&self, r: usize) {
+        if r < self.landed.load(Ordering::Acquire) {
+            return;
+        }
+        let rc = unsafe { p2hot_batch_leaves_wait(self.batch, r, r + 1) };
+        assert!(rc == P2HOT_OK, "libp2hot p2hot_batch_leaves_wait failed ({rc})");
+        self.landed.fetch_max(r + 1, Ordering::AcqRel);
+    }
+
+    /// waits for the whole leaf matrix (serializers, `leaves_as_vecs`, equality: readers that walk every row)
+    pub fn fence_all(&self) {
+        if self.num_leaves > 0 && !self.flat.as_slice().is_empty() {
+            self.fence(self.num_leaves - 1);
+        }
+    }
+
     /// the reference's `leaves: Vec<Vec<F>>` (merkle_tree.rs:47) rebuilt from the flat buffer, rows in parallel
     /// (P2HOT_LEAVES=vec, and the bit-exact harness, which compares the field itself)
     pub fn leaves_as_vecs(&self) -> Vec<Vec<F>> {
-        let flat = self.flat.as_slice();
-        if flat.is_empty() {
+        if self.flat.as_slice().is_empty() {
             return (0..self.num_leaves).map(|i| self.row(i).to_vec()).collect();
         }
-        flat.par_chunks_exact(self.width.max(1)).map(|r| r.to_vec()).collect()
+        self.fence_all();
+        (0..self.num_leaves).into_par_iter().map(|i| self.row(i).to_vec()).collect() // committed order out of the natural-order buffer
     }
 
     /// merkle_tree_prove (merkle_tree.rs:151-190)
@@ -671,10 +701,16 @@ pub(crate) fn commit_with_salts<F: RichField + Extendable<D>, C: GenericConfig<D
     let mut cap = Out::<<C::Hasher as Hasher<F>>::Hash>::new(1 << cap_height, true);
     let mut digests = Out::<<C::Hasher as Hasher<F>>::Hash>::new(num_digests, !on_device);
     let mut flat_leaves = FlatLeaves::<F>::for_output(if on_device { 0 } else { big_n * lw });
+    // the leaf matrix comes back in natural LDE order, and -- into a pinned block -- ASYNCHRONOUSLY: the call returns with the cap,
+    // the coefficients and the digests (about a third of the time at the wires shape), the 9 GB matrix keeps landing block by block
+    // behind `DeviceTree::fence` while the partial products, the Zs commitment and the first quotient batches run.  Into a heap
+    // Vec the copy would be synchronous anyway (pageable memory), and P2HOT_LEAVES_SYNC=1 asks for that on purpose
+    let async_leaves = !on_device && matches!(flat_leaves, FlatLeaves::Pinned { .. }) && std::env::var_os("P2HOT_LEAVES_SYNC").is_none();
+    let flags = P2HOT_COEFFS_PER_COLUMN | if on_device { 0 } else { P2HOT_LEAVES_NATURAL } | if async_leaves { P2HOT_LEAVES_ASYNC } else { 0 };
     with_ctx(|ctx| {
         let rc = unsafe {
             p2hot_commit_salted(
-                ctx, ptrs.as_ptr(), w, log_n as c_uint, rate_bits as c_uint, cap_height as c_uint, is_values as c_int, P2HOT_COEFFS_PER_COLUMN,
+                ctx, ptrs.as_ptr(), w, log_n as c_uint, rate_bits as c_uint, cap_height as c_uint, is_values as c_int, flags,
                 salt_ptrs.as_ptr(), salt_ptrs.len(), coeff_ptrs.as_ptr() as *mut u64, flat_leaves.ptr(), digests.ptr(), cap.ptr(), &mut handle,
             )
         };
@@ -691,6 +727,7 @@ pub(crate) fn commit_with_salts<F: RichField + Extendable<D>, C: GenericConfig<D
         num_leaves: big_n,
         num_layers: log_n + rate_bits - cap_height,
         flat: flat_leaves,
+        landed: AtomicUsize::new(if async_leaves { 0 } else { big_n }),
         rows: Mutex::new(HashMap::new()),
     });
     let leaves: Vec<Vec<F>> = if leaves_as_vecs() { device.leaves_as_vecs() } else { Vec::new() };

@@ -16,6 +16,8 @@ _ERR_NAMES = {EINVAL: "EINVAL", ENOMEM: "ENOMEM", EHIP: "EHIP", EUNSUPPORTED: "E
               ECOMM: "ECOMM"}
 KEEP_VALUES = 1
 COEFFS_PER_COLUMN = 2
+LEAVES_ASYNC = 4
+LEAVES_NATURAL = 8
 
 vp = C.c_void_p
 sz = C.c_size_t
@@ -105,6 +107,7 @@ SIGNATURES = {
     "p2hot_batch_rows": (i, [vp, vp, sz, vp]),
     "p2hot_batch_paths": (i, [vp, vp, sz, vp]),
     "p2hot_batch_digests": (i, [vp, vp]),
+    "p2hot_batch_leaves_wait": (i, [vp, sz, sz]),
     "p2hot_batch_values": (i, [vp, C.POINTER(vp)]),
     "p2hot_batch_subgroup_values": (i, [vp, sz, sz, C.POINTER(vp)]),
     "p2hot_batch_free": (None, [vp]),

@@ -113,7 +113,12 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     P2_TRY(check_log(ctx, log_n + rate_bits, "commit"));
     if (W == 0) P2_FAIL(ctx, P2HOT_EINVAL, "commit: no polynomials (the reference panics on polynomials[0], fri/oracle.rs:90)");
     if (!cols) P2_FAIL(ctx, P2HOT_EINVAL, "commit: null column table");
-    if (flags & ~(unsigned)(P2HOT_KEEP_VALUES | P2HOT_COEFFS_PER_COLUMN)) P2_FAIL(ctx, P2HOT_EINVAL, "commit: unknown flags %#x", flags);
+    if (flags & ~(unsigned)(P2HOT_KEEP_VALUES | P2HOT_COEFFS_PER_COLUMN | P2HOT_LEAVES_ASYNC | P2HOT_LEAVES_NATURAL))
+        P2_FAIL(ctx, P2HOT_EINVAL, "commit: unknown flags %#x", flags);
+    if ((flags & P2HOT_LEAVES_ASYNC) && !(leaves_out && handle_out))
+        P2_FAIL(ctx, P2HOT_EINVAL, "commit: P2HOT_LEAVES_ASYNC needs leaves_out and handle_out (the handle owns the copy in flight)");
+    if ((flags & P2HOT_LEAVES_NATURAL) && !leaves_out) P2_FAIL(ctx, P2HOT_EINVAL, "commit: P2HOT_LEAVES_NATURAL without leaves_out");
+    const bool async_leaves = (flags & P2HOT_LEAVES_ASYNC) != 0;
     // P2HOT_COEFFS_PER_COLUMN: coeffs_out is a table of W host pointers (one Vec per polynomial on the caller's side)
     uint64_t *const *coeffs_cols = (flags & P2HOT_COEFFS_PER_COLUMN) ? reinterpret_cast<uint64_t *const *>(coeffs_out) : nullptr;
     if (coeffs_cols)
@@ -185,6 +190,8 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             tail_groups *= 2;
     std::vector<hipEvent_t> tail_ev;
     [[maybe_unused]] hipEvent_t leaves_ev = nullptr;
+    const unsigned leaf_rev = (flags & P2HOT_LEAVES_NATURAL) ? log_N : 0u;  // (log_N == 0: one row, nothing to reverse)
+    p2hot_batch::LeafCopy *leafcopy = nullptr;  // P2HOT_LEAVES_ASYNC: handed to the batch handle at the end
     auto absorb_upto = [&](size_t cols_done, bool may_finish) -> int {  // cols_done leaf columns of d_lde are final
         const unsigned end = (cols_done >= LW && may_finish) ? (unsigned)LW : (unsigned)((cols_done < LW ? cols_done : LW - 1) / 8 * 8);
         if (end <= hashed) return P2HOT_OK;
@@ -231,8 +238,8 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             P2_TRY(launch_bitrev(ctx, d_salt.u(), d_lde.u() + W * N, S, N, N, log_N));
         }
         if (leaves_first) {  // the row-major matrix before the sponge: its copy starts while the leaves are hashed
-            P2_TRY(p2hot_transpose_dev(ctx, d_lde.u(), N, LW, N, d_leaves.u()));
-            if (two_streams) {
+            P2_TRY(transpose_rows(ctx, d_lde.u(), N, LW, N, d_leaves.u(), leaf_rev));
+            if (two_streams || async_leaves) {
                 P2_HIP(ctx, hipEventCreateWithFlags(&leaves_ev, hipEventDisableTiming));
                 P2_HIP(ctx, hipEventRecord(leaves_ev, ctx->stream));
             }
@@ -259,7 +266,13 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         } else {
             P2_TRY(p2hot_merkle_dev(ctx, d_lde.u(), 0, N, LW, log_N, cap_height, 0, N, d_dig.u(), d_cap.u()));
         }
-        if (leaves_out && LW && !leaves_first) P2_TRY(p2hot_transpose_dev(ctx, d_lde.u(), N, LW, N, d_leaves.u()));
+        if (leaves_out && LW && !leaves_first) {
+            P2_TRY(transpose_rows(ctx, d_lde.u(), N, LW, N, d_leaves.u(), leaf_rev));
+            if (async_leaves) {
+                P2_HIP(ctx, hipEventCreateWithFlags(&leaves_ev, hipEventDisableTiming));
+                P2_HIP(ctx, hipEventRecord(leaves_ev, ctx->stream));
+            }
+        }
         // coefficient blocks go back while the leaf sponge runs: queued behind the uploads on the copy stream, each
         // waiting for its block's transform only
         if (coeffs_out)
@@ -273,7 +286,28 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
                     P2_HIP(ctx, hipMemcpyAsync(coeffs_out + c0 * n, d_work.u() + c0 * n, cnt * n * 8, hipMemcpyDeviceToHost, copy_stream));
                 }
             }
-        if (leaves_out && LW) {
+        if (leaves_out && LW && async_leaves) {
+            // the matrix leaves in row blocks on a stream of its own, each block fenced by an event; this call does not wait for it
+            if (!ctx->leaf_stream) P2_HIP(ctx, hipStreamCreateWithFlags(&ctx->leaf_stream, hipStreamNonBlocking));
+            P2_HIP(ctx, hipStreamWaitEvent(ctx->leaf_stream, leaves_ev, 0));
+            leafcopy = new p2hot_batch::LeafCopy();
+            leafcopy->ev.reserve(66);
+            leafcopy->rows = N;
+            leafcopy->aux = leaves_ev;  // the leaf stream's wait on it may not have run yet: destroyed with the copy, not with this call
+            leaves_ev = nullptr;
+            size_t blocks = 64;
+            while (blocks > 1 && N / blocks < 1024) blocks >>= 1;  // (rows per block stays a power of two: N is one)
+            if (blocks > N) blocks = N;
+            leafcopy->rows_per_block = N / blocks;
+            const size_t bw = leafcopy->rows_per_block * LW;  // words per block
+            for (size_t k = 0; k < blocks; ++k) {
+                P2_HIP(ctx, hipMemcpyAsync(leaves_out + k * bw, d_leaves.u() + k * bw, bw * 8, hipMemcpyDeviceToHost, ctx->leaf_stream));
+                hipEvent_t e;
+                P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                leafcopy->ev.push_back(e);
+                P2_HIP(ctx, hipEventRecord(e, ctx->leaf_stream));
+            }
+        } else if (leaves_out && LW) {
             hipStream_t ls = ctx->stream;
             if (leaves_ev) {
                 P2_HIP(ctx, hipStreamWaitEvent(copy_stream, leaves_ev, 0));
@@ -304,7 +338,40 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     rc = sync_checked(ctx, rc, "commit");
     if (rc == P2HOT_OK && e1 != hipSuccess) P2_FAIL(ctx, P2HOT_EHIP, "commit: %s", hipGetErrorString(e1));
     if (rc == P2HOT_OK && handle_out) *handle_out = make_batch(ctx, d_lde, d_dig, d_work, keep_vals ? &d_vals : nullptr, W, log_n, rate_bits, cap_height, S);
+    if (leafcopy) {
+        if (rc == P2HOT_OK && handle_out && *handle_out) {
+            leafcopy->d_staging = d_leaves.p;  // stays alive behind the handle until the last block has landed
+            d_leaves.p = nullptr;
+            (*handle_out)->leafcopy = leafcopy;
+        } else {  // a failed call leaves nothing in flight
+            (void)hipStreamSynchronize(ctx->leaf_stream);
+            for (hipEvent_t ev : leafcopy->ev) (void)hipEventDestroy(ev);
+            if (leafcopy->aux) (void)hipEventDestroy(leafcopy->aux);
+            delete leafcopy;
+        }
+    }
     return rc;
+}
+
+static void leafcopy_finish(p2hot_batch *b) {  // waits for the copy in flight and returns its staging block
+    if (!b || !b->leafcopy) return;
+    if (b->ctx->leaf_stream) (void)hipStreamSynchronize(b->ctx->leaf_stream);
+    for (hipEvent_t ev : b->leafcopy->ev) (void)hipEventDestroy(ev);
+    if (b->leafcopy->aux) (void)hipEventDestroy(b->leafcopy->aux);
+    pool_release(b->ctx, b->leafcopy->d_staging);
+    delete b->leafcopy;
+    b->leafcopy = nullptr;
+}
+
+extern "C" int p2hot_batch_leaves_wait(p2hot_batch *b, size_t row_lo, size_t row_hi) {
+    if (!b) return P2HOT_EINVAL;
+    p2hot_ctx *ctx = b->ctx;
+    if (row_lo > row_hi || row_hi > b->N) P2_FAIL(ctx, P2HOT_EINVAL, "leaves_wait: rows [%zu, %zu) of %zu", row_lo, row_hi, b->N);
+    if (!b->leafcopy || row_lo == row_hi) return P2HOT_OK;
+    DeviceGuard dev_guard_(ctx);
+    const size_t rpb = b->leafcopy->rows_per_block;
+    for (size_t k = row_lo / rpb; k <= (row_hi - 1) / rpb; ++k) P2_HIP(ctx, hipEventSynchronize(b->leafcopy->ev[k]));
+    return P2HOT_OK;
 }
 
 extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
@@ -617,6 +684,7 @@ extern "C" int p2hot_batch_paths(p2hot_batch *b, const uint64_t *leaf_idx, size_
 
 extern "C" void p2hot_batch_free(p2hot_batch *b) {
     if (!b) return;
+    leafcopy_finish(b);  // P2HOT_LEAVES_ASYNC: the caller's buffer is complete (and the staging block idle) when this returns
     if (b->shared) {  // a member of a batched commitment: the last one returns the blocks
         if (b->shared->refs.fetch_sub(1) == 1) {
             (void)hipStreamSynchronize(b->ctx->stream);

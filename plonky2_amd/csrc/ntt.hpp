@@ -478,7 +478,8 @@ __global__ void canon_kernel(u64 *data, size_t count) {
 
 // column-major [W][rows] (stride between columns) -> row-major [rows][W]
 // (plonky2/src/util/mod.rs:25-31 transpose).  64-row x 32-column LDS tile.
-__global__ void __launch_bounds__(256) transpose_kernel(const u64 *in, size_t stride, unsigned W, size_t rows, u64 *out) {
+// rev_bits > 0: the destination row of source row r is reverse_bits(r, rev_bits) (a row is still written as 256-byte pieces)
+__global__ void __launch_bounds__(256) transpose_kernel(const u64 *in, size_t stride, unsigned W, size_t rows, u64 *out, unsigned rev_bits) {
     __shared__ u64 t[32][65];
     const size_t r0 = (size_t)blockIdx.x * 64;
     const unsigned c0 = blockIdx.y * 32;
@@ -490,7 +491,11 @@ __global__ void __launch_bounds__(256) transpose_kernel(const u64 *in, size_t st
     __syncthreads();
     for (unsigned e = tid; e < 32 * 64; e += 256) {
         unsigned r = e >> 5, c = e & 31;
-        if (c0 + c < W && r0 + r < rows) out[(r0 + r) * W + c0 + c] = gl::canon(t[c][r]);
+        if (c0 + c < W && r0 + r < rows) {
+            const size_t src = r0 + r;
+            const size_t dst = rev_bits ? (size_t)(__brevll((unsigned long long)src) >> (64 - rev_bits)) : src;
+            out[dst * W + c0 + c] = gl::canon(t[c][r]);
+        }
     }
 }
 

@@ -51,6 +51,7 @@ struct p2hot_ctx {
     unsigned limb_tiles_log = 4;  // contiguous limb passes: a workgroup stages its tables once for 2^this tiles (P2HOT_LIMB_TILES_LOG)
     // second stream: the VALU-bound leaf sponge of coset block b runs beside the wait-bound NTT of block b+1
     hipStream_t side = nullptr;
+    hipStream_t leaf_stream = nullptr;  // P2HOT_LEAVES_ASYNC: the leaf matrix's row blocks travel here, beside everything else (created on first use)
     std::vector<hipEvent_t> fork_events;
     hipEvent_t join_event = nullptr;
     bool overlap = false;
@@ -480,6 +481,10 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
     if (ctx->side) {
         (void)hipStreamSynchronize(ctx->side);
         (void)hipStreamDestroy(ctx->side);
+    }
+    if (ctx->leaf_stream) {
+        (void)hipStreamSynchronize(ctx->leaf_stream);
+        (void)hipStreamDestroy(ctx->leaf_stream);
     }
     for (auto e : ctx->fork_events) (void)hipEventDestroy(e);
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
@@ -1020,18 +1025,26 @@ extern "C" int p2hot_coset_lde_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, siz
                    scol, true, srow2, sbase);
 }
 
-extern "C" int p2hot_transpose_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W,
-                                   size_t rows, uint64_t *d_rowmajor) {
+// rev_bits > 0: row r of the column-major matrix lands in row reverse_bits(r, rev_bits) of the row-major one (rows == 2^rev_bits):
+// the committed LDE matrix back in NATURAL order (P2HOT_LEAVES_NATURAL)
+static int transpose_rows(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W, size_t rows, uint64_t *d_rowmajor,
+                          unsigned rev_bits) {
     if (!ctx) return P2HOT_EINVAL;
     DeviceGuard dev_guard_(ctx);
     if (W == 0 || rows == 0) return P2HOT_OK;
     if (!d_colmajor || !d_rowmajor || col_stride < rows) P2_FAIL(ctx, P2HOT_EINVAL, "transpose: bad arguments");
     if (cdiv(W, 32) > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "transpose: W too large");
+    if (rev_bits && rows != (size_t)1 << rev_bits) P2_FAIL(ctx, P2HOT_EINVAL, "transpose: a bit-reversed destination needs 2^bits rows");
     ProfScope ps(ctx, "transpose");
     P2HOT_LAUNCH(ntt::transpose_kernel, dim3(cdiv(rows, 64), cdiv(W, 32)), dim3(256), 0, ctx->stream, d_colmajor,
-                 col_stride, (unsigned)W, rows, d_rowmajor);
+                 col_stride, (unsigned)W, rows, d_rowmajor, rev_bits);
     P2_LAUNCH_CHECK(ctx);
     return P2HOT_OK;
+}
+
+extern "C" int p2hot_transpose_dev(p2hot_ctx *ctx, const uint64_t *d_colmajor, size_t col_stride, size_t W,
+                                   size_t rows, uint64_t *d_rowmajor) {
+    return transpose_rows(ctx, d_colmajor, col_stride, W, rows, d_rowmajor, 0);
 }
 
 extern "C" int p2hot_reverse_index_bits_dev(p2hot_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t batch,
@@ -1818,6 +1831,14 @@ struct p2hot_batch {
     // blocks are shared and go back to the pool with the last member
     size_t lde_stride = 0, coef_stride = 0;  // elements between consecutive columns; 0 = N / n
     struct SharedBlocks *shared = nullptr;
+    // P2HOT_LEAVES_ASYNC: the row-major leaf matrix still travelling to the caller's buffer -- its device staging block, one event
+    // per row block (rows [k * rows_per_block, ...) of the CALLER's row order), on the context's leaf stream
+    struct LeafCopy {
+        void *d_staging = nullptr;
+        std::vector<hipEvent_t> ev;
+        hipEvent_t aux = nullptr;  // "the matrix is transposed": what the leaf stream waits for before the first block
+        size_t rows_per_block = 0, rows = 0;
+    } *leafcopy = nullptr;
     size_t col_stride_lde() const { return lde_stride ? lde_stride : N; }
     size_t col_stride_coef() const { return coef_stride ? coef_stride : ((size_t)1 << log_n); }
 };

@@ -348,8 +348,15 @@ def test_leaf_matrix_is_one_flat_buffer_behind_get():
     assert "flat: flat_leaves" in body and "P2HOT_COEFFS_PER_COLUMN" in body
     assert not re.search(r"\.chunks_exact\([^)]*\)\s*\.map\(\|\w+\|\s*\w+\.to_vec\(\)\)", body), "a serial per-row / per-column copy is back"
     assert "if leaves_as_vecs() { device.leaves_as_vecs() } else { Vec::new() }" in body
-    assert re.search(r"fn row\(&self, i: usize\) -> &\[F\] \{\s*let flat = self\.flat\.as_slice\(\);\s*if !flat\.is_empty\(\) \{\s*return &flat\[i \* self\.width\.\.\(i \+ 1\) \* self\.width\]", s)
-    assert "flat.par_chunks_exact(" in s                                        # the Vec<Vec<F>> form, when asked for, is built in parallel
+    # round 5: the buffer is in natural LDE order and lands asynchronously -- `row` maps the committed index, fences, then slices
+    assert re.search(r"fn row\(&self, i: usize\) -> &\[F\] \{\s*let flat = self\.flat\.as_slice\(\);\s*if !flat\.is_empty\(\) \{.{0,400}?let r = reverse_bits\(i, [^;]*;.{0,200}?"
+                     r"self\.fence\(r\);\s*return &flat\[r \* self\.width\.\.\(r \+ 1\) \* self\.width\]", s, re.S)
+    assert "into_par_iter().map(|i| self.row(i).to_vec())" in s                # the Vec<Vec<F>> form, when asked for, is built in parallel
+    assert "P2HOT_LEAVES_NATURAL" in body and "P2HOT_LEAVES_ASYNC" in body and "landed: AtomicUsize::new(if async_leaves { 0 } else { big_n })" in body
+    fence = s[s.index("fn fence(&self, r: usize)"):s.index("pub fn fence_all")]
+    assert "p2hot_batch_leaves_wait(self.batch, r, r + 1)" in fence and "with_ctx" not in fence   # no context lock: rayon workers call it side by side
+    # the batch (which waits for the copy in flight) is released BEFORE the pinned block the copy lands in: Drop::drop runs before the fields drop
+    assert s.index("impl<F: RichField> Drop for DeviceTree<F>") > 0 and "p2hot_batch_free(self.batch)" in s
     assert "p2hot_host_alloc(ctx, len * core::mem::size_of::<F>(), &mut p)" in s and "p2hot_host_free(ctx, *ptr as *mut c_void)" in s  # pinned, cached
     for needle in ("+    pub fn num_leaves(&self) -> usize {", "+            merkle_tree_prove::<F, H>(leaf_index, self.num_leaves(), cap_height, &self.digests);",
                    "+        self.write_usize(tree.num_leaves())?;", "+            self.write_field_vec(tree.get(i))?;", "+                return device.num_leaves();"):
