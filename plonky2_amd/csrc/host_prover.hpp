@@ -199,6 +199,17 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         hashed = end;
         return P2HOT_OK;
     };
+    auto issue_leaf_blocks = [&](size_t k0, size_t k1) -> int {  // blocks [k0, k1) of the asynchronous leaf copy, one event each
+        const size_t bw = leafcopy->rows_per_block * LW;           // words per block
+        for (size_t k = k0; k < k1; ++k) {
+            P2_HIP(ctx, hipMemcpyAsync(leaves_out + k * bw, d_leaves.u() + k * bw, bw * 8, hipMemcpyDeviceToHost, ctx->leaf_stream));
+            hipEvent_t e;
+            P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            leafcopy->ev.push_back(e);
+            P2_HIP(ctx, hipEventRecord(e, ctx->leaf_stream));
+        }
+        return P2HOT_OK;
+    };
     auto body = [&]() -> int {
         if (two_streams) {
             for (size_t b = 0; b < 2 * nb; ++b) {
@@ -287,7 +298,9 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
                 }
             }
         if (leaves_out && LW && async_leaves) {
-            // the matrix leaves in row blocks on a stream of its own, each block fenced by an event; this call does not wait for it
+            // the matrix leaves in row blocks on a stream of its own, each block fenced by an event; this call does not wait for it.
+            // The first quarter of the blocks goes now, beside the leaf sponge; the rest is queued BEHIND the digests' copy (below):
+            // the 0.5 GB of digests are what this call still waits for, and they would share the link with 9 GB of leaves otherwise
             if (!ctx->leaf_stream) P2_HIP(ctx, hipStreamCreateWithFlags(&ctx->leaf_stream, hipStreamNonBlocking));
             P2_HIP(ctx, hipStreamWaitEvent(ctx->leaf_stream, leaves_ev, 0));
             leafcopy = new p2hot_batch::LeafCopy();
@@ -297,16 +310,8 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             leaves_ev = nullptr;
             size_t blocks = 64;
             while (blocks > 1 && N / blocks < 1024) blocks >>= 1;  // (rows per block stays a power of two: N is one)
-            if (blocks > N) blocks = N;
             leafcopy->rows_per_block = N / blocks;
-            const size_t bw = leafcopy->rows_per_block * LW;  // words per block
-            for (size_t k = 0; k < blocks; ++k) {
-                P2_HIP(ctx, hipMemcpyAsync(leaves_out + k * bw, d_leaves.u() + k * bw, bw * 8, hipMemcpyDeviceToHost, ctx->leaf_stream));
-                hipEvent_t e;
-                P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                leafcopy->ev.push_back(e);
-                P2_HIP(ctx, hipEventRecord(e, ctx->leaf_stream));
-            }
+            P2_TRY(issue_leaf_blocks(0, (digests_out && nd) ? blocks / 4 : blocks));
         } else if (leaves_out && LW) {
             hipStream_t ls = ctx->stream;
             if (leaves_ev) {
@@ -324,6 +329,14 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             }
         } else if (digests_out && nd) {
             P2_HIP(ctx, hipMemcpyAsync(digests_out, d_dig.p, nd * 32, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (leafcopy && leafcopy->ev.size() < N / leafcopy->rows_per_block) {  // the rest of the leaf blocks, behind the digests' copy
+            hipEvent_t e;
+            P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            leafcopy->aux2 = e;
+            P2_HIP(ctx, hipEventRecord(e, tail_groups > 1 ? copy_stream : ctx->stream));
+            P2_HIP(ctx, hipStreamWaitEvent(ctx->leaf_stream, e, 0));
+            P2_TRY(issue_leaf_blocks(leafcopy->ev.size(), N / leafcopy->rows_per_block));
         }
         if (cap_out) P2_TRY(d2h(ctx, cap_out, d_cap.p, cap_words * 8));
         return P2HOT_OK;
@@ -347,6 +360,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             (void)hipStreamSynchronize(ctx->leaf_stream);
             for (hipEvent_t ev : leafcopy->ev) (void)hipEventDestroy(ev);
             if (leafcopy->aux) (void)hipEventDestroy(leafcopy->aux);
+            if (leafcopy->aux2) (void)hipEventDestroy(leafcopy->aux2);
             delete leafcopy;
         }
     }
@@ -358,6 +372,7 @@ static void leafcopy_finish(p2hot_batch *b) {  // waits for the copy in flight a
     if (b->ctx->leaf_stream) (void)hipStreamSynchronize(b->ctx->leaf_stream);
     for (hipEvent_t ev : b->leafcopy->ev) (void)hipEventDestroy(ev);
     if (b->leafcopy->aux) (void)hipEventDestroy(b->leafcopy->aux);
+    if (b->leafcopy->aux2) (void)hipEventDestroy(b->leafcopy->aux2);
     pool_release(b->ctx, b->leafcopy->d_staging);
     delete b->leafcopy;
     b->leafcopy = nullptr;
@@ -414,6 +429,9 @@ extern "C" int p2hot_commit_cols(p2hot_ctx *ctx, p2hot_cols *cols, unsigned rate
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
     const unsigned log_N = log_n + rate_bits;
     if (cap_height > log_N) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: cap_height %u > log2(N) %u (merkle_tree.rs:195-200)", cap_height, log_N);
+    // everything that can be refused for its ARGUMENTS is refused before the consume point, so that "EINVAL / EBUSY = not consumed"
+    // (include/p2hot.h) holds for nested checks too: the transforms launch one grid row per polynomial (65535 at most)
+    if (W > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "commit_cols: %zu polynomials exceed the launch grid (65535 per call)", W);
     PoolBuf d_in(ctx);
     d_in.p = cols->d;
     delete cols;  // consumed from here on: the block is ours whatever happens below
@@ -1220,7 +1238,9 @@ static int quotient_chunks_core(p2hot_ctx *ctx, PoolBuf &d_work, unsigned num_ch
                                 unsigned quotient_degree_factor, const char *what, p2hot_cols **chunks_out) {
     const size_t n = (size_t)1 << degree_bits, m = n << qbits, keep = n * quotient_degree_factor;
     PoolBuf d_chunks(ctx);
-    P2_TRY(pool_alloc(ctx, (num_challenges ? (size_t)num_challenges * quotient_degree_factor : 1) * n * 8, &d_chunks.p));
+    // (the caller's kernel or uploads into d_work may still be in flight: every early return synchronises before the PoolBufs go back)
+    if (int rc0 = pool_alloc(ctx, (num_challenges ? (size_t)num_challenges * quotient_degree_factor : 1) * n * 8, &d_chunks.p))
+        return sync_checked(ctx, rc0, what);
     unsigned nonzero = 0;
     auto body = [&]() -> int {
         // values.coset_ifft(F::coset_shift()) (prover.rs:810-814)
@@ -1263,12 +1283,16 @@ extern "C" int p2hot_quotient_chunks(p2hot_ctx *ctx, const uint64_t *const *quot
     while ((1u << qbits) < quotient_degree_factor) ++qbits;  // log2_ceil (circuit_data.rs quotient_degree_bits)
     P2_TRY(check_log(ctx, degree_bits + qbits, "quotient_chunks"));
     const size_t n = (size_t)1 << degree_bits, m = n << qbits;
+    for (unsigned c = 0; c < num_challenges; ++c)  // every argument is checked before the first copy is queued
+        if (!quotient_values[c]) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_chunks: polynomial %u is null", c);
     PoolBuf d_work(ctx);
     P2_TRY(pool_alloc(ctx, (num_challenges ? num_challenges : 1) * m * 8 + 8, &d_work.p));
-    for (unsigned c = 0; c < num_challenges; ++c) {
-        if (!quotient_values[c]) P2_FAIL(ctx, P2HOT_EINVAL, "quotient_chunks: polynomial %u is null", c);
-        P2_HIP(ctx, hipMemcpyAsync(d_work.u() + c * m, quotient_values[c], m * 8, hipMemcpyHostToDevice, ctx->stream));
-    }
+    auto upload = [&]() -> int {
+        for (unsigned c = 0; c < num_challenges; ++c)
+            P2_HIP(ctx, hipMemcpyAsync(d_work.u() + c * m, quotient_values[c], m * 8, hipMemcpyHostToDevice, ctx->stream));
+        return P2HOT_OK;
+    };
+    if (int rc0 = upload()) return sync_checked(ctx, rc0, "quotient_chunks");  // earlier copies into d_work are drained before it goes back
     return quotient_chunks_core(ctx, d_work, num_challenges, degree_bits, qbits, quotient_degree_factor, "quotient_chunks", chunks_out);
 }
 

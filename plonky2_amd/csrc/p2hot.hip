@@ -1837,6 +1837,7 @@ struct p2hot_batch {
         void *d_staging = nullptr;
         std::vector<hipEvent_t> ev;
         hipEvent_t aux = nullptr;  // "the matrix is transposed": what the leaf stream waits for before the first block
+        hipEvent_t aux2 = nullptr; // "the digests are on their way home": what the later blocks queue behind
         size_t rows_per_block = 0, rows = 0;
     } *leafcopy = nullptr;
     size_t col_stride_lde() const { return lde_stride ? lde_stride : N; }

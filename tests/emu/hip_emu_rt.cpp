@@ -26,6 +26,24 @@ namespace emu {
 Stats stats;
 bool fault_no_device_guard = false;
 bool fault_drop_waits = false;
+// allocation-failure injection: p2hot_emu_fault("fail_malloc_at", k) -- the k-th hipMalloc / hipHostMalloc from now AND every later
+// one return hipErrorOutOfMemory until disarmed (the device is full: a retry fails too); "fail_malloc_once", k -- only the k-th
+// (a transient failure: what the block cache's "give the cached blocks back and try once more" recovers from).  `malloc_calls`
+// counts the calls since the last arming so that a sweep knows how far to go
+std::atomic<long long> fault_malloc_countdown{0}, malloc_calls{0};
+std::atomic<bool> fault_malloc_persistent{false}, fault_malloc_tripped{false};
+static bool malloc_fault_fires() {
+    ++malloc_calls;
+    if (fault_malloc_tripped.load()) return true;
+    long long c = fault_malloc_countdown.load();
+    while (c > 0) {
+        if (fault_malloc_countdown.compare_exchange_weak(c, c - 1)) {
+            if (c == 1 && fault_malloc_persistent.load()) fault_malloc_tripped = true;
+            return c == 1;
+        }
+    }
+    return false;
+}
 
 namespace {
 struct Alloc {
@@ -454,6 +472,10 @@ hipError_t hipDeviceEnablePeerAccess(int peer, unsigned) {
 
 hipError_t hipMalloc(void **p, size_t n) {
     install_handler();
+    if (malloc_fault_fires()) {
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+    }
     // the allocation is placed so that it ENDS (rounded up to 16 bytes) at a guard page: an index that runs off the end of a device
     // buffer faults on the spot, in every kernel, copy and host loop of the tier (what AddressSanitizer did while device memory was malloc'ed)
     const size_t want = ((n ? n : 1) + 15) / 16 * 16;
@@ -493,6 +515,10 @@ hipError_t hipFree(void *p) {
     return hipSuccess;
 }
 hipError_t hipHostMalloc(void **p, size_t n, unsigned) {
+    if (malloc_fault_fires()) {
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+    }
     *p = malloc(n ? n : 1);
     if (!*p) return hipErrorOutOfMemory;
     std::lock_guard<std::mutex> l(mu);
@@ -1132,6 +1158,18 @@ int p2hot_emu_fault(const char *what, int on) {
     if (!strcmp(what, "drop_stream_waits")) {  // hipStreamWaitEvent becomes a no-op: what a program that forgot its waits does
         fault_drop_waits = on != 0;
         return 0;
+    }
+    if (!strcmp(what, "fail_malloc_at") || !strcmp(what, "fail_malloc_once")) {  // (0: disarm); restarts the call counter
+        fault_malloc_tripped = false;
+        fault_malloc_persistent = what[12] == 'a';
+        fault_malloc_countdown = on > 0 ? on : 0;
+        malloc_calls = 0;
+        return 0;
+    }
+    if (!strcmp(what, "malloc_calls")) return (int)malloc_calls.load();  // hipMalloc + hipHostMalloc calls since the last arming
+    if (!strcmp(what, "live_allocs")) {                                    // device + pinned allocations alive right now
+        std::lock_guard<std::mutex> l(mu);
+        return (int)allocs.size();
     }
     return 1;
 }

@@ -406,3 +406,34 @@ def test_every_hooked_reference_function_calls_a_shim_function_that_exists(patch
     assert 'p2hot = ["std", "plonky2/p2hot"]' in cargo
     proof = open(os.path.join(patched_reference, "starky/src/proof.rs")).read()
     assert "plonky2::p2hot::eval_commitment::<F, C, D>(z, c)" in proof
+
+
+def test_first_contact_dry_run():
+    """integration/first_contact.sh --dry-run: every step of the one-command Rust first contact that needs no cargo -- the patch applies
+    to the reference, the files it adds are the ones in integration/, feature and example names exist, the shim's environment
+    variables and the TimingTree scope names the report tabulates are in the patched sources, every extern "C" symbol of the shim
+    is exported by the built library, DEPS.md exists"""
+    import subprocess
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("the reference tree is not on this box")
+    r = subprocess.run(["bash", os.path.join(ROOT, "integration", "first_contact.sh"), "--dry-run"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "first contact: all steps ok" in r.stdout and "FAIL" not in r.stdout
+    for needle in ("cargo build --release --features p2hot", "--example p2hot_dump_goldens", "pytest tests/test_oracle.py -q -k reference_run",
+                   "p2hot:: -- --test-threads=1", "P2HOT_DISABLE=1 cargo run", "--example factorial", "--example square_root"):
+        assert needle in r.stdout, needle
+
+
+def test_timing_tree_table_parses_the_reference_format(tmp_path):
+    """tools/timing_tree_table.py on lines shaped like TimingTree::print_helper's (util/timing.rs:162-175)"""
+    from tools.timing_tree_table import parse, table
+    cpu = tmp_path / "cpu.log"
+    cpu.write_text("[DEBUG plonky2::util::timing] 7.5000s to prove\n[DEBUG plonky2::util::timing] | 1.2000s to compute wires commitment\n"
+                   "[DEBUG plonky2::util::timing] | | 0.2000s to IFFT\n[DEBUG plonky2::util::timing] | | 0.5000s to FFT + blinding\n"
+                   "[DEBUG plonky2::util::timing] | | 0.1000s to IFFT\n[DEBUG plonky2::util::timing] | | 0.3000s to reduce batch of 255 polynomials\n")
+    gpu = tmp_path / "gpu.log"
+    gpu.write_text("[DEBUG plonky2::util::timing] 0.7000s to prove\n[DEBUG plonky2::util::timing] | | 0.0700s to p2hot commit\n")
+    a, b = parse(str(cpu)), parse(str(gpu))
+    assert a["IFFT"] == (pytest.approx(0.3), 2) and a["prove"][0] == 7.5 and b["p2hot commit"] == (0.07, 1)
+    t = table([a, b], ["cpu", "gpu"], ["prove", "IFFT", "p2hot commit", "reduce batch of"])
+    assert "| `IFFT` | 0.3000 s (x2) | -- |" in t and "| `p2hot commit` | -- | 0.0700 s (x1) |" in t and "`reduce batch of` | 0.3000 s (x1)" in t
