@@ -437,3 +437,18 @@ def test_timing_tree_table_parses_the_reference_format(tmp_path):
     assert a["IFFT"] == (pytest.approx(0.3), 2) and a["prove"][0] == 7.5 and b["p2hot commit"] == (0.07, 1)
     t = table([a, b], ["cpu", "gpu"], ["prove", "IFFT", "p2hot commit", "reduce batch of"])
     assert "| `IFFT` | 0.3000 s (x2) | -- |" in t and "| `p2hot commit` | -- | 0.0700 s (x1) |" in t and "`reduce batch of` | 0.3000 s (x1)" in t
+
+
+def test_status_page_names_tests_that_exist():
+    """STATUS.md (tools/gen_status.py) is generated, but its row -> test mapping is typed: every `file.py::test_name` it cites exists"""
+    import re as _re
+    from tools.gen_status import ROWS
+    for _, _, tests, _ in ROWS:
+        cur = None
+        for m in _re.finditer(r"(?:(test_\w+\.py))?::(test_\w+)", tests):
+            cur = m.group(1) or cur
+            assert cur, tests
+            src = open(os.path.join(ROOT, "tests", cur)).read()
+            assert "def %s(" % m.group(2) in src, (cur, m.group(2))
+        for f in _re.findall(r"\b(test_\w+\.py)\b", tests):
+            assert os.path.exists(os.path.join(ROOT, "tests", f)), f
