@@ -172,6 +172,12 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     // (not when the row-major leaf matrix goes back as well: that copy -- 9 GB at C3 -- is the long pole and can start as soon
     // as every column is extended, so the transforms run first and the whole sponge runs beside the copy instead)
     const bool leaves_first = ctx->host_leaves_first && leaves_out && LW && (nb > 1 || big_leaves);
+    // An ASYNCHRONOUS leaf copy keeps that order: the link is the long pole of the whole exchange (10.7 GB out at the C3 wires shape),
+    // so the matrix has to start leaving as early as it exists -- transforms, transposition, first blocks beside the sponge.  Measured
+    // (profiles/r05_async_ab.txt): this order returns the call at 93 ms and lands the last row at 213 ms; letting the sponge absorb the
+    // column blocks as they arrive instead (the no-leaves pipeline) returns the call no sooner -- the transposition then sits behind most
+    // of the hashing and the first leaf blocks queue in front of the digests: 138 / 259 ms.
+    const bool early_transpose = async_leaves && LW;  // (also for the shapes too small for leaves_first)
     const bool chunked = ctx->host_chunked_hash && nb > 1 && LW > 8 && LW <= 0xFFFFFFFFull && !leaves_first;
     PoolBuf d_state(ctx);
     ForestGeom geom{};
@@ -248,12 +254,28 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             P2_TRY(h2d_columns(ctx, d_salt.u(), salt_cols, S, N * 8, W * n * 8, W * n * 8 + S * N * 8, ctx->stream));
             P2_TRY(launch_bitrev(ctx, d_salt.u(), d_lde.u() + W * N, S, N, N, log_N));
         }
-        if (leaves_first) {  // the row-major matrix before the sponge: its copy starts while the leaves are hashed
+        if (leaves_first || early_transpose) {  // the row-major matrix before the sponge('s tail): its copy starts while the leaves are hashed
             P2_TRY(transpose_rows(ctx, d_lde.u(), N, LW, N, d_leaves.u(), leaf_rev));
             if (two_streams || async_leaves) {
                 P2_HIP(ctx, hipEventCreateWithFlags(&leaves_ev, hipEventDisableTiming));
                 P2_HIP(ctx, hipEventRecord(leaves_ev, ctx->stream));
             }
+        }
+        if (early_transpose) {
+            // the matrix leaves in row blocks on a stream of its own, each block fenced by an event; this call does not wait for it.
+            // The first quarter of the blocks goes now, beside the leaf sponge; the rest is queued BEHIND the digests' copy (below):
+            // the 0.5 GB of digests are what this call still waits for, and they would share the link with 9 GB of leaves otherwise
+            if (!ctx->leaf_stream) P2_HIP(ctx, hipStreamCreateWithFlags(&ctx->leaf_stream, hipStreamNonBlocking));
+            P2_HIP(ctx, hipStreamWaitEvent(ctx->leaf_stream, leaves_ev, 0));
+            leafcopy = new p2hot_batch::LeafCopy();
+            leafcopy->ev.reserve(66);
+            leafcopy->rows = N;
+            leafcopy->aux = leaves_ev;  // the leaf stream's wait on it may not have run yet: destroyed with the copy, not with this call
+            leaves_ev = nullptr;
+            size_t blocks = 64;
+            while (blocks > 1 && N / blocks < 1024) blocks >>= 1;  // (rows per block stays a power of two: N is one)
+            leafcopy->rows_per_block = N / blocks;
+            P2_TRY(issue_leaf_blocks(0, (digests_out && nd) ? blocks / 4 : blocks));
         }
         if (chunked && tail_groups > 1) {
             const size_t cnt = N / tail_groups;
@@ -277,13 +299,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         } else {
             P2_TRY(p2hot_merkle_dev(ctx, d_lde.u(), 0, N, LW, log_N, cap_height, 0, N, d_dig.u(), d_cap.u()));
         }
-        if (leaves_out && LW && !leaves_first) {
-            P2_TRY(transpose_rows(ctx, d_lde.u(), N, LW, N, d_leaves.u(), leaf_rev));
-            if (async_leaves) {
-                P2_HIP(ctx, hipEventCreateWithFlags(&leaves_ev, hipEventDisableTiming));
-                P2_HIP(ctx, hipEventRecord(leaves_ev, ctx->stream));
-            }
-        }
+        if (leaves_out && LW && !leaves_first && !early_transpose) P2_TRY(transpose_rows(ctx, d_lde.u(), N, LW, N, d_leaves.u(), leaf_rev));
         // coefficient blocks go back while the leaf sponge runs: queued behind the uploads on the copy stream, each
         // waiting for its block's transform only
         if (coeffs_out)
@@ -298,20 +314,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
                 }
             }
         if (leaves_out && LW && async_leaves) {
-            // the matrix leaves in row blocks on a stream of its own, each block fenced by an event; this call does not wait for it.
-            // The first quarter of the blocks goes now, beside the leaf sponge; the rest is queued BEHIND the digests' copy (below):
-            // the 0.5 GB of digests are what this call still waits for, and they would share the link with 9 GB of leaves otherwise
-            if (!ctx->leaf_stream) P2_HIP(ctx, hipStreamCreateWithFlags(&ctx->leaf_stream, hipStreamNonBlocking));
-            P2_HIP(ctx, hipStreamWaitEvent(ctx->leaf_stream, leaves_ev, 0));
-            leafcopy = new p2hot_batch::LeafCopy();
-            leafcopy->ev.reserve(66);
-            leafcopy->rows = N;
-            leafcopy->aux = leaves_ev;  // the leaf stream's wait on it may not have run yet: destroyed with the copy, not with this call
-            leaves_ev = nullptr;
-            size_t blocks = 64;
-            while (blocks > 1 && N / blocks < 1024) blocks >>= 1;  // (rows per block stays a power of two: N is one)
-            leafcopy->rows_per_block = N / blocks;
-            P2_TRY(issue_leaf_blocks(0, (digests_out && nd) ? blocks / 4 : blocks));
+            // (issued above, right after the transposition; the later blocks follow the digests below)
         } else if (leaves_out && LW) {
             hipStream_t ls = ctx->stream;
             if (leaves_ev) {
