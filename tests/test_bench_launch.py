@@ -45,6 +45,18 @@ def test_bench_gpus_2_launches_its_own_ranks():
         assert key in d
 
 
+def test_bench_gpus_8_launches_eight_ranks():
+    """the driver's `python bench.py --gpus 8` on the day an 8-GPU node exists: eight ranks on eight emulated devices, the same
+    2^7-row shape as eight LDE cosets (one per rank: C5's arrangement), the cap of every step = the oracle's golden"""
+    r = _bench("--gpus", "8", "--steps", "1", "--warmup", "1", "--log-n", "4", timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["cap_checked"] is True and [row["rank"] for row in d["ranks"]] == list(range(8))
+    assert all(row["transport"] == "rccl" and row["preflight"]["selftest"] == "ok" for row in d["ranks"])
+    assert len({row["device"] for row in d["ranks"]}) == 8
+    assert d["strong_scaling"]["value"] > 0 and "split over 8 ranks" in d["strong_scaling"]["workload"]
+
+
 def test_bench_gpus_1_needs_no_launcher_either():
     r = _bench("--gpus", "1", "--steps", "1", "--warmup", "0", "--log-n", "7", "--no-extra", "--no-cpu-baseline")
     assert r.returncode == 0, r.stderr[-2000:]
