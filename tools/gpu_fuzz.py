@@ -73,14 +73,28 @@ while time.time() < t_end:
     digests = np.zeros((max(nd, 1), 4), dtype=np.uint64)
     capv = np.zeros((1 << cap, 4), dtype=np.uint64)
     h = C.c_void_p()
+    # round 5: the leaf matrix asynchronously (a pinned block, fenced before the comparison) and / or in natural LDE order
+    lflags = int(rng.choice([0, 4, 8, 12])) if want_leaves else 0
+    blk = C.c_void_p()
+    if lflags & 4:
+        eng.check(eng.lib.p2hot_host_alloc(eng.ctx, N * LW * 8, C.byref(blk)))
+        leaves = np.frombuffer((C.c_uint64 * (N * LW)).from_address(blk.value), dtype=np.uint64).reshape(N, LW)
     args = [coeffs.ctypes.data if want_co else None, leaves.ctypes.data if want_leaves else None, digests.ctypes.data if want_dig else None,
             capv.ctypes.data, C.byref(h)]
     if S:
         sp = (C.c_void_p * S)(*[salts[j].ctypes.data for j in range(S)])
-        rc = eng.lib.p2hot_commit_salted(eng.ctx, ptrs, W, log_n, rb, cap, 1 if is_values else 0, 0, sp, S, *args)
+        rc = eng.lib.p2hot_commit_salted(eng.ctx, ptrs, W, log_n, rb, cap, 1 if is_values else 0, lflags, sp, S, *args)
     else:
-        rc = eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1 if is_values else 0, 0, *args)
-    tag = dict(W=W, log_n=log_n, rb=rb, cap=cap, values=is_values, S=S, block=block, leaves=want_leaves, dig=want_dig, co=want_co)
+        rc = eng.lib.p2hot_commit(eng.ctx, ptrs, W, log_n, rb, cap, 1 if is_values else 0, lflags, *args)
+    tag = dict(W=W, log_n=log_n, rb=rb, cap=cap, values=is_values, S=S, block=block, leaves=want_leaves, dig=want_dig, co=want_co, lflags=lflags)
+    if rc == _lib.OK and lflags & 4:
+        lo = int(rng.integers(0, N))
+        eng.check(eng.lib.p2hot_batch_leaves_wait(h, lo, N))   # a sub-range first, then the rest
+        eng.check(eng.lib.p2hot_batch_leaves_wait(h, 0, N))
+    want = o["leaves"]
+    if lflags & 8:
+        bits = log_n + rb
+        want = o["leaves"][np.array([int(format(i, "0%db" % bits)[::-1], 2) if bits else 0 for i in range(N)], dtype=np.int64)]
     bad = []
     if rc != _lib.OK:
         bad.append("rc %d %s" % (rc, eng.lib.p2hot_last_error(eng._ctx)))
@@ -89,7 +103,7 @@ while time.time() < t_end:
             bad.append("cap")
         if want_co and (coeffs != o["coeffs"] % np.uint64(P)).any():
             bad.append("coeffs")
-        if want_leaves and (leaves != o["leaves"]).any():
+        if want_leaves and (leaves != want).any():
             bad.append("leaves")
         if want_dig and nd and (digests[:nd] != o["digests"]).any():
             bad.append("digests")
@@ -103,6 +117,9 @@ while time.time() < t_end:
         if nd and (d2[:nd] != o["digests"]).any():
             bad.append("batch_digests")
         eng.lib.p2hot_batch_free(h)
+    if blk.value:
+        leaves = None
+        eng.lib.p2hot_host_free(eng.ctx, blk)
     if bad:
         fails += 1
         print("MISMATCH", bad, tag, flush=True)
