@@ -327,6 +327,25 @@ def test_reduce_and_divide(ora):
     assert lhs == rhs
 
 
+def test_eval_polys_ext_vs_python_twin_and_the_ntt(ora):
+    """OpeningSet::new's eval_commitment (plonk/proof.rs:314-327; PolynomialCoeffs::eval, field/src/polynomial/mod.rs:155-160):
+    against Horner in Python integers, and -- the reference's own property for `eval` (fft.rs:230-239: the NTT is evaluation on
+    the subgroup) -- at a base-field point w^i the value is entry i of the forward transform, with a zero second coordinate"""
+    rng = random.Random(29)
+    for lg in (0, 1, 4, 7):
+        n = 1 << lg
+        polys = [rnd_elems(rng, n) for _ in range(3)]
+        z = (rng.randrange(P), rng.randrange(P))
+        got = ora.eval_polys_ext(polys, z)
+        for j in range(3):
+            assert pyref.ext_eval([(c, 0) for c in polys[j]], z) == (int(got[j][0]), int(got[j][1]))
+        w = ora.root_of_unity(lg)
+        i = rng.randrange(n)
+        at = ora.eval_polys_ext(polys, (pow(w, i, P), 0))
+        for j in range(3):
+            assert (int(at[j][0]), int(at[j][1])) == (int(ora.fft(polys[j])[i]) % P, 0)
+
+
 # ---------------------------------------------------------------- the reference-run pin (SURVEY 8c rows 5-6)
 def test_reference_run_comparer_on_the_oracles_own_dump(ora, tmp_path):
     """tools/reference_run.py: the comparison a `reference_run.json` from the Rust dumper goes through, exercised on a dump
