@@ -760,10 +760,10 @@ def main():
     # digests stay with the rank that owns the rows (its Merkle paths never leave its cap subtrees); only the cap is
     # all-gathered (SURVEY 8e collective 2).  P2HOT_GATHER_DIGESTS=1 also reassembles the full digest array everywhere.
     gather_digests = os.environ.get("P2HOT_GATHER_DIGESTS") == "1"
-    def make_job(log_rows, comm=None):
+    def make_job(log_rows, comm=None, transport=None):
         """the sharded commit of 2^log_rows rows in total + this rank's synthetic columns (generated on its device)"""
         j = ShardedCommit(eng, W, log_rows, rb, cap, is_values=True, rank=rank, world=world, dist=dist, gather_digests=gather_digests,
-                          transport="rccl" if (emu and world > 1) else None, comm=comm)
+                          transport=transport or ("rccl" if (emu and world > 1) else None), comm=comm)
         a, b = j.column_range
         if emu:
             return j, eng.dev(splitmix_columns_numpy(a, b - a, 1 << log_rows))
@@ -782,11 +782,35 @@ def main():
         except Exception as ex:  # noqa: BLE001
             preflight["peer_access"] = "query failed: %r" % (ex,)
         t_pf = time.perf_counter()
+        err = None
         try:
+            if emu and os.environ.get("P2HOT_BENCH_EMU_FAIL_PREFLIGHT") == str(rank):  # (test tier: this rank never reaches the collective)
+                raise RuntimeError("injected preflight failure on rank %d" % rank)
             job.comm.selftest(1 << 20)
-            preflight["selftest"] = "ok"
         except Exception as ex:  # noqa: BLE001
-            raise SystemExit("bench preflight: the 1 MB all-gather through the %s transport failed on rank %d: %s" % (job.comm.transport, rank, ex))
+            err = ex
+        # every rank learns whether ANY rank failed (through the launcher's process group, not the transport under test)
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=eng.mem.device if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) and job.comm.transport == "rccl" and os.environ.get("P2HOT_BENCH_NO_FALLBACK") != "1":
+            # first contact with a real multi-GPU node happens in the driver's run, once: if the in-library RCCL communicator fails its
+            # preflight, the exchange moves to torch.distributed's own communicator (device buffers, synchronous) instead of ending the
+            # run -- the line says so (`transport`, `preflight.fallback`) and the scaling numbers are then those of that transport
+            preflight["fallback"] = "the in-library RCCL transport failed its preflight on at least one rank (%s); torch.distributed's communicator carries the exchange" % (err,)
+            job.comm.close()
+            del job, cols
+            job, cols = make_job(log_n, transport="torch" if backend == "nccl" else "gloo")  # (gloo: the emulated tier's process group)
+            preflight["transport"] = job.comm.transport
+            err = None
+            try:
+                job.comm.selftest(1 << 20)
+            except Exception as ex:  # noqa: BLE001
+                err = ex
+            flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=eng.mem.device if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            raise SystemExit("bench preflight: the 1 MB all-gather through the %s transport failed (on rank %d: %s)" % (job.comm.transport, rank, err))
+        preflight["selftest"] = "ok"
         preflight["selftest_ms"] = (time.perf_counter() - t_pf) * 1e3
         preflight["exchange"] = job.comm.exchange  # "allgather" / "broadcast": what the selftest's micro-timing of both kept
 

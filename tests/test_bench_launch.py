@@ -57,6 +57,23 @@ def test_bench_gpus_8_launches_eight_ranks():
     assert d["strong_scaling"]["value"] > 0 and "split over 8 ranks" in d["strong_scaling"]["workload"]
 
 
+def test_a_failed_rccl_preflight_falls_back_to_the_launchers_communicator():
+    """first contact with a real multi-GPU node happens once, in the driver's run: when the in-library RCCL communicator fails its
+    preflight (here: rank 1 never reaches the collective, the fake RCCL reports the lonely rank where the real one would hang),
+    every rank agrees on it through the launcher's process group, the exchange moves to that group's transport, and the line
+    says so instead of the run ending without a record"""
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--log-n", "6",
+               env_extra={"P2HOT_BENCH_EMU_FAIL_PREFLIGHT": "1", "P2HOT_EMU_RCCL_TIMEOUT_MS": "1500"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["cap_checked"] is True and d["n_gpus"] == 2
+    assert all(row["transport"] == "gloo" and "failed its preflight" in row["preflight"]["fallback"] and row["preflight"]["selftest"] == "ok" for row in d["ranks"])
+    # with the fallback switched off the same failure ends the run, by name
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--log-n", "6",
+               env_extra={"P2HOT_BENCH_EMU_FAIL_PREFLIGHT": "1", "P2HOT_EMU_RCCL_TIMEOUT_MS": "1500", "P2HOT_BENCH_NO_FALLBACK": "1"})
+    assert r.returncode != 0 and "bench preflight" in (r.stderr + r.stdout)
+
+
 def test_bench_gpus_1_needs_no_launcher_either():
     r = _bench("--gpus", "1", "--steps", "1", "--warmup", "0", "--log-n", "7", "--no-extra", "--no-cpu-baseline")
     assert r.returncode == 0, r.stderr[-2000:]
