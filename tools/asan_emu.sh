@@ -15,7 +15,7 @@ from plonky2_amd import _lib
 eb._lib_cache = _lib.load("/tmp/libp2hot_asan.so")
 eb._SO = "/tmp/libp2hot_asan.so"   # (the memory backend looks the runtime's C++ symbols up in this file)
 import pytest
-sys.exit(pytest.main(["-x", "-q", "-m", "not gpu", "tests/test_parity.py", "tests/test_asm_streams.py", "tests/test_prove_openings.py", "tests/test_permutation.py", "tests/test_distributed.py", "tests/test_emu_devices.py", "-k", "(emu or group or asm or checker or devices or rccl or queues or waits) and not c2_wires_golden and not gloo and not named_fault", "-p", "no:cacheprovider"]))
+sys.exit(pytest.main(["-x", "-q", "-m", "not gpu", "tests/test_parity.py", "tests/test_asm_streams.py", "tests/test_prove_openings.py", "tests/test_permutation.py", "tests/test_distributed.py", "tests/test_emu_devices.py", "tests/test_async_leaves.py", "tests/test_alloc_failures.py", "tests/test_proof_path.py", "-k", "(emu or group or asm or checker or devices or rccl or queues or waits or allocation or fence) and not c2_wires_golden and not gloo and not named_fault", "-p", "no:cacheprovider"]))
 P
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 \
     python /tmp/asan_run.py 2>&1 | grep -v "doesn't fully support makecontext"
