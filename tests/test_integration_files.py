@@ -452,3 +452,12 @@ def test_status_page_names_tests_that_exist():
             assert "def %s(" % m.group(2) in src, (cur, m.group(2))
         for f in _re.findall(r"\b(test_\w+\.py)\b", tests):
             assert os.path.exists(os.path.join(ROOT, "tests", f)), f
+
+
+def test_docs_stay_wrapped():
+    """DESIGN / BASELINE / INTEGRATION / README prose is hard-wrapped at 120 columns (round-4 review: 1.3-2.8 k-character lines made
+    diffs unreviewable); tables and code blocks are exempt.  `python tools/wrap_md.py FILE...` re-flows in place."""
+    from tools.wrap_md import wrap
+    for name in ("DESIGN.md", "BASELINE.md", "INTEGRATION.md", "README.md"):
+        src = open(os.path.join(ROOT, name)).read()
+        assert wrap(src) == src, "%s: run python tools/wrap_md.py %s" % (name, name)
