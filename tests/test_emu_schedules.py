@@ -13,8 +13,8 @@ import pytest
 
 from tests.conftest import ROOT
 
-SELECTION = ["tests/test_parity.py", "tests/test_prove_openings.py", "tests/test_emu_devices.py", "-k",
-             "(emu and (host_commit_in_blocks or host_pointer_commit_abi or commit_many_equals or prove_openings_many)) or "
+SELECTION = ["tests/test_parity.py", "tests/test_prove_openings.py", "tests/test_emu_devices.py", "tests/test_async_leaves.py", "-k",
+             "(emu and (host_commit_in_blocks or host_pointer_commit_abi or commit_many_equals or prove_openings_many or async_and_natural_leaves)) or "
              "group_commit_on_distinct_devices or group_prove_openings_on_distinct or peer_copy_transports"]
 
 
