@@ -29,6 +29,14 @@ def box_report(torch, device_index=0):
         for k in ("clock_rate", "memory_clock_rate", "memory_bus_width", "L2_cache_size"):
             if hasattr(p, k):
                 rep[k] = getattr(p, k)
+        # what the driver exposes about clocks (raw: the level tables of the first card; `*` marks the current level)
+        import glob
+        for name in ("pp_dpm_mclk", "pp_dpm_sclk"):
+            for path in sorted(glob.glob("/sys/class/drm/card*/device/" + name))[:1]:
+                try:
+                    rep[name] = open(path).read().split("\n")[:8]
+                except OSError:
+                    pass
         if rep.get("memory_clock_rate") and rep.get("memory_bus_width"):
             # DDR: two transfers per memory clock; kHz * bits / 8 -> GB/s
             rep["hbm_peak_GBs_from_box"] = 2 * rep["memory_clock_rate"] * 1e3 * rep["memory_bus_width"] / 8 / 1e9
