@@ -103,3 +103,23 @@ def test_async_leaves_argument_errors(eng):
     eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, 2, 3, 1, 0, 1, 0, None, leaves.ctypes.data, None, capv.ctypes.data, C.byref(h)))
     eng.check(eng.lib.p2hot_batch_leaves_wait(h, 0, 16))
     eng.lib.p2hot_batch_free(h)
+
+
+def test_salted_leaves_in_natural_order_and_asynchronously(eng, ora):
+    """blinding = true (fri/oracle.rs:123-137): the salt columns travel with the leaf rows whatever the host copy's order"""
+    rng = np.random.default_rng(17)
+    W, S, log_n, rb, cap = 6, 4, 7, 3, 2
+    n, N = 1 << log_n, 1 << (log_n + rb)
+    cols, salts = rand_field(rng, W, n), rand_field(rng, S, N)
+    o = ora.commit_salted(cols, salts, rb, cap, True)
+    want = o["leaves"][_bitrev_perm(log_n + rb)]
+    ptrs = (C.c_void_p * W)(*[cols[c].ctypes.data for c in range(W)])
+    sp = (C.c_void_p * S)(*[salts[j].ctypes.data for j in range(S)])
+    leaves = np.zeros((N, W + S), dtype=np.uint64)
+    capv = np.zeros((1 << cap, 4), dtype=np.uint64)
+    h = C.c_void_p()
+    eng.check(eng.lib.p2hot_commit_salted(eng.ctx, ptrs, W, log_n, rb, cap, 1, _lib.LEAVES_ASYNC | _lib.LEAVES_NATURAL, sp, S, None, leaves.ctypes.data,
+                                          None, capv.ctypes.data, C.byref(h)))
+    eng.check(eng.lib.p2hot_batch_leaves_wait(h, 0, N))
+    assert (capv == o["cap"]).all() and (leaves == want).all()
+    eng.lib.p2hot_batch_free(h)
