@@ -171,7 +171,13 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     // quarters of the commit -- runs beside the uploads still in flight instead of behind them.
     // (not when the row-major leaf matrix goes back as well: that copy -- 9 GB at C3 -- is the long pole and can start as soon
     // as every column is extended, so the transforms run first and the whole sponge runs beside the copy instead)
-    const bool leaves_first = ctx->host_leaves_first && leaves_out && LW && (nb > 1 || big_leaves);
+    // P2HOT_LEAVES_ASYNC with several column blocks: THREE compute / copy lanes.  The transforms (upload-bound: 25 ms for 10 ms of
+    // kernels at the C3 wires shape) and the transposition run on a stream of their own, so the leaf matrix exists -- and starts
+    // leaving on the leaf stream -- as early as in the leaves-first order; the leaf sponge absorbs each block's columns on the
+    // context's stream BESIDE them (the chunked order: the hashing, three quarters of the call, hides the uploads), so the call
+    // returns as early as a call without leaves.  Neither single-stream order gives both (profiles/r05_async_ab.txt).
+    const bool xsplit = async_leaves && ctx->host_chunked_hash && ctx->host_async_split && nb > 1 && LW > 8 && LW <= 0xFFFFFFFFull;
+    const bool leaves_first = ctx->host_leaves_first && leaves_out && LW && (nb > 1 || big_leaves) && !xsplit;
     // An ASYNCHRONOUS leaf copy keeps that order: the link is the long pole of the whole exchange (10.7 GB out at the C3 wires shape),
     // so the matrix has to start leaving as early as it exists -- transforms, transposition, first blocks beside the sponge.  Measured
     // (profiles/r05_async_ab.txt): this order returns the call at 93 ms and lands the last row at 213 ms; letting the sponge absorb the
@@ -198,10 +204,17 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     [[maybe_unused]] hipEvent_t leaves_ev = nullptr;
     const unsigned leaf_rev = (flags & P2HOT_LEAVES_NATURAL) ? log_N : 0u;  // (log_N == 0: one row, nothing to reverse)
     p2hot_batch::LeafCopy *leafcopy = nullptr;  // P2HOT_LEAVES_ASYNC: handed to the batch handle at the end
+    const hipStream_t main_stream = ctx->stream;
+    struct StreamRestore {  // the transform lane borrows `ctx->stream` (every transform launches "on the context's stream"): given back on every path
+        p2hot_ctx *c;
+        hipStream_t s;
+        ~StreamRestore() { c->stream = s; }
+    } stream_restore{ctx, main_stream};
+    std::vector<hipEvent_t> lde_ev;  // xsplit: block b is extended (transform lane -> sponge lane)
     auto absorb_upto = [&](size_t cols_done, bool may_finish) -> int {  // cols_done leaf columns of d_lde are final
         const unsigned end = (cols_done >= LW && may_finish) ? (unsigned)LW : (unsigned)((cols_done < LW ? cols_done : LW - 1) / 8 * 8);
         if (end <= hashed) return P2HOT_OK;
-        P2_TRY(hash_leaves_chunks(ctx, ctx->stream, merkle::ColMajorReader{d_lde.u(), N}, LW, geom, N, hashed, end, d_state.u(), N));
+        P2_TRY(hash_leaves_chunks(ctx, main_stream, merkle::ColMajorReader{d_lde.u(), N}, LW, geom, N, hashed, end, d_state.u(), N));
         hashed = end;
         return P2HOT_OK;
     };
@@ -227,6 +240,16 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             P2_HIP(ctx, hipEventRecord(ctx->join_event, ctx->stream));
             P2_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->join_event, 0));
         }
+        if (xsplit) {  // the transform lane: behind whatever the context's stream already holds, then on its own
+            if (!ctx->xform_stream) P2_HIP(ctx, hipStreamCreateWithFlags(&ctx->xform_stream, hipStreamNonBlocking));
+            P2_HIP(ctx, hipStreamWaitEvent(ctx->xform_stream, ctx->join_event, 0));
+            for (size_t b = 0; b < nb; ++b) {
+                hipEvent_t e;
+                P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                lde_ev.push_back(e);
+            }
+            ctx->stream = ctx->xform_stream;  // (until the transposition below; StreamRestore covers the error paths)
+        }
         for (size_t b = 0; b < nb; ++b) {
             const size_t c0 = blk0[b], cnt = blk0[b + 1] - c0;
             u64 *blk = d_work.u() + c0 * n;
@@ -245,7 +268,11 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             }
             if (two_streams) P2_HIP(ctx, hipEventRecord(done[b], ctx->stream));
             P2_TRY(p2hot_coset_lde_dev(ctx, blk, cnt, n, log_n, rate_bits, gl::COSET_SHIFT, 0, N, d_lde.u() + c0 * N, N));
-            if (chunked) P2_TRY(absorb_upto(c0 + cnt, tail_groups == 1 && !S));  // (a grouped tail keeps the last chunk)
+            if (xsplit) {  // the sponge lane picks the block up when it is extended
+                P2_HIP(ctx, hipEventRecord(lde_ev[b], ctx->stream));
+                P2_HIP(ctx, hipStreamWaitEvent(main_stream, lde_ev[b], 0));
+            }
+            if (chunked) P2_TRY(absorb_upto(c0 + cnt, tail_groups == 1 && !S && !xsplit));  // (a grouped tail, and the split lanes, keep the last chunk)
         }
         if (S) {
             // the salt vectors are LDE-value columns in natural order (oracle.rs:133-137): like the LDE values they reach the
@@ -276,6 +303,11 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             while (blocks > 1 && N / blocks < 1024) blocks >>= 1;  // (rows per block stays a power of two: N is one)
             leafcopy->rows_per_block = N / blocks;
             P2_TRY(issue_leaf_blocks(0, (digests_out && nd) ? blocks / 4 : blocks));
+        }
+        if (xsplit) {  // the transform lane is done: the salts and the transposition were its last work; the sponge's tail waits for them
+            P2_HIP(ctx, hipEventRecord(ctx->join_event, ctx->stream));
+            ctx->stream = main_stream;
+            P2_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->join_event, 0));
         }
         if (chunked && tail_groups > 1) {
             const size_t cnt = N / tail_groups;
@@ -345,8 +377,14 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         return P2HOT_OK;
     };
     int rc = body();
+    ctx->stream = main_stream;
     hipError_t e1 = hipSuccess;
     if (two_streams) e1 = hipStreamSynchronize(ctx->side);
+    if (xsplit && ctx->xform_stream) {
+        hipError_t e2 = hipStreamSynchronize(ctx->xform_stream);
+        if (e1 == hipSuccess) e1 = e2;
+    }
+    for (hipEvent_t ev : lde_ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : up) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : done) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : tail_ev) (void)hipEventDestroy(ev);

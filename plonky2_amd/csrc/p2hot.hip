@@ -52,6 +52,8 @@ struct p2hot_ctx {
     // second stream: the VALU-bound leaf sponge of coset block b runs beside the wait-bound NTT of block b+1
     hipStream_t side = nullptr;
     hipStream_t leaf_stream = nullptr;  // P2HOT_LEAVES_ASYNC: the leaf matrix's row blocks travel here, beside everything else (created on first use)
+    hipStream_t xform_stream = nullptr; // P2HOT_LEAVES_ASYNC, several column blocks: the transforms + transposition lane beside the sponge (created on first use)
+    bool host_async_split = true;       // ... (P2HOT_HOST_ASYNC_SPLIT=0: the single-stream leaves-first order)
     std::vector<hipEvent_t> fork_events;
     hipEvent_t join_event = nullptr;
     bool overlap = false;
@@ -427,6 +429,7 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     if (const char *e = getenv("P2HOT_PP_STREAMS")) ctx->pp_streams = atoi(e) != 0;
     if (const char *e = getenv("P2HOT_HOST_CHUNKED_HASH")) ctx->host_chunked_hash = atoi(e) != 0;
     if (const char *e = getenv("P2HOT_HOST_LEAVES_FIRST")) ctx->host_leaves_first = atoi(e) != 0;
+    if (const char *e = getenv("P2HOT_HOST_ASYNC_SPLIT")) ctx->host_async_split = atoi(e) != 0;
     if (const char *e = getenv("P2HOT_HOST_TAIL_MIN_LEAVES")) ctx->host_tail_min_leaves = (size_t)strtoull(e, nullptr, 10);
     // start values of p2hot_tune_quad / p2hot_tune_row for every context of the process, the ones p2hot_group_create makes
     // included (the kernel emulator's test tier lowers them: emulated cross-lane exchanges are slow)
@@ -485,6 +488,10 @@ extern "C" void p2hot_ctx_destroy(p2hot_ctx *ctx) {
     if (ctx->leaf_stream) {
         (void)hipStreamSynchronize(ctx->leaf_stream);
         (void)hipStreamDestroy(ctx->leaf_stream);
+    }
+    if (ctx->xform_stream) {
+        (void)hipStreamSynchronize(ctx->xform_stream);
+        (void)hipStreamDestroy(ctx->xform_stream);
     }
     for (auto e : ctx->fork_events) (void)hipEventDestroy(e);
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);

@@ -123,3 +123,46 @@ def test_salted_leaves_in_natural_order_and_asynchronously(eng, ora):
     eng.check(eng.lib.p2hot_batch_leaves_wait(h, 0, N))
     assert (capv == o["cap"]).all() and (leaves == want).all()
     eng.lib.p2hot_batch_free(h)
+
+
+@pytest.mark.parametrize("W,log_n,rb,cap,S,block,grouped", [(37, 6, 3, 2, 0, 16, False), (37, 6, 3, 4, 4, 16, True), (135, 5, 3, 4, 0, 16, True),
+                                                             (24, 4, 2, 3, 0, 8, False), (41, 7, 3, 4, 0, 8, True)])
+def test_async_leaves_with_split_lanes(eng, ora, monkeypatch, W, log_n, rb, cap, S, block, grouped):
+    """P2HOT_LEAVES_ASYNC with several column blocks (every commit of >= 2^22 values): the transforms and the transposition run on a
+    lane of their own, the sponge absorbs the blocks' columns beside them on the context's stream, the leaf blocks leave on the leaf
+    stream (csrc/host_prover.hpp, xsplit).  Every output against the oracle -- with the tail per group of cap subtrees and without,
+    salted and not, and with P2HOT_HOST_ASYNC_SPLIT=0 (the single-stream leaves-first order) producing the same bytes"""
+    from plonky2_amd.engine import Engine
+    monkeypatch.setenv("P2HOT_HOST_BLOCK_COLS", str(block))
+    monkeypatch.setenv("P2HOT_HOST_TAIL_MIN_LEAVES", "1" if grouped else str(1 << 40))
+    rng = np.random.default_rng(W * 5 + log_n)
+    n, N = 1 << log_n, 1 << (log_n + rb)
+    cols = rand_field(rng, W, n, noncanonical=True)
+    salts = rand_field(rng, max(S, 1), N)
+    o = ora.commit_salted(cols, salts[:S], rb, cap, True) if S else ora.commit(cols, rb, cap, True)
+    want = o["leaves"][_bitrev_perm(log_n + rb)]
+    ptrs = (C.c_void_p * W)(*[cols[c].ctypes.data for c in range(W)])
+    sp = (C.c_void_p * max(S, 1))(*[salts[j].ctypes.data for j in range(max(S, 1))])
+    for split in ("1", "0"):
+        monkeypatch.setenv("P2HOT_HOST_ASYNC_SPLIT", split)
+        e2 = Engine(0, lib=eng.lib, memory=eng.mem)
+        try:
+            for _ in range(2):   # twice: the lanes are reused
+                coeffs = np.zeros((W, n), dtype=np.uint64)
+                leaves = np.zeros((N, W + S), dtype=np.uint64)
+                digests = np.zeros((max(e2.num_digests(log_n + rb, cap), 1), 4), dtype=np.uint64)
+                capv = np.zeros((1 << cap, 4), dtype=np.uint64)
+                h = C.c_void_p()
+                e2.check(e2.lib.p2hot_commit_salted(e2.ctx, ptrs, W, log_n, rb, cap, 1, _lib.LEAVES_ASYNC | _lib.LEAVES_NATURAL, sp, S, coeffs.ctypes.data,
+                                                    leaves.ctypes.data, digests.ctypes.data, capv.ctypes.data, C.byref(h)))
+                nd = e2.num_digests(log_n + rb, cap)
+                assert (coeffs == o["coeffs"] % np.uint64(P)).all() and (capv == o["cap"]).all() and (digests[:nd] == o["digests"]).all(), split
+                e2.check(e2.lib.p2hot_batch_leaves_wait(h, 0, N))
+                assert (leaves == want).all(), split
+                idx = np.array([1, N - 1], dtype=np.uint64)
+                rows = np.zeros((2, W + S), dtype=np.uint64)
+                e2.check(e2.lib.p2hot_batch_rows(h, idx.ctypes.data, 2, rows.ctypes.data))
+                assert (rows == o["leaves"][idx.astype(np.int64)]).all()
+                e2.lib.p2hot_batch_free(h)
+        finally:
+            e2.close()
