@@ -178,12 +178,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
     // returns as early as a call without leaves.  Neither single-stream order gives both (profiles/r05_async_ab.txt).
     const bool xsplit = async_leaves && ctx->host_chunked_hash && ctx->host_async_split && nb > 1 && LW > 8 && LW <= 0xFFFFFFFFull;
     const bool leaves_first = ctx->host_leaves_first && leaves_out && LW && (nb > 1 || big_leaves) && !xsplit;
-    // An ASYNCHRONOUS leaf copy keeps that order: the link is the long pole of the whole exchange (10.7 GB out at the C3 wires shape),
-    // so the matrix has to start leaving as early as it exists -- transforms, transposition, first blocks beside the sponge.  Measured
-    // (profiles/r05_async_ab.txt): this order returns the call at 93 ms and lands the last row at 213 ms; letting the sponge absorb the
-    // column blocks as they arrive instead (the no-leaves pipeline) returns the call no sooner -- the transposition then sits behind most
-    // of the hashing and the first leaf blocks queue in front of the digests: 138 / 259 ms.
-    const bool early_transpose = async_leaves && LW;  // (also for the shapes too small for leaves_first)
+    const bool early_transpose = async_leaves && LW;  // the asynchronous copy: the matrix is transposed as soon as the last column is extended
     const bool chunked = ctx->host_chunked_hash && nb > 1 && LW > 8 && LW <= 0xFFFFFFFFull && !leaves_first;
     PoolBuf d_state(ctx);
     ForestGeom geom{};
@@ -302,7 +297,12 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
             size_t blocks = 64;
             while (blocks > 1 && N / blocks < 1024) blocks >>= 1;  // (rows per block stays a power of two: N is one)
             leafcopy->rows_per_block = N / blocks;
-            P2_TRY(issue_leaf_blocks(0, (digests_out && nd) ? blocks / 4 : blocks));
+            // how many blocks leave BEFORE the digests' copy is queued.  Measured at the C3 wires shape (profiles/r05_async_ab.txt): beside
+            // the chunked sponge every early block costs the call ~7 ms (the copy and the sponge share the chip) and buys the last row
+            // nothing -> none; in the single-stream leaves-first order a quarter of them moves the last row from 251 to 220 ms for 10 ms
+            size_t early = ctx->host_async_early_blocks != (size_t)-1 ? ctx->host_async_early_blocks : (xsplit ? 0 : blocks / 4);
+            if (early > blocks || !(digests_out && nd)) early = blocks;
+            P2_TRY(issue_leaf_blocks(0, early));
         }
         if (xsplit) {  // the transform lane is done: the salts and the transposition were its last work; the sponge's tail waits for them
             P2_HIP(ctx, hipEventRecord(ctx->join_event, ctx->stream));

@@ -54,6 +54,7 @@ struct p2hot_ctx {
     hipStream_t leaf_stream = nullptr;  // P2HOT_LEAVES_ASYNC: the leaf matrix's row blocks travel here, beside everything else (created on first use)
     hipStream_t xform_stream = nullptr; // P2HOT_LEAVES_ASYNC, several column blocks: the transforms + transposition lane beside the sponge (created on first use)
     bool host_async_split = true;       // ... (P2HOT_HOST_ASYNC_SPLIT=0: the single-stream leaves-first order)
+    size_t host_async_early_blocks = (size_t)-1; // ... of the 64 leaf blocks, how many leave before the digests' copy is queued (P2HOT_HOST_ASYNC_EARLY_BLOCKS; unset: 0 beside the split lanes, a quarter otherwise)
     std::vector<hipEvent_t> fork_events;
     hipEvent_t join_event = nullptr;
     bool overlap = false;
@@ -430,6 +431,7 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     if (const char *e = getenv("P2HOT_HOST_CHUNKED_HASH")) ctx->host_chunked_hash = atoi(e) != 0;
     if (const char *e = getenv("P2HOT_HOST_LEAVES_FIRST")) ctx->host_leaves_first = atoi(e) != 0;
     if (const char *e = getenv("P2HOT_HOST_ASYNC_SPLIT")) ctx->host_async_split = atoi(e) != 0;
+    if (const char *e = getenv("P2HOT_HOST_ASYNC_EARLY_BLOCKS")) ctx->host_async_early_blocks = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HOST_TAIL_MIN_LEAVES")) ctx->host_tail_min_leaves = (size_t)strtoull(e, nullptr, 10);
     // start values of p2hot_tune_quad / p2hot_tune_row for every context of the process, the ones p2hot_group_create makes
     // included (the kernel emulator's test tier lowers them: emulated cross-lane exchanges are slow)
