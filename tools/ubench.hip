@@ -237,11 +237,201 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t 
     if ((threadIdx.x & 63) == 0) ticks[t >> 6] = t1 - t0;
 }
 
+// ---- round 6: what decides membership of the 2.4-cycle class?  Explicit physical registers (v16..v47 destinations, v48..v55
+// sources: the VGPR bank = register number mod 4 is under control), 32 instructions per loop trip (the loop's three SALU
+// instructions are < 10 % of the slots), one template instantiation per probe.  XR(M) expands M(dst) for the 32 destinations;
+// XB(M) expands M(dst, src) with src in the SAME bank as dst, XD(M) with src in the NEXT bank.
+#define XR(M) M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31) \
+              M(32) M(33) M(34) M(35) M(36) M(37) M(38) M(39) M(40) M(41) M(42) M(43) M(44) M(45) M(46) M(47)
+#define XB(M) M(16,48) M(17,49) M(18,50) M(19,51) M(20,48) M(21,49) M(22,50) M(23,51) M(24,48) M(25,49) M(26,50) M(27,51) M(28,48) M(29,49) M(30,50) M(31,51) \
+              M(32,48) M(33,49) M(34,50) M(35,51) M(36,48) M(37,49) M(38,50) M(39,51) M(40,48) M(41,49) M(42,50) M(43,51) M(44,48) M(45,49) M(46,50) M(47,51)
+#define XD(M) M(16,49) M(17,50) M(18,51) M(19,48) M(20,49) M(21,50) M(22,51) M(23,48) M(24,49) M(25,50) M(26,51) M(27,48) M(28,49) M(29,50) M(30,51) M(31,48) \
+              M(32,49) M(33,50) M(34,51) M(35,48) M(36,49) M(37,50) M(38,51) M(39,48) M(40,49) M(41,50) M(42,51) M(43,48) M(44,49) M(45,50) M(46,51) M(47,48)
+// 16 x (cheap op on an odd register pair's low word, multiply-add on an even pair): do the two classes overlap?
+#define XP(M) M(16,18) M(20,22) M(24,26) M(28,30) M(32,34) M(36,38) M(40,42) M(44,46) M(17,18) M(21,22) M(25,26) M(29,30) M(33,34) M(37,38) M(41,42) M(45,46)
+#define Y_RMW(OPC, r) OPC " v" #r ", v" #r ", v48\n\t"
+#define Y_NODEP(OPC, r) OPC " v" #r ", v49, v50\n\t"
+#define Y_INL(OPC, r) OPC " v" #r ", 1, v" #r "\n\t"
+#define Y_SGPR(OPC, r) OPC " v" #r ", s20, v" #r "\n\t"
+#define Y_2(OPC, r, s) OPC " v" #r ", v" #r ", v" #s "\n\t"
+#define Y_ONE(OPC, r) OPC " v" #r ", v48\n\t"
+#define Y_ONE_RMW(OPC, r) OPC " v" #r ", v" #r "\n\t"
+#define P_ADDU_RMW(r) Y_RMW("v_add_u32", r)
+#define P_ADDU_E64(r) Y_RMW("v_add_u32_e64", r)
+#define P_ADDU_NODEP(r) Y_NODEP("v_add_u32", r)
+#define P_ADDU_INL(r) Y_INL("v_add_u32", r)
+#define P_ADDU_SGPR(r) Y_SGPR("v_add_u32", r)
+#define P_ADDU_2(r, s) Y_2("v_add_u32", r, s)
+#define P_ADDF_RMW(r) Y_RMW("v_add_f32", r)
+#define P_ADDF_E64(r) Y_RMW("v_add_f32_e64", r)
+#define P_ADDF_NODEP(r) Y_NODEP("v_add_f32", r)
+#define P_ADDF_2(r, s) Y_2("v_add_f32", r, s)
+#define P_MULF_RMW(r) Y_RMW("v_mul_f32", r)
+#define P_FMAC(r) Y_NODEP("v_fmac_f32", r)
+#define P_XOR_INL(r) Y_INL("v_xor_b32", r)
+#define P_XOR_RMW(r) Y_RMW("v_xor_b32", r)
+#define P_OR_RMW(r) Y_RMW("v_or_b32", r)
+#define P_AND_RMW(r) Y_RMW("v_and_b32", r)
+#define P_AND_NODEP(r) Y_NODEP("v_and_b32", r)
+#define P_LSHR_INL(r) "v_lshrrev_b32 v" #r ", 8, v" #r "\n\t"
+#define P_LSHR_VGPR(r) "v_lshrrev_b32 v" #r ", v48, v" #r "\n\t"
+#define P_LSHL_INL(r) "v_lshlrev_b32 v" #r ", 3, v" #r "\n\t"
+#define P_ASHR_INL(r) "v_ashrrev_i32 v" #r ", 8, v" #r "\n\t"
+#define P_MAXU(r) Y_RMW("v_max_u32", r)
+#define P_MINI(r) Y_RMW("v_min_i32", r)
+#define P_SUBU_NODEP(r) Y_NODEP("v_sub_u32", r)
+#define P_SUBU_RMW(r) Y_RMW("v_sub_u32", r)
+#define P_SUBREV(r) Y_RMW("v_subrev_u32", r)
+#define P_MOV(r) Y_ONE("v_mov_b32", r)
+#define P_MOV_E64(r) Y_ONE("v_mov_b32_e64", r)
+#define P_NOT(r) Y_ONE_RMW("v_not_b32", r)
+#define P_CVTFU(r) Y_ONE_RMW("v_cvt_f32_u32", r)
+#define P_CVTUF(r) Y_ONE_RMW("v_cvt_u32_f32", r)
+#define P_MOV_DPP(r) "v_mov_b32_dpp v" #r ", v48 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define P_ADDCO(r) "v_add_co_u32 v" #r ", vcc, v" #r ", v48\n\t"
+#define P_CNDM(r) "v_cndmask_b32 v" #r ", v49, v50, vcc\n\t"
+#define P_MUL24(r) Y_RMW("v_mul_u32_u24", r)
+#define P_MULHI24(r) Y_RMW("v_mul_hi_u32_u24", r)
+#define P_MAD24(r) "v_mad_u32_u24 v" #r ", v" #r ", v48, v49\n\t"
+#define P_ADD3(r) "v_add3_u32 v" #r ", v" #r ", v48, v49\n\t"
+#define P_PKADDU16(r) Y_RMW("v_pk_add_u16", r)
+#define P_ADDU16(r) Y_RMW("v_add_u16", r)
+#define P_ADDF16(r) Y_RMW("v_add_f16", r)
+#define P_MAD_ADDU(r, p) "v_add_u32 v" #r ", v" #r ", v48\n\tv_mad_u64_u32 v[" #p ":" #p "+1], s[22:23], v49, v50, v[" #p ":" #p "+1]\n\t"
+#define P_MAD_ADDF(r, p) "v_add_f32 v" #r ", v" #r ", v48\n\tv_mad_u64_u32 v[" #p ":" #p "+1], s[22:23], v49, v50, v[" #p ":" #p "+1]\n\t"
+#define P_MAD_MOV(r, p) "v_mov_b32 v" #r ", v48\n\tv_mad_u64_u32 v[" #p ":" #p "+1], s[22:23], v49, v50, v[" #p ":" #p "+1]\n\t"
+#define P_MAD_ONLY(r, p) "v_mad_u64_u32 v[" #p ":" #p "+1], s[22:23], v49, v50, v[" #p ":" #p "+1]\n\tv_mad_u64_u32 v[" #p ":" #p "+1], s[22:23], v50, v49, v[" #p ":" #p "+1]\n\t"
+#define P_ADDU_ADDF(r, p) "v_add_u32 v" #r ", v" #r ", v48\n\tv_add_f32 v" #p ", v" #p ", v49\n\t"
+#define P_SUBCO_CNDM(r, p) "v_sub_co_u32 v" #r ", vcc, v" #r ", v48\n\tv_cndmask_b32 v" #p ", v49, v50, vcc\n\t"
+// second batch: what co-issues with the 64-bit multiply-add?  (r = a 32-bit register of an odd pair, p = an even pair)
+#define MADP(p) "v_mad_u64_u32 v[" #p ":" #p "+1], s[22:23], v49, v50, v[" #p ":" #p "+1]\n\t"
+#define P_MAD_FMA64(r, p) MADP(p) "v_fma_f64 v[52:53], v[54:55], v[54:55], v[52:53]\n\t"
+#define P_MAD_PKFMA(r, p) MADP(p) "v_pk_fma_f32 v[52:53], v[54:55], v[54:55], v[52:53]\n\t"
+#define P_MAD_FMA32(r, p) MADP(p) "v_fma_f32 v" #r ", v" #r ", v50, v48\n\t"
+#define P_MAD_XOR(r, p) MADP(p) "v_xor_b32 v" #r ", v" #r ", v48\n\t"
+#define P_MAD_LSHR(r, p) MADP(p) "v_lshrrev_b32 v" #r ", 8, v" #r "\n\t"
+#define P_MAD_AND(r, p) MADP(p) "v_and_b32 v" #r ", v" #r ", v48\n\t"
+#define P_MAD_SUBU(r, p) MADP(p) "v_sub_u32 v" #r ", v" #r ", v48\n\t"
+#define P_MAD_ADDCO(r, p) MADP(p) "v_add_co_u32 v" #r ", vcc, v" #r ", v48\n\t"
+#define P_MAD_ADDCE(r, p) MADP(p) "v_addc_co_u32_e64 v" #r ", s[20:21], v" #r ", v48, s[20:21]\n\t"
+#define P_MAD_MULF(r, p) MADP(p) "v_mul_f32 v" #r ", v" #r ", v50\n\t"
+#define P_MAD_CVT64(r, p) MADP(p) "v_cvt_f64_u32 v[52:53], v48\n\t"
+#define P_MAD_2ADDF(r, p) MADP(p) "v_add_f32 v" #r ", v" #r ", v48\n\tv_add_f32 v56, v56, v48\n\t"
+#define P_MAD_MAD24(r, p) MADP(p) "v_mad_u32_u24 v" #r ", v" #r ", v48, v49\n\t"
+#define P_MAD_MULLO(r, p) MADP(p) "v_mul_lo_u32 v" #r ", v" #r ", v48\n\t"
+#define P_MAD_LSHLADD64(r, p) MADP(p) "v_lshl_add_u64 v[52:53], v[52:53], 0, v[54:55]\n\t"
+#define P_MAD_CNDM(r, p) MADP(p) "v_cndmask_b32 v" #r ", v49, v50, s[20:21]\n\t"
+#define P_FMA64_ONLY(r, p) "v_fma_f64 v[" #p ":" #p "+1], v[54:55], v[54:55], v[" #p ":" #p "+1]\n\tv_fma_f64 v[52:53], v[54:55], v[54:55], v[52:53]\n\t"
+#define P_FMA64_ADDU(r, p) "v_fma_f64 v[" #p ":" #p "+1], v[54:55], v[54:55], v[" #p ":" #p "+1]\n\tv_add_u32 v" #r ", v" #r ", v48\n\t"
+#define P_MADRUN(r, p) MADP(p)
+#define P_ADDRUN(r, p) "v_add_u32 v" #r ", v" #r ", v48\n\t"
+#define P_MAD4(r, p) MADP(p) MADP(p)
+#define P_ADD4(r, p) "v_add_u32 v" #r ", v" #r ", v48\n\tv_sub_u32 v" #r ", v" #r ", v49\n\t"
+#define XP4A(M) M(16,18) M(20,22)
+#define XP4B(M) M(24,26) M(28,30)
+#define XP4C(M) M(32,34) M(36,38)
+#define XP4D(M) M(40,42) M(44,46)
+#define XP4E(M) M(17,18) M(21,22)
+#define XP4F(M) M(25,26) M(29,30)
+#define XP4G(M) M(33,34) M(37,38)
+#define XP4H(M) M(41,42) M(45,46)
+#define XCLOB "vcc", "s20", "s21", "s22", "s23", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", \
+              "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", \
+              "v48", "v49", "v50", "v51"
+#define XCLOB2 XCLOB, "v52", "v53", "v54", "v55", "v56"
+#define P_INIT(r) "v_mov_b32 v" #r ", %0\n\t"
+#define P_SUM(r) "v_xor_b32 %0, %0, v" #r "\n\t"
+
+template <int OP>
+__global__ void __launch_bounds__(256) kx(uint64_t *out, uint32_t seed, uint64_t *ticks) {
+    uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;
+    uint32_t c = t * 2654435761u + seed;
+    asm volatile(XR(P_INIT) "v_mov_b32 v48, %0\n\tv_mov_b32 v49, %0\n\tv_mov_b32 v50, 0x3f800001\n\tv_mov_b32 v51, %0\n\ts_mov_b32 s20, 77\n\ts_mov_b32 s21, 0\n\tv_mov_b32 v52, 0\n\tv_mov_b32 v53, 0x3ff00000\n\tv_mov_b32 v54, 1\n\tv_mov_b32 v55, 0x3ff00000\n\tv_mov_b32 v56, %0" ::"v"(c) : XCLOB2);
+    uint64_t t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+    for (int it = 0; it < ITERS / 4; ++it) {
+        if (OP == 100) asm volatile(XR(P_ADDU_RMW) ::: XCLOB);
+        if (OP == 101) asm volatile(XR(P_ADDU_E64) ::: XCLOB);
+        if (OP == 102) asm volatile(XR(P_ADDU_NODEP) ::: XCLOB);
+        if (OP == 103) asm volatile(XR(P_ADDU_INL) ::: XCLOB);
+        if (OP == 104) asm volatile(XR(P_ADDU_SGPR) ::: XCLOB);
+        if (OP == 105) asm volatile(XB(P_ADDU_2) ::: XCLOB);
+        if (OP == 106) asm volatile(XD(P_ADDU_2) ::: XCLOB);
+        if (OP == 107) asm volatile(XR(P_ADDF_RMW) ::: XCLOB);
+        if (OP == 108) asm volatile(XR(P_ADDF_E64) ::: XCLOB);
+        if (OP == 109) asm volatile(XR(P_ADDF_NODEP) ::: XCLOB);
+        if (OP == 110) asm volatile(XR(P_MULF_RMW) ::: XCLOB);
+        if (OP == 111) asm volatile(XR(P_FMAC) ::: XCLOB);
+        if (OP == 112) asm volatile(XR(P_XOR_INL) ::: XCLOB);
+        if (OP == 113) asm volatile(XR(P_OR_RMW) ::: XCLOB);
+        if (OP == 114) asm volatile(XR(P_AND_NODEP) ::: XCLOB);
+        if (OP == 115) asm volatile(XR(P_LSHR_VGPR) ::: XCLOB);
+        if (OP == 116) asm volatile(XR(P_LSHL_INL) ::: XCLOB);
+        if (OP == 117) asm volatile(XR(P_ASHR_INL) ::: XCLOB);
+        if (OP == 118) asm volatile(XR(P_MAXU) ::: XCLOB);
+        if (OP == 119) asm volatile(XR(P_MINI) ::: XCLOB);
+        if (OP == 120) asm volatile(XR(P_SUBU_NODEP) ::: XCLOB);
+        if (OP == 121) asm volatile(XR(P_SUBREV) ::: XCLOB);
+        if (OP == 122) asm volatile(XR(P_MOV_E64) ::: XCLOB);
+        if (OP == 123) asm volatile(XR(P_NOT) ::: XCLOB);
+        if (OP == 124) asm volatile(XR(P_CVTFU) ::: XCLOB);
+        if (OP == 125) asm volatile(XR(P_CVTUF) ::: XCLOB);
+        if (OP == 126) asm volatile(XR(P_MOV_DPP) ::: XCLOB);
+        if (OP == 127) asm volatile(XR(P_ADDCO) ::: XCLOB);
+        if (OP == 128) asm volatile(XP(P_MAD_ADDU) ::: XCLOB);
+        if (OP == 129) asm volatile(XP(P_MAD_ADDF) ::: XCLOB);
+        if (OP == 130) asm volatile(XP(P_MAD_MOV) ::: XCLOB);
+        if (OP == 131) asm volatile(XP(P_ADDU_ADDF) ::: XCLOB);
+        if (OP == 132) asm volatile(XP(P_MAD_ONLY) ::: XCLOB);
+        if (OP == 133) asm volatile(XR(P_CNDM) ::: XCLOB);
+        if (OP == 134) asm volatile(XR(P_MUL24) ::: XCLOB);
+        if (OP == 135) asm volatile(XR(P_MULHI24) ::: XCLOB);
+        if (OP == 136) asm volatile(XR(P_MAD24) ::: XCLOB);
+        if (OP == 137) asm volatile(XR(P_ADD3) ::: XCLOB);
+        if (OP == 138) asm volatile(XR(P_AND_RMW) ::: XCLOB);
+        if (OP == 139) asm volatile(XR(P_LSHR_INL) ::: XCLOB);
+        if (OP == 140) asm volatile(XR(P_MOV) ::: XCLOB);
+        if (OP == 141) asm volatile(XR(P_XOR_RMW) ::: XCLOB);
+        if (OP == 142) asm volatile(XR(P_SUBU_RMW) ::: XCLOB);
+        if (OP == 143) asm volatile(XD(P_ADDF_2) ::: XCLOB);
+        if (OP == 144) asm volatile(XB(P_ADDF_2) ::: XCLOB);
+        if (OP == 145) asm volatile(XR(P_PKADDU16) ::: XCLOB);
+        if (OP == 146) asm volatile(XR(P_ADDU16) ::: XCLOB);
+        if (OP == 147) asm volatile(XR(P_ADDF16) ::: XCLOB);
+        if (OP == 148) asm volatile(XP(P_SUBCO_CNDM) ::: XCLOB);
+        if (OP == 149) asm volatile(XP(P_MADRUN) XP(P_ADDRUN) ::: XCLOB2);
+        if (OP == 150) asm volatile(XP(P_MAD_FMA64) ::: XCLOB2);
+        if (OP == 151) asm volatile(XP(P_MAD_PKFMA) ::: XCLOB2);
+        if (OP == 152) asm volatile(XP(P_MAD_FMA32) ::: XCLOB2);
+        if (OP == 153) asm volatile(XP(P_MAD_XOR) ::: XCLOB2);
+        if (OP == 154) asm volatile(XP(P_MAD_LSHR) ::: XCLOB2);
+        if (OP == 155) asm volatile(XP(P_MAD_AND) ::: XCLOB2);
+        if (OP == 156) asm volatile(XP(P_MAD_SUBU) ::: XCLOB2);
+        if (OP == 157) asm volatile(XP(P_MAD_ADDCO) ::: XCLOB2);
+        if (OP == 158) asm volatile(XP(P_MAD_ADDCE) ::: XCLOB2);
+        if (OP == 160) asm volatile(XP(P_MAD_MULF) ::: XCLOB2);
+        if (OP == 161) asm volatile(XP(P_MAD_CVT64) ::: XCLOB2);
+        if (OP == 162) asm volatile(XP(P_MAD_2ADDF) ::: XCLOB2);
+        if (OP == 163) asm volatile(XP(P_MAD_MAD24) ::: XCLOB2);
+        if (OP == 164) asm volatile(XP(P_MAD_MULLO) ::: XCLOB2);
+        if (OP == 165) asm volatile(XP(P_MAD_LSHLADD64) ::: XCLOB2);
+        if (OP == 166) asm volatile(XP(P_MAD_CNDM) ::: XCLOB2);
+        if (OP == 159) asm volatile(XP(P_FMA64_ONLY) ::: XCLOB2);
+        if (OP == 168) asm volatile(XP(P_FMA64_ADDU) ::: XCLOB2);
+        if (OP == 167) asm volatile(XP4A(P_MAD4) XP4A(P_ADD4) XP4B(P_MAD4) XP4B(P_ADD4) XP4C(P_MAD4) XP4C(P_ADD4) XP4D(P_MAD4) XP4D(P_ADD4) ::: XCLOB2);
+    }
+    uint64_t t1 = __builtin_readcyclecounter();
+    uint32_t s = 0;
+    asm volatile(XR(P_SUM) : "+v"(s)::XCLOB);
+    out[t] = s;
+    if ((threadIdx.x & 63) == 0) ticks[t >> 6] = t1 - t0;
+}
+
 static int g_waves = 8;        // resident waves per SIMD (blocks of 256 threads per CU)
 static const char *g_only = nullptr;
 static bool g_json = false;
 
-template <int OP>
+template <int OP, bool X = false>
 void run(const char *name, int per_iter = 8) {
     if (g_only && !strstr(name, g_only)) return;
     const int blocks = 256 * g_waves, threads = 256;  // g_waves blocks/CU -> g_waves waves/SIMD
@@ -251,12 +441,12 @@ void run(const char *name, int per_iter = 8) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    k<OP><<<blocks, threads>>>(d, 1, tk);
+    if (X) kx<OP><<<blocks, threads>>>(d, 1, tk); else k<OP><<<blocks, threads>>>(d, 1, tk);
     (void)hipDeviceSynchronize();
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0);
-        k<OP><<<blocks, threads>>>(d, 2 + rep, tk);
+        if (X) kx<OP><<<blocks, threads>>>(d, 2 + rep, tk); else k<OP><<<blocks, threads>>>(d, 2 + rep, tk);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms;
@@ -264,7 +454,7 @@ void run(const char *name, int per_iter = 8) {
         if (ms < best) best = ms;
     }
     double waves_per_simd = (double)blocks * threads / 64 / 1024;
-    double inst_per_simd = waves_per_simd * ITERS * per_iter;
+    double inst_per_simd = waves_per_simd * (X ? ITERS / 4 : ITERS) * per_iter;
     double cycles = best * 1e-3 * 2.4e9;
     static uint64_t host_ticks[256 * 8 * 4];
     (void)hipMemcpy(host_ticks, tk, (size_t)blocks * threads / 64 * 8, hipMemcpyDeviceToHost);
@@ -276,7 +466,7 @@ void run(const char *name, int per_iter = 8) {
                g_waves, best, inst_per_simd, per_iter);
     else
         printf("%-18s %7.3f ms  %5.2f cyc/inst/SIMD by wall@2.4GHz(assumed) | %5.2f ticks/inst by s_memtime (ticks/wave %.0f)\n", name, best,
-               cycles / inst_per_simd, avg / (ITERS * (double)per_iter * waves_per_simd), avg);
+               cycles / inst_per_simd, avg / ((X ? ITERS / 4 : ITERS) * (double)per_iter * waves_per_simd), avg);
     (void)hipFree(tk);
     (void)hipFree(d);
 }
@@ -344,5 +534,74 @@ int main(int argc, char **argv) {
     run<52>("mix mds valu (half layer)", 173);
     run<53>("mix mds mfma (half layer)", 169);
     run<49>("mix limb_ntt", 16);
+    run<100, true>("x add_u32 rmw", 32);
+    run<101, true>("x add_u32 e64", 32);
+    run<102, true>("x add_u32 nodep", 32);
+    run<103, true>("x add_u32 inline", 32);
+    run<104, true>("x add_u32 sgpr", 32);
+    run<105, true>("x add_u32 samebank", 32);
+    run<106, true>("x add_u32 nextbank", 32);
+    run<107, true>("x add_f32 rmw", 32);
+    run<108, true>("x add_f32 e64", 32);
+    run<109, true>("x add_f32 nodep", 32);
+    run<143, true>("x add_f32 nextbank", 32);
+    run<144, true>("x add_f32 samebank", 32);
+    run<110, true>("x mul_f32 rmw", 32);
+    run<111, true>("x fmac_f32", 32);
+    run<112, true>("x xor inline", 32);
+    run<141, true>("x xor rmw", 32);
+    run<113, true>("x or rmw", 32);
+    run<138, true>("x and rmw", 32);
+    run<114, true>("x and nodep", 32);
+    run<139, true>("x lshrrev inline", 32);
+    run<115, true>("x lshrrev vgpr", 32);
+    run<116, true>("x lshlrev inline", 32);
+    run<117, true>("x ashrrev inline", 32);
+    run<118, true>("x max_u32", 32);
+    run<119, true>("x min_i32", 32);
+    run<142, true>("x sub_u32 rmw", 32);
+    run<120, true>("x sub_u32 nodep", 32);
+    run<121, true>("x subrev_u32", 32);
+    run<140, true>("x mov", 32);
+    run<122, true>("x mov e64", 32);
+    run<123, true>("x not", 32);
+    run<124, true>("x cvt_f32_u32", 32);
+    run<125, true>("x cvt_u32_f32", 32);
+    run<126, true>("x mov dpp", 32);
+    run<127, true>("x add_co vcc", 32);
+    run<133, true>("x cndmask nodep", 32);
+    run<134, true>("x mul_u32_u24 e32", 32);
+    run<135, true>("x mul_hi_u32_u24 e32", 32);
+    run<136, true>("x mad_u32_u24", 32);
+    run<137, true>("x add3", 32);
+    run<145, true>("x pk_add_u16", 32);
+    run<146, true>("x add_u16", 32);
+    run<147, true>("x add_f16", 32);
+    run<132, true>("x mad64 only", 32);
+    run<128, true>("x mad64+add_u32 1:1", 32);
+    run<129, true>("x mad64+add_f32 1:1", 32);
+    run<130, true>("x mad64+mov 1:1", 32);
+    run<131, true>("x add_u32+add_f32 1:1", 32);
+    run<148, true>("x sub_co+cndmask 1:1", 32);
+    run<149, true>("x mad64 x16 then add_u32 x16", 32);
+    run<150, true>("x mad64+fma_f64 1:1", 32);
+    run<151, true>("x mad64+pk_fma_f32 1:1", 32);
+    run<152, true>("x mad64+fma_f32 1:1", 32);
+    run<153, true>("x mad64+xor 1:1", 32);
+    run<154, true>("x mad64+lshrrev 1:1", 32);
+    run<155, true>("x mad64+and 1:1", 32);
+    run<156, true>("x mad64+sub_u32 1:1", 32);
+    run<157, true>("x mad64+add_co vcc 1:1", 32);
+    run<158, true>("x mad64+addc e64 1:1", 32);
+    run<160, true>("x mad64+mul_f32 1:1", 32);
+    run<161, true>("x mad64+cvt_f64_u32 1:1", 32);
+    run<162, true>("x mad64+2 add_f32", 48);
+    run<163, true>("x mad64+mad_u32_u24 1:1", 32);
+    run<164, true>("x mad64+mul_lo_u32 1:1", 32);
+    run<165, true>("x mad64+lshl_add_u64 1:1", 32);
+    run<166, true>("x mad64+cndmask sgpr 1:1", 32);
+    run<159, true>("x fma_f64 only", 32);
+    run<168, true>("x fma_f64+add_u32 1:1", 32);
+    run<167, true>("x mad64 x4 / add,sub x4 runs", 32);
     return 0;
 }
