@@ -57,8 +57,10 @@ def numbers(d):
     out = {}
     out["headline"] = "C3 wires commit %.2f ms = %.2f GFE/s, %d of %d caps = golden" % (d["ms_per_step"], d["value"], d.get("caps_checked", 0), d["steps"])
     if rn:
-        out["ntt"] = "family %.2f ms per step = %.2f of 8 TB/s (LDE contiguous %.2f ms, strided %.2f ms)" % (
-            rn["family_ms_per_step"], rn["family_frac"], rn["passes"]["ntt_lde_contig"]["ms"], rn["passes"]["ntt_lde_strided"]["ms"])
+        out["ntt"] = "family (4 passes%s) %.2f ms per step = %.2f of 8 TB/s by SURVEY 8(d)'s bytes%s (LDE contiguous %.2f ms, strided %.2f ms)" % (
+            " + bit reversal" if "bitrev_permute" in rn["passes"] else "", rn["family_ms_per_step"], rn["family_frac"],
+            ", traffic %.2f x algorithmic" % rn["traffic_ratio"] if rn.get("traffic_ratio") else "",
+            rn["passes"]["ntt_lde_contig"]["ms"], rn["passes"]["ntt_lde_strided"]["ms"])
     if ms("bitrev_permute"):
         out["bitrev"] = "bit reversal %.2f ms" % ms("bitrev_permute")
     if ms("hash_leaves"):
