@@ -681,6 +681,57 @@ def ntt_roofline(kern, W, n_local, rows_local, steps, entry):
                     % ("%.2f x" % (traffic / alg) if traffic_complete and traffic else "about 2.8 x", "%.0f" % (sum(vpe) / len(vpe)) if vpe else "110")}
 
 
+def group_per_proof_path(eng, torch, world, emu, device_sync):
+    """`--gpus N`, rank 0 only, after the timed commit: the per-proof path of `other_configs.per_proof_path_k20` over a p2hot_group of
+    all N devices -- ONE process driving every GPU, the deployment a patched plonky2 uses -- as plonky2_amd/util/proof_path.py
+    run_group_path: four coset-sharded commits from host columns, p2hot_group_eval_openings, p2hot_group_prove_openings, every
+    output compared with the same oracle record the single-GPU line is checked against.  The Zs matrix and the quotient chunks
+    come from the single-GPU stages (run once, untimed, on this rank's device).  Never fatal: a failure is reported in the record.
+    P2HOT_BENCH_GROUP_PATH names the instance (default per_proof_path_k20; the emulated tier runs per_proof_path_k12)."""
+    name = os.environ.get("P2HOT_BENCH_GROUP_PATH", "per_proof_path_k20")
+    rec = {"workload": name + " over a p2hot_group of %d devices (one process): 4 sharded commits from host columns + OpeningSet + prove_openings" % world}
+    try:
+        from plonky2_amd.distributed import GroupCommit
+        from plonky2_amd.util import proof_path as pp
+        from plonky2_amd.util.synthetic import path_instance, splitmix_columns_numpy
+        inst, g = path_instance(name), pp.golden(name)
+        if g is None:
+            raise RuntimeError("no oracle record for " + name)
+        if (1 << inst["rate_bits"]) < world:
+            raise RuntimeError("the group proof is coset mode: world %d > 2^rate_bits" % world)
+        if not emu and torch.cuda.device_count() < world:
+            raise RuntimeError("rank 0 sees %d devices, the group needs %d" % (torch.cuda.device_count(), world))
+        single = pp.run_path(eng, pp.PathInputs(eng, inst), sync=device_sync, keep=True)
+        zs, chunks = single["zs"], single["chunks"]
+        rec["single_gpu_ms"] = sum(single["stage_ms"].values())
+        rec["single_gpu_checked"] = pp.compare_with_golden(single, g) == []
+        del single
+        if not emu:
+            torch.cuda.empty_cache()
+        n = 1 << inst["log_n"]
+        cs = splitmix_columns_numpy(inst["cs_seed"], inst["cs_width"], n)
+        wires = splitmix_columns_numpy(inst["wires_seed"], inst["wires_width"], n)
+        group = GroupCommit(eng.lib, world, list(range(world)))
+        try:
+            rec["uses_rccl"], rec["exchange"] = group.uses_rccl, group.exchange
+            best, res = None, None
+            for rep in range(1 if emu else 3):   # the first is the warm-up (tables, pools) unless it is the only one
+                device_sync()
+                t0 = time.perf_counter()
+                res = pp.run_group_path(group, inst, cs, wires, zs, chunks, sync=None)
+                dt_ = (time.perf_counter() - t0) * 1e3
+                if emu or rep > 0:
+                    best = dt_ if best is None else min(best, dt_)
+            bad = pp.compare_with_golden(res, g)
+            rec.update({"ms": best, "stage_ms": res["stage_ms"], "checked": not bad, "differs": bad or None,
+                        "note": "host columns in (PCIe-inclusive), results on the host; stage_ms are un-synchronised issue times"})
+        finally:
+            group.close()
+    except Exception as ex:  # noqa: BLE001
+        rec.update({"skipped": "%s: %s" % (type(ex).__name__, ex), "checked": False})
+    return rec
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` outside a launcher: re-run this file as N ranks (one process per GPU) under
     torch.distributed.run on 127.0.0.1 and a free port; the ranks inherit stdout / stderr, so rank 0's JSON line is this
@@ -799,17 +850,48 @@ def main():
         except Exception as ex:  # noqa: BLE001
             preflight["peer_access"] = "query failed: %r" % (ex,)
         t_pf = time.perf_counter()
-        err = None
-        try:
-            if emu and os.environ.get("P2HOT_BENCH_EMU_FAIL_PREFLIGHT") == str(rank):  # (test tier: this rank never reaches the collective)
-                raise RuntimeError("injected preflight failure on rank %d" % rank)
-            job.comm.selftest(1 << 20)
-        except Exception as ex:  # noqa: BLE001
-            err = ex
-        # every rank learns whether ANY rank failed (through the launcher's process group, not the transport under test)
-        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=eng.mem.device if backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()) and job.comm.transport == "rccl" and os.environ.get("P2HOT_BENCH_NO_FALLBACK") != "1":
+        flag_dev = eng.mem.device if backend == "nccl" else "cpu"
+
+        def any_rank(bad):
+            """every rank learns whether ANY rank says `bad` (through the launcher's process group, not the transport under test)"""
+            f = torch.tensor([1 if bad else 0], dtype=torch.int32, device=flag_dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)
+            return bool(int(f.item()))
+
+        def guarded_selftest(job_, not_ready=None):
+            """The 1 MB all-gather through the transport under test, entered by ALL ranks or by none: the ranks first tell each other
+            (over torch's process group) that they got as far as the collective -- a rank that failed earlier would otherwise leave the
+            healthy ones alone inside an all-gather that never completes -- and the collective itself runs under a watchdog
+            (P2HOT_BENCH_PREFLIGHT_TIMEOUT seconds, default 120), so a rank that dies INSIDE it ends the run with a message instead of
+            a hang.  Returns (error or None, stuck): stuck = a library call is still inside the collective, nothing can be reused."""
+            import threading
+            if any_rank(not_ready is not None):
+                return not_ready or RuntimeError("another rank did not reach the preflight collective"), False
+            box = {}
+
+            def run():
+                try:
+                    if not emu:
+                        torch.cuda.set_device(local_rank)  # (the current device is per thread)
+                    job_.comm.selftest(1 << 20)
+                except Exception as ex_:  # noqa: BLE001
+                    box["err"] = ex_
+            th = threading.Thread(target=run, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("P2HOT_BENCH_PREFLIGHT_TIMEOUT", "120")))
+            if th.is_alive():
+                return TimeoutError("the preflight all-gather did not complete on rank %d" % rank), True
+            return box.get("err"), False
+
+        injected = None
+        if emu and os.environ.get("P2HOT_BENCH_EMU_FAIL_PREFLIGHT") == str(rank):  # (test tier: this rank never reaches the collective)
+            injected = RuntimeError("injected preflight failure on rank %d" % rank)
+        err, stuck = guarded_selftest(job, injected)
+        failed = any_rank(err is not None)
+        if any_rank(stuck):  # some rank is still inside the library's collective: no transport can be swapped in under it
+            print("bench preflight: the 1 MB all-gather through the %s transport hung (rank %d: %s)" % (job.comm.transport, rank, err), file=sys.stderr, flush=True)
+            os._exit(3)
+        if failed and job.comm.transport == "rccl" and os.environ.get("P2HOT_BENCH_NO_FALLBACK") != "1":
             # first contact with a real multi-GPU node happens in the driver's run, once: if the in-library RCCL communicator fails its
             # preflight, the exchange moves to torch.distributed's own communicator (device buffers, synchronous) instead of ending the
             # run -- the line says so (`transport`, `preflight.fallback`) and the scaling numbers are then those of that transport
@@ -818,18 +900,17 @@ def main():
             del job, cols
             job, cols = make_job(log_n, transport="torch" if backend == "nccl" else "gloo")  # (gloo: the emulated tier's process group)
             preflight["transport"] = job.comm.transport
-            err = None
-            try:
-                job.comm.selftest(1 << 20)
-            except Exception as ex:  # noqa: BLE001
-                err = ex
-            flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=eng.mem.device if backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()):
+            err, stuck = guarded_selftest(job)
+            failed = any_rank(err is not None)
+            if any_rank(stuck):
+                print("bench preflight: the fallback transport's all-gather hung (rank %d: %s)" % (rank, err), file=sys.stderr, flush=True)
+                os._exit(3)
+        if failed:
             raise SystemExit("bench preflight: the 1 MB all-gather through the %s transport failed (on rank %d: %s)" % (job.comm.transport, rank, err))
         preflight["selftest"] = "ok"
         preflight["selftest_ms"] = (time.perf_counter() - t_pf) * 1e3
         preflight["exchange"] = job.comm.exchange  # "allgather" / "broadcast": what the selftest's micro-timing of both kept
+        preflight["rccl"] = job.comm.rccl_info() if job.comm.transport == "rccl" else None  # the file and version the library bound
 
     gnames = {(135, 16, 3, 4): "c2_wires", (135, 20, 3, 4): "c3_wires", (135, 21, 3, 4): "scale2_wires", (135, 22, 3, 4): "scale4_wires",
               (135, 23, 3, 4): "c5_wires", (135, 7, 3, 4): "tiny_wires", (135, 6, 3, 4): "tiny_strong_wires"}
@@ -975,7 +1056,27 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not emu:
             out["cpu_baseline"] = cpu_baseline(W, log_n, rb, cap, golden_cap=g["cap"] if g else None)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if world > 1 and os.environ.get("P2HOT_BENCH_NO_GROUP_PATH") != "1":
+            # (the other ranks have released their devices and wait on the host for the store key set below)
+            job.comm.close()
+            del job
+            if not emu:
+                torch.cuda.empty_cache()
+            out["group_per_proof_path"] = group_per_proof_path(eng, torch, world, emu, device_sync)
         print(json.dumps(out))
+    if dist and world > 1 and os.environ.get("P2HOT_BENCH_NO_GROUP_PATH") != "1":
+        # the per-proof path over a p2hot_group is ONE process driving every GPU (rank 0 above): the other ranks free their device
+        # memory and wait on the HOST (the rendezvous store; a device-side barrier would spin on the GPUs rank 0 is using)
+        store = torch.distributed.distributed_c10d._get_default_store()
+        if rank == 0:
+            store.set("p2hot_group_path_done", "1")
+        else:
+            if "job" in dir():
+                job.comm.close()
+                del job
+            if not emu:
+                torch.cuda.empty_cache()
+            store.wait(["p2hot_group_path_done"])
     if dist:
         dist.barrier()
         if "job" in dir():

@@ -255,7 +255,7 @@ int p2hot_fri_pow(p2hot_ctx *ctx, p2hot_challenger *challenger, unsigned pow_bit
 #define P2HOT_COEFFS_PER_COLUMN 2u
 /* p2hot_commit / _salted with leaves_out AND handle_out: the call returns when the cap, the coefficients and the digests are back;
  * the row-major leaf matrix (9.1 GB at the C3 wires shape: 3 x the rest of the call over PCIe) keeps travelling into leaves_out on
- * the context's leaf-copy stream, in 64 consecutive row blocks, first block first.  A row may be READ only after
+ * the context's leaf-copy stream, in min(64, N / 1024) consecutive row blocks (p2hot_batch_leaves_block_rows), first block first.  A row may be READ only after
  * p2hot_batch_leaves_wait(handle, row_lo, row_hi) covered it; the buffer may be FREED only after p2hot_batch_free(handle) (which
  * waits for the copy) or a wait over all rows.  leaves_out should be pinned (p2hot_host_alloc): a pageable destination makes the
  * copy a synchronous one.  The next commitments, the partial products and the quotient run beside the copy. */
@@ -335,6 +335,11 @@ int p2hot_batch_digests(p2hot_batch *batch, uint64_t *out);
  * P2HOT_LEAVES_NATURAL, committed otherwise) have landed.  A batch without a pending copy returns at once; row_hi beyond the
  * leaf count or row_lo > row_hi is EINVAL.  This is the fence behind MerkleTree::get (hash/merkle_tree.rs:227) in the Rust shim. */
 int p2hot_batch_leaves_wait(p2hot_batch *batch, size_t row_lo, size_t row_hi);
+/* rows per block of the pending copy: min(64, N / 1024) blocks (at least one), delivered in order -- once row r has landed, so has
+ * every row below (r / block_rows + 1) * block_rows, which is what a reader walking forward raises its "landed" mark to instead of
+ * asking once per row (integration/p2hot.rs DeviceTree::fence).  0 when the batch has no copy in flight.  Lock-free like the wait,
+ * and like it never writes p2hot_last_error: both may run beside a locked call of the same context. */
+size_t p2hot_batch_leaves_block_rows(const p2hot_batch *batch);
 /* the kept input values (P2HOT_KEEP_VALUES) as a BORROWED column set: valid while the batch lives; p2hot_cols_free on
  * the view leaves the batch's memory alone */
 int p2hot_batch_values(p2hot_batch *batch, p2hot_cols **out);
@@ -505,6 +510,11 @@ int p2hot_comm_selftest(p2hot_comm *comm, size_t bytes);
  * RCCL communicator p2hot_comm_selftest checks and times both and keeps the faster (rank 0's verdict, broadcast to all);
  * p2hot_group_create does the same over its ranks; P2HOT_EXCHANGE=broadcast|allgather pins one.  -1 for a null handle. */
 int p2hot_comm_exchange_mode(const p2hot_comm *comm);
+/* Which RCCL this process is bound to: the library file (dladdr of ncclGetUniqueId) into path_out (NUL-terminated, truncated to
+ * path_cap) and ncclGetVersion's code (e.g. 22203) into version_out; either may be NULL.  The library prefers the copy the
+ * process already loaded (PyTorch's, under torch.distributed.run) and falls back to /opt/rocm/lib/librccl.so.1 by path (a patched
+ * plonky2, no torch): two deployment modes, two RCCL builds -- a run reports which one it used.  P2HOT_ECOMM if none binds. */
+int p2hot_rccl_info(char *path_out, size_t path_cap, int *version_out);
 /* columns [first, first + count) of W are the ones rank `rank` of `world` transforms in the iNTT stage */
 int p2hot_shard_columns(size_t W, int world, int rank, size_t *first, size_t *count);
 /* from_values / from_coeffs (fri/oracle.rs:57-112) of this rank's share, DEVICE pointers, asynchronous:

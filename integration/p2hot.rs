@@ -281,6 +281,7 @@ extern "C" {
     pub fn p2hot_batch_paths(batch: *mut P2hotBatch, leaf_idx: *const u64, m: usize, out: *mut u64) -> c_int;
     pub fn p2hot_batch_digests(batch: *mut P2hotBatch, out: *mut u64) -> c_int;
     pub fn p2hot_batch_leaves_wait(batch: *mut P2hotBatch, row_lo: usize, row_hi: usize) -> c_int;
+    pub fn p2hot_batch_leaves_block_rows(batch: *const P2hotBatch) -> usize;
     pub fn p2hot_batch_values(batch: *mut P2hotBatch, out: *mut *mut P2hotCols) -> c_int;
     pub fn p2hot_batch_subgroup_values(batch: *mut P2hotBatch, first: usize, count: usize, out: *mut *mut P2hotCols) -> c_int;
     pub fn p2hot_batch_free(batch: *mut P2hotBatch);
@@ -331,6 +332,7 @@ extern "C" {
     pub fn p2hot_comm_world(comm: *const P2hotComm) -> c_int;
     pub fn p2hot_comm_selftest(comm: *mut P2hotComm, bytes: usize) -> c_int;
     pub fn p2hot_comm_exchange_mode(comm: *const P2hotComm) -> c_int;
+    pub fn p2hot_rccl_info(path_out: *mut c_char, path_cap: usize, version_out: *mut c_int) -> c_int;
     pub fn p2hot_shard_columns(W: usize, world: c_int, rank: c_int, first: *mut usize, count: *mut usize) -> c_int;
     pub fn p2hot_commit_sharded_dev(
         ctx: *mut P2hotCtx, comm: *mut P2hotComm, d_cols_local: *const u64, col_stride: usize, W: usize, log_n: c_uint, rate_bits: c_uint,
@@ -615,7 +617,11 @@ impl<F: RichField> DeviceTree<F> {
         }
         let rc = unsafe { p2hot_batch_leaves_wait(self.batch, r, r + 1) };
         assert!(rc == P2HOT_OK, "libp2hot p2hot_batch_leaves_wait failed ({rc})");
-        self.landed.fetch_max(r + 1, Ordering::AcqRel);
+        // the copy delivers whole row blocks in order: with row r, everything up to the end of r's block has landed, so a
+        // reader walking forward pays one FFI wait per block (64 per matrix), not one per row
+        let block = unsafe { p2hot_batch_leaves_block_rows(self.batch) };
+        let mark = if block == 0 { self.num_leaves } else { core::cmp::min((r / block + 1) * block, self.num_leaves) };
+        self.landed.fetch_max(mark, Ordering::AcqRel);
     }
 
     /// waits for the whole leaf matrix (serializers, `leaves_as_vecs`, equality: readers that walk every row)

@@ -108,6 +108,7 @@ SIGNATURES = {
     "p2hot_batch_paths": (i, [vp, vp, sz, vp]),
     "p2hot_batch_digests": (i, [vp, vp]),
     "p2hot_batch_leaves_wait": (i, [vp, sz, sz]),
+    "p2hot_batch_leaves_block_rows": (sz, [vp]),
     "p2hot_batch_values": (i, [vp, C.POINTER(vp)]),
     "p2hot_batch_subgroup_values": (i, [vp, sz, sz, C.POINTER(vp)]),
     "p2hot_batch_free": (None, [vp]),
@@ -136,6 +137,7 @@ SIGNATURES = {
     "p2hot_comm_world": (i, [vp]),
     "p2hot_comm_selftest": (i, [vp, sz]),
     "p2hot_comm_exchange_mode": (i, [vp]),
+    "p2hot_rccl_info": (i, [C.c_char_p, sz, C.POINTER(i)]),
     "p2hot_shard_columns": (i, [sz, i, i, C.POINTER(sz), C.POINTER(sz)]),
     "p2hot_commit_sharded_dev": (i, [vp, vp, vp, sz, sz, u, u, u, i, i, u, vp, vp, sz, vp, vp, vp]),
     "p2hot_group_create": (i, [i, C.POINTER(i), C.POINTER(vp)]),

@@ -613,6 +613,26 @@ extern "C" int p2hot_comm_selftest(p2hot_comm *comm, size_t bytes) {
 
 extern "C" int p2hot_comm_exchange_mode(const p2hot_comm *c) { return c ? c->exchange_mode : -1; }
 
+// Which RCCL the library is bound to in THIS process: the file and its ncclGetVersion code.  The two deployment modes bind
+// different copies -- under torch.distributed.run the one PyTorch already loaded (RTLD_NOLOAD: two RCCLs never meet in one
+// process), in a patched plonky2 (no torch) /opt/rocm's by path -- and a first multi-GPU run should say which one it used.
+extern "C" int p2hot_rccl_info(char *path_out, size_t path_cap, int *version_out) {
+    rccl::Api &a = rccl::api();
+    if (path_out && path_cap) path_out[0] = 0;
+    if (version_out) *version_out = 0;
+    if (!a.ok) return P2HOT_ECOMM;
+#ifdef P2HOT_EMU
+    if (path_out && path_cap) snprintf(path_out, path_cap, "%s", "tests/emu fake RCCL");
+#else
+    Dl_info info{};
+    if (path_out && path_cap && dladdr(reinterpret_cast<void *>(a.GetUniqueId), &info) && info.dli_fname)
+        snprintf(path_out, path_cap, "%s", info.dli_fname);
+    if (version_out)
+        if (auto get_version = reinterpret_cast<int (*)(int *)>(dlsym(a.lib, "ncclGetVersion"))) (void)get_version(version_out);
+#endif
+    return P2HOT_OK;
+}
+
 extern "C" int p2hot_shard_columns(size_t W, int world, int rank, size_t *first, size_t *count) {
     if (world < 1 || rank < 0 || rank >= world || !first || !count) return P2HOT_EINVAL;
     const size_t cpr = W ? (W + (size_t)world - 1) / (size_t)world : 0;

@@ -218,7 +218,7 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
         for (size_t k = k0; k < k1; ++k) {
             P2_HIP(ctx, hipMemcpyAsync(leaves_out + k * bw, d_leaves.u() + k * bw, bw * 8, hipMemcpyDeviceToHost, ctx->leaf_stream));
             hipEvent_t e;
-            P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            P2_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
             leafcopy->ev.push_back(e);
             P2_HIP(ctx, hipEventRecord(e, ctx->leaf_stream));
         }
@@ -410,7 +410,13 @@ static int commit_host(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, un
 
 static void leafcopy_finish(p2hot_batch *b) {  // waits for the copy in flight and returns its staging block
     if (!b || !b->leafcopy) return;
-    if (b->ctx->leaf_stream) (void)hipStreamSynchronize(b->ctx->leaf_stream);
+    // this batch's copy only: the leaf stream is the context's, and a later batch's 9 GB may be queued behind this one's.  The
+    // block events are recorded in stream order, so the last one covers every block and both auxiliary waits
+    const p2hot_batch::LeafCopy *lc = b->leafcopy;
+    if (!lc->ev.empty() && lc->rows_per_block && lc->ev.size() == lc->rows / lc->rows_per_block)
+        (void)hipEventSynchronize(lc->ev.back());
+    else if (b->ctx->leaf_stream)
+        (void)hipStreamSynchronize(b->ctx->leaf_stream);  // (a copy that was never fully issued: nothing else to wait on)
     for (hipEvent_t ev : b->leafcopy->ev) (void)hipEventDestroy(ev);
     if (b->leafcopy->aux) (void)hipEventDestroy(b->leafcopy->aux);
     if (b->leafcopy->aux2) (void)hipEventDestroy(b->leafcopy->aux2);
@@ -419,16 +425,21 @@ static void leafcopy_finish(p2hot_batch *b) {  // waits for the copy in flight a
     b->leafcopy = nullptr;
 }
 
+// LOCK-FREE (rayon workers call it while another thread is inside a locked p2hot_* call of the same context): it therefore
+// never writes the context's error text -- the code is all a failure reports
 extern "C" int p2hot_batch_leaves_wait(p2hot_batch *b, size_t row_lo, size_t row_hi) {
     if (!b) return P2HOT_EINVAL;
-    p2hot_ctx *ctx = b->ctx;
-    if (row_lo > row_hi || row_hi > b->N) P2_FAIL(ctx, P2HOT_EINVAL, "leaves_wait: rows [%zu, %zu) of %zu", row_lo, row_hi, b->N);
+    if (row_lo > row_hi || row_hi > b->N) return P2HOT_EINVAL;
     if (!b->leafcopy || row_lo == row_hi) return P2HOT_OK;
-    DeviceGuard dev_guard_(ctx);
+    DeviceGuard dev_guard_(b->ctx);
     const size_t rpb = b->leafcopy->rows_per_block;
-    for (size_t k = row_lo / rpb; k <= (row_hi - 1) / rpb; ++k) P2_HIP(ctx, hipEventSynchronize(b->leafcopy->ev[k]));
+    for (size_t k = row_lo / rpb; k <= (row_hi - 1) / rpb; ++k)
+        if (hipEventSynchronize(b->leafcopy->ev[k]) != hipSuccess) return P2HOT_EHIP;
     return P2HOT_OK;
 }
+// rows per block of the pending asynchronous leaf copy (min(64, N / 1024) blocks, at least one), 0 when nothing is in flight:
+// once row r has landed, so has every row below (r / rows_per_block + 1) * rows_per_block -- what the shim rounds its mark up to
+extern "C" size_t p2hot_batch_leaves_block_rows(const p2hot_batch *b) { return b && b->leafcopy ? b->leafcopy->rows_per_block : 0; }
 
 extern "C" int p2hot_commit(p2hot_ctx *ctx, const uint64_t *const *cols, size_t W, unsigned log_n, unsigned rate_bits,
                             unsigned cap_height, int is_values, unsigned flags, uint64_t *coeffs_out, uint64_t *leaves_out,

@@ -351,6 +351,11 @@ __device__ __forceinline__ u32 opaque_u32(u32 c) {
 #endif
     return c;
 }
+__device__ __forceinline__ void opaque_branch() {
+#ifndef P2HOT_EMU
+    asm volatile("");
+#endif
+}
 __device__ __forceinline__ unsigned wave_uniform(unsigned v) {
 #ifdef P2HOT_EMU
     return v;
@@ -551,13 +556,13 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
                     limb_mul_n<(1 << P)>(y, t);
 #pragma unroll
                     for (int q = 0; q < (1 << P); ++q)
-                        *reinterpret_cast<u64 *>(go + ((size_t)q << log_stride) * 8 + off0) = a.canon_out ? gl::canon(y[q]) : y[q];
+                        *reinterpret_cast<u64 *>(go + ((size_t)q << log_stride) * 8 + off0) = y[q];  // (a strided pass is never the last: no canon)
                 } else {
 #pragma unroll
                     for (int q = 0; q < (1 << P); ++q) {
                         const size_t step = ((size_t)q << log_stride) * 8;
                         const u64 v_ = limb_mul(conv_last(x[q]), *reinterpret_cast<const u64 *>(tw + step + off0));
-                        *reinterpret_cast<u64 *>(go + step + off0) = a.canon_out ? gl::canon(v_) : v_;
+                        *reinterpret_cast<u64 *>(go + step + off0) = v_;
 #ifndef P2HOT_EMU
                         if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four outputs at a time: the twiddle loads are not hoisted past this
 #endif
@@ -642,10 +647,16 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
             limb_round<INV, LOG_R, LOG_C, SCALE, LAST, 0>(ra, tile, ltw, lu, raw, next, out, log_stride, z, base0);
             constexpr int LAST_P = round_bits(LOG_R, n_rounds(LOG_R) - 1);
             if constexpr (LOG_C == 0 && !(LAST_P == 3 && LIMB_DIRECT_CONTIG)) {
+                // canonical representatives or not is the launch's choice: ONE wave-uniform branch around the eight stores
+                // (as `canon_out ? canon(v) : v` it was a 64-bit compare, an add and four selects per word; the empty asm keeps
+                // the optimiser from merging the two arms back into selects)
+                if (a.canon_out) {
+                    opaque_branch();
 #pragma unroll
-                for (unsigned j = 0; j < 8; ++j) {
-                    const u64 v = tile[tix(se0, e0, 64 * j)];
-                    out[e0 + 64 * j] = a.canon_out ? gl::canon(v) : v;
+                    for (unsigned j = 0; j < 8; ++j) out[e0 + 64 * j] = gl::canon(tile[tix(se0, e0, 64 * j)]);
+                } else {
+#pragma unroll
+                    for (unsigned j = 0; j < 8; ++j) out[e0 + 64 * j] = tile[tix(se0, e0, 64 * j)];
                 }
             } else if constexpr (LOG_C > 0 && LAST_P == 3) {
                 // a strided pass whose last round is radix 8 (2^9 and 2^6 rows): inter-pass twiddle + store from LDS.
@@ -668,7 +679,7 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
                     for (unsigned j = 0; j < 8; ++j) {
                         const unsigned U = U0 + 64 * j;
                         const size_t step = ((size_t)(U >> LOG_C) << log_stride) + (U & (C - 1));
-                        *reinterpret_cast<u64 *>(reinterpret_cast<char *>(out + step) + off0) = a.canon_out ? gl::canon(v8[j]) : v8[j];
+                        *reinterpret_cast<u64 *>(reinterpret_cast<char *>(out + step) + off0) = v8[j];
                     }
                 } else {
 #pragma unroll 2
@@ -677,7 +688,7 @@ __global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPa
                         const size_t step = ((size_t)(U >> LOG_C) << log_stride) + (U & (C - 1));
                         const u64 w = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ra.twid + base0 + step) + off0);
                         u64 v = limb_mul(tile[tix(se0, e0, 64 * j)], w);
-                        *reinterpret_cast<u64 *>(reinterpret_cast<char *>(out + step) + off0) = a.canon_out ? gl::canon(v) : v;
+                        *reinterpret_cast<u64 *>(reinterpret_cast<char *>(out + step) + off0) = v;
                     }
                 }
             }

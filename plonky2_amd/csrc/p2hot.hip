@@ -752,6 +752,7 @@ static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse
         else P2_LIMB_DIR(LR, ntt::SCALE_NONE, nttl::LAST_UNIT);                                                   \
     } while (0)
     if (a.scale_mode == ntt::SCALE_TABLE && a.log_r != 12 && (!srow2 || !sbase)) P2_FAIL(ctx, P2HOT_EINVAL, "limb pass: missing coset scale tables");
+    if (a.canon_out && a.log_c) P2_FAIL(ctx, P2HOT_EINVAL, "limb pass: a strided pass is never the last one and stores no canonical representatives");
     if (wlast) {
         if (inverse)
             P2_LIMB(true, 12, ntt::SCALE_NONE, nttl::LAST_CONST);

@@ -185,6 +185,10 @@ class Communicator:
         if self.world > 1 or self.transport == "rccl":
             self.engine.check(self.engine.lib.p2hot_comm_selftest(self._h, nbytes))
 
+    def rccl_info(self):
+        """which RCCL the library is bound to in this process (p2hot_rccl_info): {"path", "version"} or None"""
+        return rccl_info(self.engine.lib)
+
     @property
     def exchange(self):
         """how equal slices travel on the RCCL transport: "allgather" (ncclAllGather) or "broadcast" (grouped ncclBroadcast);
@@ -394,3 +398,13 @@ class GroupCommit:
             self.close()
         except Exception:
             pass
+
+
+def rccl_info(lib):
+    """p2hot_rccl_info: the RCCL file libp2hot bound in THIS process and its ncclGetVersion code -- PyTorch's bundled copy when
+    torch loaded it first (RTLD_NOLOAD), /opt/rocm's by path otherwise; None when no RCCL binds"""
+    buf = C.create_string_buffer(1024)
+    ver = C.c_int(0)
+    if lib.p2hot_rccl_info(buf, len(buf), C.byref(ver)) != 0:
+        return None
+    return {"path": buf.value.decode(errors="replace"), "version": int(ver.value)}

@@ -338,14 +338,19 @@ def prove_openings(batches, oracles, challenger, rate_bits, cap_height, reductio
                                            C.byref(proof)))
     if timing is not None:
         timing["prove_openings"] = timing.get("prove_openings", 0.0) + (time.perf_counter() - t0) * 1e3
-    # reshape the flat buffers (layout: include/p2hot.h, p2hot_fri_proof)
-    ncap = 1 << cap_height
-    log_N = oracles[0].degree_log + rate_bits
     widths = [o._W + getattr(o, "salt_size", 0) for o in oracles]  # evals_proofs carry whole leaves, salts included
+    bufs["final_poly"] = bufs["final_poly"][:lay.final_poly_words]
+    return shape_fri_proof(bufs, int(proof.pow_witness), qidx, widths, oracles[0].degree_log + rate_bits, cap_height, arity, Q)
+
+
+def shape_fri_proof(bufs, pow_witness, qidx, widths, log_N, cap_height, arity, Q):
+    """the flat proof buffers of p2hot_prove_openings / p2hot_group_prove_openings (layout: include/p2hot.h, p2hot_fri_proof) as the
+    FriProof-shaped dict documented at prove_openings.  widths: leaf words per oracle; log_N: log2 of the LDE size"""
+    R, ncap = len(arity), 1 << cap_height
     wsum = sum(widths)
     il = bufs["initial_leaves"][:Q * wsum].reshape(Q, wsum) if wsum else np.zeros((Q, 0), dtype=np.uint64)
     layers0 = log_N - cap_height
-    ip = bufs["initial_paths"][:Q * len(oracles) * layers0 * 4].reshape(Q, len(oracles), layers0, 4)
+    ip = bufs["initial_paths"][:Q * len(widths) * layers0 * 4].reshape(Q, len(widths), layers0, 4)
     ev_w, pa_w, lm = [], [], log_N
     for a in arity:
         ev_w.append(2 << a)
@@ -365,7 +370,8 @@ def prove_openings(batches, oracles, challenger, rate_bits, cap_height, reductio
             eo += ev_w[r]
             po += 4 * pa_w[r]
         queries.append({"initial_trees_proof": initial, "steps": steps})
+    # final_poly: (N / 2^rate) / prod(2^arity) extension coefficients -- whatever the buffer holds
     return {"commit_phase_merkle_caps": [bufs["caps"][4 * ncap * r:4 * ncap * (r + 1)].reshape(ncap, 4) for r in range(R)],
             "query_round_proofs": queries,
-            "final_poly": bufs["final_poly"][:lay.final_poly_words].reshape(-1, 2),
-            "pow_witness": int(proof.pow_witness), "query_indices": [int(x) for x in qidx[:Q]]}
+            "final_poly": np.asarray(bufs["final_poly"]).reshape(-1, 2),
+            "pow_witness": int(pow_witness), "query_indices": [int(x) for x in qidx[:Q]]}

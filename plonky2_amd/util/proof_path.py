@@ -107,7 +107,7 @@ def run_path(eng, inp, sync=None, keep=False):
     ch = Challenger(eng)
     ch.observe_elements(np.asarray(inst["transcript_seed"], dtype=np.uint64))
     zeta = ch.get_extension_challenge()
-    gz = second_point(zeta)
+    gz = second_point(zeta, inst["log_n"])
     if inst["kind"] == "plonk":
         # OpeningSet::new (plonk/proof.rs:314-345): the four commitments at zeta, the Zs commitment again at the second point
         ev_zeta = eval_openings(oracles, [zeta], eng)
@@ -128,6 +128,51 @@ def run_path(eng, inp, sync=None, keep=False):
                     "transcript_after": [int(x) for x in ch.get_n_challenges(2)], "oracles": oracles})
         if inst["kind"] == "plonk":
             out.update({"zs": eng.host(zs), "quotient_values": qvals, "chunks": chunks_host})
+    return out
+
+
+def run_group_path(group, inst, cs, wires, zs, chunks, sync=None, pipeline_chunks=8):
+    """The per-proof path over a p2hot_group (one process, every GPU of the node; SURVEY 8e + 8f-1/2): the four commitments as
+    coset-sharded commits from HOST columns (p2hot_group_commit: constants_sigmas and wires from values, the Zs / partial-products
+    matrix from values, the quotient chunks from coefficients), the OpeningSet through p2hot_group_eval_openings and the opening
+    proof through p2hot_group_prove_openings (rank 0 runs the polynomial side, the owners of the rows serve the initial trees).
+    `zs` and `chunks` are the single-GPU stages' outputs (the partial products and the quotient need whole LDE matrices on one
+    device; they are inputs here).  Returns the same dict run_path(keep=True) does, minus the single-GPU stage outputs, so
+    compare_with_golden checks it against the same oracle record."""
+    from ..fri.oracle import shape_fri_proof
+    from ..iop.challenger import Challenger
+    if inst["kind"] != "plonk":
+        raise ValueError("the group path is the plonk instance (coset mode: world <= 2^rate_bits)")
+    rb, cap, log_n = inst["rate_bits"], inst["cap_height"], inst["log_n"]
+    stage, t = {}, [time.perf_counter()]
+
+    def lap(label):
+        if sync:
+            sync()
+        now = time.perf_counter()
+        stage[label] = (now - t[0]) * 1e3
+        t[0] = now
+    commits = []
+    for label, cols, is_values in (("constants_sigmas", cs, True), ("wires", wires, True), ("Zs + partial products", zs, True),
+                                   ("quotient chunks", chunks, False)):
+        commits.append(group.commit(cols, rb, cap, is_values=is_values, want_leaves=False, want_digests=False, pipeline_chunks=pipeline_chunks))
+        lap("sharded commit: %s (W=%d, host columns in)" % (label, len(cols)))
+    ch = Challenger(group.engine0())
+    ch.observe_elements(np.asarray(inst["transcript_seed"], dtype=np.uint64))
+    zeta = ch.get_extension_challenge()
+    gz = second_point(zeta, log_n)
+    ev_zeta = [e[0] for e in group.eval_openings(commits, [zeta])]
+    ev_next = [e[0] for e in group.eval_openings([commits[2]], [gz])]
+    lap("OpeningSet over the group")
+    flat = group.prove_openings([(zeta, inst["batch_zeta"]), (gz, inst["batch_next"])], commits, ch, rb, cap, inst["arity"],
+                                inst["pow_bits"], inst["num_queries"])
+    lap("prove_openings over the group")
+    proof = shape_fri_proof(flat, flat["pow_witness"], flat["query_indices"], [c["W"] for c in commits], log_n + rb, cap,
+                            [int(a) for a in inst["arity"]], inst["num_queries"])
+    out = {"stage_ms": stage, "zeta": [int(v) for v in zeta], "second_point": gz, "openings_zeta": ev_zeta, "openings_next": ev_next,
+           "proof": proof, "caps": [c["cap"] for c in commits], "transcript_after": [int(x) for x in ch.get_n_challenges(2)]}
+    for c in commits:
+        c["free"]()
     return out
 
 

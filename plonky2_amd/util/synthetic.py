@@ -106,7 +106,16 @@ def path_instance(name):
             "per_proof_path_starky_k22": lambda: starky_path_instance(22)}[name]()
 
 
-def second_point(zeta):
-    """the bench's stand-in for g * zeta: a second extension point derived from the first (any point != zeta exercises the
-    same code; the FRI instance only needs the two points to differ)"""
-    return [(int(zeta[0]) * 7) % P, int(zeta[1])]
+POWER_OF_TWO_GENERATOR = 7277203076849721926  # field/src/goldilocks_field.rs:87 (order 2^32)
+
+
+def primitive_root_of_unity(log_n):
+    """Field::primitive_root_of_unity (field/src/types.rs:268-272): POWER_OF_TWO_GENERATOR ^ (2^(32 - log_n))"""
+    return pow(POWER_OF_TWO_GENERATOR, 1 << (32 - log_n), P)
+
+
+def second_point(zeta, log_n):
+    """g * zeta with g = primitive_root_of_unity(degree_bits) embedded in the extension field: the point the reference opens
+    the Z polynomials (plonk/circuit_data.rs:537-539) and the starky trace (starky/src/stark.rs:101-156) at besides zeta"""
+    g = primitive_root_of_unity(log_n)
+    return [(int(zeta[0]) * g) % P, (int(zeta[1]) * g) % P]

@@ -78,6 +78,7 @@ def test_a_read_before_the_fence_is_a_wrong_answer(emu, ora):
     emu.check(rc)
     assert (leaves == 0xDEAD).all(), "no fence yet: nothing may have landed under the lazy schedule"
     rpb = N // 64
+    assert emu.lib.p2hot_batch_leaves_block_rows(h) == rpb   # min(64, N / 1024) blocks: what the shim rounds its landed mark up to
     emu.check(emu.lib.p2hot_batch_leaves_wait(h, 5 * rpb + 1, 5 * rpb + 2))       # block 5: blocks 0..5 have landed (stream order)
     assert (leaves[:6 * rpb] == o["leaves"][:6 * rpb]).all()
     assert (leaves[6 * rpb:] == 0xDEAD).all(), "blocks behind the fenced one are still in flight"
@@ -99,9 +100,15 @@ def test_async_leaves_argument_errors(eng):
     assert eng.lib.p2hot_commit(eng.ctx, ptrs, 2, 3, 1, 0, 1, _lib.LEAVES_NATURAL, None, None, None, capv.ctypes.data, C.byref(h)) == _lib.EINVAL
     assert eng.lib.p2hot_commit(eng.ctx, ptrs, 2, 3, 1, 0, 1, 16, None, None, None, capv.ctypes.data, C.byref(h)) == _lib.EINVAL
     assert eng.lib.p2hot_batch_leaves_wait(None, 0, 0) == _lib.EINVAL
+    assert eng.lib.p2hot_batch_leaves_block_rows(None) == 0
     # a batch without a copy in flight: the fence is a no-op
     eng.check(eng.lib.p2hot_commit(eng.ctx, ptrs, 2, 3, 1, 0, 1, 0, None, leaves.ctypes.data, None, capv.ctypes.data, C.byref(h)))
     eng.check(eng.lib.p2hot_batch_leaves_wait(h, 0, 16))
+    assert eng.lib.p2hot_batch_leaves_block_rows(h) == 0
+    # the fence is lock-free and therefore reports by code alone: a bad range does not touch the context's error text
+    eng.lib.p2hot_last_error.restype = C.c_char_p
+    before = eng.lib.p2hot_last_error(eng.ctx)
+    assert eng.lib.p2hot_batch_leaves_wait(h, 3, 2) == _lib.EINVAL and eng.lib.p2hot_last_error(eng.ctx) == before
     eng.lib.p2hot_batch_free(h)
 
 

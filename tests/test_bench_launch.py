@@ -17,6 +17,7 @@ def _bench(*args, env_extra=None, timeout=600):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
                                                              "P2HOT_EXCHANGE", "P2HOT_TRANSPORT")}
     env["P2HOT_BENCH_EMU"] = "1"
+    env["P2HOT_BENCH_NO_GROUP_PATH"] = "1"   # (the per-proof path over a group: only the test below pays for it)
     env.update(env_extra or {})
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, capture_output=True, text=True,
                           timeout=timeout, cwd="/tmp")
@@ -43,6 +44,22 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert s["scaling"] == "strong" and s["cap_checked"] is True and s["caps_checked"] == 2 and s["value"] > 0
     for key in ("value", "ms_per_step", "roofline", "kernels", "algorithmic_bytes_per_step"):
         assert key in d
+
+
+def test_bench_gpus_2_adds_the_per_proof_path_over_the_group():
+    """behind world > 1: one `group_per_proof_path` record -- the per-proof path as ONE process driving both (emulated) devices
+    (p2hot_group: four sharded commits from host columns, p2hot_group_eval_openings, p2hot_group_prove_openings), on the k12
+    instance here, checked against the same oracle record the single-context path is (tests/golden/path_goldens.json)"""
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--log-n", "6", timeout=1500,
+               env_extra={"P2HOT_BENCH_NO_GROUP_PATH": "0", "P2HOT_BENCH_GROUP_PATH": "per_proof_path_k12", "P2HOT_BENCH_NO_STRONG": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_json_line(r.stdout)
+    gp = d["group_per_proof_path"]
+    assert gp.get("skipped") is None, gp
+    assert gp["checked"] is True and gp["single_gpu_checked"] is True and gp["differs"] is None
+    assert "per_proof_path_k12 over a p2hot_group of 2 devices" in gp["workload"] and gp["uses_rccl"] is True and gp["ms"] > 0
+    assert any(k.startswith("sharded commit: wires") for k in gp["stage_ms"]) and "prove_openings over the group" in gp["stage_ms"]
+    assert d["cap_checked"] is True
 
 
 def test_bench_gpus_8_launches_eight_ranks():

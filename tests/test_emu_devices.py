@@ -479,3 +479,12 @@ def test_forgotten_stream_waits_are_visible_as_wrong_results(ora, monkeypatch):
         lib.p2hot_emu_set_device(0)
     assert broken == (False, False), broken
     assert host_commit() and group_commit()
+
+
+def test_rccl_info_reports_the_bound_library(emu):
+    """p2hot_rccl_info: the emulator build is bound to the fake RCCL of tests/emu and says so (the product build reports the real
+    file and ncclGetVersion: tests/test_gpu_fullsize.py::test_rccl_binding_without_torch); NULL outputs are allowed"""
+    from plonky2_amd.distributed import rccl_info
+    r = rccl_info(emu.lib)
+    assert r == {"path": "tests/emu fake RCCL", "version": 0}
+    assert emu.lib.p2hot_rccl_info(None, 0, None) == 0

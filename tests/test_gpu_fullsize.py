@@ -75,6 +75,35 @@ def test_baseline_commits_bit_exact_vs_oracle_goldens(gpu, name):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("name", ["c2_wires", "c3_quotient_chunks"])
+def test_polynomial_batch_wire_bytes_vs_oracle_at_full_size(gpu, name):
+    """SURVEY 8f-4 at real sizes: the reference's `write_polynomial_batch` byte stream (util/serialization/mod.rs:1744-1763 around
+    write_merkle_tree :1417-1431: W, per polynomial its length and canonical coefficients, the leaf count, per leaf row its
+    length and words IN COMMITTED ORDER, the digest array in the reference layout, the cap, degree_log, rate_bits, blinding) of
+    the DEVICE-built batch -- host column pointers in through p2hot_commit (what the Rust shim calls), leaf rows back through
+    p2hot_batch_rows, digests through p2hot_batch_digests, coefficients through p2hot_batch_coeffs -- against SHA-256 of the
+    stream the ORACLE-built batch serialises to (tests/golden/commit_caps.json `sha256_polynomial_batch`, tools/gen_golden_caps.py
+    --batch-bytes).  C2 wires (from_values, W = 135, 2^16 rows: 0.64 GB of stream) and the C3 quotient chunks (from_coeffs,
+    W = 16, 2^20 rows: 1.5 GB).  What the Rust serializer will emit for these batches is thereby pinned; that it runs on the
+    shim's structs needs rustc (integration/first_contact.sh)."""
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    from plonky2_amd.util.synthetic import splitmix_columns_numpy
+    from tests.wire_format import polynomial_batch_sha256
+    g = _golden(name)
+    assert g and g.get("sha256_polynomial_batch"), "run tools/gen_golden_caps.py --batch-bytes"
+    W, log_n, rb, cap = g["W"], g["log_n"], g["rate_bits"], g["cap_height"]
+    cols = splitmix_columns_numpy(0, W, 1 << log_n)
+    build = PolynomialBatch.from_values if g["is_values"] else PolynomialBatch.from_coeffs
+    b = build(cols, rb, False, cap, engine=gpu)
+    assert (b.degree_log, b.rate_bits, b.blinding) == (log_n, rb, False)
+    assert gpu.lib.p2hot_batch_width(b._owner.h) == W and gpu.lib.p2hot_batch_degree_log(b._owner.h) == log_n
+    N, step = 1 << (log_n + rb), 1 << 16
+    rows = (b._owner.rows(np.arange(r, r + step, dtype=np.uint64)) for r in range(0, N, step))
+    got = polynomial_batch_sha256(b.polynomials, rows, b.merkle_tree.digests, b.merkle_tree.cap.entries, cap, b.degree_log, b.rate_bits, b.blinding)
+    assert got == g["sha256_polynomial_batch"], "write_polynomial_batch bytes of the device-built batch differ from the oracle-built one"
+    del b
+
+
 def _golden(name):
     import json
     import os
@@ -309,6 +338,34 @@ def test_rccl_communicator_one_rank(gpu, ora, chunks, gather):
         assert (gpu.host(out["coeffs"]) == o["coeffs"]).all() and (gpu.host(out["cap"]) == o["cap"]).all()
         assert (gpu.host(out["digests"]) == o["digests"]).all() and (gpu.host(out["leaves"]) == o["leaves"]).all()
     job.comm.close()
+
+
+def test_rccl_binding_without_torch(gpu):
+    """The OTHER deployment mode of the in-library RCCL transport: a patched plonky2 is a process without torch, so libp2hot binds
+    /opt/rocm's librccl by path instead of the copy PyTorch ships (host_multi.hpp rccl::api: RTLD_NOLOAD first).  A subprocess that
+    never imports torch (tests/helpers/rccl_no_torch.py: ctypes + numpy) creates the one-rank communicator, runs the preflight
+    all-gather and a sharded commit against the oracle, and reports the file and ncclGetVersion it bound; this process (torch
+    loaded first: the `gpu` fixture) reports its own binding through the same call.  Both must bind and work; the two paths are
+    printed so that GPUTEST's log says which RCCL build each mode used."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from plonky2_amd.distributed import rccl_info
+    from tests.conftest import ROOT
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_no_torch.py")], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, "no-torch RCCL process failed:\n" + r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["checked"] and rec["torch_imported"] is False and rec["exchange_mode"] in (0, 1)
+    assert rec["rccl"]["path"] and rec["rccl"]["version"] > 0
+    assert "torch" not in rec["rccl"]["path"], "a process without torch must not have bound PyTorch's bundled RCCL: %r" % rec
+    here = rccl_info(gpu.lib)            # this process: torch was imported before the library looked for RCCL
+    assert here is not None and here["path"] and here["version"] > 0
+    print("RCCL bound without torch: %s (version %d); with torch loaded first: %s (version %d)"
+          % (rec["rccl"]["path"], rec["rccl"]["version"], here["path"], here["version"]))
 
 
 def test_device_buffer_transport_hooks(gpu):

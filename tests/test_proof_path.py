@@ -98,8 +98,56 @@ def test_k12_golden_record_is_what_the_oracle_computes_now(ora):
     from plonky2_amd.util.synthetic import path_instance
     from tools.gen_golden_path import plonk_golden
     now = plonk_golden(ora, path_instance("per_proof_path_k12"), log=lambda s: None)
-    assert json.loads(json.dumps(now)) == pp.golden("per_proof_path_k12")
+    rec = dict(pp.golden("per_proof_path_k12"))
+    rec.pop("source_sha256", None)
+    assert json.loads(json.dumps(now)) == rec
+
+
+def test_golden_records_carry_the_current_source_stamp():
+    """the full-size records (k20: ~15 minutes of oracle time) are trusted files; each carries sha256 over every source that
+    decides its bytes (tools/gen_golden_path.py STAMP_SOURCES).  An edit of the oracle, the instance or the wire writer that is
+    not followed by tools/gen_golden_path.py fails here without recomputing anything."""
+    from plonky2_amd.util import proof_path as pp
+    from tools.gen_golden_path import NAMES, source_stamp
+    now = source_stamp()
+    for name in NAMES:
+        assert pp.golden(name).get("source_sha256") == now, "%s is stale: run tools/gen_golden_path.py" % name
+
+
+def test_second_point_is_g_times_zeta():
+    """plonk/circuit_data.rs:537-539: zeta_next = primitive_root_of_unity(degree_bits) * zeta (types.rs:268-272)"""
+    from plonky2_amd.util.synthetic import P, primitive_root_of_unity, second_point
+    for k in (12, 20, 22):
+        g = primitive_root_of_unity(k)
+        assert pow(g, 1 << k, P) == 1 and pow(g, 1 << (k - 1), P) == P - 1
+        assert second_point([5, 9], k) == [5 * g % P, 9 * g % P]
 
 
 def test_proof_path_k12_vs_oracle_record_and_verifier(eng, ora):
     check_path(eng, ora, "per_proof_path_k12")
+
+
+def test_group_path_k12_vs_oracle_record(emu, ora):
+    """The per-proof path over a p2hot_group of 2 ranks (both on the emulated device 0: the exchanges are copies) on the SAME oracle
+    record the single-context path is checked against: four coset-sharded commits from host columns, p2hot_group_eval_openings,
+    p2hot_group_prove_openings (plonky2_amd/util/proof_path.py run_group_path) -- caps, every opening value, alpha's consequences
+    (FRI caps, final_poly), PoW witness, query indices, SHA-256 of the FriProof bytes and the transcript afterwards.  This is the
+    line `bench.py --gpus N` adds under "group_per_proof_path" (tests/test_bench_launch.py parses it)."""
+    from plonky2_amd.distributed import GroupCommit
+    from plonky2_amd.util import proof_path as pp
+    from plonky2_amd.util.synthetic import path_instance, splitmix_columns_numpy
+    from tests.emu_backend import emu_lib
+    name = "per_proof_path_k12"
+    inst, g = path_instance(name), pp.golden(name)
+    single = pp.run_path(emu, pp.PathInputs(emu, inst), keep=True)      # the Zs matrix and the quotient chunks are single-GPU stages
+    assert pp.compare_with_golden(single, g) == []
+    n = 1 << inst["log_n"]
+    group = GroupCommit(emu_lib(), 2, [0, 0])
+    try:
+        res = pp.run_group_path(group, inst, splitmix_columns_numpy(inst["cs_seed"], inst["cs_width"], n),
+                                splitmix_columns_numpy(inst["wires_seed"], inst["wires_width"], n), single["zs"], single["chunks"],
+                                pipeline_chunks=2)
+    finally:
+        group.close()
+    assert pp.compare_with_golden(res, g) == []
+    assert pp.serialize_fri_proof(res["proof"]) == pp.serialize_fri_proof(single["proof"])

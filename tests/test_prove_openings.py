@@ -542,3 +542,28 @@ def test_prove_openings_many_equals_single_calls(eng, ora, M):
     bad = (C.c_void_p * (M * len(widths)))(*([None] * (M * len(widths))))
     cp = (C.c_void_p * M)(*[Challenger(eng)._h for _ in range(M)])
     assert eng.lib.p2hot_prove_openings_many(eng.ctx, M, None, None, bad, len(widths), cp, C.byref(fp), None) == _lib.EINVAL
+
+
+def test_polynomial_batch_bytes_streamed_and_golden(eng):
+    """the streamed writer (tests/wire_format.py iter_polynomial_batch_bytes) produces write_polynomial_batch's bytes,
+    and a library-built batch (host pointers in, rows back through p2hot_batch_rows in committed order) serialises to the bytes
+    the oracle-built batch does: `sha256_polynomial_batch` of tests/golden/commit_caps.json (tools/gen_golden_caps.py
+    --batch-bytes); the full-size shapes of the same record are compared on the GPU (tests/test_gpu_fullsize.py)."""
+    import hashlib
+    import json
+    import os
+    from plonky2_amd.fri.oracle import PolynomialBatch
+    from plonky2_amd.util.synthetic import splitmix_columns_numpy
+    from tests.conftest import ROOT
+    from tests.wire_format import iter_polynomial_batch_bytes, polynomial_batch_sha256, write_polynomial_batch
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "commit_caps.json")))["tiny_wires"]
+    W, log_n, rb, cap = g["W"], g["log_n"], g["rate_bits"], g["cap_height"]
+    b = PolynomialBatch.from_values(splitmix_columns_numpy(0, W, 1 << log_n), rb, False, cap, engine=eng)
+    N = 1 << (log_n + rb)
+    chunks = lambda: (b._owner.rows(np.arange(r, min(r + 300, N))) for r in range(0, N, 300))  # noqa: E731  (ragged on purpose)
+    whole = write_polynomial_batch(b)
+    assert b"".join(iter_polynomial_batch_bytes(b.polynomials, chunks(), b.merkle_tree.digests, b.merkle_tree.cap.entries, cap, log_n, rb, False)) == whole
+    assert hashlib.sha256(whole).hexdigest() == g["sha256_polynomial_batch"]
+    assert polynomial_batch_sha256(b.polynomials, chunks(), b.merkle_tree.digests, b.merkle_tree.cap.entries, cap, log_n, rb, False) == g["sha256_polynomial_batch"]
+    with pytest.raises(ValueError):
+        list(iter_polynomial_batch_bytes(b.polynomials, list(chunks())[:-1], b.merkle_tree.digests, b.merkle_tree.cap.entries, cap, log_n, rb, False))

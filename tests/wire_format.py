@@ -63,6 +63,46 @@ def write_polynomial_batch(batch):
                      _u64(batch.rate_bits), bytes([1 if batch.blinding else 0])])
 
 
+def iter_polynomial_batch_bytes(polys, row_chunks, digests, cap, cap_height, degree_log, rate_bits, blinding):
+    """write_polynomial_batch's bytes piece by piece, for batches whose leaf matrix is not held whole (C3 quotient chunks: 1.1 GB
+    of leaves): `row_chunks` yields [m][W] blocks of leaf rows in committed order, everything else is given whole.  Layout as
+    above (serialization/mod.rs:1744-1763 around :1417-1431); b"".join(...) == write_polynomial_batch(batch)."""
+    polys = np.asarray(polys, dtype=np.uint64)
+    W, n = polys.shape
+    yield _u64(W)
+    for c in range(W):
+        yield _u64(n)
+        yield polys[c].astype("<u8").tobytes()
+    n_rows = (np.asarray(digests).size // 4 + 2 * (1 << cap_height)) // 2     # digests.len() = 2 * (leaves - 2^cap_height)
+    yield _u64(n_rows)
+    seen = 0
+    for block in row_chunks:
+        block = np.asarray(block, dtype=np.uint64)
+        rows = np.empty((block.shape[0], block.shape[1] + 1), dtype="<u8")
+        rows[:, 0] = block.shape[1]
+        rows[:, 1:] = block
+        seen += block.shape[0]
+        yield rows.tobytes()
+    if seen != n_rows:
+        raise ValueError("row_chunks produced %d leaf rows, the digest array belongs to %d" % (seen, n_rows))
+    d = np.asarray(digests, dtype="<u8").reshape(-1, 4)
+    yield _u64(d.shape[0])
+    yield d.tobytes()
+    yield _u64(cap_height)
+    yield np.asarray(cap, dtype="<u8").tobytes()
+    yield _u64(degree_log)
+    yield _u64(rate_bits)
+    yield bytes([1 if blinding else 0])
+
+
+def polynomial_batch_sha256(polys, row_chunks, digests, cap, cap_height, degree_log, rate_bits, blinding):
+    import hashlib
+    h = hashlib.sha256()
+    for piece in iter_polynomial_batch_bytes(polys, row_chunks, digests, cap, cap_height, degree_log, rate_bits, blinding):
+        h.update(piece)
+    return h.hexdigest()
+
+
 def read_polynomial_batch(buf):
     """-> dict(polynomials [W][n], merkle_tree, degree_log, rate_bits, blinding)"""
     off = 0

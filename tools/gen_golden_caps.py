@@ -53,6 +53,18 @@ SHAPES = {
 }
 
 
+# shapes whose whole write_polynomial_batch byte stream (serialization/mod.rs:1744-1763: coefficients, leaf rows, digests, cap,
+# degree_log, rate_bits, blinding) is pinned as well: SURVEY 8f-4 at the size a build-time constants_sigmas / a proof's quotient has
+BATCH_BYTES = ("c2_wires", "c3_quotient_chunks", "tiny_wires")
+
+
+def batch_bytes_sha(ora, o, log_n, rb, cap, rows_per_chunk=1 << 16):
+    from tests.wire_format import polynomial_batch_sha256
+    leaves = o["leaves"]
+    chunks = (leaves[r:r + rows_per_chunk] for r in range(0, leaves.shape[0], rows_per_chunk))
+    return polynomial_batch_sha256(o["coeffs"] % np.uint64(ora.P), chunks, o["digests"], o["cap"], cap, log_n, rb, False)
+
+
 def inputs(name):
     W, log_n, rb, cap, is_values, kind = SHAPES[name]
     if kind == "splitmix":
@@ -171,6 +183,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--streamed", action="store_true")
+    ap.add_argument("--batch-bytes", action="store_true", help="only the shapes that pin write_polynomial_batch's bytes (BATCH_BYTES)")
     ap.add_argument("--faithful-leaves", action="store_true", help="--streamed: every leaf through the faithful sponge (20x slower)")
     args = ap.parse_args()
     if args.streamed:
@@ -185,6 +198,8 @@ def main():
     for name, (W, log_n, rb, cap, is_values, kind) in SHAPES.items():
         if args.only and name != args.only:
             continue
+        if args.batch_bytes and name not in BATCH_BYTES:
+            continue
         cols = inputs(name)
         t0 = time.time()
         o = ora.commit(cols, rb, cap, is_values)
@@ -196,10 +211,14 @@ def main():
             "sha256_digests": hashlib.sha256(o["digests"].tobytes()).hexdigest(),
             "sha256_lde": sha_colmajor_from_rows(o["leaves"]),
         }
+        if name in BATCH_BYTES:
+            rec["sha256_polynomial_batch"] = batch_bytes_sha(ora, o, log_n, rb, cap)
         # the tuned CPU code must produce the same bytes
         f = fast.commit(cols, rb, cap, is_values, want_leaves=False)
         assert (f["cap"] == o["cap"]).all() and (f["digests"] == o["digests"]).all(), name
         assert (f["coeffs"] == o["coeffs"] % np.uint64(ora.P)).all(), name
+        if args.batch_bytes and name in out:  # adding one field: everything that was there must be what the oracle computes now
+            assert all(out[name][k] == v for k, v in rec.items() if k in out[name]), name
         out[name] = rec
         print("%s: oracle %.1f s, fast %.1f s, cap[0] = %s" % (name, t1 - t0, time.time() - t1, rec["cap"][0]), flush=True)
         del o, f, cols

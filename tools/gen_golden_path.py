@@ -36,6 +36,20 @@ from plonky2_amd.util.synthetic import (P, fibonacci_trace, path_instance, secon
 
 OUT = os.path.join(ROOT, "tests", "golden", "path_goldens.json")
 NAMES = ("per_proof_path_k12", "per_proof_path_starky_k22", "per_proof_path_k20")
+# every file whose text decides a record's bytes: the oracle, its constants and binding, this script, the instance definitions and
+# the wire-format writer `proof_sha256` hashes.  Each record carries sha256 over them (`source_sha256`);
+# tests/test_proof_path.py::test_golden_records_carry_the_current_source_stamp fails in seconds when any of them changed
+# without this script having been run again (the full-size records take minutes to recompute, so the CPU tier re-derives only k12).
+STAMP_SOURCES = ("oracle/p2oracle.c", "oracle/p2oracle.h", "oracle/p2oracle.py", "oracle/poseidon_constants.h",
+                 "tools/gen_golden_path.py", "plonky2_amd/util/synthetic.py", "tests/wire_format.py")
+
+
+def source_stamp():
+    h = hashlib.sha256()
+    for rel in STAMP_SOURCES:
+        h.update(rel.encode() + b"\0")
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()
 
 
 def canon(a):
@@ -113,7 +127,7 @@ def proof_record(ora, inst, commits, log=print):
     oc = ora.Challenger()
     oc.observe_elements(np.array(inst["transcript_seed"], dtype=np.uint64))
     zeta = [int(v) for v in oc.get_extension_challenge()]
-    gz = second_point(zeta)
+    gz = second_point(zeta, inst["log_n"])
     t = time.time()
     rec = {"zeta": zeta, "second_point": gz,
            "openings_zeta": [opening_values(ora, c, zeta).tolist() for c in commits]}
@@ -198,6 +212,7 @@ def main():
         print(name, flush=True)
         t = time.time()
         data[name] = (plonk_golden if inst["kind"] == "plonk" else starky_golden)(ora, inst, log=lambda s: print(s, flush=True))
+        data[name]["source_sha256"] = source_stamp()
         print("  total %.1f s" % (time.time() - t), flush=True)
         with open(args.out, "w") as f:
             json.dump(data, f, indent=0, separators=(",", ":"))

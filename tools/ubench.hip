@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t 
 #define P_MAD_CNDM(r, p) MADP(p) "v_cndmask_b32 v" #r ", v49, v50, s[20:21]\n\t"
 #define P_FMA64_ONLY(r, p) "v_fma_f64 v[" #p ":" #p "+1], v[54:55], v[54:55], v[" #p ":" #p "+1]\n\tv_fma_f64 v[52:53], v[54:55], v[54:55], v[52:53]\n\t"
 #define P_FMA64_ADDU(r, p) "v_fma_f64 v[" #p ":" #p "+1], v[54:55], v[54:55], v[" #p ":" #p "+1]\n\tv_add_u32 v" #r ", v" #r ", v48\n\t"
+#define P_ADDCHAIN(r) "v_add_u32 v16, v16, v48\n\t"
 #define P_MADRUN(r, p) MADP(p)
 #define P_ADDRUN(r, p) "v_add_u32 v" #r ", v" #r ", v48\n\t"
 #define P_MAD4(r, p) MADP(p) MADP(p)
@@ -399,6 +400,7 @@ __global__ void __launch_bounds__(256) kx(uint64_t *out, uint32_t seed, uint64_t
         if (OP == 146) asm volatile(XR(P_ADDU16) ::: XCLOB);
         if (OP == 147) asm volatile(XR(P_ADDF16) ::: XCLOB);
         if (OP == 148) asm volatile(XP(P_SUBCO_CNDM) ::: XCLOB);
+        if (OP == 169) asm volatile(XR(P_ADDCHAIN) ::: XCLOB2);
         if (OP == 149) asm volatile(XP(P_MADRUN) XP(P_ADDRUN) ::: XCLOB2);
         if (OP == 150) asm volatile(XP(P_MAD_FMA64) ::: XCLOB2);
         if (OP == 151) asm volatile(XP(P_MAD_PKFMA) ::: XCLOB2);
@@ -583,6 +585,7 @@ int main(int argc, char **argv) {
     run<130, true>("x mad64+mov 1:1", 32);
     run<131, true>("x add_u32+add_f32 1:1", 32);
     run<148, true>("x sub_co+cndmask 1:1", 32);
+    run<169, true>("x add_u32 dependent chain", 32);
     run<149, true>("x mad64 x16 then add_u32 x16", 32);
     run<150, true>("x mad64+fma_f64 1:1", 32);
     run<151, true>("x mad64+pk_fma_f32 1:1", 32);

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 [ -x $R/tools/ubench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/ubench $R/tools/ubench.hip
-for W in 4 8; do
+for W in ${WAVES:-4 8}; do
   rm -rf $R/gpurun_out/ubench_pmc_w$W
   timeout 300 $R/tools/ubench --waves $W --json > $R/gpurun_out/ubench_w$W.jsonl 2> $R/gpurun_out/ubench_w$W.err; echo "ubench w$W rc=$?"
   timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY \

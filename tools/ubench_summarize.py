@@ -79,7 +79,7 @@ def load(w):
 
 def main(tag):
     res = {"method": __doc__.split("\n\n")[1], "simds": SIMDS, "occupancy": {}}
-    for w in (4, 8):
+    for w in (1, 2, 4, 8):
         probes = load(w)
         if probes is None:
             continue
