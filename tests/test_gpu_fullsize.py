@@ -358,7 +358,9 @@ def test_rccl_binding_without_torch(gpu):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_no_torch.py")], capture_output=True, text=True,
                        timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, "no-torch RCCL process failed:\n" + r.stdout[-2000:] + r.stderr[-4000:]
-    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]   # (RCCL prints its version banner on stdout too)
+    assert lines, "no JSON line from the no-torch RCCL process:\n" + r.stdout[-2000:] + r.stderr[-2000:]
+    rec = json.loads(lines[-1])
     assert rec["checked"] and rec["torch_imported"] is False and rec["exchange_mode"] in (0, 1)
     assert rec["rccl"]["path"] and rec["rccl"]["version"] > 0
     assert "torch" not in rec["rccl"]["path"], "a process without torch must not have bound PyTorch's bundled RCCL: %r" % rec
