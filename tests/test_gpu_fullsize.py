@@ -452,6 +452,36 @@ def test_commit_many_upload_in_staging_slices(gpu):
 
 
 # ------------------------------------------------------------------ the widened rows at the sizes bench.py times them
+@pytest.mark.parametrize("world", [2, 8])
+def test_group_proof_path_k20_on_one_gpu(gpu, world):
+    """`bench.py --gpus N`'s group_per_proof_path at FULL size with the ranks of the group all on device 0 (the box has one GPU;
+    the exchanges are copies instead of RCCL): the four coset-sharded commits of per_proof_path_k20 from host columns (W = 84,
+    135, 20, 16 at 2^20 rows), p2hot_group_eval_openings and p2hot_group_prove_openings against the same oracle record as the
+    single-context path -- caps, 275 opening values, FRI caps, final_poly, PoW witness, query indices, FriProof bytes, transcript.
+    World 8 = one LDE coset per rank (C5's arrangement)."""
+    import torch
+    from plonky2_amd.distributed import GroupCommit
+    from plonky2_amd.util import proof_path as pp
+    from plonky2_amd.util.synthetic import path_instance, splitmix_columns_numpy
+    name = "per_proof_path_k20"
+    inst, g = path_instance(name), pp.golden(name)
+    single = pp.run_path(gpu, pp.PathInputs(gpu, inst), sync=torch.cuda.synchronize, keep=True)
+    zs, chunks = single["zs"], single["chunks"]
+    assert pp.compare_with_golden(single, g) == []
+    del single
+    torch.cuda.empty_cache()
+    n = 1 << inst["log_n"]
+    group = GroupCommit(gpu.lib, world, [0] * world)
+    try:
+        res = pp.run_group_path(group, inst, splitmix_columns_numpy(inst["cs_seed"], inst["cs_width"], n),
+                                splitmix_columns_numpy(inst["wires_seed"], inst["wires_width"], n), zs, chunks)
+    finally:
+        group.close()
+    assert pp.compare_with_golden(res, g) == []
+    torch.cuda.empty_cache()
+    gpu.check(gpu.lib.p2hot_ctx_trim(gpu.ctx))
+
+
 @pytest.mark.parametrize("name", ["per_proof_path_k20", "per_proof_path_starky_k22"])
 def test_proof_path_full_size_vs_oracle_records_and_verifier(gpu, ora, name):
     """bench.py's per_proof_path_k20 (2^20 rows, 80 routed wires, degree 8, 2 challenges; 4 oracles, 255 polynomials at zeta, 2 at
