@@ -28,7 +28,18 @@ using gl::u32;
 using gl::u64;
 
 constexpr int TILE_LOG = 12;
-constexpr int NT = 512;
+constexpr int NT = 512;  // threads per TILE (a workgroup is NT * DUAL threads: DUAL = 2 transforms two tiles side by side)
+// P2HOT_LIMB_DUAL: also build the two-tiles-per-workgroup form (1024 threads = 16 waves = the CU's four waves per SIMD in ONE barrier
+// domain) and P2HOT_LIMB_PHASE: separate a round's butterfly phase (plain 32-bit adds) from its conversion phase (multiply-adds)
+// by workgroup barriers, so that every wave of a SIMD is in the same phase at the same time.  Why: profiles/r06_ubench_cheap.txt --
+// the cheap integer class issues two instructions per 4-cycle slot only while EVERY resident wave offers one.
+#ifndef P2HOT_LIMB_DUAL
+#define P2HOT_LIMB_DUAL 0
+#endif
+#ifndef P2HOT_LIMB_PHASE
+#define P2HOT_LIMB_PHASE 0
+#endif
+constexpr bool LIMB_PHASE = P2HOT_LIMB_PHASE != 0;
 #ifndef P2HOT_LIMB_MIN_WAVES
 #define P2HOT_LIMB_MIN_WAVES 4
 #endif
@@ -311,8 +322,8 @@ constexpr int round_table_off(int log_r, int r) {
 constexpr int limb_tables_w2(int log_r) { return round_table_off(log_r, n_rounds(log_r)); }
 constexpr int UFAC_WORDS = 64;  // u[a * 8 + k], a < 8, k < 8 (only round 0 ever borrows)
 constexpr bool uses_ufac(int log_r) { return round_borrows(log_r, 0) && !defers(log_r); }
-constexpr size_t limb_shmem_bytes(int log_r) {
-    return (size_t)8 * TILE_WORDS + (size_t)16 * limb_tables_w2(log_r) + (uses_ufac(log_r) ? 8 * UFAC_WORDS : 0);
+constexpr size_t limb_shmem_bytes(int log_r, int dual = 1) {
+    return (size_t)8 * TILE_WORDS * dual + (size_t)16 * limb_tables_w2(log_r) + (uses_ufac(log_r) ? 8 * UFAC_WORDS : 0);
 }
 
 __device__ __forceinline__ u64 limb_mul(u64 a, u64 b) { return gl::mul1(a, b); }
@@ -364,6 +375,17 @@ __device__ __forceinline__ unsigned wave_uniform(unsigned v) {
 #endif
 }
 
+// P2HOT_LIMB_PHASE: a workgroup barrier the instruction scheduler does not move arithmetic across
+__device__ __forceinline__ void phase_sync() {
+#ifdef P2HOT_EMU
+    __syncthreads();
+#else
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // the workgroup barrier, or -- after a round whose sub-blocks a wave owns entirely -- nothing but program order
 // (the LDS executes one wave's accesses in order; the emulator's lanes are fibers, so there it stays a barrier)
 template <bool WAVE_PRIVATE>
@@ -371,12 +393,14 @@ __device__ __forceinline__ void round_sync() {
 #ifdef P2HOT_EMU
     __syncthreads();
 #else
-    if constexpr (WAVE_PRIVATE) {
+    if constexpr (WAVE_PRIVATE && !LIMB_PHASE) {
         // the wave barrier alone is declared IntrNoMem: the wavefront-scope fences are what formally order this lane's LDS
         // stores before the other lanes' LDS loads (no instruction is emitted for them; the LDS runs a wave's accesses in order)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else if constexpr (LIMB_PHASE) {
+        phase_sync();
     } else {
         __syncthreads();
     }
@@ -395,7 +419,7 @@ __device__ __forceinline__ void load_inputs(const u64 *gin, unsigned log_stride,
     constexpr unsigned C = 1u << LOG_C;
     constexpr int UPT = 8 >> P;
     constexpr unsigned UW = 512u >> P;
-    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned wave = (threadIdx.x >> 6) & 7u, lane = threadIdx.x & 63;  // (the tile's eight waves; a DUAL workgroup has two tiles)
 #pragma unroll
     for (int uu = 0; uu < UPT; ++uu) {
         const unsigned u = wave * UW + lane + 64u * (unsigned)uu;
@@ -428,7 +452,7 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
     constexpr unsigned UW = 512u >> P;               // units per wave: a wave's units cover 512 consecutive tile elements
     [[maybe_unused]] constexpr int UNROLL = FIRST ? UPT : 1;  // `raw` is indexed by uu: registers only when unrolled
     const ntt::PassArgs &a = ra.a;
-    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned wave = (threadIdx.x >> 6) & 7u, lane = threadIdx.x & 63;
 #pragma unroll UNROLL
     for (int uu = 0; uu < UPT; ++uu) {
         const unsigned u = wave * UW + lane + 64u * (unsigned)uu;
@@ -469,6 +493,7 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
         x[0].l[2] += O2;
         x[0].l[3] += opaque_u32(O3);
         dft_limbs<P, INV>(x);
+        if constexpr (LIMB_PHASE) phase_sync();  // butterflies (plain adds) | conversions (multiply-adds): every wave switches together
         if constexpr (S_LOG > 0) {
             if constexpr (LIMB_FOLD3 && !(BORROW && !defers(LOG_R))) {
                 // all 2^P accumulator pairs of the unit, folded three rows per stream
@@ -598,23 +623,30 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
 }
 
 // One pass over 2^LOG_R x 2^LOG_C tiles (LOG_R + LOG_C = 12); LOG_C = 0 is the contiguous (last) pass.
-// grid = (tiles per polynomial >> tiles_log, polynomials, z), 512 threads, limb_shmem_bytes(LOG_R) of dynamic LDS.
+// grid = (tiles per polynomial >> tiles_log >> (DUAL - 1), polynomials, z), 512 * DUAL threads, limb_shmem_bytes(LOG_R, DUAL) of
+// dynamic LDS.  DUAL = 2: threads 512..1023 transform the NEXT tile group side by side with threads 0..511 (their own tile in LDS,
+// the round tables shared): one workgroup then holds all four waves of every SIMD, so a workgroup barrier is a SIMD-wide one.
 // Workgroup barriers: one after the first round and one per tile; the later rounds and the store phase are wave-private.
-template <bool INV, int LOG_R, int LOG_C, int SCALE, int LAST = LAST_UNIT>
-__global__ void __launch_bounds__(NT, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPassArgs ra) {
+template <bool INV, int LOG_R, int LOG_C, int SCALE, int LAST = LAST_UNIT, int DUAL = 1>
+__global__ void __launch_bounds__(NT * DUAL, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPassArgs ra) {
     static_assert(LOG_R + LOG_C == TILE_LOG, "a tile is 4096 elements");
-    P2HOT_DYN_SHARED(u64, tile);
+    static_assert(DUAL == 1 || DUAL == 2, "one or two tiles side by side");
+    P2HOT_DYN_SHARED(u64, tile_all);
     const ntt::PassArgs &a = ra.a;
-    const unsigned tid = threadIdx.x;
-    W2 *ltw = reinterpret_cast<W2 *>(tile + TILE_WORDS);
+    const unsigned tid = threadIdx.x & (NT - 1);                          // the thread's place among its tile's 512
+    const unsigned half = DUAL == 2 ? wave_uniform(threadIdx.x >> 9) : 0u;  // which of the workgroup's tiles
+    u64 *tile = tile_all + (size_t)half * TILE_WORDS;
+    W2 *ltw = reinterpret_cast<W2 *>(tile_all + (size_t)DUAL * TILE_WORDS);
     u64 *lu = reinterpret_cast<u64 *>(ltw + limb_tables_w2(LOG_R));
-    for (unsigned e = tid; e < (unsigned)limb_tables_w2(LOG_R); e += NT) ltw[e] = ra.tw_all[e];
+    for (unsigned e = threadIdx.x; e < (unsigned)limb_tables_w2(LOG_R); e += NT * DUAL) ltw[e] = ra.tw_all[e];
     if constexpr (uses_ufac(LOG_R))
-        if (tid < (unsigned)UFAC_WORDS) lu[tid] = ra.ufac[tid];
+        if (threadIdx.x < (unsigned)UFAC_WORDS) lu[threadIdx.x] = ra.ufac[threadIdx.x];
     __syncthreads();
     const unsigned log_stride = LOG_C ? a.log_nblk - LOG_R : 0u;  // the contiguous pass is the last one: blocks of one tile
     const unsigned tiles_per_blk_log = log_stride - LOG_C;
-    const size_t wg = (LOG_C && ra.xcd_remap) ? (((size_t)(blockIdx.x & 7u) << (ra.xcd_remap - 3)) | (blockIdx.x >> 3)) : blockIdx.x;
+    // (xcd_remap counts WORKGROUPS: the host passes log2 of gridDim.x; a DUAL workgroup takes two consecutive tile groups)
+    const size_t wg0 = (LOG_C && ra.xcd_remap) ? (((size_t)(blockIdx.x & 7u) << (ra.xcd_remap - 3)) | (blockIdx.x >> 3)) : blockIdx.x;
+    const size_t wg = wg0 * DUAL + half;
     const size_t z_begin = ra.zloop ? 0 : blockIdx.z, z_end = ra.zloop ? ra.zloop : blockIdx.z + 1;
     const bool same_input = a.in_z_stride == 0;  // every z slice transforms the same polynomials (coset LDE): fetch them once
     const unsigned e0 = (tid >> 6) * 512u + (tid & 63u);  // store phase: wave w moves tile elements [512 w, 512 w + 512)

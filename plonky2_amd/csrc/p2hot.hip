@@ -48,6 +48,7 @@ struct p2hot_ctx {
     bool host_leaves_first = true;  // p2hot_commit with leaves_out: transforms, then the leaf matrix's copy beside the sponge (P2HOT_HOST_LEAVES_FIRST)
     bool host_chunked_hash = true;  // p2hot_commit: the leaf sponge absorbs each block's columns as soon as they are extended
     bool pp_streams = true;       // partial products: pairs of challenges through pp_quotients2_kernel (P2HOT_PP_STREAMS=0: one kernel per challenge)
+    bool limb_dual = true;       // P2HOT_LIMB_DUAL builds: pair tile groups into 1024-thread workgroups (P2HOT_LIMB_DUAL_OFF=1 turns it off)
     unsigned limb_tiles_log = 4;  // contiguous limb passes: a workgroup stages its tables once for 2^this tiles (P2HOT_LIMB_TILES_LOG)
     // second stream: the VALU-bound leaf sponge of coset block b runs beside the wait-bound NTT of block b+1
     hipStream_t side = nullptr;
@@ -424,6 +425,7 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     if (const char *e = getenv("P2HOT_NTT_XCD_REMAP")) ctx->ntt_xcd_remap = atoi(e) != 0;
     if (const char *e = getenv("P2HOT_NTT_LIMB")) ctx->use_limb = atoi(e) != 0, ctx->force_no_limb = atoi(e) == 0;
     if (const char *e = getenv("P2HOT_LIMB_TILES_LOG")) ctx->limb_tiles_log = (unsigned)atoi(e);
+    if (const char *e = getenv("P2HOT_LIMB_DUAL_OFF")) ctx->limb_dual = !(e[0] == '1');
     if (const char *e = getenv("P2HOT_NTT_ZLOOP_MIN")) ctx->zloop_min_groups = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HORNER_2L_MIN")) ctx->horner_two_level_min = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HOST_BLOCK_COLS")) ctx->host_block_cols = (size_t)strtoull(e, nullptr, 10);
@@ -730,14 +732,36 @@ static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse
     ra.wlast[1] = gl::canon(gl::mul(last_const, nttl::B1));
     ra.wlast[2] = gl::canon(gl::mul(last_const, nttl::B2));
     ra.wlast[3] = gl::canon(gl::mul(last_const, nttl::B3));
-    const size_t shm = nttl::limb_shmem_bytes((int)a.log_r);
+    // two tiles per workgroup (1024 threads: every wave of a SIMD behind one barrier) when the build has that form and the
+    // launch has an even number of tile groups to pair
+    bool dual = false;
+#if P2HOT_LIMB_DUAL
+    dual = ctx->limb_dual && grid.x >= 2 && grid.x % 2 == 0;
+    if (dual) {
+        grid.x >>= 1;
+        if (ra.xcd_remap) ra.xcd_remap = ra.xcd_remap > 3 ? ra.xcd_remap - 1 : 0;
+    }
+#endif
+    const size_t shm = nttl::limb_shmem_bytes((int)a.log_r, dual ? 2 : 1);
     if (wlast && !(a.log_r == 12 && a.scale_mode == ntt::SCALE_NONE)) P2_FAIL(ctx, P2HOT_EINVAL, "limb pass: a final constant needs the contiguous pass");
     ra.srow2 = srow2;
     ra.sbase = sbase;
     // the last conversion multiplies by 1 (LAST_UNIT), by a constant (LAST_CONST: the inverse transform's 1/n) or -- the
     // strided first pass of a coset LDE -- by the tile's share of the coset scale (LAST_TILE)
+#if P2HOT_LIMB_DUAL
+#define P2_LIMB_DUAL_LAUNCH(INVF, LR, MODE, LASTM)                                                         \
+    if (dual) {                                                                                            \
+        auto kfn2_ = nttl::ntt_limbpass_kernel<INVF, LR, 12 - LR, MODE, LASTM, 2>;                         \
+        P2_TRY(lds_opt_in(ctx, reinterpret_cast<const void *>(kfn2_), shm));                               \
+        P2HOT_LAUNCH(kfn2_, grid, dim3(nttl::NT * 2), shm, ctx->stream, ra);                               \
+        break;                                                                                             \
+    }
+#else
+#define P2_LIMB_DUAL_LAUNCH(INVF, LR, MODE, LASTM)
+#endif
 #define P2_LIMB(INVF, LR, MODE, LASTM)                                                                     \
     do {                                                                                                   \
+        P2_LIMB_DUAL_LAUNCH(INVF, LR, MODE, LASTM)                                                         \
         auto kfn_ = nttl::ntt_limbpass_kernel<INVF, LR, 12 - LR, MODE, LASTM>;                             \
         P2_TRY(lds_opt_in(ctx, reinterpret_cast<const void *>(kfn_), shm));                                \
         P2HOT_LAUNCH(kfn_, grid, dim3(nttl::NT), shm, ctx->stream, ra);                                    \

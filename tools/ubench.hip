@@ -433,6 +433,71 @@ static int g_waves = 8;        // resident waves per SIMD (blocks of 256 threads
 static const char *g_only = nullptr;
 static bool g_json = false;
 
+// ---- round 6, third batch: does phase-synchronising the waves of a SIMD let the cheap integer class pair?  One 1024-thread
+// workgroup per CU (16 waves = 4 per SIMD, all behind ONE s_barrier domain), explicit registers as above.
+//   OP 200  every wave: 32 adds then 32 multiply-adds, no barrier          201  the same, s_barrier after each phase
+//   OP 202  96 adds / 64 multiply-adds (the limb NTT's proportions), no barrier   203  the same with barriers
+//   OP 204  even waves only adds, odd waves only multiply-adds              205  even waves v_add_u32, odd waves v_xor_b32
+//   OP 206  waves 0-1 of each SIMD adds, waves 2-3 multiply-adds (wave >> 3 parity: waves w and w+4.. share a SIMD? see ubench output)
+#define XADD32 XR(P_ADDU_RMW)
+#define XMAD32 XP(P_MAD_ONLY)
+template <int OP>
+__global__ void __launch_bounds__(1024) ky(uint64_t *out, uint32_t seed, uint64_t *ticks) {
+    uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;
+    uint32_t c = t * 2654435761u + seed;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile(XR(P_INIT) "v_mov_b32 v48, %0\n\tv_mov_b32 v49, %0\n\tv_mov_b32 v50, 0x3f800001\n\tv_mov_b32 v51, %0\n\ts_mov_b32 s20, 77" ::"v"(c) : XCLOB);
+    uint64_t t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+    for (int it = 0; it < ITERS / 8; ++it) {
+        if (OP == 200) asm volatile(XADD32 XMAD32 ::: XCLOB);
+        if (OP == 201) asm volatile(XADD32 "s_barrier\n\t" XMAD32 "s_barrier\n\t" ::: XCLOB);
+        if (OP == 202) asm volatile(XADD32 XADD32 XADD32 XMAD32 XMAD32 ::: XCLOB);
+        if (OP == 203) asm volatile(XADD32 XADD32 XADD32 "s_barrier\n\t" XMAD32 XMAD32 "s_barrier\n\t" ::: XCLOB);
+        if (OP == 204) { if (wave & 1) asm volatile(XMAD32 XMAD32 ::: XCLOB); else asm volatile(XADD32 XADD32 ::: XCLOB); }
+        if (OP == 205) { if (wave & 1) asm volatile(XR(P_XOR_RMW) XR(P_XOR_RMW) ::: XCLOB); else asm volatile(XADD32 XADD32 ::: XCLOB); }
+        if (OP == 206) { if (wave & 8) asm volatile(XMAD32 XMAD32 ::: XCLOB); else asm volatile(XADD32 XADD32 ::: XCLOB); }
+        if (OP == 207) asm volatile(XADD32 XADD32 ::: XCLOB);
+        if (OP == 208) asm volatile(XMAD32 XMAD32 ::: XCLOB);
+    }
+    uint64_t t1 = __builtin_readcyclecounter();
+    uint32_t s = 0;
+    asm volatile(XR(P_SUM) : "+v"(s)::XCLOB);
+    out[t] = s;
+    if ((threadIdx.x & 63) == 0) ticks[t >> 6] = t1 - t0;
+}
+
+template <int OP>
+void run_y(const char *name, int per_iter) {
+    if (g_only && !strstr(name, g_only)) return;
+    const int blocks = 256, threads = 1024;
+    uint64_t *d, *tk;
+    (void)hipMalloc(&d, (size_t)blocks * threads * 8);
+    (void)hipMalloc(&tk, (size_t)blocks * threads / 64 * 8);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    ky<OP><<<blocks, threads>>>(d, 1, tk);
+    (void)hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        ky<OP><<<blocks, threads>>>(d, 2 + rep, tk);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    double inst_per_simd = 4.0 * (ITERS / 8) * per_iter;
+    if (g_json)
+        printf("{\"op\": %d, \"name\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.4f, \"wave_insts_per_simd\": %.0f, \"per_iter\": %d}\n", OP, name, 4, best, inst_per_simd, per_iter);
+    else
+        printf("%-44s %7.3f ms  %5.2f cyc/inst/SIMD by wall@2.4GHz(assumed)\n", name, best, best * 1e-3 * 2.4e9 / inst_per_simd);
+    (void)hipFree(tk);
+    (void)hipFree(d);
+}
+
 template <int OP, bool X = false>
 void run(const char *name, int per_iter = 8) {
     if (g_only && !strstr(name, g_only)) return;
@@ -606,5 +671,16 @@ int main(int argc, char **argv) {
     run<159, true>("x fma_f64 only", 32);
     run<168, true>("x fma_f64+add_u32 1:1", 32);
     run<167, true>("x mad64 x4 / add,sub x4 runs", 32);
+    if (g_waves == 4) {
+        run_y<207>("y adds only (1024-thread WG)", 64);
+        run_y<208>("y mad64 only (1024-thread WG)", 64);
+        run_y<200>("y 32 adds / 32 mad64, no barrier", 64);
+        run_y<201>("y 32 adds / 32 mad64, barriers", 64);
+        run_y<202>("y 96 adds / 64 mad64, no barrier", 160);
+        run_y<203>("y 96 adds / 64 mad64, barriers", 160);
+        run_y<204>("y even waves adds, odd waves mad64", 64);
+        run_y<205>("y even waves add_u32, odd waves xor", 64);
+        run_y<206>("y waves 0-7 adds, waves 8-15 mad64", 64);
+    }
     return 0;
 }

@@ -47,7 +47,7 @@ def load(w):
     dur = defaultdict(dict)
     for c in glob.glob(os.path.join(G, "ubench_pmc_w%d" % w, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(c)):
-            m = re.search(r"\bkx?<(\d+)>", r["Kernel_Name"])
+            m = re.search(r"\bk[xy]?<(\d+)>", r["Kernel_Name"])
             if not m:
                 continue
             name = names.get(int(m.group(1)))
