@@ -24,13 +24,13 @@ ROWS = [
     ("a15", "fri_committed_trees", "test_gpu_fullsize.py::test_fri_commit_phase_full_size_vs_oracle (N = 2^23)", "fri"),
     ("a16", "Challenger", "test_parity.py::test_challenger_vs_oracle", None),
     ("b", "drop-in boundary (C ABI + Rust shim + patch)", "test_abi.py, test_integration_files.py (API linter, `git apply --check`, first_contact.sh --dry-run), test_async_leaves.py", "host"),
-    ("c", "oracle", "test_oracle.py (KATs, reference properties, restated verifier), test_fast_oracle.py, test_proof_path.py::test_k12_golden_record_is_what_the_oracle_computes_now", None),
+    ("c", "oracle", "test_oracle.py (KATs, reference properties, restated verifier), test_fast_oracle.py, test_proof_path.py::test_k12_golden_record_is_what_the_oracle_computes_now, ::test_golden_records_carry_the_current_source_stamp", None),
     ("d", "measurement", "bench.py: roofline (measured in the run), cpu_baseline, checked per-proof paths; profiles/", "roofline"),
-    ("e", "multi-GPU", "test_distributed.py (gloo 2/4/8), test_emu_rccl_ranks.py, test_emu_devices.py, test_bench_launch.py (`bench.py --gpus 2` self-launched), test_gpu_fullsize.py (C5 as 8 ranks on one GPU)", "multi"),
+    ("e", "multi-GPU", "test_distributed.py (gloo 2/4/8), test_emu_rccl_ranks.py, test_emu_devices.py, test_bench_launch.py (`bench.py --gpus 2` self-launched, incl. the per-proof path over the group), test_gpu_fullsize.py (C5 as 8 ranks on one GPU; the k20 proof over a group of 2 / 8 ranks; RCCL bound with and without torch)", "multi"),
     ("f1", "prove_openings prelude", "test_prove_openings.py::test_final_poly_and_prove_openings_vs_oracle; test_gpu_fullsize.py::test_proof_path_full_size_vs_oracle_records_and_verifier", "path"),
     ("f2", "PoW + query phase", "test_prove_openings.py::test_fri_proof_passes_the_reference_verifier; full size: the k20 / starky k22 FriProof bytes = the oracle's, verified + 6 tamperings", "path"),
     ("f3", "partial products / Z, quotient permutation terms, OpeningSet", "test_permutation.py; full size: SHA-256 of the Zs matrix, the 2^23 quotient values, the 16 chunks, all 275 openings vs the oracle record; gate sums on 4096 points + linearity", "path"),
-    ("f4", "wire formats", "tests/wire_format.py checker; the FriProof bytes of the full-size proofs hash to the oracle's; Rust serializer: never compiled", None),
+    ("f4", "wire formats", "tests/wire_format.py checker; the FriProof bytes of the full-size proofs hash to the oracle's; test_gpu_fullsize.py::test_polynomial_batch_wire_bytes_vs_oracle_at_full_size (SHA-256 of the whole write_polynomial_batch stream, C2 wires + C3 quotient chunks); Rust serializer: never compiled", None),
     ("g1", "patched CircuitBuilder::build / prove vs the Rust prover", "integration/first_contact.sh (dry-run only: no cargo in the image)", None),
 ]
 
