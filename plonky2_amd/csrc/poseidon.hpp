@@ -25,8 +25,9 @@
 #include "gl_mul3.hpp"
 #ifndef P2HOT_EMU
 #define P2_CONST_QUAL __constant__  // device constant memory; indices are wave-uniform -> scalar loads
-#define P2_LITERAL_QUAL static constexpr  // entries become instruction-stream immediates (s_mov_b32 literals)
 #endif
+#define P2_LITERAL_QUAL static constexpr  // entries become instruction-stream immediates (s_mov_b32 literals); constexpr in both builds:
+                                          // M^2 below is computed from them at compile time
 #include "poseidon_constants.h"
 
 namespace poseidon {
@@ -192,6 +193,83 @@ __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2, unsigned gr
     }
 }
 
+// M^2 = the integer square of the MDS matrix M[r][c] = C[(c - r) mod 12] + 8 [r = c = 0] (entries < 2^15, rows < 2^17), built
+// at compile time from the generated first row and checked against the generated tables it must agree with
+struct Mat12 {
+    u32 v[144];
+};
+constexpr Mat12 mds_matrix() {
+    Mat12 m{};
+    for (int r = 0; r < 12; ++r)
+        for (int c = 0; c < 12; ++c) m.v[12 * r + c] = P2_POSEIDON_M1_ROW0[(c - r + 12) % 12] - ((c - r + 12) % 12 == 0 ? 8u : 0u) + (r == 0 && c == 0 ? 8u : 0u);
+    return m;
+}
+constexpr Mat12 mat_mul(const Mat12 &a, const Mat12 &b) {
+    Mat12 m{};
+    for (int r = 0; r < 12; ++r)
+        for (int c = 0; c < 12; ++c) {
+            u64 acc = 0;
+            for (int k = 0; k < 12; ++k) acc += (u64)a.v[12 * r + k] * b.v[12 * k + c];
+            m.v[12 * r + c] = (u32)acc;
+        }
+    return m;
+}
+constexpr bool mat_checks() {
+    const Mat12 m1 = mds_matrix(), m2 = mat_mul(m1, m1), m3 = mat_mul(m1, m2);
+    for (int j = 0; j < 12; ++j) {
+        if (m1.v[j] != P2_POSEIDON_M1_ROW0[j] || m2.v[j] != P2_POSEIDON_M2_ROW0[j]) return false;
+        if (m1.v[12 * j] != P2_POSEIDON_MCOL0[j] || m2.v[12 * j] != P2_POSEIDON_MCOL0[12 + j]) return false;
+    }
+    for (int i = 0; i < 144; ++i)
+        if (m3.v[i] != P2_POSEIDON_M3[i]) return false;
+    return true;
+}
+static_assert(mat_checks(), "M, M^2, M^3: the compile-time products disagree with the generated tables");
+P2_LITERAL_QUAL Mat12 MDS2 = mat_mul(mds_matrix(), mds_matrix());
+
+// A full round's MDS and the partial round after it in one dense pass (round 3's linear layer + round 4): with x the state after
+// the full round's S-box layer, u = M x, d = sbox(u[0] + c) - u[0], the state after the partial round is
+//   y = M (u + d e0) = M^2 x + d (M e0)
+// -- one 12-row pass over M^2 (+1 term per row), one single row for u[0] and one S-box, instead of two 12-row passes.  With it the
+// 1 + 22 applications of M between the two full-round halves take 8 dense passes (this one and seven batches of three) instead of 9.
+// No pending constant on entry or exit (round 3 fuses none; c = the partial round's pushed scalar).
+__device__ __forceinline__ void mds_partial_round(u64 s[12], u64 c) {
+    u32 xl[12], xh[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        xl[i] = (u32)s[i];
+        xh[i] = (u32)(s[i] >> 32);
+    }
+    u64 al = 0, ah = 0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        al += (u64)xl[j] * P2_POSEIDON_M1_ROW0[j];
+        ah += (u64)xh[j] * P2_POSEIDON_M1_ROW0[j];
+    }
+    const u64 u0 = gl::fold1(al, ah);
+    const u64 d = gl::sub(sbox7_asm(gl::add_canon(u0, c)), u0);
+    const u32 dl = (u32)d, dh = (u32)(d >> 32);
+#pragma unroll
+    for (int g = 0; g < 12; g += 3) {
+        u64 bl[3], bh[3], y[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int i = g + t;
+            bl[t] = (u64)dl * P2_POSEIDON_MCOL0[i];
+            bh[t] = (u64)dh * P2_POSEIDON_MCOL0[i];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                bl[t] += (u64)xl[j] * MDS2.v[12 * i + j];
+                bh[t] += (u64)xh[j] * MDS2.v[12 * i + j];
+            }
+        }
+        gl::fold3(bl, bh, y);
+        s[g] = y[0];
+        s[g + 1] = y[1];
+        s[g + 2] = y[2];
+    }
+}
+
 // Three partial rounds in one dense pass.  A partial round is y <- M z with z = y except z[0] = sbox(y[0] + c); writing
 // round r's replacement as y_r[0] + d_r (d_r = sbox(y_r[0] + c_r) - y_r[0]):
 //   y1[0] = (M z)[0]
@@ -266,20 +344,21 @@ __device__ inline void permute(u64 s[12], unsigned out_groups = 0xFu) {
         sbox_layer(s);
         mds_layer(s, RC_SPLIT + 24 * (round + 1));
     }
-    // round 3: no constant is fused into its MDS -- the batched partial rounds add their scalars themselves
+    // round 3's S-box layer; its MDS and partial round 4 in ONE dense pass (M^2: mds_partial_round); no constant is fused into
+    // round 3's MDS -- the batched partial rounds add their scalars themselves (the passive part of the partial-round constants
+    // is pushed forward through the MDS at table-generation time, see the generator)
     sbox_layer(s);
-    mds_layer(s, nullptr);
-    ++round;
-    // partial rounds 4..24 in seven batches of three (their constants are scalars on word 0: the passive part of the
-    // partial-round constants is pushed forward through the MDS at table-generation time, see the generator)
+    mds_partial_round(s, P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * 4]);
+    round = 5;
+    // partial rounds 5..25 in seven batches of three, then the full constant vector of round 26 (which absorbed the pushed
+    // remainder) as twelve field additions: fused into the last batch's accumulators it would be 48 more live SGPRs in EVERY batch
+    // (measured: 96 v_readlane per batch of SGPR spill traffic, +4 % instructions)
 #pragma unroll 1
     for (int k = 0; k < 7; ++k, round += 3)
         partial_rounds3(s, P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * round], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 1)],
                         P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 2)]);
-    // round 25, then the full constant vector of round 26 (which absorbed the pushed remainder)
-    s[0] = sbox7_asm(gl::add_canon(s[0], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * round]));
-    mds_layer(s, RC_SPLIT + 24 * (round + 1));
-    ++round;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = gl::add_canon(s[i], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * round + i]);
 #pragma unroll 1
     for (int k = 0; k < 3; ++k, ++round) {
         sbox_layer(s);
