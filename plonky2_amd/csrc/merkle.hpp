@@ -71,8 +71,9 @@ __global__ void __launch_bounds__(256) hash_leaves_kernel(Reader rd, unsigned W,
             // the next chunk overwrites words 0..next-1 (overwrite-mode sponge) and the digest is words 0..3:
             // only the word triples that survive are computed by the last MDS layer
             const unsigned next = off + 8 < W ? (W - off - 8 < 8 ? W - off - 8 : 8) : 0;
-            const unsigned keep = off + 8 < W ? (0xFu << (next / 3)) & 0xFu : 0x3u;
-            poseidon::permute(s, keep);
+            // (a digest = triple 0 + word 3; the capacity behind a full absorb = word 8 + triple 3: four rows, not six)
+            const unsigned keep = off + 8 < W ? (next == 8 ? 0x8u : (0xFu << (next / 3)) & 0xFu) : 0x1u;
+            poseidon::permute(s, keep, off + 8 < W ? (next == 8 ? 8 : -1) : 3);
         }
     }
     u64 *dst = node_slot(digests, cap, h, 0, L);
@@ -107,8 +108,8 @@ __global__ void __launch_bounds__(256) hash_leaves_chunks_kernel(Reader rd, unsi
         for (unsigned i = 0; i < 8; ++i)
             if (i < cnt) s[i] = rd(L, off + i);
         const unsigned next = off + 8 < W ? (W - off - 8 < 8 ? W - off - 8 : 8) : 0;
-        const unsigned keep = off + 8 < W ? (0xFu << (next / 3)) & 0xFu : 0x3u;
-        poseidon::permute(s, keep);
+        const unsigned keep = off + 8 < W ? (next == 8 ? 0x8u : (0xFu << (next / 3)) & 0xFu) : 0x1u;
+        poseidon::permute(s, keep, off + 8 < W ? (next == 8 ? 8 : -1) : 3);
     }
     if (off_end >= W) {
         u64 *dst = node_slot(digests, cap, h, 0, L);

@@ -154,7 +154,23 @@ __device__ __forceinline__ void mds_first(u64 (&al)[3], u64 (&ah)[3], u32 l0, u3
 //   y = al + ah * 2^32 (mod P), gl::fold3.
 // rc2 points at the round's constants split as {lo32, hi32} pairs (RC_SPLIT) or is null.
 // `groups` (wave-uniform): bit g set = rows 3g..3g+2 are wanted; the other rows are left stale.
-__device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2, unsigned groups = 0xFu) {
+// one MDS row (no constant, not row 0): two 12-term chains and a single-stream fold -- for the LAST layer of a permutation, whose
+// reader wants four words (a digest, or the capacity between two absorbs): one triple and this row instead of two triples
+template <int R>
+__device__ __forceinline__ u64 mds_row(const u32 (&xl)[12], const u32 (&xh)[12]) {
+    static_assert(R > 0 && R < 12, "row 0 carries the diagonal term");
+    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u64 al = (u64)xl[R] * opaque_const(C[0]), ah = (u64)xh[R] * opaque_const(C[0]);
+#pragma unroll
+    for (int i = 1; i < 12; ++i) {
+        al += (u64)xl[(R + i) % 12] * opaque_const(C[i]);
+        ah += (u64)xh[(R + i) % 12] * opaque_const(C[i]);
+    }
+    return gl::fold1(al, ah);
+}
+
+// `single` (wave-uniform; 3, 8 or none): one more row computed on its own (mds_row)
+__device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2, unsigned groups = 0xFu, int single = -1) {
     u32 xl[12], xh[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -191,6 +207,10 @@ __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *rc2, unsigned gr
         s[g + 1] = y[1];
         s[g + 2] = y[2];
     }
+    if (single == 3)
+        s[3] = mds_row<3>(xl, xh);
+    else if (single == 8)
+        s[8] = mds_row<8>(xl, xh);
 }
 
 // M^2 = the integer square of the MDS matrix M[r][c] = C[(c - r) mod 12] + 8 [r = c = 0] (entries < 2^15, rows < 2^17), built
@@ -334,8 +354,10 @@ __device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c0, u64 c1, u64 c
 
 // the permutation; output words are NOT canonicalised (callers canonicalise what they emit).
 // Round r: ARK(r) was already added by the previous MDS (or up front for r = 0); S-box; MDS + ARK(r+1).
-// `out_groups`: which output word triples the caller reads (bit g = words 3g..3g+2); the last MDS skips the rest
-__device__ inline void permute(u64 s[12], unsigned out_groups = 0xFu) {
+// `out_groups`: which output word triples the caller reads (bit g = words 3g..3g+2), `out_single`: one more word (3 or 8) it reads;
+// the last MDS skips the rest.  A digest is words 0..3 = (triple 0, word 3); the capacity a full absorb keeps is words 8..11 =
+// (word 8, triple 3): four rows instead of the six of two triples.
+__device__ inline void permute(u64 s[12], unsigned out_groups = 0xFu, int out_single = -1) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl::add_canon(s[i], RC[i]);
     int round = 0;
@@ -365,7 +387,7 @@ __device__ inline void permute(u64 s[12], unsigned out_groups = 0xFu) {
         mds_layer(s, RC_SPLIT + 24 * (round + 1));
     }
     sbox_layer(s);
-    mds_layer(s, nullptr, out_groups);
+    mds_layer(s, nullptr, out_groups, out_single);
 }
 
 // two_to_one (hashing.rs:97-114): state = [l, r, 0^4], permute, first 4 words
@@ -377,7 +399,7 @@ __device__ __forceinline__ void two_to_one(const u64 l[4], const u64 r[4], u64 o
         s[4 + i] = r[i];
         s[8 + i] = 0;
     }
-    permute(s, 0x3u);  // words 0..3 only
+    permute(s, 0x1u, 3);  // words 0..3 only: triple 0 + word 3
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = gl::canon(s[i]);
 }

@@ -25,12 +25,14 @@ def _one(md, *subs):
 
 
 def test_leaf_sponge_keeps_its_register_budget(md):
-    """hash_leaves: 100 VGPRs (granule 8 -> 104: four waves per SIMD), no spills, no scratch"""
+    """hash_leaves: four waves per SIMD (<= 128 VGPRs: 119 since round 6, when the last MDS layer got its single-row form -- the
+    branchy tail keeps a copy of the state alive; a fifth wave would need <= 96 and was measured not to pay), no spills, no scratch
+    """
     k = _one(md, "hash_leaves_kernel", "ColMajorReader", "18hash")
-    assert k[".vgpr_count"] <= 104 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, k
+    assert k[".vgpr_count"] <= 128 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, k
     assert k.get(".sgpr_spill_count", 0) <= 96  # round constants parked in VGPR lanes outside the loops (83 v_readlane per permutation)
     lvl = _one(md, "19merkle_level_kernel")
-    assert lvl[".vgpr_count"] <= 104 and lvl[".vgpr_spill_count"] == 0 and lvl[".private_segment_fixed_size"] == 0
+    assert lvl[".vgpr_count"] <= 128 and lvl[".vgpr_spill_count"] == 0 and lvl[".private_segment_fixed_size"] == 0
 
 
 def test_limb_ntt_passes_fit_four_waves_without_spills(md):

@@ -344,10 +344,20 @@ def _fri_proof_verifies(eng, ora, log_n, widths, rb, cap, arity, pow_bits, nq, b
         bad["query_round_proofs"][-1]["steps"][0] = (evals, sib)
         with pytest.raises(fv.VerificationError):
             verify(bad)
-    bad = copy.deepcopy(proof)
-    bad["pow_witness"] = int(bad["pow_witness"]) + 1   # almost surely not a valid witness, and it shifts the query indices
-    with pytest.raises(fv.VerificationError):
-        verify(bad)
+    # another PoW witness: almost surely not a valid one, and it shifts the query indices.  "Almost": with pow_bits = 0 every witness
+    # is valid, and on a 2^8-point domain two queries land on the same indices once in 65 536 (a randomized GPU session met it:
+    # profiles/r06_fuzz.txt) -- then the tampered proof IS a valid proof, so the next witness is taken
+    for step in range(1, 6):
+        bad = copy.deepcopy(proof)
+        bad["pow_witness"] = int(bad["pow_witness"]) + step
+        chal = fv.fri_challenges(oc.clone(), bad["commit_phase_merkle_caps"], bad["final_poly"], bad["pow_witness"], log_n, rb, cap, nq)
+        if pow_bits == 0 and chal["fri_query_indices"] == [int(x) for x in proof["query_indices"]]:
+            continue
+        with pytest.raises(fv.VerificationError):
+            verify(bad)
+        break
+    else:
+        raise AssertionError("five consecutive PoW witnesses reproduce the query indices")
 
 
 def test_host_session_handles_and_errors(eng, ora):
