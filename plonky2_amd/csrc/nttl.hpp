@@ -271,6 +271,13 @@ struct LimbPassArgs {
     unsigned xcd_remap;  // > 0 (= log2 of gridDim.x): workgroup b takes slot (b % 8) * gridDim.x / 8 + b / 8 (see ntt::RegPassArgs)
     unsigned zloop;      // > 0: this workgroup produces z = 0..zloop-1 itself
     unsigned tiles_log;  // a workgroup processes 2^tiles_log consecutive tiles (the staged tables are loaded once)
+    // BRIN kernels (the first, strided pass of a two-pass coset LDE that follows an inverse transform): the coefficients are read from
+    // the inverse transform's BIT-REVERSED output and written once more in natural order -- the stand-alone bit reversal between
+    // the two transforms (fri/oracle.rs:65-69 then :91-98) disappears into this pass
+    const u64 *brin_src;     // [polynomials][brin_stride]: natural coefficient t of a polynomial lives at reverse_bits(t, LOG_R + 12)
+    size_t brin_stride;
+    u64 *nat_out;            // [polynomials][nat_stride]: canonical natural-order coefficients (`polynomials`, oracle.rs:32), or null
+    size_t nat_stride;
 };
 
 // radix bits of round r of a LOG_R-bit tile: as even as possible, larger parts first (the host builds the tables the same way)
@@ -431,6 +438,53 @@ __device__ __forceinline__ void load_inputs(const u64 *gin, unsigned log_stride,
             raw[(uu << P) + q] =
                 *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(gin + ((size_t)q << (S_LOG + log_stride))) + off0);
     }
+}
+
+// BRIN: the tile's 4096 inputs out of the bit-reversed coefficient array, through LDS.  Natural coefficient t = row * 2^12 + col
+// (row < 2^LOG_R, col = tau * 2^LOG_C + c) sits at reverse_bits(t, LOG_R + 12) = ((rev(c) << (12 - LOG_C) | rev(tau)) << LOG_R) | rev(row):
+// per column c one run of 2^LOG_R consecutive words.  The 512 threads read the 2^LOG_C runs as 16-byte pieces (a wave: one
+// contiguous KiB per load), park every word at its NATURAL tile position, and after one barrier each thread takes its first-round
+// units' inputs from there (the mapping of load_inputs) -- and stores them, canonical, to the natural-order array (128-byte runs).
+template <int LOG_R, int LOG_C>
+__device__ __forceinline__ void load_inputs_bitrev(const u64 *src, unsigned tau, u64 *tile, u64 (&raw)[8], u64 *nat, unsigned tid) {
+    static_assert(LOG_R >= 1 && LOG_C >= 1, "a strided pass");
+    constexpr int P = round_bits(LOG_R, 0);
+    constexpr int S_LOG = LOG_R - P;
+    constexpr unsigned C = 1u << LOG_C;
+    constexpr int UPT = 8 >> P;
+    constexpr unsigned UW = 512u >> P;
+    const unsigned taurev = LOG_C < 12 ? (unsigned)(__brev(tau) >> (32 - (12 - LOG_C))) : 0u;
+    W2 st[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned m = 2u * ((unsigned)j * 512u + tid);  // word index inside the tile's bit-reversed order: run (m >> LOG_R), place (m & (R - 1))
+        const unsigned cp = m >> LOG_R, rp = m & ((1u << LOG_R) - 1);
+        st[j] = *reinterpret_cast<const W2 *>(src + ((((size_t)cp << (12 - LOG_C)) | taurev) << LOG_R) + rp);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned m = 2u * ((unsigned)j * 512u + tid);
+        const unsigned cp = m >> LOG_R, rp = m & ((1u << LOG_R) - 1);
+        const unsigned c = (unsigned)(__brev(cp) >> (32 - LOG_C));
+        const unsigned row0 = (unsigned)(__brev(rp) >> (32 - LOG_R)), row1 = row0 | (1u << (LOG_R - 1));  // rp is even: rp + 1 flips the top row bit
+        tile[swz((row0 << LOG_C) | c)] = st[j].a;
+        tile[swz((row1 << LOG_C) | c)] = st[j].b;
+    }
+    __syncthreads();
+    const unsigned wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int uu = 0; uu < UPT; ++uu) {
+        const unsigned u = wave * UW + lane + 64u * (unsigned)uu;
+        const unsigned c = u & (C - 1), lo = u >> LOG_C;
+        const unsigned eb = (lo << LOG_C) + c, seb = swz(eb);
+#pragma unroll
+        for (int q = 0; q < (1 << P); ++q) {
+            const u64 v = tile[tix(seb, eb, (unsigned)q << (S_LOG + LOG_C))];
+            raw[(uu << P) + q] = v;
+            if (nat) nat[((size_t)(lo + ((unsigned)q << S_LOG)) << 12) + ((size_t)tau << LOG_C) + c] = gl::canon(v);
+        }
+    }
+    // (no second barrier: the first round overwrites exactly the eight slots this thread just read)
 }
 
 // Round RI of the tile.  FIRST round: the inputs are `raw` (already loaded); once they are split, the inputs of the next tile
@@ -627,10 +681,11 @@ __device__ __forceinline__ void limb_round(const LimbPassArgs &ra, u64 *tile, co
 // dynamic LDS.  DUAL = 2: threads 512..1023 transform the NEXT tile group side by side with threads 0..511 (their own tile in LDS,
 // the round tables shared): one workgroup then holds all four waves of every SIMD, so a workgroup barrier is a SIMD-wide one.
 // Workgroup barriers: one after the first round and one per tile; the later rounds and the store phase are wave-private.
-template <bool INV, int LOG_R, int LOG_C, int SCALE, int LAST = LAST_UNIT, int DUAL = 1>
+template <bool INV, int LOG_R, int LOG_C, int SCALE, int LAST = LAST_UNIT, int DUAL = 1, bool BRIN = false>
 __global__ void __launch_bounds__(NT * DUAL, LIMB_MIN_WAVES) ntt_limbpass_kernel(LimbPassArgs ra) {
     static_assert(LOG_R + LOG_C == TILE_LOG, "a tile is 4096 elements");
     static_assert(DUAL == 1 || DUAL == 2, "one or two tiles side by side");
+    static_assert(!BRIN || (LOG_C > 0 && DUAL == 1 && !INV), "the bit-reversed source is the first pass of a two-pass coset LDE");
     P2HOT_DYN_SHARED(u64, tile_all);
     const ntt::PassArgs &a = ra.a;
     const unsigned tid = threadIdx.x & (NT - 1);                          // the thread's place among its tile's 512
@@ -659,7 +714,12 @@ __global__ void __launch_bounds__(NT * DUAL, LIMB_MIN_WAVES) ntt_limbpass_kernel
         return a.in + (size_t)blockIdx.y * a.in_poly_stride + z * a.in_z_stride + (blk << a.log_nblk) + base0;
     };
     u64 raw[8];
-    load_inputs<LOG_R, LOG_C>(tile_in(0, z_begin), log_stride, raw);
+    if constexpr (BRIN) {  // one tile per workgroup (host: tiles_log = 0, one block); the z = 0 workgroup also writes the natural copy
+        u64 *nat = (ra.nat_out && z_begin == 0) ? ra.nat_out + (size_t)blockIdx.y * ra.nat_stride : nullptr;
+        load_inputs_bitrev<LOG_R, LOG_C>(ra.brin_src + (size_t)blockIdx.y * ra.brin_stride, (unsigned)wg, tile, raw, nat, tid);
+    } else {
+        load_inputs<LOG_R, LOG_C>(tile_in(0, z_begin), log_stride, raw);
+    }
 #pragma unroll 1
     for (size_t t = 0; t < n_tiles; ++t) {
         const size_t tau = (wg << ra.tiles_log) + t;

@@ -48,6 +48,7 @@ struct p2hot_ctx {
     bool host_leaves_first = true;  // p2hot_commit with leaves_out: transforms, then the leaf matrix's copy beside the sponge (P2HOT_HOST_LEAVES_FIRST)
     bool host_chunked_hash = true;  // p2hot_commit: the leaf sponge absorbs each block's columns as soon as they are extended
     bool pp_streams = true;       // partial products: pairs of challenges through pp_quotients2_kernel (P2HOT_PP_STREAMS=0: one kernel per challenge)
+    bool lde_reads_bitrev = true;  // from_values: fold the bit reversal between iNTT and LDE into the LDE's first pass (P2HOT_LDE_BITREV_SRC=0: off)
     bool limb_dual = true;       // P2HOT_LIMB_DUAL builds: pair tile groups into 1024-thread workgroups (P2HOT_LIMB_DUAL_OFF=1 turns it off)
     unsigned limb_tiles_log = 4;  // contiguous limb passes: a workgroup stages its tables once for 2^this tiles (P2HOT_LIMB_TILES_LOG)
     // second stream: the VALU-bound leaf sponge of coset block b runs beside the wait-bound NTT of block b+1
@@ -426,6 +427,7 @@ extern "C" int p2hot_ctx_create(int device, void *hip_stream, p2hot_ctx **out) {
     if (const char *e = getenv("P2HOT_NTT_LIMB")) ctx->use_limb = atoi(e) != 0, ctx->force_no_limb = atoi(e) == 0;
     if (const char *e = getenv("P2HOT_LIMB_TILES_LOG")) ctx->limb_tiles_log = (unsigned)atoi(e);
     if (const char *e = getenv("P2HOT_LIMB_DUAL_OFF")) ctx->limb_dual = !(e[0] == '1');
+    if (const char *e = getenv("P2HOT_LDE_BITREV_SRC")) ctx->lde_reads_bitrev = !(e[0] == '0');
     if (const char *e = getenv("P2HOT_NTT_ZLOOP_MIN")) ctx->zloop_min_groups = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HORNER_2L_MIN")) ctx->horner_two_level_min = (size_t)strtoull(e, nullptr, 10);
     if (const char *e = getenv("P2HOT_HOST_BLOCK_COLS")) ctx->host_block_cols = (size_t)strtoull(e, nullptr, 10);
@@ -708,10 +710,23 @@ static bool limb_supported(unsigned log_r, unsigned log_c) {
 }
 
 // launches one limb pass; `last_const` != 1 multiplies every output of this (last) pass by it (the 1/n of the inverse transform)
+struct BrinArgs {  // the bit-reversed coefficient source of a coset LDE's first pass + where its natural-order copy goes (nttl.hpp BRIN)
+    const u64 *src = nullptr;
+    size_t src_stride = 0;
+    u64 *nat = nullptr;
+    size_t nat_stride = 0;
+};
 static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse, const u64 *twid, unsigned xcd_remap,
-                            unsigned zloop, dim3 grid, u64 last_const, const u64 *srow2, const nttl::W2 *sbase) {
+                            unsigned zloop, dim3 grid, u64 last_const, const u64 *srow2, const nttl::W2 *sbase,
+                            const BrinArgs *brin = nullptr) {
     nttl::LimbPassArgs ra{};
     ra.a = a;
+    if (brin && brin->src) {
+        ra.brin_src = brin->src;
+        ra.brin_stride = brin->src_stride;
+        ra.nat_out = brin->nat;
+        ra.nat_stride = brin->nat_stride;
+    }
     ra.twid = twid;
     ra.xcd_remap = xcd_remap;
     ra.zloop = zloop;
@@ -736,7 +751,7 @@ static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse
     // launch has an even number of tile groups to pair
     bool dual = false;
 #if P2HOT_LIMB_DUAL
-    dual = ctx->limb_dual && grid.x >= 2 && grid.x % 2 == 0;
+    dual = ctx->limb_dual && grid.x >= 2 && grid.x % 2 == 0 && !ra.brin_src;
     if (dual) {
         grid.x >>= 1;
         if (ra.xcd_remap) ra.xcd_remap = ra.xcd_remap > 3 ? ra.xcd_remap - 1 : 0;
@@ -766,17 +781,26 @@ static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse
         P2_TRY(lds_opt_in(ctx, reinterpret_cast<const void *>(kfn_), shm));                                \
         P2HOT_LAUNCH(kfn_, grid, dim3(nttl::NT), shm, ctx->stream, ra);                                    \
     } while (0)
+#define P2_LIMB_BRIN(LR)                                                                                             \
+    do {                                                                                                                 \
+        auto kfnb_ = nttl::ntt_limbpass_kernel<false, (LR) == 12 ? 8 : (LR), (LR) == 12 ? 4 : 12 - (LR), ntt::SCALE_TABLE, nttl::LAST_TILE, 1, true>; \
+        P2_TRY(lds_opt_in(ctx, reinterpret_cast<const void *>(kfnb_), shm));                                             \
+        P2HOT_LAUNCH(kfnb_, grid, dim3(nttl::NT), shm, ctx->stream, ra);                                                 \
+    } while (0)
 #define P2_LIMB_DIR(LR, MODE, LASTM) do { if (inverse) P2_LIMB(true, LR, MODE, LASTM); else P2_LIMB(false, LR, MODE, LASTM); } while (0)
 #define P2_LIMB_MODE(LR)                                                                                          \
     do {                                                                                                          \
         if (a.scale_mode == ntt::SCALE_TABLE) {                                                                   \
             if (LR == 12) P2_LIMB_DIR(LR, ntt::SCALE_TABLE, nttl::LAST_UNIT);                                     \
+            else if (ra.brin_src) P2_LIMB_BRIN(LR);                                                               \
             else P2_LIMB_DIR(LR, ntt::SCALE_TABLE, nttl::LAST_TILE);                                              \
         } else if (a.scale_mode == ntt::SCALE_CONST) P2_LIMB_DIR(LR, ntt::SCALE_CONST, nttl::LAST_UNIT);          \
         else P2_LIMB_DIR(LR, ntt::SCALE_NONE, nttl::LAST_UNIT);                                                   \
     } while (0)
     if (a.scale_mode == ntt::SCALE_TABLE && a.log_r != 12 && (!srow2 || !sbase)) P2_FAIL(ctx, P2HOT_EINVAL, "limb pass: missing coset scale tables");
     if (a.canon_out && a.log_c) P2_FAIL(ctx, P2HOT_EINVAL, "limb pass: a strided pass is never the last one and stores no canonical representatives");
+    if (ra.brin_src && (inverse || a.log_c == 0 || ra.tiles_log || a.scale_mode != ntt::SCALE_TABLE || a.log_nblk != a.log_r + 12))
+        P2_FAIL(ctx, P2HOT_EINVAL, "limb pass: the bit-reversed source belongs to the first pass of a two-pass coset LDE");
     if (wlast) {
         if (inverse)
             P2_LIMB(true, 12, ntt::SCALE_NONE, nttl::LAST_CONST);
@@ -796,6 +820,7 @@ static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse
         default: P2_FAIL(ctx, P2HOT_EINVAL, "limb pass: unsupported tile 2^%u x 2^%u", a.log_r, a.log_c);
     }
 #undef P2_LIMB_MODE
+#undef P2_LIMB_BRIN
 #undef P2_LIMB_DIR
 #undef P2_LIMB
     return P2HOT_OK;
@@ -807,7 +832,7 @@ static int launch_limb_pass(p2hot_ctx *ctx, const ntt::PassArgs &a, bool inverse
 static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, size_t out_stride, size_t out_z_stride,
                    size_t batch, size_t zcount, unsigned log_n, const ntt::RootTable &roots, int scale_mode,
                    u64 scale_const, const u64 *srow, const u64 *scol, bool canon_last, const u64 *srow2 = nullptr,
-                   const nttl::W2 *sbase = nullptr) {
+                   const nttl::W2 *sbase = nullptr, const BrinArgs *brin = nullptr) {
     if (batch == 0 || zcount == 0) return P2HOT_OK;
     if (batch > 65535 || zcount > 65535) P2_FAIL(ctx, P2HOT_EINVAL, "batch %zu / z %zu exceed the grid limit", batch, zcount);
     std::vector<Pass> passes = plan_passes(log_n, ctx->ntt_strided_bits);
@@ -892,11 +917,12 @@ static int run_dif(p2hot_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, si
                     ra.a.scale_mode = ntt::SCALE_NONE;
                     if (i + 1 == passes.size()) last_const = scale_const;
                 }
-                P2_TRY(launch_limb_pass(ctx, ra.a, inverse, ra.twid, ra.xcd_remap, ra.zloop, grid, last_const, srow2, sbase));
+                P2_TRY(launch_limb_pass(ctx, ra.a, inverse, ra.twid, ra.xcd_remap, ra.zloop, grid, last_const, srow2, sbase, first ? brin : nullptr));
                 P2_LAUNCH_CHECK(ctx);
                 log_nblk -= a.log_r;
                 continue;
             }
+            if (first && brin && brin->src) P2_FAIL(ctx, P2HOT_EINVAL, "run_dif: the bit-reversed source needs the limb passes");
             if (maxp == 3) {  // one kernel per (direction, scale mode): the per-point mode tests are compiled out
 #define P2_NTT512C(INVF, MODE, CT) P2HOT_LAUNCH((ntt::ntt_regpass_kernel<INVF, 512, (CT) ? 8 : 6, MODE, CT>), grid, dim3(512), shm, ctx->stream, ra)
 #define P2_NTT512(INVF, MODE) do { if (a.log_c == 0 && log_nblk == a.log_r) P2_NTT512C(INVF, MODE, true); else P2_NTT512C(INVF, MODE, false); } while (0)
@@ -1039,9 +1065,28 @@ static int coset_scale_tables(p2hot_ctx *ctx, unsigned log_n, unsigned rate_bits
     return P2HOT_OK;
 }
 
+// can the coset LDE of 2^log_n coefficients read them from the inverse transform's bit-reversed output (nttl.hpp BRIN)?  Two passes,
+// both limb passes, inter-pass twiddles from the table: exactly the conditions under which run_dif launches the limb kernels
+static bool lde_can_read_bitrev(const p2hot_ctx *ctx, unsigned log_n) {
+    if (!ctx->lde_reads_bitrev || !(ctx->use_limb && ctx->use_regpass && ctx->ntt_radix_bits == 3) || log_n > 24) return false;
+    const std::vector<Pass> passes = plan_passes(log_n, ctx->ntt_strided_bits);
+    return passes.size() == 2 && passes[0].log_c > 0 && limb_supported(passes[0].log_r, passes[0].log_c) &&
+           limb_supported(passes[1].log_r, passes[1].log_c);
+}
+
+static int coset_lde_impl(p2hot_ctx *ctx, const uint64_t *d_coeffs, size_t W, size_t coeff_stride, unsigned log_n, unsigned rate_bits,
+                          uint64_t shift, size_t row_begin, size_t row_count, uint64_t *d_lde, size_t lde_stride, const BrinArgs *brin);
+
 extern "C" int p2hot_coset_lde_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, size_t W, size_t coeff_stride,
                                    unsigned log_n, unsigned rate_bits, uint64_t shift, size_t row_begin,
                                    size_t row_count, uint64_t *d_lde, size_t lde_stride) {
+    return coset_lde_impl(ctx, d_coeffs, W, coeff_stride, log_n, rate_bits, shift, row_begin, row_count, d_lde, lde_stride, nullptr);
+}
+
+// `brin` (optional): the coefficients come from brin->src in bit-reversed order instead of d_coeffs (which may then be the same
+// pointer as brin->nat: nothing reads it), and the first pass leaves their natural-order, canonical copy in brin->nat
+static int coset_lde_impl(p2hot_ctx *ctx, const uint64_t *d_coeffs, size_t W, size_t coeff_stride, unsigned log_n, unsigned rate_bits,
+                          uint64_t shift, size_t row_begin, size_t row_count, uint64_t *d_lde, size_t lde_stride, const BrinArgs *brin) {
     if (!ctx) return P2HOT_EINVAL;
     DeviceGuard dev_guard_(ctx);
     P2_TRY(check_log(ctx, log_n + rate_bits, "coset_lde"));
@@ -1056,7 +1101,7 @@ extern "C" int p2hot_coset_lde_dev(p2hot_ctx *ctx, const uint64_t *d_coeffs, siz
     const nttl::W2 *sbase;
     P2_TRY(coset_scale_tables(ctx, log_n, rate_bits, shift, b0, zc, &srow, &scol, &srow2, &sbase));
     return run_dif(ctx, d_coeffs, coeff_stride, d_lde, lde_stride, n, W, zc, log_n, ctx->fwd, ntt::SCALE_TABLE, 0, srow,
-                   scol, true, srow2, sbase);
+                   scol, true, srow2, sbase, brin);
 }
 
 // rev_bits > 0: row r of the column-major matrix lands in row reverse_bits(r, rev_bits) of the row-major one (rows == 2^rev_bits):
@@ -1250,6 +1295,7 @@ extern "C" int p2hot_commit_dev(p2hot_ctx *ctx, const uint64_t *d_cols, size_t c
     if (W > 0 && !d_lde) P2_FAIL(ctx, P2HOT_EINVAL, "commit: d_lde is required");
     const u64 *coeff_src = d_cols;
     size_t coeff_src_stride = col_stride;
+    BrinArgs brin;
     if (is_values) {
         // "IFFT" (oracle.rs:65-69): DIF chain with inverse roots and n^-1, then bit-reverse into d_coeffs
         if (W > 0) {
@@ -1258,7 +1304,17 @@ extern "C" int p2hot_commit_dev(p2hot_ctx *ctx, const uint64_t *d_cols, size_t c
             P2_TRY(scratch_get(ctx, 0, W * n * 8, (void **)&tmp));
             P2_TRY(run_dif(ctx, d_cols, col_stride, tmp, n, 0, W, 1, log_n, ctx->inv, ntt::SCALE_CONST,
                            gl::inv(n % gl::P), nullptr, nullptr, false));
-            P2_TRY(launch_bitrev(ctx, tmp, d_coeffs, W, n, coeff_stride, log_n));
+            // the bit reversal into `polynomials` order: its own kernel, or -- when the LDE below is ONE launch sequence of two limb
+            // passes -- folded into the LDE's first pass, which reads the bit-reversed array and writes the natural copy itself
+            const bool one_lde = !(ctx->overlap && (row_count >> log_n) > 1 && row_count % n == 0);
+            if (one_lde && row_count > 0 && lde_can_read_bitrev(ctx, log_n)) {
+                brin.src = tmp;
+                brin.src_stride = n;
+                brin.nat = d_coeffs;
+                brin.nat_stride = coeff_stride;
+            } else {
+                P2_TRY(launch_bitrev(ctx, tmp, d_coeffs, W, n, coeff_stride, log_n));
+            }
         }
         coeff_src = d_coeffs;
         coeff_src_stride = coeff_stride;
@@ -1294,8 +1350,8 @@ extern "C" int p2hot_commit_dev(p2hot_ctx *ctx, const uint64_t *d_cols, size_t c
     } else
     {
         (void)blocks;
-        P2_TRY(p2hot_coset_lde_dev(ctx, coeff_src, W, coeff_src_stride, log_n, rate_bits, gl::COSET_SHIFT, row_begin,
-                                   row_count, d_lde, lde_stride));
+        P2_TRY(coset_lde_impl(ctx, coeff_src, W, coeff_src_stride, log_n, rate_bits, gl::COSET_SHIFT, row_begin, row_count, d_lde,
+                              lde_stride, brin.src ? &brin : nullptr));
         P2_TRY(p2hot_merkle_dev(ctx, d_lde, 0, lde_stride, W, log_N, cap_height, row_begin, row_count, d_digests, d_cap));
     }
     if (d_leaves) P2_TRY(p2hot_transpose_dev(ctx, d_lde, lde_stride, W, row_count, d_leaves));

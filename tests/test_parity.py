@@ -821,3 +821,23 @@ def test_host_pointer_commit_random_shapes(eng, ora):
         else:
             assert rc == _lib.EINVAL
         eng.lib.p2hot_batch_free(h)
+
+
+@pytest.mark.parametrize("W,log_n,rb,cap", [(2, 16, 1, 2), (1, 17, 2, 3), (3, 18, 0, 1)])
+def test_from_values_reads_the_bit_reversed_inverse_transform(eng, ora, W, log_n, rb, cap):
+    """from_values at sizes whose coset LDE is two limb passes (2^16 rows and up): the bit reversal between the inverse transform and
+    the LDE (fri/oracle.rs:65-69 then :91-98) has no kernel of its own -- the LDE's first pass reads the bit-reversed array and
+    writes `polynomials` in natural order (nttl.hpp load_inputs_bitrev, tile rows 2^4 / 2^5 / 2^6 here; 2^8 at the bench's 2^20) --
+    and coefficients, LDE matrix, digests and cap are the oracle's."""
+    rng = np.random.default_rng(log_n * 13 + W)
+    cols = rand_field(rng, W, 1 << log_n, noncanonical=True)
+    o = ora.commit(cols, rb, cap, True)
+    eng.profile(True)
+    eng.profile_results(reset=True)
+    r = eng.commit(eng.dev(cols), log_n, rb, cap, True)
+    eng.sync()
+    prof = eng.profile_results(reset=True)
+    eng.profile(False)
+    assert "bitrev_permute" not in prof, "the stand-alone bit reversal ran"
+    assert (eng.host(r["coeffs"]) == o["coeffs"]).all(), "natural-order canonical coefficients"
+    assert (eng.host(r["lde"]).T == o["leaves"]).all() and (eng.host(r["digests"]) == o["digests"]).all() and (eng.host(r["cap"]) == o["cap"]).all()
