@@ -635,7 +635,8 @@ def roofline_line(vl, hbm_achieved, hash_bytes, perms, h, launches_per_step, e):
 
 
 def ntt_roofline(kern, W, n_local, rows_local, steps, entry):
-    """The NTT family of a step (iNTT strided + contiguous, the bit reversal between them and the LDE, LDE strided + contiguous)
+    """The NTT family of a step (iNTT strided + contiguous, the bit reversal between them and the LDE -- its own launch, or since
+    round 6 folded into the LDE's strided pass --, LDE strided + contiguous)
     on SURVEY section 8(d)'s contract: each LOGICAL array counted once per LOGICAL stage, no credit for a multi-pass transform --
     `algorithmic_bytes` = iNTT 16*W*n + coset LDE 8*W*n + 8*W*N; `family_frac` = that / the five launches' time / 8 TB/s;
     `traffic` = the PMC bytes of the same five launches (profiles/pmc_traffic.json), `traffic_ratio` = traffic / algorithmic.
@@ -646,6 +647,9 @@ def ntt_roofline(kern, W, n_local, rows_local, steps, entry):
            "bitrev_permute": (16 * W * n_local, ("bitrev_tiled_kernel",)),
            "ntt_lde_strided": (8 * W * n_local + 8 * W * rows_local, ("ntt_limbpass_kernel<false", ",4,")),
            "ntt_lde_contig": (16 * W * rows_local, ("ntt_limbpass_kernel<false,12,0",))}
+    if "bitrev_permute" not in kern:  # the bit reversal is folded into the LDE's strided pass (nttl.hpp BRIN), which also writes the
+        b_, n_ = per["ntt_lde_strided"]  # natural-order coefficients: 8*W*n more bytes for that launch, 16*W*n fewer for the family
+        per["ntt_lde_strided"] = (b_ + 8 * W * n_local, n_)
     stage_bytes = {"intt": 16 * W * n_local, "coset_lde": 8 * W * n_local + 8 * W * rows_local}
     alg = sum(stage_bytes.values())
     passes, tot_ms, traffic, traffic_complete = {}, 0.0, 0.0, True
@@ -667,14 +671,14 @@ def ntt_roofline(kern, W, n_local, rows_local, steps, entry):
         return None
     fam = alg / (tot_ms * 1e-3) / 1e9
     vpe = [p["valu_insts_per_element"] for k, p in passes.items() if k.endswith("_contig") and p.get("valu_insts_per_element")]
-    return {"kernel": "ntt_limbpass_kernel (24-bit-limb radix-8 passes, nttl.hpp) + bitrev_tiled_kernel: iNTT, bit reversal and coset LDE of one from_values commit",
+    return {"kernel": "ntt_limbpass_kernel (24-bit-limb radix-8 passes, nttl.hpp; + bitrev_tiled_kernel where the bit reversal is not folded): iNTT, bit reversal and coset LDE of one from_values commit",
             "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": fam, "frac": fam / HBM_PEAK_GBS,
             "algorithmic_bytes": alg, "algorithmic_bytes_by_stage": stage_bytes,
             "family_ms_per_step": tot_ms, "family_achieved": fam, "family_frac": fam / HBM_PEAK_GBS,
             "traffic": traffic if traffic_complete and traffic else None, "traffic_ratio": traffic / alg if traffic_complete and traffic else None,
             "traffic_stale": pmc_stale(),
             "passes": passes,
-            "note": "SURVEY 8(d): iNTT 16*W*n + LDE 8*W*n + 8*W*N counted once each; a two-pass transform plus the stand-alone bit reversal moves "
+            "note": "SURVEY 8(d): iNTT 16*W*n + LDE 8*W*n + 8*W*N counted once each; a two-pass transform plus the bit reversal (folded into the LDE's strided pass where that pass is a limb pass) moves "
                     "%s that (`traffic_ratio`), so `pass_frac` (each launch against the bytes it moves itself) is higher than `family_frac`.  The passes "
                     "retire ~%s VALU instructions per element-pass (carry-free 24-bit limbs: half of them plain 32-bit adds) with VALU, LDS "
                     "and HBM all busy (profiles/*_pmc_sq.txt)"

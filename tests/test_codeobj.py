@@ -45,8 +45,9 @@ def test_limb_ntt_passes_fit_four_waves_without_spills(md):
         assert k[".vgpr_count"] <= 128 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, n
         assert k[".max_flat_workgroup_size"] == 512
         assert codeobj.waves_per_simd(k[".vgpr_count"], 512) >= 4, n
-    # the four launches of the headline commit (iNTT strided / contiguous with the 1/n fold, LDE strided / contiguous)
-    for sub in ("ILb1ELi8ELi4ELi0ELi0E", "ILb1ELi12ELi0ELi0ELi1E", "ILb0ELi8ELi4ELi2ELi2E", "ILb0ELi12ELi0ELi0ELi0E"):
+    # the four launches of the headline commit (iNTT strided / contiguous with the 1/n fold, LDE strided -- the form that reads the
+    # bit-reversed inverse transform: ..., DUAL = 1, BRIN = true -- / contiguous)
+    for sub in ("ILb1ELi8ELi4ELi0ELi0ELi1ELb0E", "ILb1ELi12ELi0ELi0ELi1ELi1ELb0E", "ILb0ELi8ELi4ELi2ELi2ELi1ELb1E", "ILb0ELi12ELi0ELi0ELi0ELi1ELb0E"):
         assert md[_one(md, "ntt_limbpass_kernel", sub)[".name"]][".vgpr_count"] <= 112
 
 
