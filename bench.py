@@ -1080,7 +1080,8 @@ def main():
                 del job
             if not emu:
                 torch.cuda.empty_cache()
-            store.wait(["p2hot_group_path_done"])
+            import datetime
+            store.wait(["p2hot_group_path_done"], datetime.timedelta(minutes=30))  # (rank 0: a single-GPU proof, the group's RCCL init, three group proofs)
     if dist:
         dist.barrier()
         if "job" in dir():
