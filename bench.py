@@ -624,8 +624,10 @@ def roofline_line(vl, hbm_achieved, hash_bytes, perms, h, launches_per_step, e):
                                 "traffic_stale = the kernel sources changed since they were collected)",
               **({"overlap": "launched on a second stream beside the next coset block's LDE; durations are wall "
                              "time while sharing the GPU"} if launches_per_step > 1 else {}),
-              "note": "integer-VALU-issue bound (%.3g permutations per launch, %.2f Gperm/s, 13.2 k VALU instructions each); "
-                      "algorithmic bytes per launch = 8*W*rows + 32*rows = %d" % (perms, perms / (h["ms_per_launch"] * 1e-3) / 1e9, hash_bytes),
+              "note": "integer-VALU-issue bound (%.3g permutations per launch, %.2f Gperm/s, %s VALU instructions each); "
+                      "algorithmic bytes per launch = 8*W*rows + 32*rows = %d"
+                      % (perms, perms / (h["ms_per_launch"] * 1e-3) / 1e9,
+                         "%.2f k" % (e["sq_insts_valu_per_launch"] / launches_per_step * 64 / perms / 1e3) if e and e.get("sq_insts_valu_per_launch") else "~13 k", hash_bytes),
               "hbm_frac": hbm["frac"], "hbm": hbm}
     if vl:
         nom = vl["valu_nominal"]
