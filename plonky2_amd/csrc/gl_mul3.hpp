@@ -167,6 +167,82 @@ __device__ __forceinline__ u64 mul1_lowregs(u64 a, u64 b) {
     return ra;
 }
 
+// ---- mul3cf / mul1cf: the same product with a CARRY-FREE 128-bit assembly (round 6; used by the Poseidon S-boxes) -------------------
+// On gfx950 a v_mov_b32 next to a multiply-add costs ~1.5 cycles where a carry add costs 4.3 (profiles/r06_ubench_cheap.txt: cheap
+// FP32-class instructions and v_mov overlap the 64-bit multiply-add, integer carry arithmetic does not).  So the partial products are
+// chained through the multiply-add's 64-bit ADDEND instead of being summed with v_add_co / v_addc -- every step fits 64 bits:
+//    T.hi = 0
+//    P  = a0*b0                      T.lo = P.hi
+//    M  = a1*b0 + T   (< 2^64)       T.lo = M.lo
+//    N  = a0*b1 + T   (< 2^64)       T.lo = M.hi        N.lo is limb 1 of the product, P.lo limb 0
+//    T  = a1*b1 + T                  T += N.hi * 1      (<= (2^32-1)^2 + 2 (2^32-1) = 2^64 - 1): T = the high 64 bits
+// 5 multiply-adds + 4 moves instead of 4 multiply-adds + 3 carry adds; the reduction is the one above (steps 8-14), reading
+// lo = {P.lo, N.lo}, hi = T.  16 instructions, measured as a dependency-free mix at 52.0 cycles per product against 56.6
+// (tools/ubench.hip probes 170 / 171).  Register sets: P, M, N, T pairs + two SGPR carry pairs per stream.
+#define P2_CA "v[70:71]", "v70", "v71", "v[72:73]", "v72", "v73", "v[74:75]", "v74", "v75", "v[76:77]", "v76", "v77", "s[40:41]", "s[42:43]"
+#define P2_CB "v[78:79]", "v78", "v79", "v[80:81]", "v80", "v81", "v[82:83]", "v82", "v83", "v[84:85]", "v84", "v85", "s[44:45]", "s[46:47]"
+#define P2_CC "v[86:87]", "v86", "v87", "v[88:89]", "v88", "v89", "v[90:91]", "v90", "v91", "v[92:93]", "v92", "v93", "s[48:49]", "s[50:51]"
+#define P2_CF0(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mov_b32 " T1 ", 0\n\t"
+#define P2_CF1(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_u64_u32 " P ", " C1 ", %[" a0 "], %[" b0 "], 0\n\t"
+#define P2_CF2(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mov_b32 " T0 ", " P1 "\n\t"
+#define P2_CF3(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_u64_u32 " M ", " C1 ", %[" a1 "], %[" b0 "], " T "\n\t"
+#define P2_CF4(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mov_b32 " T0 ", " M0 "\n\t"
+#define P2_CF5(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_u64_u32 " N ", " C1 ", %[" a0 "], %[" b1 "], " T "\n\t"
+#define P2_CF6(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mov_b32 " T0 ", " M1 "\n\t"
+#define P2_CF7(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_u64_u32 " T ", " C1 ", %[" a1 "], %[" b1 "], " T "\n\t"
+#define P2_CF8(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_u64_u32 " T ", " C1 ", " N1 ", 1, " T "\n\t"
+#define P2_CF9(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_sub_co_u32 " M0 ", " C1 ", " P0 ", " T1 "\n\t"
+#define P2_CF10(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_subb_co_u32 " M1 ", " C1 ", " N0 ", 0, " C1 "\n\t"
+#define P2_CF11(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_u64_u32 " M ", " C2 ", " T0 ", -1, " M "\n\t"
+#define P2_CF12(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_cndmask_b32 " N0 ", 0, 1, " C2 "\n\t"
+#define P2_CF13(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_subb_co_u32 " N0 ", " C1 ", " N0 ", 0, " C1 "\n\t"
+#define P2_CF14(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_add_u32 " M1 ", " M1 ", " N0 "\n\t"
+#define P2_CF15(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_i64_i32 %[" r0 "], " C1 ", " N0 ", -1, " M "\n\t"
+#define P2_CROW(ST)                                          \
+    P2_APPLY(ST, P2_CA, "xa0", "xa1", "ya0", "ya1", "ra0")   \
+    P2_APPLY(ST, P2_CB, "xb0", "xb1", "yb0", "yb1", "rb0")   \
+    P2_APPLY(ST, P2_CC, "xc0", "xc1", "yc0", "yc1", "rc0")
+#define P2_CF_CLOBBERS3                                                                                                      \
+    "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", \
+        "v88", "v89", "v90", "v91", "v92", "v93", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51"
+
+// r[k] = a[k] * b[k] (mod P), k = 0..2: three carry-free streams round-robin (every SGPR producer / consumer pair three
+// instructions apart: no s_nop)
+__device__ __forceinline__ void mul3cf(const u64 a[3], const u64 b[3], u64 r[3]) {
+    if (!P2_ASM_INTERPRETED()) {
+        for (int k = 0; k < 3; ++k) r[k] = mul(a[k], b[k]);
+        return;
+    }
+    u64 ra, rb, rc;
+    P2_ASM(P2_CROW(P2_CF0) P2_CROW(P2_CF1) P2_CROW(P2_CF2) P2_CROW(P2_CF3) P2_CROW(P2_CF4) P2_CROW(P2_CF5) P2_CROW(P2_CF6) P2_CROW(P2_CF7)
+               P2_CROW(P2_CF8) P2_CROW(P2_CF9) P2_CROW(P2_CF10) P2_CROW(P2_CF11) P2_CROW(P2_CF12) P2_CROW(P2_CF13) P2_CROW(P2_CF14)
+                   P2_CROW(P2_CF15),
+           (P2_O([ra0], "=&v", ra), P2_O([rb0], "=&v", rb), P2_O([rc0], "=&v", rc)),
+           (P2_I([xa0], "v", (u32)a[0]), P2_I([xa1], "v", (u32)(a[0] >> 32)), P2_I([ya0], "v", (u32)b[0]),
+            P2_I([ya1], "v", (u32)(b[0] >> 32)), P2_I([xb0], "v", (u32)a[1]), P2_I([xb1], "v", (u32)(a[1] >> 32)),
+            P2_I([yb0], "v", (u32)b[1]), P2_I([yb1], "v", (u32)(b[1] >> 32)), P2_I([xc0], "v", (u32)a[2]),
+            P2_I([xc1], "v", (u32)(a[2] >> 32)), P2_I([yc0], "v", (u32)b[2]), P2_I([yc1], "v", (u32)(b[2] >> 32))),
+           (P2_CF_CLOBBERS3));
+    r[0] = ra;
+    r[1] = rb;
+    r[2] = rc;
+}
+
+// one carry-free stream (the partial rounds' dependent S-box chains): the two adjacent SGPR producer / consumer rows (9 -> 10,
+// 11 -> 12) get their two wait states as `s_nop 1`
+#define P2_CA1(ST) P2_APPLY(ST, P2_CA, "xa0", "xa1", "ya0", "ya1", "ra0")
+__device__ __forceinline__ u64 mul1cf(u64 a, u64 b) {
+    if (!P2_ASM_INTERPRETED()) return mul(a, b);
+    u64 ra;
+    P2_ASM(P2_CA1(P2_CF0) P2_CA1(P2_CF1) P2_CA1(P2_CF2) P2_CA1(P2_CF3) P2_CA1(P2_CF4) P2_CA1(P2_CF5) P2_CA1(P2_CF6) P2_CA1(P2_CF7)
+               P2_CA1(P2_CF8) P2_CA1(P2_CF9) P2_NOP P2_CA1(P2_CF10) P2_CA1(P2_CF11) P2_NOP P2_CA1(P2_CF12) P2_CA1(P2_CF13)
+                   P2_CA1(P2_CF14) P2_CA1(P2_CF15),
+           (P2_O([ra0], "=&v", ra)),
+           (P2_I([xa0], "v", (u32)a), P2_I([xa1], "v", (u32)(a >> 32)), P2_I([ya0], "v", (u32)b), P2_I([ya1], "v", (u32)(b >> 32))),
+           ("v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "s40", "s41", "s42", "s43"));
+    return ra;
+}
+
 // ---- fold3: three MDS-row recombinations in one interleaved stream ------------------------------
 // A row's two accumulators al = sum c*x.lo32, ah = sum c*x.hi32 (each < 2^63) stand for
 //   y = al + ah*2^32 = al + ah.lo * 2^32 + ah.hi * 2^64 = al + ah.hi * (2^32 - 1) + ah.lo * 2^32   (mod P):

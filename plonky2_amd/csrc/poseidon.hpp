@@ -44,21 +44,34 @@ __device__ __forceinline__ u64 sbox7(u64 x) {  // poseidon.rs:690-696
     return gl::mul(x3, x4);
 }
 
+// P2HOT_SBOX_CF (default 1): the S-box products through the carry-free multiply streams (gl::mul3cf / mul1cf: the partial products
+// chained through the multiply-add's addend, v_mov instead of carry adds -- round 6); 0: the round-3 streams (gl::mul3 / mul1)
+#ifndef P2HOT_SBOX_CF
+#define P2HOT_SBOX_CF 1
+#endif
+__device__ __forceinline__ u64 sbox_mul1(u64 a, u64 b) { return P2HOT_SBOX_CF ? gl::mul1cf(a, b) : gl::mul1(a, b); }
+__device__ __forceinline__ void sbox_mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
+    if (P2HOT_SBOX_CF)
+        gl::mul3cf(a, b, r);
+    else
+        gl::mul3(a, b, r);
+}
+
 // x^7 of one word with the hand-scheduled multiply (the partial rounds' single S-box)
 __device__ __forceinline__ u64 sbox7_asm(u64 x) {
-    u64 x2 = gl::mul1(x, x);
-    u64 x4 = gl::mul1(x2, x2);
-    u64 x3 = gl::mul1(x, x2);
-    return gl::mul1(x3, x4);
+    u64 x2 = sbox_mul1(x, x);
+    u64 x4 = sbox_mul1(x2, x2);
+    u64 x3 = sbox_mul1(x, x2);
+    return sbox_mul1(x3, x4);
 }
 
 // x^7 of three independent words at once: x2 = x*x; (x3 = x*x2 and x4 = x2*x2 are independent); x7 = x3*x4
 __device__ __forceinline__ void sbox7_x3(u64 &a, u64 &b, u64 &c) {
     u64 x[3] = {a, b, c}, x2[3], x3[3], x4[3];
-    gl::mul3(x, x, x2);
-    gl::mul3(x, x2, x3);
-    gl::mul3(x2, x2, x4);
-    gl::mul3(x3, x4, x);
+    sbox_mul3(x, x, x2);
+    sbox_mul3(x, x2, x3);
+    sbox_mul3(x2, x2, x4);
+    sbox_mul3(x3, x4, x);
     a = x[0];
     b = x[1];
     c = x[2];

@@ -15,7 +15,7 @@ namespace {
 
 enum Op {
     V_MAD_U64_U32, V_MAD_I64_I32, V_ADD_CO_U32, V_ADDC_CO_U32, V_SUB_CO_U32, V_SUBB_CO_U32, V_CNDMASK_B32, V_ADD_U32,
-    V_LSHLREV_B32, V_LSHRREV_B32, V_LSHLREV_B64, V_LSHRREV_B64, V_ALIGNBIT_B32, S_NOP, N_OPS
+    V_LSHLREV_B32, V_LSHRREV_B32, V_LSHLREV_B64, V_LSHRREV_B64, V_ALIGNBIT_B32, V_MOV_B32, S_NOP, N_OPS
 };
 // operand roles: D / d = 64 / 32-bit VGPR destination, C = carry-out SGPR, c = carry-in or select SGPR, a / A = 32 / 64-bit
 // source, i = immediate only
@@ -27,7 +27,7 @@ const OpDesc OPS[N_OPS] = {
     {"v_mad_u64_u32", "DCaaA"}, {"v_mad_i64_i32", "DCaaA"}, {"v_add_co_u32", "dCaa"},   {"v_addc_co_u32", "dCaac"},
     {"v_sub_co_u32", "dCaa"},   {"v_subb_co_u32", "dCaac"}, {"v_cndmask_b32", "daac"},  {"v_add_u32", "daa"},
     {"v_lshlrev_b32", "daa"},   {"v_lshrrev_b32", "daa"},   {"v_lshlrev_b64", "DaA"},   {"v_lshrrev_b64", "DaA"},
-    {"v_alignbit_b32", "daaa"}, {"s_nop", "i"},
+    {"v_alignbit_b32", "daaa"}, {"v_mov_b32", "da"},        {"s_nop", "i"},
 };
 
 enum Kind { K_ARG, K_VGPR, K_SGPR, K_IMM };
@@ -393,6 +393,7 @@ void run(const char *tmpl, std::initializer_list<Arg> outs, std::initializer_lis
                 wr32(o[0], (uint32_t)(cat >> (rd32(o[3], in) & 31)));
                 break;
             }
+            case V_MOV_B32: wr32(o[0], rd32(o[1], in)); break;
             case S_NOP: break;
             default: break;
         }

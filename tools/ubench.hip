@@ -336,6 +336,21 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t 
 #define XP4F(M) M(25,26) M(29,30)
 #define XP4G(M) M(33,34) M(37,38)
 #define XP4H(M) M(41,42) M(45,46)
+// ---- round 6, fourth batch: the S-box multiply's 128-bit assembly without carries?  Today: 4 multiply-adds + v_add_co + 2 v_addc (then 7
+// reduction instructions).  Alternative: chain the partial products through the multiply-add's 64-bit addend -- t = a0*b0;
+// M = a1*b0 + (t.hi, 0); M2 = a0*b1 + (M.lo, 0); Q = a1*b1 + (M.hi, 0); Q += M2.hi * 1 -- 5 multiply-adds + 3 v_mov_b32 (the moves
+// build the (x, 0) pairs and ride the multiply-adds), same 7 reduction instructions.  Mixes only (no data dependence), x3 streams.
+#define MUL_OLD(p, r) MADP(p) MADP(p) MADP(p) MADP(p) \
+    "v_add_co_u32 v" #r ", s[20:21], v" #r ", v48\n\tv_addc_co_u32 v" #r ", s[20:21], v" #r ", v48, s[20:21]\n\tv_addc_co_u32 v" #r ", s[20:21], v" #r ", 0, s[20:21]\n\t" \
+    "v_subb_co_u32 v" #r ", s[20:21], v" #r ", v48, s[20:21]\n\tv_subb_co_u32 v" #r ", s[20:21], v" #r ", 0, s[20:21]\n\t" MADP(p) \
+    "v_cndmask_b32 v" #r ", 0, 1, s[20:21]\n\tv_subb_co_u32 v" #r ", s[20:21], v" #r ", 0, s[20:21]\n\tv_add_u32 v" #r ", v" #r ", v48\n\t" \
+    "v_mad_i64_i32 v[" #p ":" #p "+1], s[22:23], v49, -1, v[" #p ":" #p "+1]\n\t"
+#define MUL_NEW(p, r) MADP(p) "v_mov_b32 v" #r ", v48\n\t" MADP(p) "v_mov_b32 v" #r ", v49\n\t" MADP(p) "v_mov_b32 v" #r ", v50\n\t" MADP(p) MADP(p) \
+    "v_sub_co_u32 v" #r ", s[20:21], v" #r ", v48\n\tv_subb_co_u32 v" #r ", s[20:21], v" #r ", 0, s[20:21]\n\t" MADP(p) \
+    "v_cndmask_b32 v" #r ", 0, 1, s[20:21]\n\tv_subb_co_u32 v" #r ", s[20:21], v" #r ", 0, s[20:21]\n\tv_add_u32 v" #r ", v" #r ", v48\n\t" \
+    "v_mad_i64_i32 v[" #p ":" #p "+1], s[22:23], v49, -1, v[" #p ":" #p "+1]\n\t"
+#define MUL3_OLD MUL_OLD(18, 16) MUL_OLD(22, 20) MUL_OLD(26, 24)
+#define MUL3_NEW MUL_NEW(18, 16) MUL_NEW(22, 20) MUL_NEW(26, 24)
 #define XCLOB "vcc", "s20", "s21", "s22", "s23", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", \
               "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", \
               "v48", "v49", "v50", "v51"
@@ -401,6 +416,8 @@ __global__ void __launch_bounds__(256) kx(uint64_t *out, uint32_t seed, uint64_t
         if (OP == 147) asm volatile(XR(P_ADDF16) ::: XCLOB);
         if (OP == 148) asm volatile(XP(P_SUBCO_CNDM) ::: XCLOB);
         if (OP == 169) asm volatile(XR(P_ADDCHAIN) ::: XCLOB2);
+        if (OP == 170) asm volatile(MUL3_OLD MUL3_OLD ::: XCLOB2);
+        if (OP == 171) asm volatile(MUL3_NEW MUL3_NEW ::: XCLOB2);
         if (OP == 149) asm volatile(XP(P_MADRUN) XP(P_ADDRUN) ::: XCLOB2);
         if (OP == 150) asm volatile(XP(P_MAD_FMA64) ::: XCLOB2);
         if (OP == 151) asm volatile(XP(P_MAD_PKFMA) ::: XCLOB2);
@@ -651,6 +668,8 @@ int main(int argc, char **argv) {
     run<131, true>("x add_u32+add_f32 1:1", 32);
     run<148, true>("x sub_co+cndmask 1:1", 32);
     run<169, true>("x add_u32 dependent chain", 32);
+    run<170, true>("x mul mix: 4 mad + 3 carry (14 instr) x6", 84);
+    run<171, true>("x mul mix: 5 mad + 3 mov (15 instr) x6", 90);
     run<149, true>("x mad64 x16 then add_u32 x16", 32);
     run<150, true>("x mad64+fma_f64 1:1", 32);
     run<151, true>("x mad64+pk_fma_f32 1:1", 32);
