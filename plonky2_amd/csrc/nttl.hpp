@@ -53,6 +53,9 @@ constexpr bool LIMB_PHASE = P2HOT_LIMB_PHASE != 0;
 #define P2HOT_LIMB_MUL3 1
 #endif
 constexpr bool LIMB_DEFER = P2HOT_LIMB_DEFER != 0;  // a borrowed first-round table defers its small factor to a later round's table
+#ifndef P2HOT_LIMB_MULCF
+#define P2HOT_LIMB_MULCF 0  // the carry-free multiply streams (gl::mul3cf) for the passes' general multiplies: measured no faster here (LDE strided
+#endif                      // pass 4.35 - 4.36 against 4.33 - 4.34 ms, +2.7 % instructions: profiles/r06_sbox_carryfree_ab.txt), unlike in the leaf sponge
 #ifndef P2HOT_LIMB_FOLD3
 #define P2HOT_LIMB_FOLD3 0
 #endif
@@ -344,7 +347,10 @@ __device__ __forceinline__ void limb_mul_n(u64 (&v)[N], const u64 (&w)[N]) {
         for (; q + 3 <= N; q += 3) {
             const u64 a3[3] = {v[q], v[q + 1], v[q + 2]}, b3[3] = {w[q], w[q + 1], w[q + 2]};
             u64 r3[3];
-            gl::mul3(a3, b3, r3);
+            if constexpr (P2HOT_LIMB_MULCF != 0)
+                gl::mul3cf(a3, b3, r3);  // carry-free streams (gl_mul3.hpp, round 6): moves ride the multiply-adds, carry adds do not
+            else
+                gl::mul3(a3, b3, r3);
             v[q] = r3[0], v[q + 1] = r3[1], v[q + 2] = r3[2];
         }
         if (N - q == 2) {
