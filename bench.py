@@ -27,7 +27,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 P = 0xFFFFFFFF00000001
-from plonky2_amd.util.chip import HBM_PEAK_GBS, NUM_SIMDS, VALU_NOMINAL_GWAVE_INST_PER_S, box_report  # noqa: E402  (constants cite the guide)
+from plonky2_amd.util.chip import (CO_ISSUED_MOVES_PER_SBOX_PRODUCT, HBM_PEAK_GBS, NUM_SIMDS, POSEIDON_SBOX_PRODUCTS_PER_PERMUTATION,  # noqa: E402
+                                   VALU_NOMINAL_GWAVE_INST_PER_S, box_report)  # (constants cite the guide)
 
 
 from plonky2_amd.util.synthetic import splitmix_columns_numpy, splitmix_columns_torch  # noqa: E402,F401
@@ -566,25 +567,34 @@ def other_configs(eng, torch, reps=3, only=None):
     return out
 
 
-def valu_line(e, launches_per_step, h):
+def valu_line(e, launches_per_step, h, perms=None):
     """Issue-rate view of the dominant kernel, MEASURED IN THIS RUN: achieved = (wave64 VALU instructions one launch retires) /
     (the kernel's average duration in this run's timed region, HIP events on its launch stream).  The instruction count is a
     property of the kernel binary and the shape (SQ_INSTS_VALU of the committed PMC pass, profiles/pmc_traffic.json: it does not
     vary from run to run); the time is this run's.  Priced against two ceilings, neither capped:
       valu_nominal    1024 SIMDs x 2.4 GHz / 4 cycles per single-issue wave64 instruction = 614.4 Gwave-inst/s
-                      (plonky2_amd/util/chip.py; spec clock, so a chip that clocks to its power budget shows below 1)
-      valu_empirical  the kernel's OWN instruction mix issued as dependency-free streams (tools/ubench.hip `mix hash_leaves`:
-                      59 % multiply-adds, 25 % carry adds / subtracts, 6 % selects, 10 % moves and plain adds), as measured on an
-                      MI355X under rocprofv3 --pmc (profiles/ubench.json): 1024 x probe clock / probe cycles per instruction;
-                      `frac_raw` only -- a self-measured ceiling that a kernel can tie or beat by scatter, so it is never clamped
+                      (plonky2_amd/util/chip.py; spec clock, so a chip that clocks to its power budget shows below 1).  Since round 6
+                      the S-box products carry four v_mov_b32 each that CO-ISSUE with the multiply-adds (they take no slot of their
+                      own: profiles/r06_ubench_cheap.txt, r06_sbox_carryfree_ab.txt): this view counts the FULL-PRICE instructions,
+                      SQ_INSTS_VALU minus 4 x 472 moves per permutation (`co_issued_moves_per_launch`)
+      valu_empirical  the kernel's OWN instruction mix issued as dependency-free streams (tools/ubench.hip `mix hash_leaves r06`:
+                      59 % multiply-adds, 14 % carry adds / subtracts, 6 % selects, 15 % moves, 6 % plain adds), as measured on an
+                      MI355X under rocprofv3 --pmc (profiles/ubench.json): 1024 x probe clock / probe cycles per instruction,
+                      against ALL of the kernel's instructions; `frac_raw` only -- a self-measured ceiling that a kernel can tie
+                      or beat by scatter, so it is never clamped
     The committed PMC pass's own cycles per instruction (true shader cycles, clock-free) stay under `pmc_pass`."""
     if not e or not e.get("sq_insts_valu_per_launch") or not h.get("ms_per_launch") or h["ms_per_launch"] != h["ms_per_launch"]:
         return None
-    n = e["sq_insts_valu_per_launch"] / launches_per_step
+    n_all = e["sq_insts_valu_per_launch"] / launches_per_step
+    # the S-box products' v_mov_b32 co-issue with the multiply-adds (plonky2_amd/util/chip.py): the 4-cycle-slot ceiling prices the rest
+    n_mov = (perms / 64.0) * POSEIDON_SBOX_PRODUCTS_PER_PERMUTATION * CO_ISSUED_MOVES_PER_SBOX_PRODUCT if perms else 0.0
+    n = n_all - n_mov
     live = n / (h["ms_per_launch"] * 1e-3) / 1e9
-    out = {"kernel": "hash_leaves", "bound": "valu-issue", "wave_insts_per_launch": n, "live_ms_per_launch": h["ms_per_launch"],
-           "achieved_Gwave_inst_per_s": live,
+    out = {"kernel": "hash_leaves", "bound": "valu-issue", "wave_insts_per_launch": n_all, "co_issued_moves_per_launch": n_mov,
+           "full_price_wave_insts_per_launch": n, "live_ms_per_launch": h["ms_per_launch"],
+           "achieved_Gwave_inst_per_s": live, "all_insts_Gwave_inst_per_s": n_all / (h["ms_per_launch"] * 1e-3) / 1e9,
            "valu_nominal": {"peak": VALU_NOMINAL_GWAVE_INST_PER_S, "unit": "Gwave-inst/s", "frac": live / VALU_NOMINAL_GWAVE_INST_PER_S,
+                            "counts": "full-price instructions: SQ_INSTS_VALU minus the S-box products' co-issued v_mov_b32 (4 x 472 per permutation)",
                             "peak_source": "plonky2_amd/util/chip.py: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"},
            "source": "instruction count: profiles/pmc_traffic.json (SQ_INSTS_VALU per launch, committed PMC pass); time: this run's HIP events"}
     if e.get("clock_ghz") and e.get("ms_per_launch_under_pmc"):
@@ -597,13 +607,16 @@ def valu_line(e, launches_per_step, h):
     ub = ubench_json()
     if ub:
         occ = ub.get("occupancy", {})
-        probes = {w + ("" if nm == "mix hash_leaves" else " x4"): o["probes"].get(nm, {}) for w, o in occ.items() for nm in ("mix hash_leaves", "mix hash_leaves x4")}
+        r06 = any("mix hash_leaves r06" in o.get("probes", {}) for o in occ.values())  # the mix with the S-box products' moves, if it was probed
+        names = ("mix hash_leaves r06", "mix hash_leaves r06 x4") if r06 else ("mix hash_leaves", "mix hash_leaves x4")
+        probes = {w + ("" if not nm.endswith("x4") else " x4"): o["probes"].get(nm, {}) for w, o in occ.items() for nm in names}
         rated = [(NUM_SIMDS * p_["clock_ghz"] / p_["cyc_per_inst"], w) for w, p_ in probes.items() if p_.get("cyc_per_inst") and p_.get("clock_ghz")]
         if rated:
             peak, w = max(rated)
-            out["valu_empirical"] = {"peak": peak, "unit": "Gwave-inst/s", "frac_raw": live / peak,
-                                     "probe": "tools/ubench.hip `mix hash_leaves` (%s: waves per SIMD, x4 = 128 instructions per loop trip): %.3f cycles per "
-                                              "instruction at %.2f GHz" % (w[1:], probes[w]["cyc_per_inst"], probes[w]["clock_ghz"]),
+            live_all = out["all_insts_Gwave_inst_per_s"] if r06 else live  # the r06 mix contains the moves: it is compared with ALL instructions
+            out["valu_empirical"] = {"peak": peak, "unit": "Gwave-inst/s", "frac_raw": live_all / peak,
+                                     "probe": "tools/ubench.hip `%s` (%s: waves per SIMD, x4 = 128 instructions per loop trip): %.3f cycles per "
+                                              "instruction at %.2f GHz" % (names[0], w[1:], probes[w]["cyc_per_inst"], probes[w]["clock_ghz"]),
                                      "cycles_per_inst_by_occupancy": {w_: round(p_["cyc_per_inst"], 3) for w_, p_ in probes.items() if p_.get("cyc_per_inst")},
                                      "peak_source": "profiles/ubench.json (tools/ubench_pmc.sh: every probe under rocprofv3 --pmc, true cycles)"}
         out["classes_cycles_per_inst"] = {w: {c: round(v["cyc_per_inst_median"], 2) for c, v in o.get("classes", {}).items()} for w, o in occ.items()}
@@ -1023,7 +1036,7 @@ def main():
         hash_bytes = 8 * W * rows_per_launch + 32 * rows_per_launch
         achieved = hash_bytes / (h["ms_per_launch"] * 1e-3) / 1e9
         perms = rows_per_launch * ((W + 7) // 8)
-        vl = valu_line(pmc_entry(W, log_n, rb, cap, world, "hash_leaves_kernel", "ColMajorReader"), launches_per_step, h)
+        vl = valu_line(pmc_entry(W, log_n, rb, cap, world, "hash_leaves_kernel", "ColMajorReader"), launches_per_step, h, perms)
         out = {
             "metric": "LDE+Poseidon-commit GFE/s", "value": fe / (dt / args.steps) / 1e9, "unit": "GFE/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
