@@ -601,9 +601,12 @@ def valu_line(e, launches_per_step, h, perms=None):
         clock = e["clock_ghz"]
         cyc = e["ms_per_launch_under_pmc"] * 1e-3 * clock * 1e9 * NUM_SIMDS / e["sq_insts_valu_per_launch"]
         out["pmc_pass"] = {"clock_ghz": clock, "ms_per_launch": e["ms_per_launch_under_pmc"], "cycles_per_inst": cyc,
+                           # 4 cycles x ALL instructions / the pass's cycles: above 1 since the moves share slots; the share of the
+                           # 4-cycle slots that full-price instructions take is the line below it
                            "valu_busy_frac": e.get("valu_busy_frac"),
+                           "full_price_slot_frac": 4.0 * (n / n_all) / cyc,
                            # the clock this run's kernel time implies if it retired its instructions at the PMC pass's cycles each
-                           "implied_live_clock_ghz": live * cyc / NUM_SIMDS}
+                           "implied_live_clock_ghz": out["all_insts_Gwave_inst_per_s"] * cyc / NUM_SIMDS}
     ub = ubench_json()
     if ub:
         occ = ub.get("occupancy", {})
