@@ -574,11 +574,11 @@ def valu_line(e, launches_per_step, h, perms=None):
     vary from run to run); the time is this run's.  Priced against two ceilings, neither capped:
       valu_nominal    1024 SIMDs x 2.4 GHz / 4 cycles per single-issue wave64 instruction = 614.4 Gwave-inst/s
                       (plonky2_amd/util/chip.py; spec clock, so a chip that clocks to its power budget shows below 1).  Since round 6
-                      the S-box products carry four v_mov_b32 each that CO-ISSUE with the multiply-adds (they take no slot of their
+                      the S-box products carry three v_mov_b32 each that CO-ISSUE with the multiply-adds (they take no slot of their
                       own: profiles/r06_ubench_cheap.txt, r06_sbox_carryfree_ab.txt): this view counts the FULL-PRICE instructions,
-                      SQ_INSTS_VALU minus 4 x 472 moves per permutation (`co_issued_moves_per_launch`)
-      valu_empirical  the kernel's OWN instruction mix issued as dependency-free streams (tools/ubench.hip `mix hash_leaves r06`:
-                      59 % multiply-adds, 14 % carry adds / subtracts, 6 % selects, 15 % moves, 6 % plain adds), as measured on an
+                      SQ_INSTS_VALU minus 3 x 472 moves per permutation (`co_issued_moves_per_launch`)
+      valu_empirical  the kernel's OWN instruction mix issued as dependency-free streams (tools/ubench.hip `mix hash_leaves r06b`:
+                      60 % multiply-adds, 15 % carry adds / subtracts, 6 % selects, 12 % moves, 6 % plain adds), as measured on an
                       MI355X under rocprofv3 --pmc (profiles/ubench.json): 1024 x probe clock / probe cycles per instruction,
                       against ALL of the kernel's instructions; `frac_raw` only -- a self-measured ceiling that a kernel can tie
                       or beat by scatter, so it is never clamped
@@ -594,7 +594,7 @@ def valu_line(e, launches_per_step, h, perms=None):
            "full_price_wave_insts_per_launch": n, "live_ms_per_launch": h["ms_per_launch"],
            "achieved_Gwave_inst_per_s": live, "all_insts_Gwave_inst_per_s": n_all / (h["ms_per_launch"] * 1e-3) / 1e9,
            "valu_nominal": {"peak": VALU_NOMINAL_GWAVE_INST_PER_S, "unit": "Gwave-inst/s", "frac": live / VALU_NOMINAL_GWAVE_INST_PER_S,
-                            "counts": "full-price instructions: SQ_INSTS_VALU minus the S-box products' co-issued v_mov_b32 (4 x 472 per permutation)",
+                            "counts": "full-price instructions: SQ_INSTS_VALU minus the S-box products' co-issued v_mov_b32 (3 x 472 per permutation)",
                             "peak_source": "plonky2_amd/util/chip.py: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"},
            "source": "instruction count: profiles/pmc_traffic.json (SQ_INSTS_VALU per launch, committed PMC pass); time: this run's HIP events"}
     if e.get("clock_ghz") and e.get("ms_per_launch_under_pmc"):
@@ -610,8 +610,9 @@ def valu_line(e, launches_per_step, h, perms=None):
     ub = ubench_json()
     if ub:
         occ = ub.get("occupancy", {})
-        r06 = any("mix hash_leaves r06" in o.get("probes", {}) for o in occ.values())  # the mix with the S-box products' moves, if it was probed
-        names = ("mix hash_leaves r06", "mix hash_leaves r06 x4") if r06 else ("mix hash_leaves", "mix hash_leaves x4")
+        # the mix with the S-box products' moves, if it was probed (r06b: the 14-instruction products that ship; r06: the 16-instruction ones)
+        r06 = next((nm for nm in ("mix hash_leaves r06b", "mix hash_leaves r06") if any(nm in o.get("probes", {}) for o in occ.values())), None)
+        names = (r06, r06 + " x4") if r06 else ("mix hash_leaves", "mix hash_leaves x4")
         probes = {w + ("" if not nm.endswith("x4") else " x4"): o["probes"].get(nm, {}) for w, o in occ.items() for nm in names}
         rated = [(NUM_SIMDS * p_["clock_ghz"] / p_["cyc_per_inst"], w) for w, p_ in probes.items() if p_.get("cyc_per_inst") and p_.get("clock_ghz")]
         if rated:

@@ -243,6 +243,106 @@ __device__ __forceinline__ u64 mul1cf(u64 a, u64 b) {
     return ra;
 }
 
+// ---- mul3cg / mul1cg: the 14-instruction form of the carry-free assembly (round 6, second step; what the Poseidon S-boxes run) -------
+// Only the two chained addends that SAVE carry adds are kept; the one carry the 128-bit assembly really has stays a carry, because it is
+// free on both ends -- the multiply-add writes it (VOP3B sdst) and the reduction's first subtract takes it as its borrow-in:
+//    T.hi = 0
+//    P  = a0*b0                      T.lo = P.hi
+//    M  = a1*b0 + T   (< 2^64)
+//    N  = a0*b1 + M   (carry cm, weight 2^96 = -1 mod P)          N.lo is limb 1 of the product, P.lo limb 0
+//                                    T.lo = N.hi
+//    T  = a1*b1 + T   (< 2^64)       T = the high 64 bits without cm: exactly the (lo, hi, cm) of mul3's steps 1-7, so the reduction
+//                                    (steps 8-14, cm as the borrow-in of the first subtract) and its bounds are mul3's.
+// 4 multiply-adds + 3 moves + the 7-instruction reduction: 14 instructions like mul3, of which 11 pay a full issue slot (mul3: 14,
+// mul3cf: 12 of 16).
+#define P2_CG0(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mov_b32 " T1 ", 0\n\t"
+#define P2_CG1(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_u64_u32 " P ", " C1 ", %[" a0 "], %[" b0 "], 0\n\t"
+#define P2_CG2(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mov_b32 " T0 ", " P1 "\n\t"
+#define P2_CG3(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_u64_u32 " M ", " C1 ", %[" a1 "], %[" b0 "], " T "\n\t"
+#define P2_CG4(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_u64_u32 " N ", " C2 ", %[" a0 "], %[" b1 "], " M "\n\t"
+#define P2_CG5(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mov_b32 " T0 ", " N1 "\n\t"
+#define P2_CG6(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_u64_u32 " T ", " C1 ", %[" a1 "], %[" b1 "], " T "\n\t"
+#define P2_CG7(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_subb_co_u32 " M0 ", " C1 ", " P0 ", " T1 ", " C2 "\n\t"
+#define P2_CG8 P2_CF10
+#define P2_CG9 P2_CF11
+#define P2_CG10 P2_CF12
+#define P2_CG11 P2_CF13
+#define P2_CG12 P2_CF14
+#define P2_CG13 P2_CF15
+
+// r[k] = a[k] * b[k] (mod P), k = 0..2: three streams round-robin (every SGPR producer / consumer pair at least three instructions
+// apart: no s_nop)
+__device__ __forceinline__ void mul3cg(const u64 a[3], const u64 b[3], u64 r[3]) {
+    if (!P2_ASM_INTERPRETED()) {
+        for (int k = 0; k < 3; ++k) r[k] = mul(a[k], b[k]);
+        return;
+    }
+    u64 ra, rb, rc;
+    P2_ASM(P2_CROW(P2_CG0) P2_CROW(P2_CG1) P2_CROW(P2_CG2) P2_CROW(P2_CG3) P2_CROW(P2_CG4) P2_CROW(P2_CG5) P2_CROW(P2_CG6) P2_CROW(P2_CG7)
+               P2_CROW(P2_CG8) P2_CROW(P2_CG9) P2_CROW(P2_CG10) P2_CROW(P2_CG11) P2_CROW(P2_CG12) P2_CROW(P2_CG13),
+           (P2_O([ra0], "=&v", ra), P2_O([rb0], "=&v", rb), P2_O([rc0], "=&v", rc)),
+           (P2_I([xa0], "v", (u32)a[0]), P2_I([xa1], "v", (u32)(a[0] >> 32)), P2_I([ya0], "v", (u32)b[0]),
+            P2_I([ya1], "v", (u32)(b[0] >> 32)), P2_I([xb0], "v", (u32)a[1]), P2_I([xb1], "v", (u32)(a[1] >> 32)),
+            P2_I([yb0], "v", (u32)b[1]), P2_I([yb1], "v", (u32)(b[1] >> 32)), P2_I([xc0], "v", (u32)a[2]),
+            P2_I([xc1], "v", (u32)(a[2] >> 32)), P2_I([yc0], "v", (u32)b[2]), P2_I([yc1], "v", (u32)(b[2] >> 32))),
+           (P2_CF_CLOBBERS3));
+    r[0] = ra;
+    r[1] = rb;
+    r[2] = rc;
+}
+
+// mul3ch: mul3cg with ONE (x, 0) pair shared by the three streams (P2HOT_SBOX_CF=3) -- each move sits directly in front of the
+// multiply-add that reads the pair, the high multiply-add writes the (dead) M pair instead of T, so T.hi is zeroed once per block
+// instead of once per stream: 40 instructions per three products instead of 42, two VGPR pairs fewer.
+#define P2_HT "v[76:77]", "v76", "v77"
+#define P2_HA "v[70:71]", "v70", "v71", "v[72:73]", "v72", "v73", "v[74:75]", "v74", "v75", P2_HT, "s[40:41]", "s[42:43]"
+#define P2_HB "v[78:79]", "v78", "v79", "v[80:81]", "v80", "v81", "v[82:83]", "v82", "v83", P2_HT, "s[44:45]", "s[46:47]"
+#define P2_HC "v[86:87]", "v86", "v87", "v[88:89]", "v88", "v89", "v[90:91]", "v90", "v91", P2_HT, "s[48:49]", "s[50:51]"
+#define P2_CH23(...) P2_CG2(__VA_ARGS__) P2_CG3(__VA_ARGS__)
+#define P2_CH6(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_u64_u32 " M ", " C1 ", %[" a1 "], %[" b1 "], " T "\n\t"
+#define P2_CH56(...) P2_CG5(__VA_ARGS__) P2_CH6(__VA_ARGS__)
+#define P2_CH7(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_subb_co_u32 " P0 ", " C1 ", " P0 ", " M1 ", " C2 "\n\t"
+#define P2_CH8(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_subb_co_u32 " P1 ", " C1 ", " N0 ", 0, " C1 "\n\t"
+#define P2_CH9(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_u64_u32 " P ", " C2 ", " M0 ", -1, " P "\n\t"
+#define P2_CH12(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_add_u32 " P1 ", " P1 ", " N0 "\n\t"
+#define P2_CH13(P, P0, P1, M, M0, M1, N, N0, N1, T, T0, T1, C1, C2, a0, a1, b0, b1, r0) "v_mad_i64_i32 %[" r0 "], " C1 ", " N0 ", -1, " P "\n\t"
+#define P2_HROW(ST)                                          \
+    P2_APPLY(ST, P2_HA, "xa0", "xa1", "ya0", "ya1", "ra0")   \
+    P2_APPLY(ST, P2_HB, "xb0", "xb1", "yb0", "yb1", "rb0")   \
+    P2_APPLY(ST, P2_HC, "xc0", "xc1", "yc0", "yc1", "rc0")
+__device__ __forceinline__ void mul3ch(const u64 a[3], const u64 b[3], u64 r[3]) {
+    if (!P2_ASM_INTERPRETED()) {
+        for (int k = 0; k < 3; ++k) r[k] = mul(a[k], b[k]);
+        return;
+    }
+    u64 ra, rb, rc;
+    P2_ASM("v_mov_b32 v77, 0\n\t" P2_HROW(P2_CG1) P2_HROW(P2_CH23) P2_HROW(P2_CG4) P2_HROW(P2_CH56) P2_HROW(P2_CH7) P2_HROW(P2_CH8)
+               P2_HROW(P2_CH9) P2_HROW(P2_CG10) P2_HROW(P2_CG11) P2_HROW(P2_CH12) P2_HROW(P2_CH13),
+           (P2_O([ra0], "=&v", ra), P2_O([rb0], "=&v", rb), P2_O([rc0], "=&v", rc)),
+           (P2_I([xa0], "v", (u32)a[0]), P2_I([xa1], "v", (u32)(a[0] >> 32)), P2_I([ya0], "v", (u32)b[0]),
+            P2_I([ya1], "v", (u32)(b[0] >> 32)), P2_I([xb0], "v", (u32)a[1]), P2_I([xb1], "v", (u32)(a[1] >> 32)),
+            P2_I([yb0], "v", (u32)b[1]), P2_I([yb1], "v", (u32)(b[1] >> 32)), P2_I([xc0], "v", (u32)a[2]),
+            P2_I([xc1], "v", (u32)(a[2] >> 32)), P2_I([yc0], "v", (u32)b[2]), P2_I([yc1], "v", (u32)(b[2] >> 32))),
+           ("v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v86", "v87", "v88", "v89",
+            "v90", "v91", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51"));
+    r[0] = ra;
+    r[1] = rb;
+    r[2] = rc;
+}
+
+// one stream (the partial rounds' dependent S-box chains): cm has its two wait states from the move and the multiply-add between its
+// producer and its consumer; the two adjacent SGPR producer / consumer rows (7 -> 8, 9 -> 10) get theirs as `s_nop 1`
+__device__ __forceinline__ u64 mul1cg(u64 a, u64 b) {
+    if (!P2_ASM_INTERPRETED()) return mul(a, b);
+    u64 ra;
+    P2_ASM(P2_CA1(P2_CG0) P2_CA1(P2_CG1) P2_CA1(P2_CG2) P2_CA1(P2_CG3) P2_CA1(P2_CG4) P2_CA1(P2_CG5) P2_CA1(P2_CG6) P2_CA1(P2_CG7) P2_NOP
+               P2_CA1(P2_CG8) P2_CA1(P2_CG9) P2_NOP P2_CA1(P2_CG10) P2_CA1(P2_CG11) P2_CA1(P2_CG12) P2_CA1(P2_CG13),
+           (P2_O([ra0], "=&v", ra)),
+           (P2_I([xa0], "v", (u32)a), P2_I([xa1], "v", (u32)(a >> 32)), P2_I([ya0], "v", (u32)b), P2_I([ya1], "v", (u32)(b >> 32))),
+           ("v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "s40", "s41", "s42", "s43"));
+    return ra;
+}
+
 // ---- fold3: three MDS-row recombinations in one interleaved stream ------------------------------
 // A row's two accumulators al = sum c*x.lo32, ah = sum c*x.hi32 (each < 2^63) stand for
 //   y = al + ah*2^32 = al + ah.lo * 2^32 + ah.hi * 2^64 = al + ah.hi * (2^32 - 1) + ah.lo * 2^32   (mod P):

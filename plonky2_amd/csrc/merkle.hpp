@@ -271,7 +271,7 @@ __global__ void field_selftest_kernel(const u64 *a, const u64 *b, size_t count, 
     u64 ok = (gl::canon(rr[1]) == gl::canon(rr[0])) && (gl::canon(rr[2]) == gl::canon(gl::mul(x, x))) ? 0 : 1;
     // the other hand-written streams against the compiler's arithmetic, one flag bit each:
     // 2 = the low-register single stream, 4 = the power-of-two twiddle multiplies of the radix-8 butterflies (ntt.hpp),
-    // 8 / 16 = the MDS row recombinations fold1 / fold3 on accumulators below 2^63, 32 / 64 = the two-stream mul2 / fold2, 128 = gl::mul_add, 256 = gl::mad3, 512 = gl::mul3cf / mul1cf
+    // 8 / 16 = the MDS row recombinations fold1 / fold3 on accumulators below 2^63, 32 / 64 = the two-stream mul2 / fold2, 128 = gl::mul_add, 256 = gl::mad3, 512 = gl::mul3cf / mul1cf / mul3cg / mul1cg
     if (gl::canon(gl::mul1_lowregs(x, y)) != gl::canon(gl::mul(x, y))) ok |= 2;
 #define P2_CHK_POW2(S)                                                                                              \
     if (gl::canon(ntt::mul_pow2_asm<S>(x)) != gl::canon(gl::mul(x, (S) < 64 ? 1ull << ((S) & 63) : 0xFFFFFFFFull << (((S) - 64) & 31)))) \
@@ -311,13 +311,20 @@ __global__ void field_selftest_kernel(const u64 *a, const u64 *b, size_t count, 
         for (int k = 0; k < 3; ++k)
             if (gl::canon(r3[k]) != gl::canon(gl::add(gl::mul(a3[k], b3[k]), c3[k]))) ok |= 256;
     }
-    {  // 512 = the carry-free multiply streams of the Poseidon S-boxes (gl::mul3cf / mul1cf: partial products chained through the addend)
+    {  // 512 = the carry-free multiply streams of the Poseidon S-boxes (gl::mul3cf / mul1cf and mul3cg / mul1cg: partial products chained through the addend)
         const u64 a3[3] = {x, y, x ^ 0x9E3779B97F4A7C15ull}, b3[3] = {y, y, x};
         u64 r3[3];
         gl::mul3cf(a3, b3, r3);
         for (int k = 0; k < 3; ++k)
             if (gl::canon(r3[k]) != gl::canon(gl::mul(a3[k], b3[k]))) ok |= 512;
         if (gl::canon(gl::mul1cf(x, y)) != gl::canon(gl::mul(x, y)) || gl::canon(gl::mul1cf(y, y)) != gl::canon(gl::mul(y, y))) ok |= 512;
+        gl::mul3cg(a3, b3, r3);
+        for (int k = 0; k < 3; ++k)
+            if (gl::canon(r3[k]) != gl::canon(gl::mul(a3[k], b3[k]))) ok |= 512;
+        gl::mul3ch(a3, b3, r3);
+        for (int k = 0; k < 3; ++k)
+            if (gl::canon(r3[k]) != gl::canon(gl::mul(a3[k], b3[k]))) ok |= 512;
+        if (gl::canon(gl::mul1cg(x, y)) != gl::canon(gl::mul(x, y)) || gl::canon(gl::mul1cg(y, y)) != gl::canon(gl::mul(y, y))) ok |= 512;
     }
     out[2 * count + t] = gl::canon(rr[0]);
     out[5 * count + t] = ok;

@@ -44,14 +44,22 @@ __device__ __forceinline__ u64 sbox7(u64 x) {  // poseidon.rs:690-696
     return gl::mul(x3, x4);
 }
 
-// P2HOT_SBOX_CF (default 1): the S-box products through the carry-free multiply streams (gl::mul3cf / mul1cf: the partial products
-// chained through the multiply-add's addend, v_mov instead of carry adds -- round 6); 0: the round-3 streams (gl::mul3 / mul1)
+// P2HOT_SBOX_CF (default 2): the S-box products through the carry-free multiply streams of round 6 -- 2: gl::mul3cg / mul1cg (two
+// partial products chained through the multiply-add's addend, the one real carry left to the multiply-add's own carry-out: 14
+// instructions, 3 of them co-issued moves); 1: gl::mul3cf / mul1cf (all three chained: 16 instructions, 4 moves); 0: the round-3
+// streams (gl::mul3 / mul1: 14 instructions, 3 carry adds)
 #ifndef P2HOT_SBOX_CF
-#define P2HOT_SBOX_CF 1
+#define P2HOT_SBOX_CF 2
 #endif
-__device__ __forceinline__ u64 sbox_mul1(u64 a, u64 b) { return P2HOT_SBOX_CF ? gl::mul1cf(a, b) : gl::mul1(a, b); }
+__device__ __forceinline__ u64 sbox_mul1(u64 a, u64 b) {
+    return P2HOT_SBOX_CF >= 2 ? gl::mul1cg(a, b) : P2HOT_SBOX_CF ? gl::mul1cf(a, b) : gl::mul1(a, b);
+}
 __device__ __forceinline__ void sbox_mul3(const u64 a[3], const u64 b[3], u64 r[3]) {
-    if (P2HOT_SBOX_CF)
+    if (P2HOT_SBOX_CF == 3)
+        gl::mul3ch(a, b, r);
+    else if (P2HOT_SBOX_CF == 2)
+        gl::mul3cg(a, b, r);
+    else if (P2HOT_SBOX_CF)
         gl::mul3cf(a, b, r);
     else
         gl::mul3(a, b, r);

@@ -20,13 +20,14 @@ CYCLES_PER_VALU_INST_WAVE64 = 4.0
 VALU_NOMINAL_GWAVE_INST_PER_S = NUM_SIMDS * PEAK_CLOCK_GHZ / CYCLES_PER_VALU_INST_WAVE64   # 614.4
 
 
-# Since round 6 the Poseidon S-box products assemble their 128 bits without carry adds (csrc/gl_mul3.hpp mul3cf / mul1cf): four
-# v_mov_b32 per product that CO-ISSUE with the multiply-adds (profiles/r06_ubench_cheap.txt: a v_mov next to v_mad_u64_u32 costs 1.5 cycles,
-# not a slot of its own; in the kernel 99 % of the 4-cycle slots are taken by the other instructions, profiles/r06_sbox_carryfree_ab.txt).
-# The 4-cycle-slot ceiling above therefore prices the FULL-PRICE instructions: all VALU instructions minus these moves, whose number is
-# a property of the algorithm -- 8 full rounds x 12 + 22 partial rounds = 118 S-boxes x 4 products (x^2, x^3, x^4, x^7).
+# Since round 6 the Poseidon S-box products assemble their 128 bits through the multiply-add's 64-bit addend (csrc/gl_mul3.hpp mul3cg /
+# mul1cg): three v_mov_b32 per product that CO-ISSUE with the multiply-adds (profiles/r06_ubench_cheap.txt: a v_mov next to v_mad_u64_u32
+# costs 1.5 cycles or less, not a slot of its own; in the kernel 99 % of the 4-cycle slots are taken by the other instructions,
+# profiles/r06_sbox_carryfree_ab.txt, r06_sbox_hybrid_ab.txt).  The 4-cycle-slot ceiling above therefore prices the FULL-PRICE
+# instructions: all VALU instructions minus these moves, whose number is a property of the algorithm -- 8 full rounds x 12 + 22 partial
+# rounds = 118 S-boxes x 4 products (x^2, x^3, x^4, x^7).
 POSEIDON_SBOX_PRODUCTS_PER_PERMUTATION = (8 * 12 + 22) * 4   # 472
-CO_ISSUED_MOVES_PER_SBOX_PRODUCT = 4
+CO_ISSUED_MOVES_PER_SBOX_PRODUCT = 3
 
 
 def box_report(torch, device_index=0):

@@ -158,6 +158,42 @@
     "v_mad_u64_u32 %8, s[22:23], %17, %16, %8\n\t" \
     "v_mad_u64_u32 %9, s[22:23], %16, %16, %9\n\t" \
     "v_mad_u64_u32 %10, s[22:23], %16, %17, %10"
+// the leaf sponge's mix with the 14-instruction S-box products (gl::mul3cg: one chained addend less, the real carry left to the
+// multiply-add's carry-out): 32 slots = 19 multiply-adds (one signed), 5 carry instructions, 2 selects, 4 v_mov_b32, 2 plain adds -- per
+// permutation 60 % / 15 % / 6 % / 12 % / 6 % of 12.99 k instructions
+#define MIX_HASH6B \
+    "v_mad_u64_u32 %8, s[22:23], %16, %17, %8\n\t" \
+    "v_mov_b32 %0, %16\n\t" \
+    "v_mad_u64_u32 %9, s[22:23], %17, %16, %9\n\t" \
+    "v_sub_co_u32 %1, vcc, %1, %16\n\t" \
+    "v_mad_u64_u32 %10, s[22:23], %16, %16, %10\n\t" \
+    "v_mov_b32 %2, %17\n\t" \
+    "v_subb_co_u32 %3, vcc, %3, %17, vcc\n\t" \
+    "v_mad_u64_u32 %11, s[22:23], %16, %17, %11\n\t" \
+    "v_mad_u64_u32 %12, s[22:23], %17, %16, %12\n\t" \
+    "v_cndmask_b32 %4, %4, %17, vcc\n\t" \
+    "v_mad_u64_u32 %13, s[22:23], %16, %16, %13\n\t" \
+    "v_mov_b32 %5, %16\n\t" \
+    "v_mad_u64_u32 %14, s[22:23], %16, %17, %14\n\t" \
+    "v_mad_u64_u32 %15, s[22:23], %17, %16, %15\n\t" \
+    "v_add_co_u32 %6, vcc, %6, %16\n\t" \
+    "v_mad_u64_u32 %8, s[22:23], %16, %16, %8\n\t" \
+    "v_mov_b32 %7, %17\n\t" \
+    "v_subb_co_u32 %0, vcc, %0, %17, vcc\n\t" \
+    "v_mad_u64_u32 %9, s[22:23], %16, %17, %9\n\t" \
+    "v_mad_u64_u32 %10, s[22:23], %17, %16, %10\n\t" \
+    "v_cndmask_b32 %1, %1, %17, vcc\n\t" \
+    "v_mad_i64_i32 %11, s[22:23], %16, %16, %11\n\t" \
+    "v_mad_u64_u32 %12, s[22:23], %16, %17, %12\n\t" \
+    "v_add_u32 %2, %2, %16\n\t" \
+    "v_mad_u64_u32 %13, s[22:23], %17, %16, %13\n\t" \
+    "v_subb_co_u32 %3, vcc, %3, %16, vcc\n\t" \
+    "v_mad_u64_u32 %14, s[22:23], %16, %16, %14\n\t" \
+    "v_mad_u64_u32 %15, s[22:23], %16, %17, %15\n\t" \
+    "v_add_u32 %4, %4, %17\n\t" \
+    "v_mad_u64_u32 %8, s[22:23], %17, %16, %8\n\t" \
+    "v_mad_u64_u32 %9, s[22:23], %16, %16, %9\n\t" \
+    "v_mad_u64_u32 %10, s[22:23], %16, %17, %10"
 // the limb NTT passes' mix (16 slots: 5 multiply-adds, 7 plain 32-bit add / sub / and, 2 carry adds, 1 v_alignbit, 1 v_lshl_add_u64)
 #define MIX_NTT                                                                                                   \
     "v_mad_u64_u32 %8, vcc, %16, %17, %8\n\tv_add_u32 %0, %0, %16\n\tv_sub_u32 %1, %1, %16\n\tv_mad_u64_u32 %9, vcc, %16, %17, %9\n\t" \
@@ -261,6 +297,8 @@ __global__ void __launch_bounds__(256) k(uint64_t *out, uint32_t seed, uint64_t 
         if (OP == 50) asm volatile(MIX_HASH "\n\t" MIX_HASH "\n\t" MIX_HASH "\n\t" MIX_HASH OPS);
         if (OP == 54) asm volatile(MIX_HASH6 OPS);
         if (OP == 55) asm volatile(MIX_HASH6 "\n\t" MIX_HASH6 "\n\t" MIX_HASH6 "\n\t" MIX_HASH6 OPS);  // 128 slots per loop trip: the loop's own SALU is < 3 %
+        if (OP == 56) asm volatile(MIX_HASH6B OPS);
+        if (OP == 57) asm volatile(MIX_HASH6B "\n\t" MIX_HASH6B "\n\t" MIX_HASH6B "\n\t" MIX_HASH6B OPS);
         if (OP == 51) asm volatile(MFMA8 OPS_M);
         if (OP == 52) asm volatile(MIX_MDS_VALU OPS_M);
         if (OP == 53) asm volatile(MIX_MDS_MFMA OPS_M);
@@ -653,6 +691,8 @@ int main(int argc, char **argv) {
     run<50>("mix hash_leaves x4", 128);
     run<54>("mix hash_leaves r06", 32);
     run<55>("mix hash_leaves r06 x4", 128);
+    run<56>("mix hash_leaves r06b", 32);
+    run<57>("mix hash_leaves r06b x4", 128);
     run<51>("v_mfma_i32_4x4x4_16b_i8", 9);   // 8 MFMAs + 1 v_mov per trip
     run<52>("mix mds valu (half layer)", 173);
     run<53>("mix mds mfma (half layer)", 169);
