@@ -54,8 +54,9 @@ constexpr bool LIMB_PHASE = P2HOT_LIMB_PHASE != 0;
 #endif
 constexpr bool LIMB_DEFER = P2HOT_LIMB_DEFER != 0;  // a borrowed first-round table defers its small factor to a later round's table
 #ifndef P2HOT_LIMB_MULCF
-#define P2HOT_LIMB_MULCF 0  // the carry-free multiply streams (gl::mul3cf) for the passes' general multiplies: measured no faster here (LDE strided
-#endif                      // pass 4.35 - 4.36 against 4.33 - 4.34 ms, +2.7 % instructions: profiles/r06_sbox_carryfree_ab.txt), unlike in the leaf sponge
+#define P2HOT_LIMB_MULCF 2  // the passes' general multiplies (coset scale, inter-pass twiddle): 2 = gl::mul3cg / mul1cg, the 14-instruction stream with 3
+#endif                      // co-issued moves the Poseidon S-boxes run (same count as gl::mul3; LDE strided pass -2.8 % cycles under PMC, 4.31 - 4.34
+                            // against 4.35 ms: profiles/r06_sbox_hybrid_ab.txt); 1 = gl::mul3cf (16 instructions: measured no faster here); 0 = gl::mul3
 #ifndef P2HOT_LIMB_FOLD3
 #define P2HOT_LIMB_FOLD3 0
 #endif
@@ -336,7 +337,7 @@ constexpr size_t limb_shmem_bytes(int log_r, int dual = 1) {
     return (size_t)8 * TILE_WORDS * dual + (size_t)16 * limb_tables_w2(log_r) + (uses_ufac(log_r) ? 8 * UFAC_WORDS : 0);
 }
 
-__device__ __forceinline__ u64 limb_mul(u64 a, u64 b) { return gl::mul1(a, b); }
+__device__ __forceinline__ u64 limb_mul(u64 a, u64 b) { return P2HOT_LIMB_MULCF == 2 ? gl::mul1cg(a, b) : gl::mul1(a, b); }
 // v[q] *= w[q] for N independent pairs: three-stream gl::mul3 blocks (no wait states, three chains in flight) where the
 // build asks for them, single streams otherwise
 template <int N>
@@ -347,7 +348,9 @@ __device__ __forceinline__ void limb_mul_n(u64 (&v)[N], const u64 (&w)[N]) {
         for (; q + 3 <= N; q += 3) {
             const u64 a3[3] = {v[q], v[q + 1], v[q + 2]}, b3[3] = {w[q], w[q + 1], w[q + 2]};
             u64 r3[3];
-            if constexpr (P2HOT_LIMB_MULCF != 0)
+            if constexpr (P2HOT_LIMB_MULCF == 2)
+                gl::mul3cg(a3, b3, r3);  // the 14-instruction form with 3 co-issued moves (what the Poseidon S-boxes run)
+            else if constexpr (P2HOT_LIMB_MULCF != 0)
                 gl::mul3cf(a3, b3, r3);  // carry-free streams (gl_mul3.hpp, round 6): moves ride the multiply-adds, carry adds do not
             else
                 gl::mul3(a3, b3, r3);
