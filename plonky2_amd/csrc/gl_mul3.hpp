@@ -14,6 +14,9 @@
 //          see the bounds in gl::reduce128): e by a v_cndmask and a v_subb, then u + (e << 32) - e as a 32-bit add on
 //          the high word and one SIGNED multiply-add (v_mad_i64_i32, e * -1), which writes the 64-bit result pair
 //                                                                               (goldilocks_field.rs:402-415)
+// Since round 6 the hot kernels (Poseidon S-boxes, the limb NTT's general multiplies) run mul3cg / mul1cg below: the same 14
+// instructions with steps 5-7 (three carry adds) replaced by three co-issued v_mov_b32 and two chained addends; mul3 / mul2 / mad3
+// stay for the plonk and FRI kernels.
 // Temporaries are fixed VGPR/SGPR pairs (declared as clobbers) because inline-asm operands cannot
 // name the halves of a 64-bit register pair.  The emulator build runs these blocks either through its instruction
 // interpreter (asm_block.h: the same template strings, hazard- and clobber-checked) or, by default, as gl::mul.
