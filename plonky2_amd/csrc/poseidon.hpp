@@ -65,6 +65,29 @@ __device__ __forceinline__ void sbox_mul3(const u64 a[3], const u64 b[3], u64 r[
         gl::mul3(a, b, r);
 }
 
+// a + c for a round constant c (canonical): the 64-bit add, its wrap as a compare, and the fold-back of 2^64 = 2^32 - 1 as ONE multiply-add
+// on the select (hipcc's form of gl::add_canon is a second 64-bit add and two selects: 5 instructions instead of 4)
+__device__ __forceinline__ u64 ark(u64 a, u64 c) {
+    if (!P2_ASM_INTERPRETED()) return gl::add_canon(a, c);
+    const u64 s = a + c;
+    const u32 e = s < c ? 0xFFFFFFFFu : 0u;
+    u64 r, d;
+    P2_ASM_NC("v_mad_u64_u32 %0, %1, %2, 1, %3", (P2_O(, "=v", r), P2_O(, "=&s", d)), (P2_I(, "v", e), P2_I(, "v", s)));
+    return r;
+}
+// A wave-uniform zero the optimiser cannot see through, made where it is used: a constant-table index built on it is loaded THERE
+// (s_load) instead of being hoisted out of the leaf loop into SGPRs that are spilled to VGPR lanes and read back with v_readlane --
+// VALU instructions -- at every use (24 per constant vector, measured on the ISA)
+__device__ __forceinline__ u32 opaque_zero() {
+#ifndef P2HOT_EMU
+    u32 z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return z;
+#else
+    return 0;
+#endif
+}
+
 // x^7 of one word with the hand-scheduled multiply (the partial rounds' single S-box)
 __device__ __forceinline__ u64 sbox7_asm(u64 x) {
     u64 x2 = sbox_mul1(x, x);
@@ -266,42 +289,55 @@ constexpr bool mat_checks() {
     return true;
 }
 static_assert(mat_checks(), "M, M^2, M^3: the compile-time products disagree with the generated tables");
-P2_LITERAL_QUAL Mat12 MDS2 = mat_mul(mds_matrix(), mds_matrix());
+// The partial rounds REPLACE word 0 (y <- M (D y + s e0), D = diag(0, 1, .., 1), s = sbox(y[0] + c)) -- written with D instead of
+// with the difference s - y[0], a batch of rounds is linear in (z, s_1, s_2, ..) with NON-NEGATIVE integer coefficients, entry by entry
+// at most those of M^2 and M^3, and needs no field subtraction (round 6; a gl::sub is 11 VALU instructions as hipcc writes it):
+//   M (D (M z) + s1 e0)                   = (MD) M z + s1 (M e0)
+//   M (D (M (D (M z) + s1 e0)) + s2 e0)   = (MD)(MD) M z + s1 (MD) M e0 + s2 (M e0)            MD = M with column 0 zeroed
+constexpr Mat12 mat_drop_col0(const Mat12 &a) {
+    Mat12 m = a;
+    for (int r = 0; r < 12; ++r) m.v[12 * r] = 0;
+    return m;
+}
+P2_LITERAL_QUAL Mat12 MDS1 = mds_matrix();
+P2_LITERAL_QUAL Mat12 MDM = mat_mul(mat_drop_col0(mds_matrix()), mds_matrix());
+P2_LITERAL_QUAL Mat12 MDMDM = mat_mul(mat_drop_col0(mds_matrix()), mat_mul(mat_drop_col0(mds_matrix()), mds_matrix()));
 
 // A full round's MDS and the partial round after it in one dense pass (round 3's linear layer + round 4): with x the state after
-// the full round's S-box layer, u = M x, d = sbox(u[0] + c) - u[0], the state after the partial round is
-//   y = M (u + d e0) = M^2 x + d (M e0)
-// -- one 12-row pass over M^2 (+1 term per row), one single row for u[0] and one S-box, instead of two 12-row passes.  With it the
+// the full round's S-box layer, u = M x, s = sbox(u[0] + c), the state after the partial round is
+//   y = M (D u + s e0) = (MD) M x + s (M e0)
+// -- one 12-row pass over (MD) M (+1 term per row), one single row for u[0] and one S-box, instead of two 12-row passes.  With it the
 // 1 + 22 applications of M between the two full-round halves take 8 dense passes (this one and seven batches of three) instead of 9.
 // No pending constant on entry or exit (round 3 fuses none; c = the partial round's pushed scalar).
-__device__ __forceinline__ void mds_partial_round(u64 s[12], u64 c) {
+// c rides the u[0] chain as its starting addend (halves, like every constant here); cn = the NEXT partial round's scalar, fused into
+// row 0 the same way, so that no partial round adds its constant with instructions of its own.
+__device__ __forceinline__ void mds_partial_round(u64 s[12], u64 c, u64 cn) {
     u32 xl[12], xh[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         xl[i] = (u32)s[i];
         xh[i] = (u32)(s[i] >> 32);
     }
-    u64 al = 0, ah = 0;
+    u64 al = (u32)c, ah = c >> 32;
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         al += (u64)xl[j] * P2_POSEIDON_M1_ROW0[j];
         ah += (u64)xh[j] * P2_POSEIDON_M1_ROW0[j];
     }
-    const u64 u0 = gl::fold1(al, ah);
-    const u64 d = gl::sub(sbox7_asm(gl::add_canon(u0, c)), u0);
-    const u32 dl = (u32)d, dh = (u32)(d >> 32);
+    const u64 s1 = sbox7_asm(gl::fold1(al, ah));
+    const u32 sl = (u32)s1, sh = (u32)(s1 >> 32);
 #pragma unroll
     for (int g = 0; g < 12; g += 3) {
         u64 bl[3], bh[3], y[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int i = g + t;
-            bl[t] = (u64)dl * P2_POSEIDON_MCOL0[i];
-            bh[t] = (u64)dh * P2_POSEIDON_MCOL0[i];
+            bl[t] = (u64)sl * MDS1.v[12 * i] + (i == 0 ? (u64)(u32)cn : 0);
+            bh[t] = (u64)sh * MDS1.v[12 * i] + (i == 0 ? cn >> 32 : 0);
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
-                bl[t] += (u64)xl[j] * MDS2.v[12 * i + j];
-                bh[t] += (u64)xh[j] * MDS2.v[12 * i + j];
+                bl[t] += (u64)xl[j] * MDM.v[12 * i + j];
+                bh[t] += (u64)xh[j] * MDM.v[12 * i + j];
             }
         }
         gl::fold3(bl, bh, y);
@@ -311,21 +347,21 @@ __device__ __forceinline__ void mds_partial_round(u64 s[12], u64 c) {
     }
 }
 
-// Three partial rounds in one dense pass.  A partial round is y <- M z with z = y except z[0] = sbox(y[0] + c); writing
-// round r's replacement as y_r[0] + d_r (d_r = sbox(y_r[0] + c_r) - y_r[0]):
+// Three partial rounds in one dense pass.  A partial round is y <- M (D y + s e0) with s = sbox(y[0] + c); with z the state whose
+// word 0 already went through round 0's S-box:
 //   y1[0] = (M z)[0]
-//   y2[0] = (M^2 z)[0] + d1 M[0][0]
-//   y3    = M^3 z + d1 (M^2 e0) + d2 (M e0)          (z = the state with round 0's S-box applied to word 0)
-// and the integer powers of the MDS matrix stay small (M^3 < 2^21 per entry, < 2^25 per row), so a row of M^3 z is
-// still two 32x32+64 multiply-add chains (accumulators < 2^58): three rounds cost one 12-row pass (+2 terms per
-// row), two single rows and three S-boxes instead of three 12-row passes.  The matrix entries are s_mov_b32 literals
-// in the instruction stream (P2_LITERAL_QUAL).  A fourth power does not pay: the rows of M^4 sum to 1.04 * 2^32 (the
-// chains would overflow); splitting off its near-constant part t * J costs a scalar t * sum(z) added to all 24
-// accumulators, and the measured gain was 1 %.  c0..c2 are the rounds' scalar constants
-// (P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 r]); the state carries NO pending constant on entry or exit.
-__device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c0, u64 c1, u64 c2) {
+//   y2[0] = ((MD) M z)[0] + s1 M[0][0]
+//   y3    = (MD)(MD) M z + s1 ((MD) M e0) + s2 (M e0)
+// and the integer products of the MDS matrix stay small ((MD)(MD) M <= M^3 < 2^21 per entry, < 2^25 per row), so a row is still two
+// 32x32+64 multiply-add chains (accumulators < 2^58): three rounds cost one 12-row pass (+2 terms per row), two single rows and three
+// S-boxes instead of three 12-row passes.  The matrix entries are s_mov_b32 literals in the instruction stream (P2_LITERAL_QUAL).  A
+// fourth power does not pay: the rows of M^4 sum to 1.04 * 2^32 (the chains would overflow); splitting off its near-constant part
+// t * J costs a scalar t * sum(z) added to all 24 accumulators, and the measured gain was 1 %.  The rounds' scalar constants
+// (P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 r]) ride the chains as starting addends: c1, c2 those of this batch's second and third round,
+// cn that of the NEXT pass's first round (fused into row 0); this batch's first is already in s[0].
+__device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c1, u64 c2, u64 cn) {
     u32 xl[12], xh[12];
-    const u64 z0 = sbox7_asm(gl::add_canon(s[0], c0));
+    const u64 z0 = sbox7_asm(s[0]);  // round 0's scalar is already in s[0]: the previous pass fused it into its row 0
     xl[0] = (u32)z0;
     xh[0] = (u32)(z0 >> 32);
 #pragma unroll
@@ -333,37 +369,35 @@ __device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c0, u64 c1, u64 c
         xl[i] = (u32)s[i];
         xh[i] = (u32)(s[i] >> 32);
     }
-    u64 al = 0, ah = 0;
+    u64 al = (u32)c1, ah = c1 >> 32;
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         al += (u64)xl[j] * P2_POSEIDON_M1_ROW0[j];
         ah += (u64)xh[j] * P2_POSEIDON_M1_ROW0[j];
     }
-    const u64 y1 = gl::fold1(al, ah);
-    const u64 d1 = gl::sub(sbox7_asm(gl::add_canon(y1, c1)), y1);
-    const u32 d1l = (u32)d1, d1h = (u32)(d1 >> 32);
-    al = (u64)d1l * P2_POSEIDON_MCOL0[0];
-    ah = (u64)d1h * P2_POSEIDON_MCOL0[0];
+    const u64 s1 = sbox7_asm(gl::fold1(al, ah));
+    const u32 s1l = (u32)s1, s1h = (u32)(s1 >> 32);
+    al = (u64)s1l * MDS1.v[0] + (u32)c2;
+    ah = (u64)s1h * MDS1.v[0] + (c2 >> 32);
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
-        al += (u64)xl[j] * P2_POSEIDON_M2_ROW0[j];
-        ah += (u64)xh[j] * P2_POSEIDON_M2_ROW0[j];
+        al += (u64)xl[j] * MDM.v[j];
+        ah += (u64)xh[j] * MDM.v[j];
     }
-    const u64 y2 = gl::fold1(al, ah);
-    const u64 d2 = gl::sub(sbox7_asm(gl::add_canon(y2, c2)), y2);
-    const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
+    const u64 s2 = sbox7_asm(gl::fold1(al, ah));
+    const u32 s2l = (u32)s2, s2h = (u32)(s2 >> 32);
 #pragma unroll
     for (int g = 0; g < 12; g += 3) {
         u64 bl[3], bh[3], y[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int i = g + t;
-            bl[t] = (u64)d1l * P2_POSEIDON_MCOL0[12 + i] + (u64)d2l * P2_POSEIDON_MCOL0[i];
-            bh[t] = (u64)d1h * P2_POSEIDON_MCOL0[12 + i] + (u64)d2h * P2_POSEIDON_MCOL0[i];
+            bl[t] = (u64)s1l * MDM.v[12 * i] + (u64)s2l * MDS1.v[12 * i] + (i == 0 ? (u64)(u32)cn : 0);
+            bh[t] = (u64)s1h * MDM.v[12 * i] + (u64)s2h * MDS1.v[12 * i] + (i == 0 ? cn >> 32 : 0);
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
-                bl[t] += (u64)xl[j] * P2_POSEIDON_M3[12 * i + j];
-                bh[t] += (u64)xh[j] * P2_POSEIDON_M3[12 * i + j];
+                bl[t] += (u64)xl[j] * MDMDM.v[12 * i + j];
+                bh[t] += (u64)xh[j] * MDMDM.v[12 * i + j];
             }
         }
         gl::fold3(bl, bh, y);
@@ -379,8 +413,9 @@ __device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c0, u64 c1, u64 c
 // the last MDS skips the rest.  A digest is words 0..3 = (triple 0, word 3); the capacity a full absorb keeps is words 8..11 =
 // (word 8, triple 3): four rows instead of the six of two triples.
 __device__ inline void permute(u64 s[12], unsigned out_groups = 0xFu, int out_single = -1) {
+    const u32 z0 = opaque_zero();
 #pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = gl::add_canon(s[i], RC[i]);
+    for (int i = 0; i < 12; ++i) s[i] = ark(s[i], RC[i + z0]);
     int round = 0;
 #pragma unroll 1
     for (int k = 0; k < 3; ++k, ++round) {
@@ -391,17 +426,19 @@ __device__ inline void permute(u64 s[12], unsigned out_groups = 0xFu, int out_si
     // round 3's MDS -- the batched partial rounds add their scalars themselves (the passive part of the partial-round constants
     // is pushed forward through the MDS at table-generation time, see the generator)
     sbox_layer(s);
-    mds_partial_round(s, P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * 4]);
+    mds_partial_round(s, P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * 4], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * 5]);
     round = 5;
-    // partial rounds 5..25 in seven batches of three, then the full constant vector of round 26 (which absorbed the pushed
-    // remainder) as twelve field additions: fused into the last batch's accumulators it would be 48 more live SGPRs in EVERY batch
-    // (measured: 96 v_readlane per batch of SGPR spill traffic, +4 % instructions)
+    // partial rounds 5..25 in seven batches of three (each batch's first scalar was fused into row 0 of the pass before it), then
+    // the constant vector of round 26 (which absorbed the pushed remainder; its word 0 rode the last batch) as eleven field additions:
+    // fused into the last batch's accumulators the vector would be 44 more live SGPRs in EVERY batch (measured: 96 v_readlane per
+    // batch of SGPR spill traffic, +4 % instructions)
 #pragma unroll 1
     for (int k = 0; k < 7; ++k, round += 3)
-        partial_rounds3(s, P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * round], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 1)],
-                        P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 2)]);
+        partial_rounds3(s, P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 1)], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 2)],
+                        P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 3)]);  // the last batch's cn is round 26's word 0
+    const u32 z26 = opaque_zero();
 #pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = gl::add_canon(s[i], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * round + i]);
+    for (int i = 1; i < 12; ++i) s[i] = ark(s[i], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * round + i + z26]);
 #pragma unroll 1
     for (int k = 0; k < 3; ++k, ++round) {
         sbox_layer(s);
