@@ -359,7 +359,9 @@ __device__ __forceinline__ void mds_partial_round(u64 s[12], u64 c, u64 cn) {
 // t * J costs a scalar t * sum(z) added to all 24 accumulators, and the measured gain was 1 %.  The rounds' scalar constants
 // (P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 r]) ride the chains as starting addends: c1, c2 those of this batch's second and third round,
 // cn that of the NEXT pass's first round (fused into row 0); this batch's first is already in s[0].
-__device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c1, u64 c2, u64 cn) {
+// TAIL (the last batch): cv = the constant VECTOR of the full round that follows, fused into all twelve rows (cn unused).
+template <bool TAIL = false>
+__device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c1, u64 c2, u64 cn, const u64 *cv = nullptr) {
     u32 xl[12], xh[12];
     const u64 z0 = sbox7_asm(s[0]);  // round 0's scalar is already in s[0]: the previous pass fused it into its row 0
     xl[0] = (u32)z0;
@@ -392,8 +394,9 @@ __device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c1, u64 c2, u64 c
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int i = g + t;
-            bl[t] = (u64)s1l * MDM.v[12 * i] + (u64)s2l * MDS1.v[12 * i] + (i == 0 ? (u64)(u32)cn : 0);
-            bh[t] = (u64)s1h * MDM.v[12 * i] + (u64)s2h * MDS1.v[12 * i] + (i == 0 ? cn >> 32 : 0);
+            const u64 ci = TAIL ? cv[i] : (i == 0 ? cn : 0);
+            bl[t] = (u64)s1l * MDM.v[12 * i] + (u64)s2l * MDS1.v[12 * i] + (u32)ci;
+            bh[t] = (u64)s1h * MDM.v[12 * i] + (u64)s2h * MDS1.v[12 * i] + (ci >> 32);
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
                 bl[t] += (u64)xl[j] * MDMDM.v[12 * i + j];
@@ -407,6 +410,10 @@ __device__ __forceinline__ void partial_rounds3(u64 s[12], u64 c1, u64 c2, u64 c
     }
 }
 
+#ifndef P2HOT_TAIL_BATCH
+#define P2HOT_TAIL_BATCH 1  // 1: the last batch of partial rounds is its own copy with round 26's constant vector fused into its rows (eleven
+                            // 4-instruction additions less per permutation: -0.3 % cycles, profiles/r06_partial_rounds_ab.txt); 0: one rolled loop
+#endif
 // the permutation; output words are NOT canonicalised (callers canonicalise what they emit).
 // Round r: ARK(r) was already added by the previous MDS (or up front for r = 0); S-box; MDS + ARK(r+1).
 // `out_groups`: which output word triples the caller reads (bit g = words 3g..3g+2), `out_single`: one more word (3 or 8) it reads;
@@ -428,17 +435,23 @@ __device__ inline void permute(u64 s[12], unsigned out_groups = 0xFu, int out_si
     sbox_layer(s);
     mds_partial_round(s, P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * 4], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * 5]);
     round = 5;
-    // partial rounds 5..25 in seven batches of three (each batch's first scalar was fused into row 0 of the pass before it), then
-    // the constant vector of round 26 (which absorbed the pushed remainder; its word 0 rode the last batch) as eleven field additions:
-    // fused into the last batch's accumulators the vector would be 44 more live SGPRs in EVERY batch (measured: 96 v_readlane per
-    // batch of SGPR spill traffic, +4 % instructions)
+    // partial rounds 5..25 in seven batches of three (each batch's first scalar was fused into row 0 of the pass before it).  The
+    // constant vector of round 26 (which absorbed the pushed remainder) rides the LAST batch's rows; that batch is its own copy of the
+    // code, outside the rolled loop: fused into the loop's accumulators the vector would be 44 more live SGPRs in EVERY batch
+    // (measured: 96 v_readlane per batch of SGPR spill traffic, +4 % instructions)
 #pragma unroll 1
-    for (int k = 0; k < 7; ++k, round += 3)
+    for (int k = 0; k < (P2HOT_TAIL_BATCH ? 6 : 7); ++k, round += 3)
         partial_rounds3(s, P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 1)], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 2)],
                         P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * (round + 3)]);  // the last batch's cn is round 26's word 0
     const u32 z26 = opaque_zero();
+    if (P2HOT_TAIL_BATCH) {
+        partial_rounds3<true>(s, P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * 24], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * 25], 0,
+                              P2_POSEIDON_PUSHED_ROUND_CONSTANTS + 12 * 26 + z26);
+        round = 26;
+    } else {
 #pragma unroll
-    for (int i = 1; i < 12; ++i) s[i] = ark(s[i], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * round + i + z26]);
+        for (int i = 1; i < 12; ++i) s[i] = ark(s[i], P2_POSEIDON_PUSHED_ROUND_CONSTANTS[12 * round + i + z26]);
+    }
 #pragma unroll 1
     for (int k = 0; k < 3; ++k, ++round) {
         sbox_layer(s);
