@@ -19,7 +19,10 @@
 //    {lo32, hi32} words, seed the two accumulators straight from SGPRs.  In the partial rounds the
 //    constants of the 11 passive words are pushed forward through the (linear) MDS at table-generation
 //    time, so those rounds add a single scalar to word 0 and round 26 absorbs the remainder.
-//  * Round loops stay rolled so the kernel body fits the instruction cache.
+//  * The partial rounds run three to a dense pass over integer products of the MDS matrix, written with the projection
+//    D = diag(0, 1, .., 1) (a round REPLACES word 0) so that no field subtraction is needed; their scalars are chain addends too.
+//  * Round loops stay rolled so the kernel body fits the instruction cache (one batch of partial rounds is peeled: it carries
+//    round 26's constant vector).
 #pragma once
 #include "gl.hpp"
 #include "gl_mul3.hpp"
